@@ -1,0 +1,62 @@
+"""ctypes binding of libfulgor_gpu.so (include/fulgor_gpu.h). Fails loudly when the library is absent:
+there is no Python or CPU stand-in for the HIP path."""
+import ctypes as C
+import os
+
+from . import _build
+
+_lib = None
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_GPU
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). The engine has no fallback path." % path)
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.fgpu_last_error.restype = C.c_char_p
+    L.fgpu_kernel_name.restype = C.c_char_p
+    L.fgpu_kernel_name.argtypes = [C.c_int]
+    L.fgpu_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.fgpu_close.argtypes = [vp]
+    L.fgpu_close.restype = None
+    L.fgpu_save.argtypes = [vp, C.c_char_p]
+    L.fgpu_selfcheck.argtypes = [vp, C.c_uint64]
+    L.fgpu_info.argtypes = [vp, u64p, u64p, u64p, u64p, u64p, C.POINTER(C.c_int)]
+    L.fgpu_free.argtypes = [vp]
+    L.fgpu_free.restype = None
+    for name in ("fgpu_fetch_color_set_ids", "fgpu_full_intersection"):
+        getattr(L, name).argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp)]
+    L.fgpu_threshold_union.argtypes = [vp, vp, vp, C.c_uint64, C.c_double, C.POINTER(vp), C.POINTER(vp)]
+    L.fgpu_intersect_ids.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp)]
+    L.fgpu_reads_upload.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp)]
+    L.fgpu_reads_free.argtypes = [vp]
+    L.fgpu_reads_free.restype = None
+    L.fgpu_result_create.argtypes = [vp, C.POINTER(vp)]
+    L.fgpu_result_free.argtypes = [vp]
+    L.fgpu_result_free.restype = None
+    L.fgpu_run.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_double, vp]
+    L.fgpu_result_sizes.argtypes = [vp, u64p, u64p, u64p]
+    L.fgpu_result_download.argtypes = [vp, vp, vp]
+    L.fgpu_result_accumulate_hits.argtypes = [vp, vp, vp]
+    L.fgpu_result_algorithmic_bytes.argtypes = [vp, u64p, u64p]
+    L.fgpu_timing_enable.argtypes = [vp, C.c_int]
+    L.fgpu_timing_reset.argtypes = [vp]
+    L.fgpu_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), u64p]
+    L.fgpu_export_sizes.argtypes = [vp, u64p, u64p, u64p, u64p, u64p]
+    L.fgpu_export.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libfulgor_gpu: %s (code %d)" % (lib().fgpu_last_error().decode(), rc))

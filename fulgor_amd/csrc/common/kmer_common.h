@@ -1,0 +1,128 @@
+// Shared host/device definitions of the k-mer dictionary ("k2u") layout used by the MI355X engine.
+//
+// This replaces the role of sshash::dictionary / streaming_query in the reference
+// (call sites: src/ps_full_intersection.cpp:341-352, src/ps_threshold_union.cpp:330-346).
+// The reference's SSHash sources are not vendored (external/sshash is empty), and per SURVEY F7 the
+// per-read result does not depend on the dictionary's internals; this layout is therefore designed
+// for the GPU: bit-plane packed unitig strings, one 8-byte record per super-k-mer, a
+// pilot-displaced perfect hash over canonical minimizers.
+//
+// Everything in this header compiles for both host (g++) and device (hipcc).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define FG_HD __host__ __device__ __forceinline__
+#else
+#define FG_HD inline
+#endif
+
+namespace fg {
+
+// ---- base encoding -------------------------------------------------------------------------
+// A=0 C=1 G=2 T=3 (complement = 3-x = flip both bits). 0xFF = not a nucleotide.
+FG_HD uint32_t base_code(uint8_t c) {
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return 0xFF;
+    }
+}
+
+// ---- bit-plane L-mers (L <= 32) --------------------------------------------------------------
+// An L-mer is two 32-bit planes: lo = bit0 of every base, hi = bit1; base i (i=0 is the first /
+// leftmost base) lives at bit i of each plane.
+FG_HD uint32_t low_mask32(uint32_t L) { return L >= 32 ? 0xFFFFFFFFu : ((1u << L) - 1u); }
+
+FG_HD uint32_t brev32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bitreverse32(x);
+#else
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+    return (x >> 16) | (x << 16);
+#endif
+}
+
+// reverse complement of one plane of an L-mer: reverse the L bits, then flip them
+FG_HD uint32_t rc_plane(uint32_t p, uint32_t L) { return (~brev32(p) >> (32 - L)) & low_mask32(L); }
+
+// 64-bit key of an L-mer and its canonical (strand independent) form
+FG_HD uint64_t lmer_key(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+FG_HD uint64_t canonical_key(uint32_t lo, uint32_t hi, uint32_t L) {
+    uint64_t f = lmer_key(lo, hi);
+    uint64_t r = lmer_key(rc_plane(lo, L), rc_plane(hi, L));
+    return f < r ? f : r;
+}
+
+// murmur3 finalizer: a bijection on u64
+FG_HD uint64_t mix64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+FG_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+// Minimizer order: smaller (hash >> 36) first; ties are broken by position (leftmost in the
+// orientation in which the window is read), so that reading the same window on the other strand
+// selects the rightmost tie. 28 bits leave room for a 4-bit position in a packed u32 min.
+constexpr uint32_t MIN_ORDER_SHIFT = 36;
+
+// ---- perfect hash over canonical minimizer keys ------------------------------------------------
+// bucket = fastrange(high32(h), num_buckets); slot = fastrange(low32(h) ^ (pilot * PHI32), num_slots)
+constexpr uint32_t PHI32 = 0x9E3779B1u;
+FG_HD uint32_t phf_bucket(uint64_t h, uint32_t num_buckets) { return mulhi32((uint32_t)(h >> 32), num_buckets); }
+FG_HD uint32_t phf_slot(uint64_t h, uint32_t pilot, uint32_t num_slots) {
+    uint32_t v = (uint32_t)h ^ (pilot * PHI32);
+    v ^= v >> 15;
+    v *= 0x2c1b3c6du;
+    v ^= v >> 12;
+    return mulhi32(v, num_slots);
+}
+
+// ---- 8-byte super-k-mer record -----------------------------------------------------------------
+// bits  0..31  pos   : absolute base offset of the minimizer occurrence in the concatenated unitigs
+// bits 32..35  jmin  : smallest offset (minimizer start - k-mer start) of a k-mer of this super-k-mer
+// bits 36..39  jmax  : largest such offset                       (requires k - m <= 15)
+// bits 40..62  csid  : colour-set id of the unitig (u2c folded in; index.hpp:37 in the reference)
+// bit  63      tag   : 0 = record, 1 = reference into the overflow array {offset:32, count:31}
+constexpr uint64_t REC_TAG = 1ULL << 63;
+constexpr uint32_t REC_MAX_CSID = (1u << 23) - 1;
+// empty slot: jmin=15 > jmax=0 never matches
+constexpr uint64_t REC_EMPTY = (15ULL << 32);
+
+FG_HD uint64_t rec_pack(uint32_t pos, uint32_t jmin, uint32_t jmax, uint32_t csid) {
+    return (uint64_t)pos | ((uint64_t)jmin << 32) | ((uint64_t)jmax << 36) | ((uint64_t)csid << 40);
+}
+FG_HD uint32_t rec_pos(uint64_t r) { return (uint32_t)r; }
+FG_HD uint32_t rec_jmin(uint64_t r) { return (uint32_t)(r >> 32) & 15u; }
+FG_HD uint32_t rec_jmax(uint64_t r) { return (uint32_t)(r >> 36) & 15u; }
+FG_HD uint32_t rec_csid(uint64_t r) { return (uint32_t)(r >> 40) & REC_MAX_CSID; }
+FG_HD uint64_t ovf_pack(uint32_t off, uint32_t cnt) { return REC_TAG | (uint64_t)off | ((uint64_t)cnt << 32); }
+FG_HD uint32_t ovf_off(uint64_t r) { return (uint32_t)r; }
+FG_HD uint32_t ovf_cnt(uint64_t r) { return (uint32_t)(r >> 32) & 0x7FFFFFFFu; }
+
+// ---- unitig strings ----------------------------------------------------------------------------
+// word w holds bases [32w, 32w+32): low 32 bits = lo plane, high 32 bits = hi plane.
+// extract an L-mer (L<=32) starting at base s from two consecutive words
+FG_HD void string_lmer(uint64_t w0, uint64_t w1, uint32_t sh, uint32_t L, uint32_t& lo, uint32_t& hi) {
+    uint64_t l = ((uint64_t)(uint32_t)w1 << 32) | (uint32_t)w0;
+    uint64_t h = (w1 & 0xFFFFFFFF00000000ULL) | (w0 >> 32);
+    lo = (uint32_t)(l >> sh) & low_mask32(L);
+    hi = (uint32_t)(h >> sh) & low_mask32(L);
+}
+
+// ---- colour-list skip samples --------------------------------------------------------------------
+// One sample every SAMPLE_STRIDE codes of a gap-coded list: {prev value:32 | bit offset from the
+// start of the list:32}. Sample j is the decoder state after (j+1)*SAMPLE_STRIDE codes.
+constexpr uint32_t SAMPLE_STRIDE = 32;
+
+}  // namespace fg

@@ -1,0 +1,650 @@
+// libfulgor_gpu.so: C ABI (include/fulgor_gpu.h) over the HIP kernels. Host side = index ingestion,
+// one-time upload to HBM, batch plumbing, HIP-event timing. No CPU execution path for queries: every
+// query entry point launches the kernels in hip/kernels.hip.h or fails.
+#include <hip/hip_runtime.h>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fulgor_gpu.h"
+#include "hip/kernels.hip.h"
+#include "host/index_io.hpp"
+
+using namespace fg;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) HIP_TRY(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
+template <typename T>
+void upload(DevBuf& b, const std::vector<T>& v, hipStream_t s) {
+    b.ensure(std::max<size_t>(16, v.size() * sizeof(T)));
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+}
+
+const char* KERNEL_NAMES[FGPU_K_COUNT] = {"k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits"};
+
+}  // namespace
+
+struct fgpu_index {
+    HostIndex host;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    DevBuf d_strings, d_pilots, d_slots, d_overflow, d_bits, d_offsets, d_sample_off, d_samples;
+    DevDict dd{};
+    DevColors dc{};
+    // timing
+    bool timing = false;
+    double ms[FGPU_K_COUNT] = {0};
+    uint64_t launches[FGPU_K_COUNT] = {0};
+    struct Pending { int kernel; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+
+    hipEvent_t get_event() {
+        if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        return e;
+    }
+    void collect_timing() {
+        for (auto& p : pending) {
+            float t = 0;
+            HIP_TRY(hipEventElapsedTime(&t, p.a, p.b));
+            ms[p.kernel] += t;
+            launches[p.kernel] += 1;
+            event_pool.push_back(p.a);
+            event_pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+};
+
+// RAII bracket: records HIP events around a kernel on the engine's stream
+struct Timed {
+    fgpu_index* ix;
+    int kernel;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(fgpu_index* i, int k) : ix(i), kernel(k) {
+        if (ix->timing) { a = ix->get_event(); b = ix->get_event(); HIP_TRY(hipEventRecord(a, ix->stream)); }
+    }
+    ~Timed() {
+        if (ix->timing) { (void)hipEventRecord(b, ix->stream); ix->pending.push_back({kernel, a, b}); }
+    }
+};
+
+struct fgpu_reads {
+    fgpu_index* ix = nullptr;
+    DevBuf d_bases, d_offs;
+    uint64_t n = 0;
+    std::vector<uint64_t> cum_kmers;  // prefix sums of max(0, len-k+1)
+    std::vector<uint64_t> h_offs;
+    uint32_t max_kmers = 0;
+};
+
+struct fgpu_result {
+    fgpu_index* ix = nullptr;
+    DevBuf d_nids, d_npos, d_idoff, d_ids_pool, d_cnt_pool, d_cursor, d_bitmap, d_counts, d_offsets, d_block_sums,
+        d_block_mapped, d_totals, d_colors, d_acct;
+    uint64_t* h_totals = nullptr;  // pinned {total colours, mapped reads, ids used}
+    uint64_t n = 0, total = 0, mapped = 0, total_kmers = 0, total_bases = 0;
+    bool have_ids = false;
+};
+
+namespace {
+
+void upload_index(fgpu_index* ix) {
+    const Dict& d = ix->host.dict;
+    const HybridSets& h = ix->host.hybrid;
+    hipStream_t s = ix->stream;
+    upload(ix->d_strings, d.strings, s);
+    upload(ix->d_pilots, d.pilots, s);
+    upload(ix->d_slots, d.slots, s);
+    upload(ix->d_overflow, d.overflow, s);
+    upload(ix->d_bits, h.bits, s);
+    upload(ix->d_offsets, h.offsets, s);
+    upload(ix->d_sample_off, h.sample_off, s);
+    upload(ix->d_samples, h.samples, s);
+    HIP_TRY(hipStreamSynchronize(s));
+    ix->dd = DevDict{ix->d_strings.as<uint64_t>(), ix->d_pilots.as<uint32_t>(), ix->d_slots.as<uint64_t>(),
+                     ix->d_overflow.as<uint64_t>(), d.num_buckets, d.num_slots, d.k, d.m};
+    uint32_t w32 = (h.num_colors + 31) / 32;
+    w32 += w32 & 1;
+    ix->dc = DevColors{ix->d_bits.as<uint64_t>(), ix->d_offsets.as<uint64_t>(), ix->d_sample_off.as<uint64_t>(),
+                       ix->d_samples.as<uint64_t>(), h.num_colors, h.sparse_thr, h.dense_thr, w32};
+}
+
+// waves per block such that the dynamic LDS request fits; throws if one wave does not fit a CU
+uint32_t pick_waves(size_t per_wave, const void* kernel) {
+    const size_t LDS_CU = 160 * 1024;
+    if (per_wave > LDS_CU) throw std::runtime_error("colour count too large for the per-wave LDS layout of this kernel");
+    uint32_t w = 4;
+    while (w > 1 && w * per_wave > 64 * 1024) w >>= 1;
+    if (w * per_wave > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)per_wave));
+    return w;
+}
+
+uint32_t grid_for(uint64_t units, uint32_t per_block, int num_cus, uint32_t blocks_per_cu) {
+    uint64_t need = (units + per_block - 1) / per_block;
+    uint64_t cap = (uint64_t)num_cus * blocks_per_cu;
+    return (uint32_t)std::max<uint64_t>(1, std::min(need, cap));
+}
+
+void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t count, fgpu_result* res) {
+    hipStream_t s = ix->stream;
+    res->n = count;
+    res->total_kmers = rd->cum_kmers[first + count] - rd->cum_kmers[first];
+    res->total_bases = rd->h_offs[first + count] - rd->h_offs[first];
+    res->d_nids.ensure(count * 4 + 16);
+    res->d_npos.ensure(count * 4 + 16);
+    res->d_idoff.ensure(count * 8 + 16);
+    res->d_ids_pool.ensure(res->total_kmers * 4 + 16);
+    res->d_cnt_pool.ensure(res->total_kmers * 4 + 16);
+    res->d_cursor.ensure(16);
+    HIP_TRY(hipMemsetAsync(res->d_cursor.p, 0, 16, s));
+    if (count == 0) return;
+    const uint32_t grid = grid_for(count, 4, ix->num_cus, 8);
+    Timed t(ix, FGPU_K_LOOKUP);
+    if (rd->max_kmers <= 128) {
+        hipLaunchKernelGGL(k1_lookup<128>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
+                           rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
+                           res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
+                           res->d_cursor.as<unsigned long long>());
+    } else if (rd->max_kmers <= 1024) {
+        hipLaunchKernelGGL(k1_lookup<1024>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
+                           rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
+                           res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
+                           res->d_cursor.as<unsigned long long>());
+    } else {
+        throw std::runtime_error("reads with more than 1024 k-mers are not supported by this build");
+    }
+    HIP_TRY(hipGetLastError());
+    res->have_ids = true;
+}
+
+void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
+    hipStream_t s = ix->stream;
+    const uint64_t n = res->n;
+    const uint32_t W = ix->dc.w32;
+    res->d_bitmap.ensure(n * W * 4 + 16);
+    res->d_counts.ensure(n * 4 + 16);
+    res->d_offsets.ensure((n + 1) * 8 + 16);
+    const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    res->d_block_sums.ensure(std::max<uint64_t>(1, nb) * 8);
+    res->d_block_mapped.ensure(std::max<uint64_t>(1, nb) * 8);
+    res->d_totals.ensure(32);
+    if (!res->h_totals) HIP_TRY(hipHostMalloc((void**)&res->h_totals, 32));
+    res->total = res->mapped = 0;
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(res->d_offsets.p, 0, 8, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return;
+    }
+    if (algo == FGPU_FULL_INTERSECTION) {
+        const size_t per_wave = 2 * (size_t)W * 4 + wave_scratch_bytes();
+        const uint32_t wpb = pick_waves(per_wave, (const void*)k2a_intersect);
+        const uint32_t grid = grid_for(n, wpb, ix->num_cus, 32 / wpb);
+        Timed t(ix, FGPU_K_INTERSECT);
+        hipLaunchKernelGGL(k2a_intersect, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_nids.as<uint32_t>(),
+                           res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), n, res->d_bitmap.as<uint32_t>(),
+                           res->d_counts.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+    } else if (algo == FGPU_THRESHOLD_UNION) {
+        const size_t per_wave = (size_t)W * 32 * 4 + wave_scratch_bytes();
+        const uint32_t wpb = pick_waves(per_wave, (const void*)k3a_union);
+        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(32 / wpb, (150 * 1024) / (wpb * per_wave)));
+        const uint32_t grid = grid_for(n, wpb, ix->num_cus, per_cu);
+        Timed t(ix, FGPU_K_UNION);
+        hipLaunchKernelGGL(k3a_union, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_nids.as<uint32_t>(),
+                           res->d_npos.as<uint32_t>(), res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(),
+                           res->d_cnt_pool.as<uint32_t>(), tau, n, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+    } else {
+        throw std::runtime_error("unknown algorithm");
+    }
+    {
+        Timed t(ix, FGPU_K_SCAN);
+        hipLaunchKernelGGL(scan_block_sums, dim3((uint32_t)nb), dim3(256), 0, s, res->d_counts.as<uint32_t>(), n,
+                           res->d_block_sums.as<uint64_t>(), res->d_block_mapped.as<uint64_t>());
+        hipLaunchKernelGGL(scan_top, dim3(1), dim3(256), 0, s, res->d_block_sums.as<uint64_t>(),
+                           res->d_block_mapped.as<uint64_t>(), nb, res->d_totals.as<uint64_t>());
+        hipLaunchKernelGGL(scan_apply, dim3((uint32_t)nb), dim3(256), 0, s, res->d_counts.as<uint32_t>(), n,
+                           res->d_block_sums.as<uint64_t>(), res->d_offsets.as<uint64_t>());
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(res->h_totals, res->d_totals.p, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    res->total = res->h_totals[0];
+    res->mapped = res->h_totals[1];
+    res->d_colors.ensure(res->total * 4 + 16);
+    if (res->total) {
+        const uint32_t grid = grid_for(n, 4, ix->num_cus, 8);
+        Timed t(ix, FGPU_K_EXPAND);
+        hipLaunchKernelGGL(k2b_expand, dim3(grid), dim3(256), 0, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
+                           res->d_offsets.as<uint64_t>(), n, W, res->d_colors.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    if (ix->timing) ix->collect_timing();
+}
+
+template <typename F>
+int guarded(F f) {
+    try {
+        f();
+        return 0;
+    } catch (std::bad_alloc&) {
+        return fail(-ENOMEM, "out of host memory");
+    } catch (std::exception& e) {
+        return fail(-EIO, e.what());
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fgpu_last_error(void) { return g_err.c_str(); }
+const char* fgpu_kernel_name(int kernel) { return kernel >= 0 && kernel < FGPU_K_COUNT ? KERNEL_NAMES[kernel] : ""; }
+
+int fgpu_open(const char* path, int device, fgpu_index** out) {
+    if (!path || !out) return fail(-EINVAL, "null argument");
+    *out = nullptr;
+    fgpu_index* ix = nullptr;
+    int rc = guarded([&] {
+        int ndev = 0;
+        if (device != FGPU_HOST_ONLY) {
+            if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+                throw std::runtime_error("no HIP device available: the pseudoalignment engine has no CPU execution path");
+            if (device < 0 || device >= ndev) throw std::runtime_error("invalid device ordinal");
+        }
+        ix = new fgpu_index();
+        open_index(path, ix->host);
+        if (ix->host.type != IDX_HYBRID) throw std::runtime_error("only hybrid (.fur-equivalent) indexes are supported by this build");
+        ix->device = device;
+        if (device == FGPU_HOST_ONLY) return;  // ingestion / export / save only; queries are refused
+        HIP_TRY(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        ix->num_cus = prop.multiProcessorCount;
+        HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+        upload_index(ix);
+    });
+    if (rc) { delete ix; return rc; }
+    *out = ix;
+    return 0;
+}
+
+void fgpu_close(fgpu_index* ix) {
+    if (!ix) return;
+    if (ix->device == FGPU_HOST_ONLY) { delete ix; return; }
+    (void)hipSetDevice(ix->device);
+    for (DevBuf* b : {&ix->d_strings, &ix->d_pilots, &ix->d_slots, &ix->d_overflow, &ix->d_bits, &ix->d_offsets,
+                      &ix->d_sample_off, &ix->d_samples})
+        b->release();
+    for (auto e : ix->event_pool) (void)hipEventDestroy(e);
+    if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    delete ix;
+}
+
+int fgpu_save(const fgpu_index* ix, const char* path) {
+    if (!ix || !path) return fail(-EINVAL, "null argument");
+    return guarded([&] { save_binary(ix->host, path); });
+}
+
+int fgpu_info(const fgpu_index* ix, uint64_t* k, uint64_t* num_colors, uint64_t* num_color_sets, uint64_t* num_unitigs,
+              uint64_t* num_kmers, int* index_type) {
+    if (!ix) return fail(-EINVAL, "null argument");
+    if (k) *k = ix->host.dict.k;
+    if (num_colors) *num_colors = ix->host.hybrid.num_colors;
+    if (num_color_sets) *num_color_sets = ix->host.hybrid.num_sets();
+    if (num_unitigs) *num_unitigs = ix->host.dict.num_unitigs();
+    if (num_kmers) *num_kmers = ix->host.dict.num_kmers;
+    if (index_type) *index_type = ix->host.type;
+    return 0;
+}
+
+void fgpu_free(void* p) { free(p); }
+
+int fgpu_selfcheck(const fgpu_index* ix, uint64_t unitig_stride) {
+    if (!ix) return fail(-EINVAL, "null argument");
+    return guarded([&] { verify_dict(ix->host.dict, unitig_stride ? unitig_stride : 1); });
+}
+
+#define NEED_DEVICE(ix)                                                                                         \
+    if ((ix)->device == FGPU_HOST_ONLY)                                                                         \
+        return fail(-ENODEV, "index was opened host-only (device = -1): queries need a GPU, there is no CPU path")
+
+int fgpu_reads_upload(fgpu_index* ix, const char* bases, const uint64_t* offs, uint64_t n, fgpu_reads** out) {
+    if (!ix || !offs || !out || (n && !bases)) return fail(-EINVAL, "null argument");
+    NEED_DEVICE(ix);
+    *out = nullptr;
+    fgpu_reads* rd = nullptr;
+    int rc = guarded([&] {
+        HIP_TRY(hipSetDevice(ix->device));
+        rd = new fgpu_reads();
+        rd->ix = ix;
+        rd->n = n;
+        rd->h_offs.assign(offs, offs + n + 1);
+        rd->cum_kmers.assign(n + 1, 0);
+        const uint32_t k = ix->host.dict.k;
+        for (uint64_t i = 0; i < n; ++i) {
+            if (offs[i + 1] < offs[i]) throw std::runtime_error("read offsets are not monotone");
+            uint64_t len = offs[i + 1] - offs[i];
+            uint64_t nk = len >= k ? len - k + 1 : 0;
+            if (nk > 1024) throw std::runtime_error("reads with more than 1024 k-mers are not supported by this build");
+            rd->max_kmers = std::max<uint32_t>(rd->max_kmers, (uint32_t)nk);
+            rd->cum_kmers[i + 1] = rd->cum_kmers[i] + nk;
+        }
+        const uint64_t nb = offs[n];
+        rd->d_bases.ensure(nb + 256);
+        rd->d_offs.ensure((n + 1) * 8);
+        if (nb) HIP_TRY(hipMemcpyAsync(rd->d_bases.p, bases, nb, hipMemcpyHostToDevice, ix->stream));
+        HIP_TRY(hipMemcpyAsync(rd->d_offs.p, offs, (n + 1) * 8, hipMemcpyHostToDevice, ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+    });
+    if (rc) { if (rd) { rd->d_bases.release(); rd->d_offs.release(); delete rd; } return rc; }
+    *out = rd;
+    return 0;
+}
+
+void fgpu_reads_free(fgpu_reads* rd) {
+    if (!rd) return;
+    (void)hipSetDevice(rd->ix->device);
+    rd->d_bases.release();
+    rd->d_offs.release();
+    delete rd;
+}
+
+int fgpu_result_create(fgpu_index* ix, fgpu_result** out) {
+    if (!ix || !out) return fail(-EINVAL, "null argument");
+    NEED_DEVICE(ix);
+    *out = new fgpu_result();
+    (*out)->ix = ix;
+    return 0;
+}
+
+void fgpu_result_free(fgpu_result* r) {
+    if (!r) return;
+    (void)hipSetDevice(r->ix->device);
+    for (DevBuf* b : {&r->d_nids, &r->d_npos, &r->d_idoff, &r->d_ids_pool, &r->d_cnt_pool, &r->d_cursor, &r->d_bitmap,
+                      &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct})
+        b->release();
+    if (r->h_totals) (void)hipHostFree(r->h_totals);
+    delete r;
+}
+
+int fgpu_run(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t count, int algo, double tau, fgpu_result* res) {
+    if (!ix || !rd || !res) return fail(-EINVAL, "null argument");
+    if (first > rd->n || count > rd->n - first) return fail(-EINVAL, "read range out of bounds");
+    if (algo == FGPU_THRESHOLD_UNION && !(tau > 0.0 && tau <= 1.0))
+        return fail(-EINVAL, "threshold must be a float in (0.0,1.0]");  // tools/pseudoalign.cpp:275-278
+    return guarded([&] {
+        HIP_TRY(hipSetDevice(ix->device));
+        stage_lookup(ix, rd, first, count, res);
+        stage_colors(ix, algo, tau, res);
+    });
+}
+
+int fgpu_result_sizes(const fgpu_result* r, uint64_t* num_reads, uint64_t* total_colors, uint64_t* num_mapped) {
+    if (!r) return fail(-EINVAL, "null argument");
+    if (num_reads) *num_reads = r->n;
+    if (total_colors) *total_colors = r->total;
+    if (num_mapped) *num_mapped = r->mapped;
+    return 0;
+}
+
+int fgpu_result_download(const fgpu_result* r, uint64_t* offsets, uint32_t* colors) {
+    if (!r || !offsets) return fail(-EINVAL, "null argument");
+    return guarded([&] {
+        HIP_TRY(hipSetDevice(r->ix->device));
+        HIP_TRY(hipMemcpy(offsets, r->d_offsets.p, (r->n + 1) * 8, hipMemcpyDeviceToHost));
+        if (r->total && colors) HIP_TRY(hipMemcpy(colors, r->d_colors.p, r->total * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+int fgpu_result_accumulate_hits(fgpu_index* ix, const fgpu_result* r, void* device_u64_hits) {
+    if (!ix || !r || !device_u64_hits) return fail(-EINVAL, "null argument");
+    return guarded([&] {
+        HIP_TRY(hipSetDevice(ix->device));
+        if (r->n) {
+            const uint32_t W = ix->dc.w32;
+            const uint32_t threads = std::min<uint32_t>(256, ((W + 63) / 64) * 64);
+            const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(512, (r->n + 255) / 256));
+            Timed t(ix, FGPU_K_HITS);
+            hipLaunchKernelGGL(k_hits, dim3(grid), dim3(threads), 0, ix->stream, r->d_bitmap.as<uint32_t>(), r->n, W, ix->dc.n,
+                               (unsigned long long*)device_u64_hits);
+            hipLaunchKernelGGL(k_add_totals, dim3(1), dim3(64), 0, ix->stream, (unsigned long long*)device_u64_hits, ix->dc.n,
+                               r->n, r->d_totals.as<uint64_t>());
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+        if (ix->timing) ix->collect_timing();
+    });
+}
+
+int fgpu_result_algorithmic_bytes(const fgpu_result* r, uint64_t* intersect_bytes, uint64_t* lookup_bytes) {
+    if (!r) return fail(-EINVAL, "null argument");
+    fgpu_index* ix = r->ix;
+    return guarded([&] {
+        HIP_TRY(hipSetDevice(ix->device));
+        uint64_t acct = 0;
+        if (r->n) {
+            const_cast<fgpu_result*>(r)->d_acct.ensure(16);
+            HIP_TRY(hipMemsetAsync(r->d_acct.p, 0, 16, ix->stream));
+            hipLaunchKernelGGL(k_account, dim3(1024), dim3(256), 0, ix->stream, ix->dc, r->d_nids.as<uint32_t>(),
+                               r->d_idoff.as<uint64_t>(), r->d_ids_pool.as<uint32_t>(), r->d_counts.as<uint32_t>(), r->n,
+                               r->d_acct.as<unsigned long long>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(&acct, r->d_acct.p, 8, hipMemcpyDeviceToHost, ix->stream));
+            HIP_TRY(hipStreamSynchronize(ix->stream));
+        }
+        if (intersect_bytes) *intersect_bytes = acct;
+        // ceil(L/4) bytes of 2-bit read + one 8-byte record per k-mer
+        if (lookup_bytes) *lookup_bytes = (r->total_bases + 3) / 4 + 8 * r->total_kmers;
+    });
+}
+
+int fgpu_timing_enable(fgpu_index* ix, int on) {
+    if (!ix) return fail(-EINVAL, "null argument");
+    ix->timing = on != 0;
+    return 0;
+}
+int fgpu_timing_reset(fgpu_index* ix) {
+    if (!ix) return fail(-EINVAL, "null argument");
+    for (int i = 0; i < FGPU_K_COUNT; ++i) { ix->ms[i] = 0; ix->launches[i] = 0; }
+    return 0;
+}
+int fgpu_timing_get(fgpu_index* ix, int kernel, double* total_ms, uint64_t* launches) {
+    if (!ix || kernel < 0 || kernel >= FGPU_K_COUNT) return fail(-EINVAL, "bad argument");
+    if (total_ms) *total_ms = ix->ms[kernel];
+    if (launches) *launches = ix->launches[kernel];
+    return 0;
+}
+
+// ---- host-buffer convenience calls -------------------------------------------------------------------
+static int run_host(fgpu_index* ix, const char* bases, const uint64_t* offs, uint64_t n, int algo, double tau,
+                    uint64_t** out_offsets, uint32_t** out_colors) {
+    if (!ix || !out_offsets || !out_colors) return fail(-EINVAL, "null argument");
+    *out_offsets = nullptr;
+    *out_colors = nullptr;
+    fgpu_reads* rd = nullptr;
+    fgpu_result* res = nullptr;
+    int rc = fgpu_reads_upload(ix, bases, offs, n, &rd);
+    if (!rc) rc = fgpu_result_create(ix, &res);
+    if (!rc) rc = fgpu_run(ix, rd, 0, n, algo, tau, res);
+    if (!rc) {
+        uint64_t* o = (uint64_t*)malloc((n + 1) * 8);
+        uint32_t* c = (uint32_t*)malloc(std::max<uint64_t>(1, res->total) * 4);
+        if (!o || !c) { free(o); free(c); rc = fail(-ENOMEM, "out of host memory"); }
+        else {
+            rc = fgpu_result_download(res, o, c);
+            if (rc) { free(o); free(c); } else { *out_offsets = o; *out_colors = c; }
+        }
+    }
+    fgpu_result_free(res);
+    fgpu_reads_free(rd);
+    return rc;
+}
+
+int fgpu_full_intersection(fgpu_index* ix, const char* bases, const uint64_t* offs, uint64_t n, uint64_t** out_offsets,
+                           uint32_t** out_colors) {
+    return run_host(ix, bases, offs, n, FGPU_FULL_INTERSECTION, 0.0, out_offsets, out_colors);
+}
+
+int fgpu_threshold_union(fgpu_index* ix, const char* bases, const uint64_t* offs, uint64_t n, double tau,
+                         uint64_t** out_offsets, uint32_t** out_colors) {
+    return run_host(ix, bases, offs, n, FGPU_THRESHOLD_UNION, tau, out_offsets, out_colors);
+}
+
+int fgpu_fetch_color_set_ids(fgpu_index* ix, const char* bases, const uint64_t* offs, uint64_t n, uint64_t** out_offsets,
+                             uint32_t** out_ids) {
+    if (!ix || !out_offsets || !out_ids) return fail(-EINVAL, "null argument");
+    *out_offsets = nullptr;
+    *out_ids = nullptr;
+    fgpu_reads* rd = nullptr;
+    fgpu_result* res = nullptr;
+    int rc = fgpu_reads_upload(ix, bases, offs, n, &rd);
+    if (!rc) rc = fgpu_result_create(ix, &res);
+    if (!rc) rc = guarded([&] {
+        HIP_TRY(hipSetDevice(ix->device));
+        stage_lookup(ix, rd, 0, n, res);
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+        if (ix->timing) ix->collect_timing();
+        std::vector<uint32_t> nids(n);
+        std::vector<uint64_t> idoff(n);
+        unsigned long long used = 0;
+        if (n) {
+            HIP_TRY(hipMemcpy(nids.data(), res->d_nids.p, n * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(idoff.data(), res->d_idoff.p, n * 8, hipMemcpyDeviceToHost));
+        }
+        HIP_TRY(hipMemcpy(&used, res->d_cursor.p, 8, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> pool(used);
+        if (used) HIP_TRY(hipMemcpy(pool.data(), res->d_ids_pool.p, used * 4, hipMemcpyDeviceToHost));
+        uint64_t* o = (uint64_t*)malloc((n + 1) * 8);
+        uint32_t* v = (uint32_t*)malloc(std::max<uint64_t>(1, used) * 4);
+        if (!o || !v) { free(o); free(v); throw std::bad_alloc(); }
+        o[0] = 0;
+        for (uint64_t r = 0; r < n; ++r) {
+            memcpy(v + o[r], pool.data() + idoff[r], (size_t)nids[r] * 4);
+            o[r + 1] = o[r] + nids[r];
+        }
+        *out_offsets = o;
+        *out_ids = v;
+    });
+    fgpu_result_free(res);
+    fgpu_reads_free(rd);
+    return rc;
+}
+
+int fgpu_intersect_ids(fgpu_index* ix, const uint32_t* ids, const uint64_t* id_offs, uint64_t n, uint64_t** out_offsets,
+                       uint32_t** out_colors) {
+    if (!ix || !id_offs || !out_offsets || !out_colors) return fail(-EINVAL, "null argument");
+    NEED_DEVICE(ix);
+    *out_offsets = nullptr;
+    *out_colors = nullptr;
+    fgpu_result* res = nullptr;
+    int rc = fgpu_result_create(ix, &res);
+    if (!rc) rc = guarded([&] {
+        HIP_TRY(hipSetDevice(ix->device));
+        const uint64_t ns = ix->host.hybrid.num_sets();
+        std::vector<uint32_t> nids(n);
+        for (uint64_t r = 0; r < n; ++r) {
+            if (id_offs[r + 1] < id_offs[r]) throw std::runtime_error("id offsets are not monotone");
+            nids[r] = (uint32_t)(id_offs[r + 1] - id_offs[r]);
+        }
+        for (uint64_t i = 0; i < id_offs[n]; ++i)
+            if (ids[i] >= ns) throw std::runtime_error("colour-set id out of range");
+        res->n = n;
+        res->d_nids.ensure(n * 4 + 16);
+        res->d_npos.ensure(n * 4 + 16);
+        res->d_idoff.ensure(n * 8 + 16);
+        res->d_ids_pool.ensure(id_offs[n] * 4 + 16);
+        if (n) {
+            HIP_TRY(hipMemcpy(res->d_nids.p, nids.data(), n * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(res->d_idoff.p, id_offs, n * 8, hipMemcpyHostToDevice));
+        }
+        if (id_offs[n]) HIP_TRY(hipMemcpy(res->d_ids_pool.p, ids, id_offs[n] * 4, hipMemcpyHostToDevice));
+        stage_colors(ix, FGPU_FULL_INTERSECTION, 0.0, res);
+        uint64_t* o = (uint64_t*)malloc((n + 1) * 8);
+        uint32_t* c = (uint32_t*)malloc(std::max<uint64_t>(1, res->total) * 4);
+        if (!o || !c) { free(o); free(c); throw std::bad_alloc(); }
+        HIP_TRY(hipMemcpy(o, res->d_offsets.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+        if (res->total) HIP_TRY(hipMemcpy(c, res->d_colors.p, res->total * 4, hipMemcpyDeviceToHost));
+        *out_offsets = o;
+        *out_colors = c;
+    });
+    fgpu_result_free(res);
+    return rc;
+}
+
+// ---- export ---------------------------------------------------------------------------------------------
+int fgpu_export_sizes(const fgpu_index* ix, uint64_t* unitig_bases, uint64_t* num_unitigs, uint64_t* color_words,
+                      uint64_t* color_bits, uint64_t* num_sets) {
+    if (!ix) return fail(-EINVAL, "null argument");
+    if (unitig_bases) *unitig_bases = ix->host.dict.total_bases;
+    if (num_unitigs) *num_unitigs = ix->host.dict.num_unitigs();
+    if (color_words) *color_words = (ix->host.hybrid.nbits + 63) / 64;
+    if (color_bits) *color_bits = ix->host.hybrid.nbits;
+    if (num_sets) *num_sets = ix->host.hybrid.num_sets();
+    return 0;
+}
+
+int fgpu_export(const fgpu_index* ix, char* unitig_bases, uint64_t* unitig_off, uint32_t* unitig_csid, uint64_t* color_words,
+                uint64_t* color_offsets, uint32_t* thresholds) {
+    if (!ix) return fail(-EINVAL, "null argument");
+    const Dict& d = ix->host.dict;
+    const HybridSets& h = ix->host.hybrid;
+    if (unitig_bases)
+        for (uint64_t i = 0; i < d.total_bases; ++i) {
+            const uint64_t w = d.strings[i >> 5];
+            const uint32_t c = (uint32_t)((w >> (i & 31)) & 1) | (uint32_t)(((w >> (32 + (i & 31))) & 1) << 1);
+            unitig_bases[i] = "ACGT"[c];
+        }
+    if (unitig_off) memcpy(unitig_off, d.unitig_off.data(), d.unitig_off.size() * 8);
+    if (unitig_csid) memcpy(unitig_csid, d.unitig_csid.data(), d.unitig_csid.size() * 4);
+    if (color_words) memcpy(color_words, h.bits.data(), ((h.nbits + 63) / 64) * 8);
+    if (color_offsets) memcpy(color_offsets, h.offsets.data(), h.offsets.size() * 8);
+    if (thresholds) { thresholds[0] = h.num_colors; thresholds[1] = h.sparse_thr; thresholds[2] = h.dense_thr; }
+    return 0;
+}
+
+}  // extern "C"

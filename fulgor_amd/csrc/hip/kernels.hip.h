@@ -1,0 +1,680 @@
+// HIP kernels of the pseudoalignment hot path for gfx950 (CDNA4, wave64). Integer/bit work only.
+//
+//   k1_lookup      read -> k-mers -> minimizer perfect-hash lookup -> sorted distinct colour-set ids
+//                  (+ multiplicities). Replaces index::fetch_color_set_ids and the k-mer streaming half
+//                  of pseudoalign_threshold_union (ps_full_intersection.cpp:334-374,
+//                  ps_threshold_union.cpp:327-387) including u2c (index.hpp:37).
+//   k2a_intersect  hybrid `intersect` (ps_full_intersection.cpp:32-127) -> result bitmap + size
+//   k3a_union      hybrid `merge`     (ps_threshold_union.cpp:16-40)   -> result bitmap + size
+//   scan_*         sizes -> CSR offsets
+//   k2b_expand     bitmap -> sorted u32 colour list (the vector<uint32_t> the reference returns)
+//   k_hits         per-colour hit counts over a batch
+//
+// One wavefront owns one read. Cross-lane steps use ballot / mbcnt / shuffles; per-wave scratch lives
+// in LDS; there is no inter-workgroup communication inside a launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../common/kmer_common.h"
+
+namespace fg {
+
+struct DevDict {
+    const uint64_t* strings;
+    const uint32_t* pilots;
+    const uint64_t* slots;
+    const uint64_t* overflow;
+    uint32_t num_buckets, num_slots, k, m;
+};
+
+struct DevColors {
+    const uint64_t* bits;
+    const uint64_t* offsets;
+    const uint64_t* sample_off;
+    const uint64_t* samples;
+    uint32_t n, sparse_thr, dense_thr;
+    uint32_t w32;  // 32-bit words per result bitmap, rounded up to an even number
+};
+
+constexpr uint32_t NEG = 0xFFFFFFFFu;
+enum { D_ENC_NONE = -1, D_ENC_DELTA_GAPS = 0, D_ENC_BITMAP = 1, D_ENC_COMPLEMENT = 2 };
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// order LDS traffic of one wave: LDS ops of a wave complete in issue order; the wait + compiler
+// barrier makes earlier writes visible to later reads by other lanes of the same wave
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    return v;
+}
+// inclusive prefix sum across the 64 lanes
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = (uint32_t)__shfl_up((int)v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+// number of set bits of a wave-uniform 64-bit mask below this lane
+__device__ __forceinline__ uint32_t mask_rank(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// bits [off, off+L) of the 128-bit value B:A (off in [0,63], L <= 32)
+__device__ __forceinline__ uint32_t extract128(uint64_t A, uint64_t B, uint32_t off, uint32_t L) {
+    uint64_t v = off ? ((A >> off) | (B << (64 - off))) : A;
+    return (uint32_t)v & low_mask32(L);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k-mer dictionary probe
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t try_record(const DevDict& d, uint64_t rec, uint32_t jd, uint32_t qlo, uint32_t qhi) {
+    if (jd < rec_jmin(rec) || jd > rec_jmax(rec)) return NEG;
+    const uint32_t s = rec_pos(rec) - jd;
+    const uint64_t* w = d.strings + (s >> 5);
+    uint32_t lo, hi;
+    string_lmer(w[0], w[1], s & 31u, d.k, lo, hi);
+    return (lo == qlo && hi == qhi) ? rec_csid(rec) : NEG;
+}
+
+// Probe the bucket of minimizer hash h. A: query strand == unitig strand, minimizer at offset jA;
+// B: query is the reverse complement, minimizer at offset jB of the reverse-complemented k-mer.
+__device__ __forceinline__ uint32_t probe(const DevDict& d, uint64_t h, bool doA, bool doB, uint32_t jA, uint32_t jB,
+                                          uint32_t klo, uint32_t khi, uint32_t rlo, uint32_t rhi) {
+    const uint32_t pilot = d.pilots[phf_bucket(h, d.num_buckets)];
+    uint64_t e = d.slots[phf_slot(h, pilot, d.num_slots)];
+    const uint64_t* p = nullptr;
+    uint32_t cnt = 1;
+    if (e & REC_TAG) {
+        p = d.overflow + ovf_off(e);
+        cnt = ovf_cnt(e);
+        e = p[0];
+    }
+    for (uint32_t i = 0;;) {
+        if (doA) {
+            uint32_t c = try_record(d, e, jA, klo, khi);
+            if (c != NEG) return c;
+        }
+        if (doB) {
+            uint32_t c = try_record(d, e, jB, rlo, rhi);
+            if (c != NEG) return c;
+        }
+        if (++i >= cnt) break;
+        e = p[i];
+    }
+    return NEG;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: reads -> sorted distinct colour-set ids with multiplicities
+// ---------------------------------------------------------------------------------------------
+// Outputs per read r (relative to `first`): nids[r], npos[r] (# positive k-mers), idoff[r] (start in the
+// id pool, bump-allocated per wave), and in the pools: ids ascending + how many positive k-mers had it.
+template <int KMAX>
+__global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __restrict__ bases,
+                                                 const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
+                                                 uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
+                                                 uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
+                                                 uint32_t* __restrict__ cnt_pool, unsigned long long* pool_cursor) {
+    __shared__ uint64_t s_hash[4][80];
+    __shared__ uint32_t s_ids[4][KMAX];
+    __shared__ uint32_t s_uid[4][KMAX];
+    __shared__ uint32_t s_ucnt[4][KMAX];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    uint64_t* hsh = s_hash[wv];
+    uint32_t* ids = s_ids[wv];
+    uint32_t* uid = s_uid[wv];
+    uint32_t* ucnt = s_ucnt[wv];
+    const uint32_t k = d.k, m = d.m, W = k - m + 1;
+    const uint64_t total_waves = (uint64_t)gridDim.x * 4;
+
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + wv; r < n_reads; r += total_waves) {
+        const uint64_t rb = offs[first + r];
+        const uint32_t len = (uint32_t)(offs[first + r + 1] - rb);
+        const uint32_t nk = len >= k ? min(len - k + 1, (uint32_t)KMAX) : 0;  // host guarantees <= KMAX
+        const uint8_t* seq = bases + rb;
+
+        // bit planes of bases [w0, w0+64) (A) and [w0+64, w0+128) (B), built with ballots
+        uint64_t loA, hiA, nvA;
+        {
+            uint32_t c = (uint32_t)lane < len ? base_code(seq[lane]) : 0xFFu;
+            loA = __ballot(c <= 3 && (c & 1));
+            hiA = __ballot(c <= 3 && (c & 2));
+            nvA = __ballot(c > 3);
+        }
+        for (uint32_t w0 = 0; w0 < nk; w0 += 64) {
+            const uint32_t p1 = w0 + 64 + lane;
+            const uint32_t c1 = p1 < len ? base_code(seq[p1]) : 0xFFu;
+            const uint64_t loB = __ballot(c1 <= 3 && (c1 & 1));
+            const uint64_t hiB = __ballot(c1 <= 3 && (c1 & 2));
+            const uint64_t nvB = __ballot(c1 > 3);
+
+            // hash of the canonical m-mer starting at every base of the window (+ k-m extra on the right)
+            hsh[lane] = mix64(canonical_key(extract128(loA, loB, lane, m), extract128(hiA, hiB, lane, m), m));
+            if ((uint32_t)lane < k - m) {
+                uint32_t l2 = (uint32_t)(loB >> lane) & low_mask32(m), h2 = (uint32_t)(hiB >> lane) & low_mask32(m);
+                hsh[64 + lane] = mix64(canonical_key(l2, h2, m));
+            }
+            wave_lds_sync();
+
+            const bool active = w0 + lane < nk;
+            uint32_t csid = NEG;
+            const uint32_t knv = extract128(nvA, nvB, lane, k);
+            if (active && knv == 0) {
+                const uint32_t klo = extract128(loA, loB, lane, k), khi = extract128(hiA, hiB, lane, k);
+                uint32_t bestL = 0xFFFFFFFFu, bestR = 0xFFFFFFFFu;
+                for (uint32_t j = 0; j < W; ++j) {
+                    const uint32_t o = (uint32_t)(hsh[lane + j] >> MIN_ORDER_SHIFT) << 4;
+                    bestL = min(bestL, o | j);          // leftmost smallest
+                    bestR = min(bestR, o | (15u - j));  // rightmost smallest
+                }
+                const uint32_t jL = bestL & 15u, jR = 15u - (bestR & 15u);
+                const uint64_t hL = hsh[lane + jL], hR = hsh[lane + jR];
+                const uint32_t rlo = rc_plane(klo, k), rhi = rc_plane(khi, k);
+                csid = probe(d, hL, true, hL == hR, jL, k - m - jR, klo, khi, rlo, rhi);
+                if (csid == NEG && hL != hR) csid = probe(d, hR, false, true, jL, k - m - jR, klo, khi, rlo, rhi);
+            }
+            if (active) ids[w0 + lane] = csid;
+            wave_lds_sync();
+            loA = loB; hiA = hiB; nvA = nvB;
+        }
+
+        // sort + unique + count by repeated minimum extraction (typically < 10 distinct ids per read)
+        uint32_t cnt = 0, positives = 0;
+        uint32_t last = 0;
+        bool have_last = false;
+        for (;;) {
+            uint32_t lm = NEG;
+            for (uint32_t i = lane; i < nk; i += 64) {
+                uint32_t v = ids[i];
+                if (v != NEG && (!have_last || v > last)) lm = min(lm, v);
+            }
+            const uint32_t wm = wave_min_u32(lm);
+            if (wm == NEG) break;
+            uint32_t c = 0;
+            for (uint32_t i = lane; i < nk; i += 64) c += (ids[i] == wm);
+            c = wave_sum_u32(c);
+            if (lane == 0) { uid[cnt] = wm; ucnt[cnt] = c; }
+            positives += c;
+            last = wm;
+            have_last = true;
+            ++cnt;
+        }
+        wave_lds_sync();
+        unsigned long long base = 0;
+        if (lane == 0 && cnt) base = atomicAdd(pool_cursor, (unsigned long long)cnt);
+        base = __shfl(base, 0);
+        for (uint32_t j = lane; j < cnt; j += 64) {
+            ids_pool[base + j] = uid[j];
+            cnt_pool[base + j] = ucnt[j];
+        }
+        if (lane == 0) {
+            nids[r] = cnt;
+            npos[r] = positives;
+            idoff[r] = base;
+        }
+        wave_lds_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Elias-delta decoding straight from the colour bit vector
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t bits_window(const uint64_t* __restrict__ bits, uint64_t pos) {
+    const uint64_t* w = bits + (pos >> 6);
+    const uint32_t sh = (uint32_t)pos & 63u;
+    uint64_t v = w[0] >> sh;
+    if (sh) v |= w[1] << (64 - sh);
+    return v;
+}
+// delta(x): gamma(len) then `len` low bits. A code of a 32-bit value is at most 11 + 32 bits long, so
+// one 64-bit window always holds it.
+__device__ __forceinline__ uint32_t read_delta(const uint64_t* __restrict__ bits, uint64_t& pos) {
+    const uint64_t v = bits_window(bits, pos);
+    const uint32_t z = (uint32_t)__builtin_ctzll(v | (1ULL << 63));
+    const uint32_t len = (((uint32_t)(v >> (z + 1)) & ((1u << z) - 1u)) | (1u << z)) - 1u;
+    const uint32_t used = 2 * z + 1;
+    const uint64_t body = len ? ((v >> used) & ((1ULL << len) - 1ULL)) : 0ULL;
+    pos += used + len;
+    return (uint32_t)((body | (1ULL << len)) - 1ULL);
+}
+
+struct ListHeader {
+    uint64_t begin, body, soff;
+    uint32_t ncodes, size;
+    int type;
+};
+
+__device__ __forceinline__ ListHeader read_header(const DevColors& c, uint32_t id) {
+    ListHeader h;
+    h.begin = c.offsets[id];
+    uint64_t pos = h.begin;
+    h.size = read_delta(c.bits, pos);
+    h.body = pos;
+    h.soff = c.sample_off[id];
+    if (h.size < c.sparse_thr) { h.type = D_ENC_DELTA_GAPS; h.ncodes = h.size; }
+    else if (h.size < c.dense_thr) { h.type = D_ENC_BITMAP; h.ncodes = 0; }
+    else { h.type = D_ENC_COMPLEMENT; h.ncodes = c.n - h.size; }
+    return h;
+}
+
+// decode segment `seg` (SAMPLE_STRIDE codes) of a gap-coded list and feed every value to f
+template <typename F>
+__device__ __forceinline__ void decode_segment(const DevColors& c, uint64_t begin, uint64_t body, uint64_t soff,
+                                               uint32_t ncodes, uint32_t seg, F f) {
+    uint64_t pos = body;
+    uint32_t prev = 0xFFFFFFFFu;
+    if (seg) {
+        const uint64_t s = c.samples[soff + seg - 1];
+        pos = begin + (uint32_t)s;
+        prev = (uint32_t)(s >> 32);
+    }
+    const uint32_t nc = min(SAMPLE_STRIDE, ncodes - seg * SAMPLE_STRIDE);
+    for (uint32_t i = 0; i < nc; ++i) {
+        prev = prev + 1u + read_delta(c.bits, pos);
+        f(prev);
+    }
+}
+
+// per-wave LDS carve shared by k2a / k3a
+struct WaveScratch {
+    uint64_t* h_begin;
+    uint64_t* h_body;
+    uint64_t* h_soff;
+    uint32_t* h_ncodes;
+    uint32_t* pref;
+    int32_t* h_score;
+};
+__host__ __device__ inline uint32_t wave_scratch_bytes() { return 64 * (8 * 3 + 4 * 3); }
+__device__ __forceinline__ WaveScratch carve_scratch(unsigned char* p) {
+    WaveScratch s;
+    s.h_begin = (uint64_t*)p;
+    s.h_body = s.h_begin + 64;
+    s.h_soff = s.h_body + 64;
+    s.h_ncodes = (uint32_t*)(s.h_soff + 64);
+    s.pref = s.h_ncodes + 64;
+    s.h_score = (int32_t*)(s.pref + 64);
+    return s;
+}
+
+// first i in [0,64) with pref[i] > t (pref non-decreasing, pref[63] > t)
+__device__ __forceinline__ uint32_t upper_slot(const uint32_t* pref, uint32_t t) {
+    uint32_t lo = 0, hi = 63;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (pref[mid] > t) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2a: full intersection of hybrid colour sets -> bitmap + cardinality
+// ---------------------------------------------------------------------------------------------
+// Semantics of `intersect` (ps_full_intersection.cpp:32-127): the result is the set intersection of the
+// given lists. Here: R = all colours; complemented lists clear their missing colours (all their gap
+// segments run concurrently across lanes); bitmap lists are ANDed word-wise; each sparse list is
+// decoded into T and ANDed.
+__global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint32_t* __restrict__ nids,
+                                                     const uint64_t* __restrict__ idoff,
+                                                     const uint32_t* __restrict__ ids_pool, uint64_t n_reads,
+                                                     uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t W = c.w32;
+    const uint32_t per_wave = 2 * W * 4 + wave_scratch_bytes();
+    unsigned char* mine = smem + (size_t)wv * per_wave;
+    WaveScratch sc = carve_scratch(mine);
+    uint32_t* R = (uint32_t*)(mine + wave_scratch_bytes());
+    uint32_t* T = R + W;
+    const uint64_t total_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+
+    for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wv; r < n_reads; r += total_waves) {
+        const uint32_t cnt = nids[r];
+        const uint64_t off = idoff[r];
+        uint32_t* bm = out_bitmap + r * W;
+        if (cnt == 0) {
+            for (uint32_t w = lane; w < W; w += 64) bm[w] = 0;
+            if (lane == 0) out_count[r] = 0;
+            continue;
+        }
+        for (uint32_t w = lane; w < W; w += 64) {
+            const uint32_t lo = w * 32;
+            R[w] = lo >= c.n ? 0u : (c.n - lo >= 32 ? 0xFFFFFFFFu : ((1u << (c.n - lo)) - 1u));
+        }
+        for (uint32_t g = 0; g < cnt; g += 64) {
+            ListHeader h;
+            h.type = D_ENC_NONE; h.ncodes = 0; h.begin = h.body = h.soff = 0; h.size = 0;
+            if (g + lane < cnt) h = read_header(c, ids_pool[off + g + lane]);
+            const uint32_t nseg = (h.ncodes + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
+            sc.h_begin[lane] = h.begin; sc.h_body[lane] = h.body; sc.h_soff[lane] = h.soff; sc.h_ncodes[lane] = h.ncodes;
+            const uint32_t incl = wave_incl_scan_u32(h.type == D_ENC_COMPLEMENT ? nseg : 0u);
+            sc.pref[lane] = incl;
+            const uint32_t total_seg = (uint32_t)__shfl((int)incl, 63);
+            wave_lds_sync();
+
+            // bitmap lists: word-wise AND
+            uint64_t mb = __ballot(h.type == D_ENC_BITMAP);
+            while (mb) {
+                const int src = __builtin_ctzll(mb);
+                mb &= mb - 1;
+                const uint64_t body = sc.h_body[src];
+                for (uint32_t w = lane; w < W; w += 64) R[w] &= (uint32_t)bits_window(c.bits, body + 32ull * w);
+            }
+            wave_lds_sync();
+
+            // complemented lists: all segments of all lists, one per lane
+            for (uint32_t t0 = 0; t0 < total_seg; t0 += 64) {
+                const uint32_t t = t0 + lane;
+                if (t < total_seg) {
+                    const uint32_t i = upper_slot(sc.pref, t);
+                    const uint32_t nc = sc.h_ncodes[i];
+                    const uint32_t ns = (nc + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
+                    const uint32_t seg = t - (sc.pref[i] - ns);
+                    decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg,
+                                   [&](uint32_t v) { atomicAnd(&R[v >> 5], ~(1u << (v & 31))); });
+                }
+            }
+            wave_lds_sync();
+
+            // sparse lists, one at a time: T = list, R &= T
+            uint64_t ms = __ballot(h.type == D_ENC_DELTA_GAPS);
+            while (ms) {
+                const int src = __builtin_ctzll(ms);
+                ms &= ms - 1;
+                for (uint32_t w = lane; w < W; w += 64) T[w] = 0;
+                wave_lds_sync();
+                const uint32_t nc = sc.h_ncodes[src];
+                const uint32_t ns = (nc + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
+                for (uint32_t seg = lane; seg < ns; seg += 64)
+                    decode_segment(c, sc.h_begin[src], sc.h_body[src], sc.h_soff[src], nc, seg,
+                                   [&](uint32_t v) { atomicOr(&T[v >> 5], 1u << (v & 31)); });
+                wave_lds_sync();
+                for (uint32_t w = lane; w < W; w += 64) R[w] &= T[w];
+                wave_lds_sync();
+            }
+        }
+        uint32_t pc = 0;
+        for (uint32_t w = lane; w < W; w += 64) {
+            const uint32_t x = R[w];
+            bm[w] = x;
+            pc += __popc(x);
+        }
+        pc = wave_sum_u32(pc);
+        if (lane == 0) out_count[r] = pc;
+        wave_lds_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3a: threshold union of hybrid colour sets -> bitmap + cardinality
+// ---------------------------------------------------------------------------------------------
+// `merge` (ps_threshold_union.cpp:16-40): scores[c] += score for members of sparse/bitmap lists,
+// -= score for the missing colours of complemented lists while min_score is lowered by that score;
+// keep c iff scores[c] >= min_score. min_score = uint64(double(#positive k-mers) * tau) (:389).
+__global__ void k3a_union(DevColors c, const uint32_t* __restrict__ nids, const uint32_t* __restrict__ npos,
+                          const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
+                          const uint32_t* __restrict__ cnt_pool, double tau, uint64_t n_reads,
+                          uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t W = c.w32;
+    const uint32_t n = c.n;
+    const uint32_t per_wave = W * 32 * 4 + wave_scratch_bytes();
+    unsigned char* mine = smem + (size_t)wv * per_wave;
+    WaveScratch sc = carve_scratch(mine);
+    int32_t* scores = (int32_t*)(mine + wave_scratch_bytes());
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+
+    for (uint64_t r = (uint64_t)blockIdx.x * waves_per_block + wv; r < n_reads; r += total_waves) {
+        const uint32_t cnt = nids[r];
+        const uint64_t off = idoff[r];
+        uint32_t* bm = out_bitmap + r * W;
+        if (cnt == 0) {
+            for (uint32_t w = lane; w < W; w += 64) bm[w] = 0;
+            if (lane == 0) out_count[r] = 0;
+            continue;
+        }
+        const long long min_score = (long long)(unsigned long long)((double)npos[r] * tau);
+        for (uint32_t i = lane; i < W * 32; i += 64) scores[i] = 0;
+        long long comp_total = 0;
+        wave_lds_sync();
+        for (uint32_t g = 0; g < cnt; g += 64) {
+            ListHeader h;
+            h.type = D_ENC_NONE; h.ncodes = 0; h.begin = h.body = h.soff = 0; h.size = 0;
+            int32_t score = 0;
+            if (g + lane < cnt) {
+                h = read_header(c, ids_pool[off + g + lane]);
+                score = (int32_t)cnt_pool[off + g + lane];
+            }
+            const uint32_t nseg = (h.ncodes + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
+            sc.h_begin[lane] = h.begin; sc.h_body[lane] = h.body; sc.h_soff[lane] = h.soff; sc.h_ncodes[lane] = h.ncodes;
+            sc.h_score[lane] = h.type == D_ENC_COMPLEMENT ? -score : score;
+            comp_total += (long long)wave_sum_u32(h.type == D_ENC_COMPLEMENT ? (uint32_t)score : 0u);
+            const uint32_t incl = wave_incl_scan_u32(nseg);  // gap-coded lists of both kinds
+            sc.pref[lane] = incl;
+            const uint32_t total_seg = (uint32_t)__shfl((int)incl, 63);
+            wave_lds_sync();
+
+            uint64_t mb = __ballot(h.type == D_ENC_BITMAP);
+            while (mb) {
+                const int src = __builtin_ctzll(mb);
+                mb &= mb - 1;
+                const uint64_t body = sc.h_body[src];
+                const int32_t s = sc.h_score[src];
+                for (uint32_t w = lane; w * 32 < n; w += 64) {
+                    uint32_t x = (uint32_t)bits_window(c.bits, body + 32ull * w);
+                    if (n - w * 32 < 32) x &= (1u << (n - w * 32)) - 1u;
+                    while (x) {
+                        const uint32_t b = __builtin_ctz(x);
+                        x &= x - 1;
+                        scores[w * 32 + b] += s;  // a list holds distinct colours: no two lanes share a slot
+                    }
+                }
+                wave_lds_sync();
+            }
+
+            for (uint32_t t0 = 0; t0 < total_seg; t0 += 64) {
+                const uint32_t t = t0 + lane;
+                if (t < total_seg) {
+                    const uint32_t i = upper_slot(sc.pref, t);
+                    const uint32_t nc = sc.h_ncodes[i];
+                    const uint32_t ns = (nc + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
+                    const uint32_t seg = t - (sc.pref[i] - ns);
+                    const int32_t s = sc.h_score[i];
+                    decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg,
+                                   [&](uint32_t v) { atomicAdd(&scores[v], s); });
+                }
+            }
+            wave_lds_sync();
+        }
+        uint32_t pc = 0;
+        for (uint32_t cb = 0; cb < W * 32; cb += 64) {
+            const uint32_t col = cb + lane;
+            const bool pass = col < n && ((long long)scores[col] + comp_total >= min_score);
+            const uint64_t M = __ballot(pass);
+            if (lane == 0) {
+                bm[cb >> 5] = (uint32_t)M;
+                if ((cb >> 5) + 1 < W) bm[(cb >> 5) + 1] = (uint32_t)(M >> 32);
+            }
+            pc += __popcll(M);
+        }
+        if (lane == 0) out_count[r] = pc;
+        wave_lds_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sizes -> CSR offsets (three small launches)
+// ---------------------------------------------------------------------------------------------
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_TILE = 256 * SCAN_ITEMS;
+
+__global__ __launch_bounds__(256) void scan_block_sums(const uint32_t* __restrict__ counts, uint64_t n,
+                                                       uint64_t* __restrict__ block_sums, uint64_t* __restrict__ block_mapped) {
+    __shared__ uint64_t s_sum[4], s_map[4];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0, mp = 0;
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) { uint32_t v = counts[base + i]; s += v; mp += v != 0; }
+    s = wave_sum_u32(s);  // tile total fits 32 bits only if counts are small; widen below
+    mp = wave_sum_u32(mp);
+    if (lane_id() == 0) { s_sum[threadIdx.x >> 6] = s; s_map[threadIdx.x >> 6] = mp; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        block_sums[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        block_mapped[blockIdx.x] = s_map[0] + s_map[1] + s_map[2] + s_map[3];
+    }
+}
+
+// single block: exclusive scan of the block sums in place; totals[0] = sum, totals[1] = mapped reads
+__global__ __launch_bounds__(256) void scan_top(uint64_t* __restrict__ block_sums, const uint64_t* __restrict__ block_mapped,
+                                                uint64_t nb, uint64_t* __restrict__ totals) {
+    __shared__ uint64_t s_part[256];
+    __shared__ uint64_t s_carry;
+    uint64_t mapped = 0;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint64_t b0 = 0; b0 < nb; b0 += 256) {
+        const uint64_t i = b0 + threadIdx.x;
+        const uint64_t v = i < nb ? block_sums[i] : 0;
+        if (i < nb) mapped += block_mapped[i];
+        s_part[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            uint64_t t = threadIdx.x >= (unsigned)o ? s_part[threadIdx.x - o] : 0;
+            __syncthreads();
+            s_part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const uint64_t carry = s_carry;
+        if (i < nb) block_sums[i] = carry + s_part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = carry + s_part[255];
+        __syncthreads();
+    }
+    s_part[threadIdx.x] = mapped;
+    __syncthreads();
+    for (int o = 128; o; o >>= 1) {
+        if (threadIdx.x < (unsigned)o) s_part[threadIdx.x] += s_part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { totals[0] = s_carry; totals[1] = s_part[0]; }
+}
+
+__global__ __launch_bounds__(256) void scan_apply(const uint32_t* __restrict__ counts, uint64_t n,
+                                                  const uint64_t* __restrict__ block_sums, uint64_t* __restrict__ offsets) {
+    __shared__ uint64_t s_part[256];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint64_t s = 0;
+    for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = base + i < n ? counts[base + i] : 0; s += v[i]; }
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        uint64_t t = threadIdx.x >= (unsigned)o ? s_part[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint64_t run = block_sums[blockIdx.x] + s_part[threadIdx.x] - s;
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n) { offsets[base + i] = run; run += v[i]; }
+    if (base <= n - 1 && n - 1 < base + SCAN_ITEMS) offsets[n] = run;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2b: bitmap -> ascending u32 colour list. 64 colours at a time: the bitmap word is the lane mask,
+// mbcnt gives each set lane its slot, one compacted store per word.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k2b_expand(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
+                                                  const uint64_t* __restrict__ out_off, uint64_t n_reads, uint32_t W,
+                                                  uint32_t* __restrict__ colors) {
+    const int lane = lane_id();
+    const uint64_t total_waves = (uint64_t)gridDim.x * 4;
+    const uint32_t W64 = W >> 1;
+    for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n_reads; r += total_waves) {
+        if (counts[r] == 0) continue;
+        uint32_t* out = colors + out_off[r];
+        const uint64_t* bm = (const uint64_t*)(bitmap + r * W);
+        uint32_t base = 0;
+        for (uint32_t wb = 0; wb < W64; wb += 64) {
+            const uint64_t mine = wb + lane < W64 ? bm[wb + lane] : 0ull;
+            const uint32_t nw = min(64u, W64 - wb);
+            for (uint32_t i = 0; i < nw; ++i) {
+                const uint32_t mlo = __builtin_amdgcn_readlane((uint32_t)mine, i);
+                const uint32_t mhi = __builtin_amdgcn_readlane((uint32_t)(mine >> 32), i);
+                const uint64_t M = ((uint64_t)mhi << 32) | mlo;
+                if (M == 0) continue;
+                if ((M >> lane) & 1) out[base + mask_rank(M)] = (wb + i) * 64 + lane;
+                base += __popcll(M);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-colour hit counts: hits[c] += #reads of the batch whose result contains c
+// ---------------------------------------------------------------------------------------------
+__global__ void k_hits(const uint32_t* __restrict__ bitmap, uint64_t n_reads, uint32_t W, uint32_t n,
+                       unsigned long long* __restrict__ hits) {
+    const uint64_t per_block = (n_reads + gridDim.x - 1) / gridDim.x;
+    const uint64_t r0 = (uint64_t)blockIdx.x * per_block, r1 = min(n_reads, r0 + per_block);
+    for (uint32_t w = threadIdx.x; w < W; w += blockDim.x) {
+        uint32_t acc[32];
+#pragma unroll
+        for (int b = 0; b < 32; ++b) acc[b] = 0;
+        for (uint64_t r = r0; r < r1; ++r) {
+            const uint32_t x = bitmap[r * W + w];
+#pragma unroll
+            for (int b = 0; b < 32; ++b) acc[b] += (x >> b) & 1u;
+        }
+#pragma unroll
+        for (int b = 0; b < 32; ++b)
+            if (acc[b] && w * 32 + b < n) atomicAdd(&hits[w * 32 + b], (unsigned long long)acc[b]);
+    }
+}
+
+__global__ void k_add_totals(unsigned long long* hits, uint32_t n, uint64_t num_reads, const uint64_t* totals) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        hits[n] += num_reads;
+        hits[n + 1] += totals[1];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// algorithmic bytes of the colour-intersection stage:
+//   sum over reads of  sum_c ceil(list bits / 8) + 16|C| + 4|C| + 4|R| + 8
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_account(DevColors c, const uint32_t* __restrict__ nids,
+                                                 const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
+                                                 const uint32_t* __restrict__ counts, uint64_t n_reads,
+                                                 unsigned long long* __restrict__ out) {
+    uint64_t acc = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t cnt = nids[r];
+        const uint64_t off = idoff[r];
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const uint32_t id = ids_pool[off + i];
+            acc += (c.offsets[id + 1] - c.offsets[id] + 7) / 8;
+        }
+        acc += 20ull * cnt + 4ull * counts[r] + 8;
+    }
+    for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane_id() == 0 && acc) atomicAdd(out, (unsigned long long)acc);
+}
+
+}  // namespace fg

@@ -1,0 +1,204 @@
+// Index ingestion for the MI355X engine.
+//
+// (1) The reference's text interchange format, written by `fulgor dump` and read by `fulgor load`
+//     (src/index.cpp:59-120 and :122-305; README "Dump output format"):
+//        <base>.metadata.txt  k= / num_kmers= / num_colors= / num_unitigs= / num_color_sets=
+//        <base>.filenames.txt one filename per colour
+//        <base>.unitigs.fa    "> color_set_id=<id>" + sequence, sorted by colour-set id
+//        <base>.color_sets.txt "size=<n> c0 c1 ..." one set per line, id = line number
+//     load_dump() mirrors index<ColorSets>::load: encode the sets with the hybrid codec, build the
+//     k-mer dictionary over the unitigs, derive u2c from the headers.
+// (2) An own binary container (".fgidx") holding the engine's HBM-ready arrays for fast reload.
+//
+// The reference's binary .fur/.mfur/.dfur/.mdfur files embed an SSHash dictionary whose layout is
+// defined by a submodule that is not vendored; they are rejected loudly by open_index().
+#pragma once
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include "dict_build.hpp"
+#include "hybrid_codec.hpp"
+
+namespace fg {
+
+inline bool ends_with(const std::string& s, const std::string& suf) {
+    return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+inline void load_dump(const std::string& base, HostIndex& idx, uint32_t m = 0, unsigned nthreads = 0) {
+    uint64_t k = 0, num_kmers = 0, num_colors = 0, num_unitigs = 0, num_color_sets = 0;
+    {
+        std::ifstream in(base + ".metadata.txt");
+        if (!in.is_open()) throw std::runtime_error("cannot open metadata file");
+        std::string line;
+        while (std::getline(in, line)) {
+            size_t eq = line.find('=');
+            if (eq == std::string::npos) continue;
+            std::string key = line.substr(0, eq);
+            uint64_t v = std::strtoull(line.c_str() + eq + 1, nullptr, 10);
+            if (key == "k") k = v;
+            else if (key == "num_kmers") num_kmers = v;
+            else if (key == "num_colors") num_colors = v;
+            else if (key == "num_unitigs") num_unitigs = v;
+            else if (key == "num_color_sets") num_color_sets = v;
+        }
+    }
+    if (k == 0 || num_colors == 0 || num_unitigs == 0 || num_color_sets == 0)
+        throw std::runtime_error("incomplete metadata file");
+    {
+        std::ifstream in(base + ".filenames.txt");
+        if (!in.is_open()) throw std::runtime_error("cannot open filenames file");
+        idx.filenames.clear();
+        std::string f;
+        for (uint64_t i = 0; i < num_colors && (in >> f); ++i) idx.filenames.push_back(f);
+        if (idx.filenames.size() != num_colors) throw std::runtime_error("filenames file is short");
+    }
+    // colour sets
+    {
+        std::ifstream in(base + ".color_sets.txt");
+        if (!in.is_open()) throw std::runtime_error("cannot open color sets file");
+        HybridEncoder enc;
+        enc.init(num_colors);
+        std::string line;
+        std::vector<uint32_t> v;
+        for (uint64_t i = 0; i < num_color_sets; ++i) {
+            if (!std::getline(in, line)) throw std::runtime_error("color sets file is short");
+            size_t p = line.find("size=");
+            if (p == std::string::npos) throw std::runtime_error("malformed color set line");
+            const char* c = line.c_str() + p + 5;
+            char* end = nullptr;
+            uint64_t size = std::strtoull(c, &end, 10);
+            if (size == 0 || size > num_colors) throw std::runtime_error("bad color set size");
+            v.clear();
+            c = end;
+            for (uint64_t j = 0; j < size; ++j) {
+                v.push_back((uint32_t)std::strtoul(c, &end, 10));
+                if (end == c) throw std::runtime_error("color set line is short");
+                c = end;
+                if (v.back() >= num_colors || (j && v[j] <= v[j - 1])) throw std::runtime_error("color set not increasing");
+            }
+            enc.encode(v.data(), v.size());
+        }
+        enc.finish(idx.hybrid);
+        hybrid_build_samples(idx.hybrid, nthreads);
+    }
+    // unitigs
+    std::string bases;
+    std::vector<uint64_t> off(1, 0);
+    std::vector<uint32_t> csid;
+    {
+        std::ifstream in(base + ".unitigs.fa");
+        if (!in.is_open()) throw std::runtime_error("cannot open unitigs file");
+        std::string header, seq;
+        uint64_t prev = 0;
+        for (uint64_t i = 0; i < num_unitigs; ++i) {
+            if (!std::getline(in, header) || !std::getline(in, seq)) throw std::runtime_error("unitigs file is short");
+            size_t p = header.find("color_set_id=");
+            if (p == std::string::npos) throw std::runtime_error("malformed unitig header");
+            uint64_t id = std::strtoull(header.c_str() + p + 13, nullptr, 10);
+            if (id >= num_color_sets || id < prev) throw std::runtime_error("unitigs are not sorted by color_set_id");
+            prev = id;
+            while (!seq.empty() && (seq.back() == '\r' || seq.back() == ' ')) seq.pop_back();
+            bases += seq;
+            off.push_back(bases.size());
+            csid.push_back((uint32_t)id);
+        }
+    }
+    if (m == 0) m = k >= 13 ? (uint32_t)k - 12 : 1;  // k=31 -> m=19
+    idx.type = IDX_HYBRID;
+    build_dict(idx.dict, (uint32_t)k, m, bases.data(), bases.size(), off, csid, nthreads);
+    if (num_kmers && idx.dict.num_kmers != num_kmers) throw std::runtime_error("num_kmers does not match metadata");
+}
+
+// ---- own binary container ------------------------------------------------------------------------
+namespace detail {
+static const char FGIDX_MAGIC[8] = {'F', 'G', 'I', 'D', 'X', '0', '0', '1'};
+template <typename T>
+void wr(std::ofstream& o, const T& v) { o.write(reinterpret_cast<const char*>(&v), sizeof(T)); }
+template <typename T>
+void rd(std::ifstream& i, T& v) {
+    i.read(reinterpret_cast<char*>(&v), sizeof(T));
+    if (!i) throw std::runtime_error("truncated index file");
+}
+template <typename T>
+void wrv(std::ofstream& o, const std::vector<T>& v) {
+    uint64_t n = v.size();
+    wr(o, n);
+    if (n) o.write(reinterpret_cast<const char*>(v.data()), n * sizeof(T));
+}
+template <typename T>
+void rdv(std::ifstream& i, std::vector<T>& v) {
+    uint64_t n;
+    rd(i, n);
+    if (n > (1ULL << 40)) throw std::runtime_error("corrupt index file");
+    v.resize(n);
+    if (n) i.read(reinterpret_cast<char*>(v.data()), n * sizeof(T));
+    if (!i) throw std::runtime_error("truncated index file");
+}
+}  // namespace detail
+
+inline void save_binary(const HostIndex& idx, const std::string& path) {
+    using namespace detail;
+    std::ofstream o(path, std::ios::binary);
+    if (!o.is_open()) throw std::runtime_error("cannot open output index file");
+    o.write(FGIDX_MAGIC, 8);
+    int32_t type = idx.type;
+    wr(o, type);
+    const Dict& d = idx.dict;
+    wr(o, d.k); wr(o, d.m); wr(o, d.num_kmers); wr(o, d.total_bases); wr(o, d.seed);
+    wr(o, d.num_buckets); wr(o, d.num_slots);
+    wrv(o, d.strings); wrv(o, d.pilots); wrv(o, d.slots); wrv(o, d.overflow);
+    wrv(o, d.unitig_off); wrv(o, d.unitig_csid);
+    const HybridSets& h = idx.hybrid;
+    wr(o, h.num_colors); wr(o, h.sparse_thr); wr(o, h.dense_thr); wr(o, h.nbits);
+    wrv(o, h.offsets); wrv(o, h.bits); wrv(o, h.sample_off); wrv(o, h.samples);
+    uint64_t nf = idx.filenames.size();
+    wr(o, nf);
+    for (auto& f : idx.filenames) {
+        std::vector<char> c(f.begin(), f.end());
+        wrv(o, c);
+    }
+    if (!o) throw std::runtime_error("write error on index file");
+}
+
+inline void load_binary(const std::string& path, HostIndex& idx) {
+    using namespace detail;
+    std::ifstream i(path, std::ios::binary);
+    if (!i.is_open()) throw std::runtime_error("cannot open index file");
+    char magic[8];
+    i.read(magic, 8);
+    if (!i || std::memcmp(magic, FGIDX_MAGIC, 8) != 0) throw std::runtime_error("not an .fgidx file (bad magic/version)");
+    int32_t type;
+    rd(i, type);
+    idx.type = type;
+    Dict& d = idx.dict;
+    rd(i, d.k); rd(i, d.m); rd(i, d.num_kmers); rd(i, d.total_bases); rd(i, d.seed);
+    rd(i, d.num_buckets); rd(i, d.num_slots);
+    rdv(i, d.strings); rdv(i, d.pilots); rdv(i, d.slots); rdv(i, d.overflow);
+    rdv(i, d.unitig_off); rdv(i, d.unitig_csid);
+    HybridSets& h = idx.hybrid;
+    rd(i, h.num_colors); rd(i, h.sparse_thr); rd(i, h.dense_thr); rd(i, h.nbits);
+    rdv(i, h.offsets); rdv(i, h.bits); rdv(i, h.sample_off); rdv(i, h.samples);
+    uint64_t nf;
+    rd(i, nf);
+    idx.filenames.clear();
+    for (uint64_t f = 0; f < nf; ++f) {
+        std::vector<char> c;
+        rdv(i, c);
+        idx.filenames.emplace_back(c.begin(), c.end());
+    }
+}
+
+// path dispatch: ".fgidx" container, a reference binary index (rejected), or a dump basename
+inline void open_index(const std::string& path, HostIndex& idx, unsigned nthreads = 0) {
+    if (ends_with(path, ".fgidx")) { load_binary(path, idx); return; }
+    // suffix sniffing order of the reference CLI: mdfur, mfur, dfur, fur (tools/pseudoalign.cpp:294-306)
+    if (ends_with(path, "fur"))
+        throw std::runtime_error(
+            "binary Fulgor index files embed an SSHash dictionary whose on-disk layout is not available "
+            "to this build; run `fulgor dump -i " + path + " -o <base>` with the reference and open <base> instead");
+    load_dump(path, idx, 0, nthreads);
+}
+
+}  // namespace fg

@@ -1,0 +1,58 @@
+// Host-side model of a Fulgor index as the MI355X engine keeps it (and uploads it to HBM).
+//
+// Mirrors `template <typename ColorSets> struct index` (include/index.hpp:16-110 in the reference):
+//   m_k2u  (sshash::dictionary)  -> Dict          (own GPU layout, see common/kmer_common.h)
+//   m_u2c + rank9                -> Dict::unitig_csid dense table (u2c(), index.hpp:37) folded into records
+//   m_color_sets (hybrid)        -> HybridSets    (same bit stream as hybrid.hpp:37-95 writes; the
+//                                   Elias-Fano offsets are held decoded as plain u64)
+//   m_filenames                  -> filenames
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../common/kmer_common.h"
+
+namespace fg {
+
+// same numbering as the reference's enum index_t (include/util.hpp:18)
+enum IndexType : int { IDX_HYBRID = 0, IDX_DIFF = 1, IDX_META = 2, IDX_META_DIFF = 3 };
+// same numbering as enum encoding_t (include/util.hpp:19)
+enum Encoding : int { ENC_DELTA_GAPS = 0, ENC_BITMAP = 1, ENC_COMPLEMENT = 2, ENC_SYMDIFF = 3 };
+
+struct HybridSets {  // fulgor::hybrid, include/color_sets/hybrid.hpp:338-352
+    uint32_t num_colors = 0;
+    uint32_t sparse_thr = 0;  // m_sparse_set_threshold_size      = u32(0.25 * n)
+    uint32_t dense_thr = 0;   // m_very_dense_set_threshold_size  = u32(0.75 * n)
+    std::vector<uint64_t> offsets;  // num_sets + 1 bit offsets into `bits`
+    std::vector<uint64_t> bits;     // the bit vector, padded with 2 zero words
+    uint64_t nbits = 0;
+    // acceleration structure built at load: decoder restart points every SAMPLE_STRIDE codes
+    std::vector<uint64_t> sample_off;  // num_sets + 1 indices into `samples`
+    std::vector<uint64_t> samples;     // {prev value : 32 | bit offset from list start : 32}
+    uint64_t num_sets() const { return offsets.empty() ? 0 : offsets.size() - 1; }
+};
+
+struct Dict {
+    uint32_t k = 0, m = 0;
+    uint64_t num_kmers = 0;
+    uint64_t total_bases = 0;
+    std::vector<uint64_t> strings;  // bit-plane words, padded with 2 zero words
+    uint64_t seed = 0;
+    uint32_t num_buckets = 0, num_slots = 0;
+    std::vector<uint32_t> pilots;
+    std::vector<uint64_t> slots;
+    std::vector<uint64_t> overflow;
+    // unitig table (export / u2c)
+    std::vector<uint64_t> unitig_off;    // num_unitigs + 1 base offsets into the concatenation
+    std::vector<uint32_t> unitig_csid;   // u2c
+    uint64_t num_unitigs() const { return unitig_csid.size(); }
+};
+
+struct HostIndex {
+    int type = IDX_HYBRID;
+    Dict dict;
+    HybridSets hybrid;
+    std::vector<std::string> filenames;
+};
+
+}  // namespace fg

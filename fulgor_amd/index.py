@@ -1,0 +1,231 @@
+"""Host-side mirror of the reference's index API for the pseudoalignment path.
+
+Same member names and argument meaning as `template <typename ColorSets> struct index`
+(include/index.hpp:16-110 in jermp/fulgor): `fetch_color_set_ids`, `pseudoalign_full_intersection`,
+`pseudoalign_threshold_union`, `k`, `num_colors`, ... The per-read members are thin single-read calls;
+the `*_batch` members are what a driver loop uses (one C-ABI call per batch of reads). Every call runs
+the HIP kernels through libfulgor_gpu.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+
+FULL_INTERSECTION = 0
+THRESHOLD_UNION = 1
+KERNELS = ("k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits")
+
+
+def pack_reads(reads):
+    """list of str/bytes -> (uint8 bases, uint64 offsets[n+1])"""
+    bs = [r if isinstance(r, (bytes, bytearray)) else r.encode("ascii") for r in reads]
+    offs = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    bases = np.frombuffer(b"".join(bs), dtype=np.uint8) if bs else np.zeros(0, dtype=np.uint8)
+    return np.ascontiguousarray(bases), offs
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _take_csr(L, n, p_off, p_val):
+    offs = np.ctypeslib.as_array(C.cast(p_off, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+    total = int(offs[n])
+    vals = (np.ctypeslib.as_array(C.cast(p_val, C.POINTER(C.c_uint32)), shape=(max(total, 1),))[:total].copy())
+    L.fgpu_free(p_off)
+    L.fgpu_free(p_val)
+    return offs, vals
+
+
+class Reads:
+    """A batch of reads resident in HBM."""
+
+    def __init__(self, index, bases, offs):
+        self._L = _native.lib()
+        self.index = index
+        self.n = len(offs) - 1
+        h = C.c_void_p()
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        _native.check(self._L.fgpu_reads_upload(index._h, _ptr(bases), _ptr(offs), self.n, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._L.fgpu_reads_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Result:
+    """CSR results of one pass, resident in HBM; reusable across passes."""
+
+    def __init__(self, index):
+        self._L = _native.lib()
+        self.index = index
+        h = C.c_void_p()
+        _native.check(self._L.fgpu_result_create(index._h, C.byref(h)))
+        self._h = h
+
+    def sizes(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _native.check(self._L.fgpu_result_sizes(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value  # reads, total colours, mapped reads
+
+    def download(self):
+        n, total, _ = self.sizes()
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        cols = np.zeros(max(total, 1), dtype=np.uint32)
+        _native.check(self._L.fgpu_result_download(self._h, _ptr(offs), _ptr(cols)))
+        return offs, cols[:total]
+
+    def accumulate_hits(self, device_ptr):
+        _native.check(self._L.fgpu_result_accumulate_hits(self.index._h, self._h, C.c_void_p(device_ptr)))
+
+    def algorithmic_bytes(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _native.check(self._L.fgpu_result_algorithmic_bytes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self._h:
+            self._L.fgpu_result_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Index:
+    """index<ColorSets> resident in HBM (load = essentials::load + one upload)."""
+
+    def __init__(self, path, device=0):
+        self._L = _native.lib()
+        h = C.c_void_p()
+        _native.check(self._L.fgpu_open(str(path).encode(), int(device), C.byref(h)))
+        self._h = h
+        vals = [C.c_uint64() for _ in range(5)]
+        t = C.c_int()
+        _native.check(self._L.fgpu_info(h, *[C.byref(v) for v in vals], C.byref(t)))
+        self._k, self._num_colors, self._num_color_sets, self._num_unitigs, self._num_kmers = [v.value for v in vals]
+        self.index_type = t.value
+
+    # --- accessors, include/index.hpp:64-68 ---
+    def k(self):
+        return self._k
+
+    def num_colors(self):
+        return self._num_colors
+
+    def num_color_sets(self):
+        return self._num_color_sets
+
+    def num_unitigs(self):
+        return self._num_unitigs
+
+    def num_kmers(self):
+        return self._num_kmers
+
+    def save(self, path):
+        _native.check(self._L.fgpu_save(self._h, str(path).encode()))
+
+    def selfcheck(self, unitig_stride=1):
+        _native.check(self._L.fgpu_selfcheck(self._h, unitig_stride))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fgpu_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    # --- batch members (one C-ABI call each) ---
+    def _call(self, fn, bases, offs, *extra):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n = len(offs) - 1
+        po, pv = C.c_void_p(), C.c_void_p()
+        _native.check(fn(self._h, _ptr(bases), _ptr(offs), n, *extra, C.byref(po), C.byref(pv)))
+        return _take_csr(self._L, n, po, pv)
+
+    def fetch_color_set_ids_batch(self, bases, offs):
+        return self._call(self._L.fgpu_fetch_color_set_ids, bases, offs)
+
+    def pseudoalign_full_intersection_batch(self, bases, offs):
+        return self._call(self._L.fgpu_full_intersection, bases, offs)
+
+    def pseudoalign_threshold_union_batch(self, bases, offs, threshold):
+        return self._call(self._L.fgpu_threshold_union, bases, offs, C.c_double(threshold))
+
+    def intersect_ids_batch(self, ids, id_offs):
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        id_offs = np.ascontiguousarray(id_offs, dtype=np.uint64)
+        n = len(id_offs) - 1
+        po, pv = C.c_void_p(), C.c_void_p()
+        _native.check(self._L.fgpu_intersect_ids(self._h, _ptr(ids), _ptr(id_offs), n, C.byref(po), C.byref(pv)))
+        return _take_csr(self._L, n, po, pv)
+
+    # --- per-read members with the reference's names ---
+    def fetch_color_set_ids(self, sequence):
+        b, o = pack_reads([sequence])
+        return self.fetch_color_set_ids_batch(b, o)[1].tolist()
+
+    def pseudoalign_full_intersection(self, color_set_ids):
+        ids = np.asarray(color_set_ids, dtype=np.uint32)
+        return self.intersect_ids_batch(ids, np.array([0, len(ids)], dtype=np.uint64))[1].tolist()
+
+    def pseudoalign_threshold_union(self, sequence, threshold):
+        b, o = pack_reads([sequence])
+        return self.pseudoalign_threshold_union_batch(b, o, threshold)[1].tolist()
+
+    # --- device-resident driver API ---
+    def upload_reads(self, bases, offs):
+        return Reads(self, bases, offs)
+
+    def new_result(self):
+        return Result(self)
+
+    def run(self, reads, result, algo=FULL_INTERSECTION, threshold=0.0, first=0, count=None):
+        if count is None:
+            count = reads.n - first
+        _native.check(self._L.fgpu_run(self._h, reads._h, first, count, algo, C.c_double(threshold), result._h))
+
+    def timing_enable(self, on=True):
+        _native.check(self._L.fgpu_timing_enable(self._h, 1 if on else 0))
+
+    def timing_reset(self):
+        _native.check(self._L.fgpu_timing_reset(self._h))
+
+    def timing(self):
+        out = {}
+        for i, name in enumerate(KERNELS):
+            ms, n = C.c_double(), C.c_uint64()
+            _native.check(self._L.fgpu_timing_get(self._h, i, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    def export(self):
+        """Encoded index content (unitigs + hybrid colour stream) as numpy arrays."""
+        v = [C.c_uint64() for _ in range(5)]
+        _native.check(self._L.fgpu_export_sizes(self._h, *[C.byref(x) for x in v]))
+        nb, nu, nw, nbits, ns = [x.value for x in v]
+        out = {
+            "k": self._k,
+            "unitig_bases": np.zeros(nb, dtype=np.uint8),
+            "unitig_off": np.zeros(nu + 1, dtype=np.uint64),
+            "unitig_csid": np.zeros(nu, dtype=np.uint32),
+            "color_words": np.zeros(nw, dtype=np.uint64),
+            "color_offsets": np.zeros(ns + 1, dtype=np.uint64),
+            "thresholds": np.zeros(3, dtype=np.uint32),
+            "color_bits": nbits,
+        }
+        _native.check(self._L.fgpu_export(self._h, _ptr(out["unitig_bases"]), _ptr(out["unitig_off"]),
+                                          _ptr(out["unitig_csid"]), _ptr(out["color_words"]),
+                                          _ptr(out["color_offsets"]), _ptr(out["thresholds"])))
+        return out

@@ -1,0 +1,84 @@
+"""Read sources for the driver: FASTA/FASTQ parsing (src/ps_utils.cpp:245-305: read id = 0-based file
+order) and the seeded synthetic read generator of SURVEY §8(d) (native, csrc/tools/readgen.cpp)."""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+
+from . import _build
+
+_tools = None
+
+
+def _lib():
+    global _tools
+    if _tools is None:
+        if not os.path.exists(_build.LIB_TOOLS):
+            raise RuntimeError("%s is missing: run __graft_entry__.build()" % _build.LIB_TOOLS)
+        L = C.CDLL(_build.LIB_TOOLS)
+        L.fgt_genomes_new.restype = C.c_void_p
+        L.fgt_genomes_add_fasta.argtypes = [C.c_void_p, C.c_char_p]
+        L.fgt_genomes_add_fasta.restype = C.c_int64
+        L.fgt_genomes_add_raw.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.fgt_genomes_add_raw.restype = C.c_int64
+        L.fgt_genomes_free.argtypes = [C.c_void_p]
+        L.fgt_genomes_free.restype = None
+        L.fgt_generate_reads.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int]
+        _tools = L
+    return _tools
+
+
+class ReadGenerator:
+    def __init__(self, fasta_paths=(), raw_sequences=()):
+        self._L = _lib()
+        self._h = C.c_void_p(self._L.fgt_genomes_new())
+        for p in fasta_paths:
+            if self._L.fgt_genomes_add_fasta(self._h, str(p).encode()) < 0:
+                raise RuntimeError("cannot read genome %s" % p)
+        for s in raw_sequences:
+            a = np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray)) else np.ascontiguousarray(s, dtype=np.uint8)
+            self._L.fgt_genomes_add_raw(self._h, a.ctypes.data_as(C.c_void_p), len(a))
+
+    def generate(self, first, count, read_len=150, seed=42, threads=None):
+        """reads [first, first+count) of the global read set -> (uint8 bases, uint64 offsets)"""
+        out = np.empty(count * read_len, dtype=np.uint8)
+        threads = threads or os.cpu_count() or 1
+        rc = self._L.fgt_generate_reads(self._h, first, count, read_len, seed, out.ctypes.data_as(C.c_void_p), threads)
+        if rc != 0:
+            raise RuntimeError("read generation failed (no window of %d ACGT bases?)" % read_len)
+        offs = np.arange(count + 1, dtype=np.uint64) * np.uint64(read_len)
+        return out, offs
+
+    def close(self):
+        if self._h:
+            self._L.fgt_genomes_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def parse_fastx(path):
+    """FASTA/FASTQ (optionally .gz) -> list of sequences (bytes) in file order."""
+    op = gzip.open if str(path).endswith(".gz") else open
+    seqs = []
+    with op(path, "rb") as f:
+        first = f.read(1)
+        f.seek(0)
+        if first == b"@":
+            for i, line in enumerate(f):
+                if i % 4 == 1:
+                    seqs.append(line.strip())
+        else:
+            cur = None
+            for line in f:
+                if line.startswith(b">"):
+                    if cur is not None:
+                        seqs.append(b"".join(cur))
+                    cur = []
+                elif cur is not None:
+                    cur.append(line.strip())
+            if cur is not None:
+                seqs.append(b"".join(cur))
+    return seqs

@@ -1,0 +1,109 @@
+/* libfulgor_gpu.so — C ABI of the MI355X pseudoalignment engine.
+ *
+ * The reference (jermp/fulgor v4.2.0) has no FFI layer: the hot path sits behind three const member
+ * functions of `template <typename ColorSets> struct index` (include/index.hpp:39-46)
+ *
+ *   void fetch_color_set_ids(std::string const& sequence, std::vector<uint32_t>& color_set_ids) const;
+ *   void pseudoalign_full_intersection(std::vector<uint32_t>& color_set_ids,
+ *                                      std::vector<uint32_t>& results, std::vector<uint32_t>& tmp) const;
+ *   void pseudoalign_threshold_union(std::string const& sequence, std::vector<uint32_t>& results,
+ *                                    const double threshold) const;
+ *
+ * called once per read from pseudoalign_worker (tools/pseudoalign.cpp:22-51). A GPU wants batches, so
+ * every entry point below is the batch-oriented restatement of one of those members: reads are passed
+ * as concatenated ASCII bases + (n+1) offsets, results come back as CSR (offsets[n+1] + values) with
+ * every per-read list sorted ascending, exactly the vectors the members would have produced, in read
+ * order. Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Errors: every int-returning function returns 0 on success and a negative errno-style code on
+ * failure; fgpu_last_error() then holds a message (thread local). The reference throws
+ * std::runtime_error on load failures (include/util.hpp:91-95, src/index.cpp:65,138) and has no error
+ * path on queries; a missing GPU / failed HIP call is reported here as -EIO and never falls back to
+ * the CPU.
+ */
+#ifndef FULGOR_GPU_H
+#define FULGOR_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fgpu_index fgpu_index;   /* index resident in HBM (replaces index<ColorSets>)          */
+typedef struct fgpu_reads fgpu_reads;   /* a batch of reads resident in HBM                            */
+typedef struct fgpu_result fgpu_result; /* CSR results of one batch, resident in HBM, reusable         */
+
+enum { FGPU_FULL_INTERSECTION = 0, FGPU_THRESHOLD_UNION = 1 }; /* pseudoalignment_algorithm, src/ps_utils.cpp:12 */
+enum { FGPU_HYBRID = 0, FGPU_DIFF = 1, FGPU_META = 2, FGPU_META_DIFF = 3 }; /* index_t, include/util.hpp:18 */
+
+const char* fgpu_last_error(void);
+
+/* essentials::load(index, filename) + upload (tools/pseudoalign.cpp:340). `path` is a dump basename as
+ * written by `fulgor dump` (src/index.cpp:59-120) or an .fgidx container written by fgpu_save.
+ * device >= 0: HIP device ordinal. device == FGPU_HOST_ONLY: ingest on the host only (for fgpu_save /
+ * fgpu_info / fgpu_export / fgpu_selfcheck); every query entry point then fails with -ENODEV. */
+#define FGPU_HOST_ONLY (-1)
+int fgpu_open(const char* path, int device, fgpu_index** out);
+/* build-time self check (the reference's `--check`, include/builders/builder.hpp:221-277): every k-mer
+ * of every `unitig_stride`-th unitig must resolve to its unitig's colour-set id through the dictionary */
+int fgpu_selfcheck(const fgpu_index* idx, uint64_t unitig_stride);
+void fgpu_close(fgpu_index* idx);
+int fgpu_save(const fgpu_index* idx, const char* path);
+/* index::k / num_colors / num_color_sets / num_unitigs (include/index.hpp:64-68), ColorSets::type */
+int fgpu_info(const fgpu_index* idx, uint64_t* k, uint64_t* num_colors, uint64_t* num_color_sets,
+              uint64_t* num_unitigs, uint64_t* num_kmers, int* index_type);
+
+/* ---- host-buffer calls: one per reference member; outputs are malloc'd, release with fgpu_free ---- */
+/* index::fetch_color_set_ids (src/ps_full_intersection.cpp:334-374) */
+int fgpu_fetch_color_set_ids(fgpu_index* idx, const char* bases, const uint64_t* offs, uint64_t n,
+                             uint64_t** out_offsets, uint32_t** out_ids);
+/* fetch_color_set_ids + index::pseudoalign_full_intersection (src/ps_full_intersection.cpp:376-400),
+ * i.e. the FULL_INTERSECTION arm of pseudoalign_worker (tools/pseudoalign.cpp:27-30) */
+int fgpu_full_intersection(fgpu_index* idx, const char* bases, const uint64_t* offs, uint64_t n,
+                           uint64_t** out_offsets, uint32_t** out_colors);
+/* index::pseudoalign_threshold_union (src/ps_threshold_union.cpp:320-402) */
+int fgpu_threshold_union(fgpu_index* idx, const char* bases, const uint64_t* offs, uint64_t n, double tau,
+                         uint64_t** out_offsets, uint32_t** out_colors);
+/* index::pseudoalign_full_intersection given the colour-set ids (the --deduplicate path feeds it this
+ * way, src/ps_utils.cpp:307-415) */
+int fgpu_intersect_ids(fgpu_index* idx, const uint32_t* ids, const uint64_t* id_offs, uint64_t n,
+                       uint64_t** out_offsets, uint32_t** out_colors);
+void fgpu_free(void* p);
+
+/* ---- device-resident calls (what the driver loop and bench.py use) -------------------------------- */
+int fgpu_reads_upload(fgpu_index* idx, const char* bases, const uint64_t* offs, uint64_t n, fgpu_reads** out);
+void fgpu_reads_free(fgpu_reads* reads);
+int fgpu_result_create(fgpu_index* idx, fgpu_result** out);
+void fgpu_result_free(fgpu_result* res);
+/* one pass of the hot path over reads [first, first+count) of an uploaded batch; results replace the
+ * previous contents of `res`. Returns after the kernels have completed. */
+int fgpu_run(fgpu_index* idx, const fgpu_reads* reads, uint64_t first, uint64_t count, int algo, double tau,
+             fgpu_result* res);
+/* ps_options counters (src/ps_utils.cpp:417-448): reads processed / reads with a non-empty result */
+int fgpu_result_sizes(const fgpu_result* res, uint64_t* num_reads, uint64_t* total_colors, uint64_t* num_mapped);
+int fgpu_result_download(const fgpu_result* res, uint64_t* offsets /* n+1 */, uint32_t* colors /* total */);
+/* adds this result's per-colour hit counts (#reads whose result contains colour c) followed by
+ * {num_reads, num_mapped} into a DEVICE array of num_colors+2 uint64 (the vector RCCL all-reduces) */
+int fgpu_result_accumulate_hits(fgpu_index* idx, const fgpu_result* res, void* device_u64_hits);
+/* algorithmic bytes of the last run: colour-intersection stage and lookup stage */
+int fgpu_result_algorithmic_bytes(const fgpu_result* res, uint64_t* intersect_bytes, uint64_t* lookup_bytes);
+
+/* per-kernel HIP-event timing on the engine's stream */
+enum { FGPU_K_LOOKUP = 0, FGPU_K_INTERSECT = 1, FGPU_K_UNION = 2, FGPU_K_SCAN = 3, FGPU_K_EXPAND = 4,
+       FGPU_K_HITS = 5, FGPU_K_COUNT = 6 };
+int fgpu_timing_enable(fgpu_index* idx, int on);
+int fgpu_timing_reset(fgpu_index* idx);
+int fgpu_timing_get(fgpu_index* idx, int kernel, double* total_ms, uint64_t* launches);
+const char* fgpu_kernel_name(int kernel);
+
+/* ---- index export (lets tests hand the same encoded index to the oracle) -------------------------- */
+int fgpu_export_sizes(const fgpu_index* idx, uint64_t* unitig_bases, uint64_t* num_unitigs, uint64_t* color_words,
+                      uint64_t* color_bits, uint64_t* num_sets);
+int fgpu_export(const fgpu_index* idx, char* unitig_bases, uint64_t* unitig_off, uint32_t* unitig_csid,
+                uint64_t* color_words, uint64_t* color_offsets, uint32_t* thresholds /* n, sparse, dense */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

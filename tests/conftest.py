@@ -1,0 +1,84 @@
+import glob
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(ROOT, "data")
+S10_GENOMES = sorted(glob.glob(os.path.join(ROOT, "tests", "data", "salmonella_10", "*.fasta.gz")))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def has_gpu():
+    return os.path.exists("/dev/kfd")
+
+
+@pytest.fixture(scope="session")
+def built():
+    from fulgor_amd import _build
+    _build.build_all()
+    return _build
+
+
+@pytest.fixture(scope="session")
+def s10_dump(built):
+    """salmonella_10 in the reference's dump format (built once from the genomes, colour = sorted file order)"""
+    base = os.path.join(DATA, "s10")
+    if not os.path.exists(base + ".unitigs.fa"):
+        os.makedirs(DATA, exist_ok=True)
+        subprocess.run([built.BIN_CCDBG, "31", base] + S10_GENOMES, check=True)
+    return base
+
+
+@pytest.fixture(scope="session")
+def s10_fgidx(built, s10_dump):
+    import fulgor_amd
+    p = os.path.join(DATA, "s10.fgidx")
+    if not os.path.exists(p):
+        ix = fulgor_amd.Index(s10_dump, device=-1)
+        ix.save(p)
+        ix.close()
+    return p
+
+
+@pytest.fixture(scope="session")
+def s10_oracle(built, s10_dump):
+    from oracle.pyoracle import OracleIndex
+    return OracleIndex.from_dump(s10_dump)
+
+
+@pytest.fixture(scope="session")
+def s10_gpu(built, s10_fgidx):
+    import fulgor_amd
+    return fulgor_amd.Index(s10_fgidx, device=0)
+
+
+def load_golden_reads():
+    from fulgor_amd.reads import parse_fastx
+    return parse_fastx(os.path.join(GOLDEN, "s10_reads.fa"))
+
+
+def load_golden_tsv(name):
+    out = []
+    with open(os.path.join(GOLDEN, name)) as f:
+        for line in f:
+            t = line.rstrip("\n").split("\t")
+            assert int(t[0]) == len(out)
+            cols = [int(x) for x in t[2:]]
+            assert int(t[1]) == len(cols)
+            out.append(cols)
+    return out
+
+
+def csr_to_lists(offs, vals):
+    offs = np.asarray(offs, dtype=np.int64)
+    return [vals[offs[i]:offs[i + 1]].tolist() for i in range(len(offs) - 1)]

@@ -1,0 +1,161 @@
+"""GPU suite: the HIP path, called through the C ABI, against (1) the committed golden vectors of the
+independent k-mer oracle, (2) the oracle (CPU restatement of the reference) on seeded reads, bit-exact,
+(3) size-independent properties at BASELINE config size (1M reads on salmonella_10)."""
+import numpy as np
+import pytest
+
+import fulgor_amd
+from conftest import S10_GENOMES, csr_to_lists, load_golden_reads, load_golden_tsv
+from fulgor_amd import pack_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gpu_full_intersection_matches_golden(s10_gpu):
+    b, o = pack_reads(load_golden_reads())
+    offs, cols = s10_gpu.pseudoalign_full_intersection_batch(b, o)
+    assert csr_to_lists(offs, cols) == load_golden_tsv("s10_full_intersection.tsv")
+
+
+@pytest.mark.parametrize("tau", [0.8, 1.0, 0.01])
+def test_gpu_threshold_union_matches_golden(s10_gpu, tau):
+    b, o = pack_reads(load_golden_reads())
+    offs, cols = s10_gpu.pseudoalign_threshold_union_batch(b, o, tau)
+    assert csr_to_lists(offs, cols) == load_golden_tsv("s10_threshold_union_%s.tsv" % tau)
+
+
+@pytest.fixture(scope="module")
+def seeded_reads(built):
+    from fulgor_amd.reads import ReadGenerator
+    g = ReadGenerator(S10_GENOMES)
+    return g.generate(0, 50000, 150, 7)
+
+
+def test_gpu_fetch_color_set_ids_equals_oracle(s10_gpu, s10_oracle, seeded_reads):
+    b, o = seeded_reads
+    go, gi = s10_gpu.fetch_color_set_ids_batch(b, o)
+    oo, oi = s10_oracle.fetch_color_set_ids(b, o)
+    assert np.array_equal(go, oo) and np.array_equal(gi, oi)
+
+
+def test_gpu_full_intersection_equals_oracle(s10_gpu, s10_oracle, seeded_reads):
+    b, o = seeded_reads
+    go, gc = s10_gpu.pseudoalign_full_intersection_batch(b, o)
+    oo, oc = s10_oracle.full_intersection(b, o)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+
+
+@pytest.mark.parametrize("tau", [0.8, 0.5, 1.0])
+def test_gpu_threshold_union_equals_oracle(s10_gpu, s10_oracle, seeded_reads, tau):
+    b, o = seeded_reads
+    go, gc = s10_gpu.pseudoalign_threshold_union_batch(b, o, tau)
+    oo, oc = s10_oracle.threshold_union(b, o, tau)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+
+
+def test_gpu_intersect_ids_equals_oracle(s10_gpu, s10_oracle, seeded_reads):
+    b, o = seeded_reads
+    ido, ids = s10_oracle.fetch_color_set_ids(b, o)
+    go, gc = s10_gpu.intersect_ids_batch(ids, ido)
+    oo, oc = s10_oracle.intersect_ids(ids, ido)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+    # random id lists (not produced by any read): every hybrid encoding mixed, up to 40 lists
+    rng = np.random.default_rng(3)
+    ns = s10_gpu.num_color_sets()
+    lens = rng.integers(0, 40, size=3000)
+    lists = [np.unique(rng.integers(0, ns, size=l)).astype(np.uint32) for l in lens]
+    ido = np.zeros(len(lists) + 1, dtype=np.uint64)
+    ido[1:] = np.cumsum([len(l) for l in lists])
+    ids = np.concatenate(lists) if lists else np.zeros(0, dtype=np.uint32)
+    go, gc = s10_gpu.intersect_ids_batch(ids, ido)
+    oo, oc = s10_oracle.intersect_ids(ids, ido, self_check=True)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+
+
+def test_gpu_per_read_members(s10_gpu, s10_oracle):
+    reads = load_golden_reads()[:20]
+    gold = load_golden_tsv("s10_full_intersection.tsv")
+    for i, r in enumerate(reads):
+        ids = s10_gpu.fetch_color_set_ids(r)
+        assert s10_gpu.pseudoalign_full_intersection(ids) == gold[i]
+
+
+def test_gpu_edge_batches(s10_gpu):
+    # empty batch
+    offs, cols = s10_gpu.pseudoalign_full_intersection_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert offs.tolist() == [0] and len(cols) == 0
+    # only empty / too-short reads
+    b, o = pack_reads([b"", b"ACGT", b"A" * 30])
+    offs, cols = s10_gpu.pseudoalign_full_intersection_batch(b, o)
+    assert offs.tolist() == [0, 0, 0, 0]
+    offs, cols = s10_gpu.pseudoalign_threshold_union_batch(b, o, 0.8)
+    assert offs.tolist() == [0, 0, 0, 0]
+    with pytest.raises(RuntimeError, match="threshold"):
+        s10_gpu.pseudoalign_threshold_union_batch(b, o, 0.0)
+    with pytest.raises(RuntimeError, match="threshold"):
+        s10_gpu.pseudoalign_threshold_union_batch(b, o, 1.5)
+
+
+def test_gpu_long_reads_up_to_1024_kmers(s10_gpu, s10_oracle):
+    from oracle.kmer_oracle import read_fasta
+    src = max(read_fasta(S10_GENOMES[5]), key=len)
+    reads = [src[i * 1000:i * 1000 + l] for i, l in enumerate([1054, 700, 300, 151, 1000, 31, 64, 95, 96, 159])]
+    b, o = pack_reads(reads)
+    for got, want in ((s10_gpu.pseudoalign_full_intersection_batch(b, o), s10_oracle.full_intersection(b, o)),
+                      (s10_gpu.pseudoalign_threshold_union_batch(b, o, 0.8), s10_oracle.threshold_union(b, o, 0.8)),
+                      (s10_gpu.fetch_color_set_ids_batch(b, o), s10_oracle.fetch_color_set_ids(b, o))):
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    b, o = pack_reads([src[:1100]])
+    with pytest.raises(RuntimeError, match="1024 k-mers"):
+        s10_gpu.pseudoalign_full_intersection_batch(b, o)
+
+
+def test_gpu_config_size_1M_reads_bit_exact_and_properties(s10_gpu, s10_oracle, built):
+    """BASELINE configs[1]: salmonella_10, 1M synthetic 150 bp reads, full-intersection, bit-exact vs CPU."""
+    from fulgor_amd.reads import ReadGenerator
+    g = ReadGenerator(S10_GENOMES)
+    b, o = g.generate(0, 1_000_000, 150, 42)
+    reads = s10_gpu.upload_reads(b, o)
+    res = s10_gpu.new_result()
+    s10_gpu.run(reads, res, fulgor_amd.FULL_INTERSECTION)
+    n, total, mapped = res.sizes()
+    go, gc = res.download()
+    oo, oc = s10_oracle.full_intersection(b, o)
+    assert n == 1_000_000 and np.array_equal(go, oo) and np.array_equal(gc, oc)
+    # properties: strictly increasing per read, in range, mapped counter, idempotence of a second pass
+    d = np.diff(gc.astype(np.int64))
+    starts = go[1:-1].astype(np.int64)
+    starts = starts[(starts > 0) & (starts < len(gc))]
+    d[starts - 1] = 1
+    assert (d > 0).all() and gc.max() < s10_gpu.num_colors()
+    assert mapped == int((np.diff(go.astype(np.int64)) > 0).sum())
+    s10_gpu.run(reads, res, fulgor_amd.FULL_INTERSECTION)
+    go2, gc2 = res.download()
+    assert np.array_equal(go, go2) and np.array_equal(gc, gc2)
+    # chunked passes give the same answers as one pass
+    s10_gpu.run(reads, res, fulgor_amd.FULL_INTERSECTION, first=300_000, count=200_000)
+    go3, gc3 = res.download()
+    a, bnd = int(go[300_000]), int(go[500_000])
+    assert np.array_equal(gc3, gc[a:bnd]) and np.array_equal(go3.astype(np.int64), go[300_000:500_001].astype(np.int64) - a)
+    # threshold-union at the same size
+    s10_gpu.run(reads, res, fulgor_amd.THRESHOLD_UNION, 0.8)
+    to, tc = res.download()
+    oo, oc = s10_oracle.threshold_union(b, o, 0.8)
+    assert np.array_equal(to, oo) and np.array_equal(tc, oc)
+
+
+def test_gpu_hit_counts(s10_gpu, seeded_reads):
+    import torch
+    b, o = seeded_reads
+    reads = s10_gpu.upload_reads(b, o)
+    res = s10_gpu.new_result()
+    s10_gpu.run(reads, res, fulgor_amd.FULL_INTERSECTION)
+    n = s10_gpu.num_colors()
+    hits = torch.zeros(n + 2, dtype=torch.int64, device="cuda:0")
+    res.accumulate_hits(hits.data_ptr())
+    res.accumulate_hits(hits.data_ptr())
+    go, gc = res.download()
+    want = np.bincount(gc, minlength=n)
+    got = hits.cpu().numpy()
+    assert np.array_equal(got[:n], 2 * want)
+    assert got[n] == 2 * 50000 and got[n + 1] == 2 * int((np.diff(go.astype(np.int64)) > 0).sum())

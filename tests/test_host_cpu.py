@@ -1,0 +1,105 @@
+"""CPU suite part 2: host logic of the engine (dump ingestion, hybrid encoder, dictionary, container),
+the C ABI surface, and the loud failure of query entry points without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import fulgor_amd
+from conftest import ROOT, has_gpu
+
+
+@pytest.fixture(scope="module")
+def host_index(s10_fgidx):
+    return fulgor_amd.Index(s10_fgidx, device=-1)
+
+
+def test_header_symbols_are_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "fulgor_gpu.h")).read()
+    names = set(re.findall(r"\b(fgpu_[a-z_]+)\s*\(", hdr))
+    assert len(names) >= 25
+    lib = C.CDLL(built.LIB_GPU)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_info_matches_dump_metadata(host_index, s10_dump):
+    meta = dict(l.strip().split("=") for l in open(s10_dump + ".metadata.txt"))
+    assert host_index.k() == int(meta["k"]) == 31
+    assert host_index.num_colors() == int(meta["num_colors"]) == 10
+    assert host_index.num_color_sets() == int(meta["num_color_sets"])
+    assert host_index.num_unitigs() == int(meta["num_unitigs"])
+    assert host_index.num_kmers() == int(meta["num_kmers"]) == 6898179
+
+
+def test_hybrid_encoder_is_bit_identical_to_oracle(host_index, s10_oracle):
+    ex = host_index.export()
+    words, offs = s10_oracle.encoded_colors()
+    assert np.array_equal(ex["color_offsets"], offs)
+    assert np.array_equal(ex["color_words"], words)
+    assert ex["thresholds"].tolist() == [10, 2, 7]  # u32(0.25*n), u32(0.75*n): hybrid.hpp:20-21
+
+
+def test_dictionary_selfcheck(host_index):
+    host_index.selfcheck(unitig_stride=7)  # every k-mer of every 7th unitig, both strands
+
+
+def test_dump_and_container_agree(host_index, s10_dump):
+    a = fulgor_amd.Index(s10_dump, device=-1).export()
+    b = host_index.export()
+    for key in ("unitig_bases", "unitig_off", "unitig_csid", "color_words", "color_offsets", "thresholds"):
+        assert np.array_equal(a[key], b[key]), key
+
+
+def test_export_unitigs_match_dump_text(host_index, s10_dump):
+    ex = host_index.export()
+    with open(s10_dump + ".unitigs.fa") as f:
+        for u in range(50):
+            hdr, seq = f.readline(), f.readline().strip()
+            assert int(hdr.split("color_set_id=")[1]) == ex["unitig_csid"][u]
+            a, b = int(ex["unitig_off"][u]), int(ex["unitig_off"][u + 1])
+            assert bytes(ex["unitig_bases"][a:b]).decode() == seq
+
+
+def test_queries_fail_loudly_on_host_only_handle(host_index):
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        host_index.fetch_color_set_ids("ACGT" * 40)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        host_index.pseudoalign_threshold_union("ACGT" * 40, 0.8)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        host_index.pseudoalign_full_intersection([0, 1])
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
+def test_open_on_device_fails_without_gpu(s10_fgidx):
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        fulgor_amd.Index(s10_fgidx, device=0)
+
+
+def test_reference_binary_index_is_rejected(tmp_path):
+    p = tmp_path / "x.mdfur"
+    p.write_bytes(b"\x04\x02\x00")
+    with pytest.raises(RuntimeError, match="fulgor dump"):
+        fulgor_amd.Index(str(p), device=-1)
+
+
+def test_bad_container_is_rejected(tmp_path):
+    p = tmp_path / "x.fgidx"
+    p.write_bytes(b"NOTANIDX" + b"\0" * 64)
+    with pytest.raises(RuntimeError, match="magic"):
+        fulgor_amd.Index(str(p), device=-1)
+
+
+def test_readgen_is_sliceable_and_seeded(built):
+    from conftest import S10_GENOMES
+    from fulgor_amd.reads import ReadGenerator
+    g = ReadGenerator(S10_GENOMES[:2])
+    b, o = g.generate(0, 70000, 150, 42)
+    b2, _ = g.generate(65000, 3000, 150, 42)  # crosses the 65536-read shard boundary
+    assert np.array_equal(b[65000 * 150:68000 * 150], b2)
+    b3, _ = g.generate(0, 1000, 150, 43)
+    assert not np.array_equal(b[:150000], b3)
+    assert set(np.unique(b).tolist()) <= set(b"ACGT")
+    assert o[-1] == 70000 * 150

@@ -1,0 +1,50 @@
+"""CPU suite part 1: the oracle (C++ restatement of the reference algorithms) against the golden vectors
+produced by the independent k-mer-level oracle, and against the reference's own brute-force definitions
+(util::check_intersection / check_union restated; self_check=True)."""
+import numpy as np
+import pytest
+
+from conftest import csr_to_lists, load_golden_reads, load_golden_tsv
+from fulgor_amd import pack_reads
+
+
+def test_oracle_full_intersection_matches_golden(s10_oracle):
+    reads = load_golden_reads()
+    b, o = pack_reads(reads)
+    offs, cols = s10_oracle.full_intersection(b, o, threads=4, self_check=True)
+    assert csr_to_lists(offs, cols) == load_golden_tsv("s10_full_intersection.tsv")
+
+
+@pytest.mark.parametrize("tau", [0.8, 1.0, 0.01])
+def test_oracle_threshold_union_matches_golden(s10_oracle, tau):
+    reads = load_golden_reads()
+    b, o = pack_reads(reads)
+    offs, cols = s10_oracle.threshold_union(b, o, tau, threads=4, self_check=True)
+    assert csr_to_lists(offs, cols) == load_golden_tsv("s10_threshold_union_%s.tsv" % tau)
+
+
+def test_oracle_intersect_ids_equals_two_step(s10_oracle):
+    reads = load_golden_reads()
+    b, o = pack_reads(reads)
+    ido, ids = s10_oracle.fetch_color_set_ids(b, o, threads=4)
+    lists = csr_to_lists(ido, ids)
+    assert all(l == sorted(set(l)) for l in lists)  # sorted unique (ps_full_intersection.cpp:371-373)
+    o2, c2 = s10_oracle.intersect_ids(ids, ido, threads=4, self_check=True)
+    o1, c1 = s10_oracle.full_intersection(b, o, threads=4)
+    assert np.array_equal(o1, o2) and np.array_equal(c1, c2)
+
+
+def test_oracle_ascii_format(s10_oracle):
+    offs = np.array([0, 3, 3, 4], dtype=np.uint64)
+    cols = np.array([1, 20, 300, 7], dtype=np.uint32)
+    assert s10_oracle.format_ascii(offs, cols, first_id=5) == b"5\t3\t1\t20\t300\n6\t0\n7\t1\t7\n"
+
+
+def test_oracle_strand_symmetry(s10_oracle):
+    comp = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+    reads = load_golden_reads()[:300]
+    rc = [r.translate(comp)[::-1] for r in reads]
+    b1, o1 = pack_reads(reads)
+    b2, o2 = pack_reads(rc)
+    assert csr_to_lists(*s10_oracle.full_intersection(b1, o1)) == csr_to_lists(*s10_oracle.full_intersection(b2, o2))
+    assert csr_to_lists(*s10_oracle.threshold_union(b1, o1, 0.8)) == csr_to_lists(*s10_oracle.threshold_union(b2, o2, 0.8))
