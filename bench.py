@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — pseudoaligned reads/s of the MI355X engine (BASELINE.json metric), one process per GPU.
+
+A step = one pass of the hot path (k-mer lookup -> colour-set ids -> full-intersection / threshold-union
+-> CSR colour lists -> per-colour hit counts) over this rank's reads, which are resident in HBM when the
+timed region starts; the per-colour hit counts are all-reduced over RCCL at the end of every step.
+Weak scaling: every rank gets `--reads` reads (rank r owns global reads [r*reads, (r+1)*reads)); the
+index is replicated. Prints ONE JSON line on rank 0.
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def s10_genomes():
+    g = sorted(glob.glob(os.path.join(ROOT, "tests", "data", "salmonella_10", "*.fasta.gz")))
+    assert len(g) == 10, "tests/data/salmonella_10 is incomplete"
+    return g
+
+
+def prepare_workload(name, rank):
+    """returns (index path, ReadGenerator, description). Rank 0 builds missing caches; others wait."""
+    import __graft_entry__ as ge
+    from fulgor_amd.reads import ReadGenerator
+    if name == "s10":
+        fg, _ = ge._s10_index()
+        return fg, ReadGenerator(s10_genomes()), "salmonella_10 (real genomes, 10 colours, 6.9M 31-mers, 171 colour sets)"
+    if name == "s4546syn":
+        from fulgor_amd import synth
+        fg, extra = synth.ensure_s4546(os.path.join(ROOT, "data"), s10_genomes())
+        return fg, ReadGenerator(s10_genomes(), raw_sequences=extra), synth.DESCRIPTION
+    raise SystemExit("unknown workload %s" % name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("FULGOR_BENCH_WORKLOAD", "s10"))
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the BASELINE config size)")
+    ap.add_argument("--algo", default="full-intersection", choices=["full-intersection", "threshold-union"])
+    ap.add_argument("--tau", type=float, default=0.8)
+    ap.add_argument("--chunk", type=int, default=1 << 20, help="reads per kernel pass")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    import fulgor_amd  # binds libfulgor_gpu.so to torch's HIP runtime (fulgor_amd/_native.py)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+
+    default_reads = {"s10": 1_000_000, "s4546syn": 10_000_000}
+    n_reads = args.reads or default_reads[args.workload]
+    if rank == 0:
+        fg, gen, desc = prepare_workload(args.workload, rank)
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        fg, gen, desc = prepare_workload(args.workload, rank)
+
+    ix = fulgor_amd.Index(fg, device=local_rank)
+    algo = fulgor_amd.FULL_INTERSECTION if args.algo == "full-intersection" else fulgor_amd.THRESHOLD_UNION
+    bases, offs = gen.generate(rank * n_reads, n_reads, 150, 42)
+    reads = ix.upload_reads(bases, offs)
+    res = ix.new_result()
+    ncol = ix.num_colors()
+    hits = torch.zeros(ncol + 2, dtype=torch.int64, device="cuda:%d" % local_rank)
+
+    def step():
+        hits.zero_()
+        torch.cuda.synchronize()
+        for first in range(0, n_reads, args.chunk):
+            cnt = min(args.chunk, n_reads - first)
+            ix.run(reads, res, algo, args.tau, first, cnt)
+            res.accumulate_hits(hits.data_ptr())
+        if world > 1:
+            dist.all_reduce(hits)  # RCCL: per-colour hit counts + {reads, mapped}
+
+    for _ in range(args.warmup):
+        step()
+    ix.timing_enable(True)
+    ix.timing_reset()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    timing = ix.timing()
+    ix.timing_enable(False)
+    h = hits.cpu().numpy()
+    total_reads_job, mapped_job = int(h[ncol]), int(h[ncol + 1])
+
+    # algorithmic bytes of one step on this rank, from the resident per-read id lists / sizes
+    acct = {"lists": 0, "output": 0, "lookup": 0}
+    total_colors = 0
+    for first in range(0, n_reads, args.chunk):
+        cnt = min(args.chunk, n_reads - first)
+        ix.run(reads, res, algo, args.tau, first, cnt)
+        a = res.algorithmic_bytes()
+        for k_ in acct:
+            acct[k_] += a[k_]
+        total_colors += res.sizes()[1]
+
+    if rank == 0:
+        stage_kernel = "k2a_intersect" if algo == fulgor_amd.FULL_INTERSECTION else "k3a_union"
+        kbytes = {"k1_lookup": acct["lookup"], stage_kernel: acct["lists"], "k2b_expand": acct["output"]}
+        cand = {k_: timing[k_] for k_ in kbytes if timing[k_][1] > 0}
+        dom = max(cand, key=lambda k_: cand[k_][0])
+        dom_ms, dom_launches = cand[dom]
+        launches_per_step = dom_launches / args.steps
+        avg_ms = dom_ms / dom_launches
+        achieved = kbytes[dom] / launches_per_step / (avg_ms * 1e-3) / 1e9
+        kernels = {k_: {"avg_ms": round(v[0] / v[1], 4), "launches": v[1]} for k_, v in timing.items() if v[1]}
+        stage_ms = sum(timing[k_][0] for k_ in (stage_kernel, "scan", "k2b_expand")) / args.steps
+        out = {
+            "metric": "pseudoaligned reads/sec (150 bp, k=31)",
+            "value": round(world * n_reads * args.steps / elapsed, 1),
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "%s, %s, %d synthetic 150 bp reads per GPU (seed 42), k=31, chunk %d reads/pass"
+                                   % (desc, args.algo + (" tau=%g" % args.tau if algo else ""), n_reads, args.chunk),
+                       "index_replicated": True, "reads_per_gpu": n_reads,
+                       "mapped_fraction": round(mapped_job / max(1, total_reads_job), 4),
+                       "avg_colours_per_read": round(total_colors / n_reads, 2)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(kbytes[dom] / launches_per_step),
+                         "avg_launch_ms": round(avg_ms, 4),
+                         "stage": {"kernels": [stage_kernel, "scan", "k2b_expand"],
+                                   "bytes_per_step": acct["lists"] + acct["output"], "ms_per_step": round(stage_ms, 4),
+                                   "achieved": round((acct["lists"] + acct["output"]) / (stage_ms * 1e-3) / 1e9, 2)}},
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ix, bases, offs, algo, args.tau)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ix, bases, offs, algo, tau):
+    """The oracle (CPU restatement of the reference, same worker-pool threading) timed on the host cores
+    on a bounded prefix of the same reads; kind = "port" because the reference binary cannot be built."""
+    from oracle.pyoracle import OracleIndex
+    orc = OracleIndex.from_export(ix.export())
+    cores = os.cpu_count() or 1
+    probe = min(len(offs) - 1, 20000)
+    sec, _, _ = orc.time_pseudoalign(bases[:int(offs[probe])], offs[:probe + 1], algo, tau, cores)
+    n = int(min(len(offs) - 1, max(probe, probe * 12.0 / max(sec, 1e-6))))
+    sec, mapped, _ = orc.time_pseudoalign(bases[:int(offs[n])], offs[:n + 1], algo, tau, cores)
+    return {"value": round(n / sec, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "first %d reads of rank 0's read set, %d worker threads, output discarded (%.1f s)" % (n, cores, sec)}
+
+
+if __name__ == "__main__":
+    main()

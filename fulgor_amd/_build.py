@@ -64,3 +64,5 @@ def build_all(force=False):
     build_gpu(force)
     build_tools(force)
     build_oracle(force)
+    from . import synth
+    synth.build_tool()

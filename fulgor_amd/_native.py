@@ -1,6 +1,7 @@
 """ctypes binding of libfulgor_gpu.so (include/fulgor_gpu.h). Fails loudly when the library is absent:
 there is no Python or CPU stand-in for the HIP path."""
 import ctypes as C
+import importlib.util
 import os
 
 from . import _build
@@ -9,6 +10,20 @@ _lib = None
 
 u64p = C.POINTER(C.c_uint64)
 u32p = C.POINTER(C.c_uint32)
+
+
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's). Two HIP/HSA
+    runtimes in one process cannot both own the GPU, so when torch is installed its copy is mapped first
+    and libfulgor_gpu.so binds to it; torch later reuses the same instance."""
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
 
 
 def lib():
@@ -20,6 +35,7 @@ def lib():
         raise RuntimeError(
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). The engine has no fallback path." % path)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(path)
     vp = C.c_void_p
     L.fgpu_last_error.restype = C.c_char_p
@@ -47,7 +63,7 @@ def lib():
     L.fgpu_result_sizes.argtypes = [vp, u64p, u64p, u64p]
     L.fgpu_result_download.argtypes = [vp, vp, vp]
     L.fgpu_result_accumulate_hits.argtypes = [vp, vp, vp]
-    L.fgpu_result_algorithmic_bytes.argtypes = [vp, u64p, u64p]
+    L.fgpu_result_algorithmic_bytes.argtypes = [vp, u64p, u64p, u64p]
     L.fgpu_timing_enable.argtypes = [vp, C.c_int]
     L.fgpu_timing_reset.argtypes = [vp]
     L.fgpu_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), u64p]

@@ -123,6 +123,6 @@ FG_HD void string_lmer(uint64_t w0, uint64_t w1, uint32_t sh, uint32_t L, uint32
 // ---- colour-list skip samples --------------------------------------------------------------------
 // One sample every SAMPLE_STRIDE codes of a gap-coded list: {prev value:32 | bit offset from the
 // start of the list:32}. Sample j is the decoder state after (j+1)*SAMPLE_STRIDE codes.
-constexpr uint32_t SAMPLE_STRIDE = 32;
+constexpr uint32_t SAMPLE_STRIDE = 16;
 
 }  // namespace fg

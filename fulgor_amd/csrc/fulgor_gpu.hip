@@ -122,9 +122,10 @@ struct fgpu_reads {
 struct fgpu_result {
     fgpu_index* ix = nullptr;
     DevBuf d_nids, d_npos, d_idoff, d_ids_pool, d_cnt_pool, d_cursor, d_bitmap, d_counts, d_offsets, d_block_sums,
-        d_block_mapped, d_totals, d_colors, d_acct;
+        d_block_mapped, d_totals, d_colors, d_acct, d_partial;
     uint64_t* h_totals = nullptr;  // pinned {total colours, mapped reads, ids used}
     uint64_t n = 0, total = 0, mapped = 0, total_kmers = 0, total_bases = 0;
+    uint32_t id_stride = 0;
     bool have_ids = false;
 };
 
@@ -162,9 +163,15 @@ uint32_t pick_waves(size_t per_wave, const void* kernel) {
     return w;
 }
 
-uint32_t grid_for(uint64_t units, uint32_t per_block, int num_cus, uint32_t blocks_per_cu) {
+// persistent grid: exactly as many blocks as can be resident (a larger grid-stride grid would run a
+// second, partially filled round), fewer when there is not enough work
+template <typename K>
+uint32_t resident_grid(K kernel, uint64_t units, uint32_t per_block, int num_cus, int block_threads, size_t dyn_lds) {
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, dyn_lds));
+    if (per_cu < 1) per_cu = 1;
     uint64_t need = (units + per_block - 1) / per_block;
-    uint64_t cap = (uint64_t)num_cus * blocks_per_cu;
+    uint64_t cap = (uint64_t)num_cus * (uint64_t)per_cu;
     return (uint32_t)std::max<uint64_t>(1, std::min(need, cap));
 }
 
@@ -176,25 +183,25 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     res->d_nids.ensure(count * 4 + 16);
     res->d_npos.ensure(count * 4 + 16);
     res->d_idoff.ensure(count * 8 + 16);
-    res->d_ids_pool.ensure(res->total_kmers * 4 + 16);
-    res->d_cnt_pool.ensure(res->total_kmers * 4 + 16);
-    res->d_cursor.ensure(16);
-    HIP_TRY(hipMemsetAsync(res->d_cursor.p, 0, 16, s));
+    const uint32_t stride = std::max<uint32_t>(1, rd->max_kmers);  // at most one id per k-mer
+    res->id_stride = stride;
+    res->d_ids_pool.ensure(count * (uint64_t)stride * 4 + 16);
+    res->d_cnt_pool.ensure(count * (uint64_t)stride * 4 + 16);
     if (count == 0) return;
-    const uint32_t grid = grid_for(count, 4, ix->num_cus, 8);
+    if (rd->max_kmers > 1024) throw std::runtime_error("reads with more than 1024 k-mers are not supported by this build");
+    const uint32_t grid = rd->max_kmers <= 128 ? resident_grid(k1_lookup<128>, count, 4, ix->num_cus, 256, 0)
+                                               : resident_grid(k1_lookup<1024>, count, 4, ix->num_cus, 256, 0);
     Timed t(ix, FGPU_K_LOOKUP);
     if (rd->max_kmers <= 128) {
         hipLaunchKernelGGL(k1_lookup<128>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
                            rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
                            res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
-                           res->d_cursor.as<unsigned long long>());
-    } else if (rd->max_kmers <= 1024) {
+                           stride);
+    } else {
         hipLaunchKernelGGL(k1_lookup<1024>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
                            rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
                            res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
-                           res->d_cursor.as<unsigned long long>());
-    } else {
-        throw std::runtime_error("reads with more than 1024 k-mers are not supported by this build");
+                           stride);
     }
     HIP_TRY(hipGetLastError());
     res->have_ids = true;
@@ -219,9 +226,9 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         return;
     }
     if (algo == FGPU_FULL_INTERSECTION) {
-        const size_t per_wave = 2 * (size_t)W * 4 + wave_scratch_bytes();
+        const size_t per_wave = (size_t)W * 4 + (size_t)W * 32 + wave_scratch_bytes();
         const uint32_t wpb = pick_waves(per_wave, (const void*)k2a_intersect);
-        const uint32_t grid = grid_for(n, wpb, ix->num_cus, 32 / wpb);
+        const uint32_t grid = resident_grid(k2a_intersect, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
         Timed t(ix, FGPU_K_INTERSECT);
         hipLaunchKernelGGL(k2a_intersect, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_nids.as<uint32_t>(),
                            res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), n, res->d_bitmap.as<uint32_t>(),
@@ -230,8 +237,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     } else if (algo == FGPU_THRESHOLD_UNION) {
         const size_t per_wave = (size_t)W * 32 * 4 + wave_scratch_bytes();
         const uint32_t wpb = pick_waves(per_wave, (const void*)k3a_union);
-        const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(32 / wpb, (150 * 1024) / (wpb * per_wave)));
-        const uint32_t grid = grid_for(n, wpb, ix->num_cus, per_cu);
+        const uint32_t grid = resident_grid(k3a_union, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
         Timed t(ix, FGPU_K_UNION);
         hipLaunchKernelGGL(k3a_union, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_nids.as<uint32_t>(),
                            res->d_npos.as<uint32_t>(), res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(),
@@ -256,7 +262,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     res->mapped = res->h_totals[1];
     res->d_colors.ensure(res->total * 4 + 16);
     if (res->total) {
-        const uint32_t grid = grid_for(n, 4, ix->num_cus, 8);
+        const uint32_t grid = resident_grid(k2b_expand, n, 4, ix->num_cus, 256, 0);
         Timed t(ix, FGPU_K_EXPAND);
         hipLaunchKernelGGL(k2b_expand, dim3(grid), dim3(256), 0, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
                            res->d_offsets.as<uint64_t>(), n, W, res->d_colors.as<uint32_t>());
@@ -406,7 +412,7 @@ void fgpu_result_free(fgpu_result* r) {
     if (!r) return;
     (void)hipSetDevice(r->ix->device);
     for (DevBuf* b : {&r->d_nids, &r->d_npos, &r->d_idoff, &r->d_ids_pool, &r->d_cnt_pool, &r->d_cursor, &r->d_bitmap,
-                      &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct})
+                      &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct, &r->d_partial})
         b->release();
     if (r->h_totals) (void)hipHostFree(r->h_totals);
     delete r;
@@ -448,10 +454,13 @@ int fgpu_result_accumulate_hits(fgpu_index* ix, const fgpu_result* r, void* devi
         if (r->n) {
             const uint32_t W = ix->dc.w32;
             const uint32_t threads = std::min<uint32_t>(256, ((W + 63) / 64) * 64);
-            const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(512, (r->n + 255) / 256));
+            const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ix->num_cus * 8, (r->n + 63) / 64));
+            const_cast<fgpu_result*>(r)->d_partial.ensure((size_t)grid * W * 32 * 4);
             Timed t(ix, FGPU_K_HITS);
-            hipLaunchKernelGGL(k_hits, dim3(grid), dim3(threads), 0, ix->stream, r->d_bitmap.as<uint32_t>(), r->n, W, ix->dc.n,
-                               (unsigned long long*)device_u64_hits);
+            hipLaunchKernelGGL(k_hits, dim3(grid), dim3(threads), 0, ix->stream, r->d_bitmap.as<uint32_t>(), r->n, W,
+                               r->d_partial.as<uint32_t>());
+            hipLaunchKernelGGL(k_hits_reduce, dim3((ix->dc.n + 255) / 256), dim3(256), 0, ix->stream, r->d_partial.as<uint32_t>(),
+                               grid, W, ix->dc.n, (unsigned long long*)device_u64_hits);
             hipLaunchKernelGGL(k_add_totals, dim3(1), dim3(64), 0, ix->stream, (unsigned long long*)device_u64_hits, ix->dc.n,
                                r->n, r->d_totals.as<uint64_t>());
             HIP_TRY(hipGetLastError());
@@ -461,12 +470,12 @@ int fgpu_result_accumulate_hits(fgpu_index* ix, const fgpu_result* r, void* devi
     });
 }
 
-int fgpu_result_algorithmic_bytes(const fgpu_result* r, uint64_t* intersect_bytes, uint64_t* lookup_bytes) {
+int fgpu_result_algorithmic_bytes(const fgpu_result* r, uint64_t* list_bytes, uint64_t* output_bytes, uint64_t* lookup_bytes) {
     if (!r) return fail(-EINVAL, "null argument");
     fgpu_index* ix = r->ix;
     return guarded([&] {
         HIP_TRY(hipSetDevice(ix->device));
-        uint64_t acct = 0;
+        uint64_t acct[2] = {0, 0};
         if (r->n) {
             const_cast<fgpu_result*>(r)->d_acct.ensure(16);
             HIP_TRY(hipMemsetAsync(r->d_acct.p, 0, 16, ix->stream));
@@ -474,10 +483,11 @@ int fgpu_result_algorithmic_bytes(const fgpu_result* r, uint64_t* intersect_byte
                                r->d_idoff.as<uint64_t>(), r->d_ids_pool.as<uint32_t>(), r->d_counts.as<uint32_t>(), r->n,
                                r->d_acct.as<unsigned long long>());
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(&acct, r->d_acct.p, 8, hipMemcpyDeviceToHost, ix->stream));
+            HIP_TRY(hipMemcpyAsync(acct, r->d_acct.p, 16, hipMemcpyDeviceToHost, ix->stream));
             HIP_TRY(hipStreamSynchronize(ix->stream));
         }
-        if (intersect_bytes) *intersect_bytes = acct;
+        if (list_bytes) *list_bytes = acct[0];
+        if (output_bytes) *output_bytes = acct[1];
         // ceil(L/4) bytes of 2-bit read + one 8-byte record per k-mer
         if (lookup_bytes) *lookup_bytes = (r->total_bases + 3) / 4 + 8 * r->total_kmers;
     });
@@ -550,21 +560,20 @@ int fgpu_fetch_color_set_ids(fgpu_index* ix, const char* bases, const uint64_t* 
         HIP_TRY(hipStreamSynchronize(ix->stream));
         if (ix->timing) ix->collect_timing();
         std::vector<uint32_t> nids(n);
-        std::vector<uint64_t> idoff(n);
-        unsigned long long used = 0;
+        const uint64_t stride = res->id_stride;
+        std::vector<uint32_t> pool(n * stride);
         if (n) {
             HIP_TRY(hipMemcpy(nids.data(), res->d_nids.p, n * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(idoff.data(), res->d_idoff.p, n * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(pool.data(), res->d_ids_pool.p, n * stride * 4, hipMemcpyDeviceToHost));
         }
-        HIP_TRY(hipMemcpy(&used, res->d_cursor.p, 8, hipMemcpyDeviceToHost));
-        std::vector<uint32_t> pool(used);
-        if (used) HIP_TRY(hipMemcpy(pool.data(), res->d_ids_pool.p, used * 4, hipMemcpyDeviceToHost));
+        uint64_t used = 0;
+        for (uint64_t r = 0; r < n; ++r) used += nids[r];
         uint64_t* o = (uint64_t*)malloc((n + 1) * 8);
         uint32_t* v = (uint32_t*)malloc(std::max<uint64_t>(1, used) * 4);
         if (!o || !v) { free(o); free(v); throw std::bad_alloc(); }
         o[0] = 0;
         for (uint64_t r = 0; r < n; ++r) {
-            memcpy(v + o[r], pool.data() + idoff[r], (size_t)nids[r] * 4);
+            memcpy(v + o[r], pool.data() + r * stride, (size_t)nids[r] * 4);
             o[r + 1] = o[r] + nids[r];
         }
         *out_offsets = o;

@@ -121,14 +121,15 @@ __device__ __forceinline__ uint32_t probe(const DevDict& d, uint64_t h, bool doA
 // ---------------------------------------------------------------------------------------------
 // K1: reads -> sorted distinct colour-set ids with multiplicities
 // ---------------------------------------------------------------------------------------------
-// Outputs per read r (relative to `first`): nids[r], npos[r] (# positive k-mers), idoff[r] (start in the
-// id pool, bump-allocated per wave), and in the pools: ids ascending + how many positive k-mers had it.
+// Outputs per read r (relative to `first`): nids[r], npos[r] (# positive k-mers), idoff[r] = r * stride
+// (fixed-stride slab: no allocation traffic between waves), and in the pools: ids ascending + how many
+// positive k-mers had each id.
 template <int KMAX>
 __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __restrict__ bases,
                                                  const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
                                                  uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
                                                  uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
-                                                 uint32_t* __restrict__ cnt_pool, unsigned long long* pool_cursor) {
+                                                 uint32_t* __restrict__ cnt_pool, uint32_t stride) {
     __shared__ uint64_t s_hash[4][80];
     __shared__ uint32_t s_ids[4][KMAX];
     __shared__ uint32_t s_uid[4][KMAX];
@@ -214,9 +215,7 @@ __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __res
             ++cnt;
         }
         wave_lds_sync();
-        unsigned long long base = 0;
-        if (lane == 0 && cnt) base = atomicAdd(pool_cursor, (unsigned long long)cnt);
-        base = __shfl(base, 0);
+        const uint64_t base = r * (uint64_t)stride;
         for (uint32_t j = lane; j < cnt; j += 64) {
             ids_pool[base + j] = uid[j];
             cnt_pool[base + j] = ucnt[j];
@@ -252,6 +251,20 @@ __device__ __forceinline__ uint32_t read_delta(const uint64_t* __restrict__ bits
     return (uint32_t)((body | (1ULL << len)) - 1ULL);
 }
 
+// Narrow form for indexes with fewer than 65536 colours: every value fits 16 bits, so a delta code is
+// at most 9 + 16 = 25 bits and a 32-bit window (one 8-byte load + v_alignbit) always holds it.
+// `base` points at the 32-bit word holding the first bit of the segment, `rel` is the bit offset from it.
+__device__ __forceinline__ uint32_t read_delta_narrow(const uint32_t* __restrict__ base, uint32_t& rel) {
+    const uint32_t* w = base + (rel >> 5);
+    const uint32_t v = __builtin_amdgcn_alignbit(w[1], w[0], rel & 31u);
+    const uint32_t z = (uint32_t)__builtin_ctz(v | 0x80000000u);
+    const uint32_t len = (__builtin_amdgcn_ubfe(v, z + 1, z) | (1u << z)) - 1u;
+    const uint32_t used = 2 * z + 1;
+    const uint32_t body = __builtin_amdgcn_ubfe(v, used, len);
+    rel += used + len;
+    return (body | (1u << len)) - 1u;
+}
+
 struct ListHeader {
     uint64_t begin, body, soff;
     uint32_t ncodes, size;
@@ -283,9 +296,18 @@ __device__ __forceinline__ void decode_segment(const DevColors& c, uint64_t begi
         prev = (uint32_t)(s >> 32);
     }
     const uint32_t nc = min(SAMPLE_STRIDE, ncodes - seg * SAMPLE_STRIDE);
-    for (uint32_t i = 0; i < nc; ++i) {
-        prev = prev + 1u + read_delta(c.bits, pos);
-        f(prev);
+    if (c.n < 65536u) {
+        const uint32_t* base = (const uint32_t*)c.bits + (pos >> 5);
+        uint32_t rel = (uint32_t)pos & 31u;
+        for (uint32_t i = 0; i < nc; ++i) {
+            prev = prev + 1u + read_delta_narrow(base, rel);
+            f(prev);
+        }
+    } else {
+        for (uint32_t i = 0; i < nc; ++i) {
+            prev = prev + 1u + read_delta(c.bits, pos);
+            f(prev);
+        }
     }
 }
 
@@ -324,9 +346,22 @@ __device__ __forceinline__ uint32_t upper_slot(const uint32_t* pref, uint32_t t)
 // K2a: full intersection of hybrid colour sets -> bitmap + cardinality
 // ---------------------------------------------------------------------------------------------
 // Semantics of `intersect` (ps_full_intersection.cpp:32-127): the result is the set intersection of the
-// given lists. Here: R = all colours; complemented lists clear their missing colours (all their gap
-// segments run concurrently across lanes); bitmap lists are ANDed word-wise; each sparse list is
-// decoded into T and ANDed.
+// given lists. Here, per read (one wave):
+//   R = all colours (n-bit bitmap in LDS)
+//   bitmap lists      : R &= list, word-wise
+//   complemented lists: every missing colour clears its bit in R            (ds_and)
+//   sparse lists      : every member bumps a per-colour byte counter        (ds_add); afterwards
+//                       R &= {c : counter[c] == number of sparse lists}
+// All gap-coded lists of a read are cut into SAMPLE_STRIDE-code segments (restart samples built at
+// load) and ALL segments of ALL lists are decoded concurrently, one segment per lane.
+__device__ __forceinline__ uint32_t bytes_equal_mask4(uint32_t x, uint32_t pattern) {
+    // 4 byte lanes of x compared with the same lanes of pattern -> 4-bit mask (bit b = byte b equal)
+    const uint32_t y = x ^ pattern;
+    uint32_t t = (y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    t = ~(t | y | 0x7F7F7F7Fu);            // 0x80 in every byte of y that is zero
+    return ((t >> 7) * 0x00204081u >> 21) & 0xFu;
+}
+
 __global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint32_t* __restrict__ nids,
                                                      const uint64_t* __restrict__ idoff,
                                                      const uint32_t* __restrict__ ids_pool, uint64_t n_reads,
@@ -334,12 +369,15 @@ __global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint32_t
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = c.w32;
-    const uint32_t per_wave = 2 * W * 4 + wave_scratch_bytes();
+    const uint32_t per_wave = W * 4 + W * 32 + wave_scratch_bytes();
     unsigned char* mine = smem + (size_t)wv * per_wave;
     WaveScratch sc = carve_scratch(mine);
     uint32_t* R = (uint32_t*)(mine + wave_scratch_bytes());
-    uint32_t* T = R + W;
+    uint32_t* CNT = R + W;  // W*8 words: one byte counter per colour
     const uint64_t total_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+
+    for (uint32_t w = lane; w < W * 8; w += 64) CNT[w] = 0;
+    wave_lds_sync();
 
     for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wv; r < n_reads; r += total_waves) {
         const uint32_t cnt = nids[r];
@@ -354,18 +392,23 @@ __global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint32_t
             const uint32_t lo = w * 32;
             R[w] = lo >= c.n ? 0u : (c.n - lo >= 32 ? 0xFFFFFFFFu : ((1u << (c.n - lo)) - 1u));
         }
+        uint32_t sparse_pending = 0;  // sparse lists counted in CNT and not yet folded into R
         for (uint32_t g = 0; g < cnt; g += 64) {
             ListHeader h;
             h.type = D_ENC_NONE; h.ncodes = 0; h.begin = h.body = h.soff = 0; h.size = 0;
             if (g + lane < cnt) h = read_header(c, ids_pool[off + g + lane]);
             const uint32_t nseg = (h.ncodes + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
             sc.h_begin[lane] = h.begin; sc.h_body[lane] = h.body; sc.h_soff[lane] = h.soff; sc.h_ncodes[lane] = h.ncodes;
-            const uint32_t incl = wave_incl_scan_u32(h.type == D_ENC_COMPLEMENT ? nseg : 0u);
+            sc.h_score[lane] = h.type;
+            const uint32_t incl = wave_incl_scan_u32(nseg);  // bitmap lists have ncodes = 0
             sc.pref[lane] = incl;
             const uint32_t total_seg = (uint32_t)__shfl((int)incl, 63);
+            const uint32_t sparse_here = __popcll(__ballot(h.type == D_ENC_DELTA_GAPS));
+            // exactly one sparse list in the whole read: a plain bitmap T (aliasing the counters) is enough
+            const bool single_sparse = sparse_here == 1 && sparse_pending == 0 && g + 64 >= cnt;
+            if (!single_sparse) sparse_pending += sparse_here;
             wave_lds_sync();
 
-            // bitmap lists: word-wise AND
             uint64_t mb = __ballot(h.type == D_ENC_BITMAP);
             while (mb) {
                 const int src = __builtin_ctzll(mb);
@@ -375,7 +418,6 @@ __global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint32_t
             }
             wave_lds_sync();
 
-            // complemented lists: all segments of all lists, one per lane
             for (uint32_t t0 = 0; t0 < total_seg; t0 += 64) {
                 const uint32_t t = t0 + lane;
                 if (t < total_seg) {
@@ -383,26 +425,36 @@ __global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint32_t
                     const uint32_t nc = sc.h_ncodes[i];
                     const uint32_t ns = (nc + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
                     const uint32_t seg = t - (sc.pref[i] - ns);
-                    decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg,
-                                   [&](uint32_t v) { atomicAnd(&R[v >> 5], ~(1u << (v & 31))); });
+                    if (sc.h_score[i] == D_ENC_COMPLEMENT)
+                        decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg,
+                                       [&](uint32_t v) { atomicAnd(&R[v >> 5], ~(1u << (v & 31))); });
+                    else if (single_sparse)
+                        decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg,
+                                       [&](uint32_t v) { atomicOr(&CNT[v >> 5], 1u << (v & 31)); });
+                    else
+                        decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg,
+                                       [&](uint32_t v) { atomicAdd(&CNT[v >> 2], 1u << (8 * (v & 3))); });
                 }
             }
             wave_lds_sync();
+            if (single_sparse) {
+                for (uint32_t w = lane; w < W; w += 64) { R[w] &= CNT[w]; CNT[w] = 0; }
+                wave_lds_sync();
+            }
 
-            // sparse lists, one at a time: T = list, R &= T
-            uint64_t ms = __ballot(h.type == D_ENC_DELTA_GAPS);
-            while (ms) {
-                const int src = __builtin_ctzll(ms);
-                ms &= ms - 1;
-                for (uint32_t w = lane; w < W; w += 64) T[w] = 0;
-                wave_lds_sync();
-                const uint32_t nc = sc.h_ncodes[src];
-                const uint32_t ns = (nc + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
-                for (uint32_t seg = lane; seg < ns; seg += 64)
-                    decode_segment(c, sc.h_begin[src], sc.h_body[src], sc.h_soff[src], nc, seg,
-                                   [&](uint32_t v) { atomicOr(&T[v >> 5], 1u << (v & 31)); });
-                wave_lds_sync();
-                for (uint32_t w = lane; w < W; w += 64) R[w] &= T[w];
+            // fold the byte counters into R before they could overflow, and at the end
+            if (sparse_pending && (g + 64 >= cnt || sparse_pending > 255 - 64)) {
+                const uint32_t pattern = sparse_pending * 0x01010101u;
+                for (uint32_t w = lane; w < W; w += 64) {
+                    uint32_t m = 0;
+#pragma unroll
+                    for (uint32_t q = 0; q < 8; ++q) {
+                        m |= bytes_equal_mask4(CNT[w * 8 + q], pattern) << (4 * q);
+                        CNT[w * 8 + q] = 0;
+                    }
+                    R[w] &= m;
+                }
+                sparse_pending = 0;
                 wave_lds_sync();
             }
         }
@@ -627,25 +679,42 @@ __global__ __launch_bounds__(256) void k2b_expand(const uint32_t* __restrict__ b
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-colour hit counts: hits[c] += #reads of the batch whose result contains c
+// per-colour hit counts: hits[c] += #reads of the batch whose result contains c.
+// Stage 1: each block sums its slice of reads into partial[block][W*32] (thread = one 32-colour word,
+// 32 register counters, 4 reads in flight). Stage 2: column sums of the partials into the u64 totals.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_hits(const uint32_t* __restrict__ bitmap, uint64_t n_reads, uint32_t W, uint32_t n,
-                       unsigned long long* __restrict__ hits) {
+__global__ void k_hits(const uint32_t* __restrict__ bitmap, uint64_t n_reads, uint32_t W, uint32_t* __restrict__ partial) {
     const uint64_t per_block = (n_reads + gridDim.x - 1) / gridDim.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * per_block, r1 = min(n_reads, r0 + per_block);
     for (uint32_t w = threadIdx.x; w < W; w += blockDim.x) {
         uint32_t acc[32];
 #pragma unroll
         for (int b = 0; b < 32; ++b) acc[b] = 0;
-        for (uint64_t r = r0; r < r1; ++r) {
+        uint64_t r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            const uint32_t x0 = bitmap[r * W + w], x1 = bitmap[(r + 1) * W + w], x2 = bitmap[(r + 2) * W + w],
+                           x3 = bitmap[(r + 3) * W + w];
+#pragma unroll
+            for (int b = 0; b < 32; ++b) acc[b] += ((x0 >> b) & 1u) + ((x1 >> b) & 1u) + ((x2 >> b) & 1u) + ((x3 >> b) & 1u);
+        }
+        for (; r < r1; ++r) {
             const uint32_t x = bitmap[r * W + w];
 #pragma unroll
             for (int b = 0; b < 32; ++b) acc[b] += (x >> b) & 1u;
         }
+        uint32_t* dst = partial + ((uint64_t)blockIdx.x * W + w) * 32;
 #pragma unroll
-        for (int b = 0; b < 32; ++b)
-            if (acc[b] && w * 32 + b < n) atomicAdd(&hits[w * 32 + b], (unsigned long long)acc[b]);
+        for (int b = 0; b < 32; ++b) dst[b] = acc[b];
     }
+}
+
+__global__ void k_hits_reduce(const uint32_t* __restrict__ partial, uint32_t nblocks, uint32_t W, uint32_t n,
+                              unsigned long long* __restrict__ hits) {
+    const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= n) return;
+    unsigned long long s = 0;
+    for (uint32_t b = 0; b < nblocks; ++b) s += partial[(uint64_t)b * W * 32 + col];
+    hits[col] += s;
 }
 
 __global__ void k_add_totals(unsigned long long* hits, uint32_t n, uint64_t num_reads, const uint64_t* totals) {
@@ -663,18 +732,22 @@ __global__ __launch_bounds__(256) void k_account(DevColors c, const uint32_t* __
                                                  const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
                                                  const uint32_t* __restrict__ counts, uint64_t n_reads,
                                                  unsigned long long* __restrict__ out) {
-    uint64_t acc = 0;
+    uint64_t in_bytes = 0, out_bytes = 0;  // out[0]: list side (lists + offsets + ids), out[1]: result side
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t cnt = nids[r];
         const uint64_t off = idoff[r];
         for (uint32_t i = 0; i < cnt; ++i) {
             const uint32_t id = ids_pool[off + i];
-            acc += (c.offsets[id + 1] - c.offsets[id] + 7) / 8;
+            in_bytes += (c.offsets[id + 1] - c.offsets[id] + 7) / 8;
         }
-        acc += 20ull * cnt + 4ull * counts[r] + 8;
+        in_bytes += 20ull * cnt;
+        out_bytes += 4ull * counts[r] + 8;
     }
-    for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane_id() == 0 && acc) atomicAdd(out, (unsigned long long)acc);
+    for (int o = 32; o; o >>= 1) { in_bytes += __shfl_xor(in_bytes, o); out_bytes += __shfl_xor(out_bytes, o); }
+    if (lane_id() == 0) {
+        if (in_bytes) atomicAdd(out, (unsigned long long)in_bytes);
+        if (out_bytes) atomicAdd(out + 1, (unsigned long long)out_bytes);
+    }
 }
 
 }  // namespace fg

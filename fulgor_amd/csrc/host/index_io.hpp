@@ -113,7 +113,7 @@ inline void load_dump(const std::string& base, HostIndex& idx, uint32_t m = 0, u
 
 // ---- own binary container ------------------------------------------------------------------------
 namespace detail {
-static const char FGIDX_MAGIC[8] = {'F', 'G', 'I', 'D', 'X', '0', '0', '1'};
+static const char FGIDX_MAGIC[8] = {'F', 'G', 'I', 'D', 'X', '0', '0', '2'};  // 002: decoder samples rebuilt at load
 template <typename T>
 void wr(std::ofstream& o, const T& v) { o.write(reinterpret_cast<const char*>(&v), sizeof(T)); }
 template <typename T>
@@ -152,7 +152,7 @@ inline void save_binary(const HostIndex& idx, const std::string& path) {
     wrv(o, d.unitig_off); wrv(o, d.unitig_csid);
     const HybridSets& h = idx.hybrid;
     wr(o, h.num_colors); wr(o, h.sparse_thr); wr(o, h.dense_thr); wr(o, h.nbits);
-    wrv(o, h.offsets); wrv(o, h.bits); wrv(o, h.sample_off); wrv(o, h.samples);
+    wrv(o, h.offsets); wrv(o, h.bits);  // restart samples are an acceleration structure: rebuilt at load
     uint64_t nf = idx.filenames.size();
     wr(o, nf);
     for (auto& f : idx.filenames) {
@@ -179,7 +179,8 @@ inline void load_binary(const std::string& path, HostIndex& idx) {
     rdv(i, d.unitig_off); rdv(i, d.unitig_csid);
     HybridSets& h = idx.hybrid;
     rd(i, h.num_colors); rd(i, h.sparse_thr); rd(i, h.dense_thr); rd(i, h.nbits);
-    rdv(i, h.offsets); rdv(i, h.bits); rdv(i, h.sample_off); rdv(i, h.samples);
+    rdv(i, h.offsets); rdv(i, h.bits);
+    hybrid_build_samples(h);
     uint64_t nf;
     rd(i, nf);
     idx.filenames.clear();

@@ -88,9 +88,9 @@ class Result:
         _native.check(self._L.fgpu_result_accumulate_hits(self.index._h, self._h, C.c_void_p(device_ptr)))
 
     def algorithmic_bytes(self):
-        a, b = C.c_uint64(), C.c_uint64()
-        _native.check(self._L.fgpu_result_algorithmic_bytes(self._h, C.byref(a), C.byref(b)))
-        return a.value, b.value
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _native.check(self._L.fgpu_result_algorithmic_bytes(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"lists": a.value, "output": b.value, "lookup": c.value}
 
     def close(self):
         if self._h:

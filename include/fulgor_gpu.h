@@ -86,8 +86,12 @@ int fgpu_result_download(const fgpu_result* res, uint64_t* offsets /* n+1 */, ui
 /* adds this result's per-colour hit counts (#reads whose result contains colour c) followed by
  * {num_reads, num_mapped} into a DEVICE array of num_colors+2 uint64 (the vector RCCL all-reduces) */
 int fgpu_result_accumulate_hits(fgpu_index* idx, const fgpu_result* res, void* device_u64_hits);
-/* algorithmic bytes of the last run: colour-intersection stage and lookup stage */
-int fgpu_result_algorithmic_bytes(const fgpu_result* res, uint64_t* intersect_bytes, uint64_t* lookup_bytes);
+/* algorithmic bytes of the last run. Colour-intersection stage, per read:
+ *   list side   = sum over its colour-set ids of ceil(list bits / 8) + 16 (two offsets) + 4 (the id)
+ *   output side = 4 * |result| + 8 (CSR offset)
+ * lookup stage = ceil(bases / 4) + 8 per k-mer */
+int fgpu_result_algorithmic_bytes(const fgpu_result* res, uint64_t* list_bytes, uint64_t* output_bytes,
+                                  uint64_t* lookup_bytes);
 
 /* per-kernel HIP-event timing on the engine's stream */
 enum { FGPU_K_LOOKUP = 0, FGPU_K_INTERSECT = 1, FGPU_K_UNION = 2, FGPU_K_SCAN = 3, FGPU_K_EXPAND = 4,

@@ -159,3 +159,55 @@ def test_gpu_hit_counts(s10_gpu, seeded_reads):
     got = hits.cpu().numpy()
     assert np.array_equal(got[:n], 2 * want)
     assert got[n] == 2 * 50000 and got[n + 1] == 2 * int((np.diff(go.astype(np.int64)) > 0).sum())
+
+
+# ---- synthetic salmonella_4546-shaped index (n = 4546: sparse, bitmap and complement lists of real size) ----
+@pytest.fixture(scope="module")
+def s4546(built):
+    import os
+    from conftest import DATA
+    from fulgor_amd import synth
+    from fulgor_amd.reads import ReadGenerator
+    from oracle.pyoracle import OracleIndex
+    fg, extra = synth.ensure_s4546(DATA, S10_GENOMES)
+    ix = fulgor_amd.Index(fg, device=0)
+    orc = OracleIndex.from_export(ix.export())  # raises if a k-mer occurs in two unitigs
+    gen = ReadGenerator(S10_GENOMES, raw_sequences=extra)
+    return ix, orc, gen
+
+
+def test_s4546_full_intersection_equals_oracle(s4546):
+    ix, orc, gen = s4546
+    b, o = gen.generate(0, 30000, 150, 42)
+    go, gc = ix.pseudoalign_full_intersection_batch(b, o)
+    oo, oc = orc.full_intersection(b, o, threads=32)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+    orc.full_intersection(b[:150 * 500], o[:501], threads=8, self_check=True)  # restatement vs check_intersection
+    i1, d1 = ix.fetch_color_set_ids_batch(b, o)
+    i2, d2 = orc.fetch_color_set_ids(b, o, threads=32)
+    assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+
+
+@pytest.mark.parametrize("tau", [0.8, 0.3, 1.0])
+def test_s4546_threshold_union_equals_oracle(s4546, tau):
+    ix, orc, gen = s4546
+    b, o = gen.generate(100000, 20000, 150, 42)
+    go, gc = ix.pseudoalign_threshold_union_batch(b, o, tau)
+    oo, oc = orc.threshold_union(b, o, tau, threads=32)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+    orc.threshold_union(b[:150 * 300], o[:301], tau, threads=8, self_check=True)
+
+
+def test_s4546_random_id_lists(s4546):
+    """intersections of arbitrary colour-set ids: many sparse lists, > 64 lists per read, all encodings"""
+    ix, orc, _ = s4546
+    rng = np.random.default_rng(11)
+    ns = ix.num_color_sets()
+    lens = np.concatenate([rng.integers(0, 12, size=1500), rng.integers(60, 140, size=40)])
+    lists = [np.unique(rng.integers(0, ns, size=l)).astype(np.uint32) for l in lens]
+    ido = np.zeros(len(lists) + 1, dtype=np.uint64)
+    ido[1:] = np.cumsum([len(l) for l in lists])
+    ids = np.concatenate(lists)
+    go, gc = ix.intersect_ids_batch(ids, ido)
+    oo, oc = orc.intersect_ids(ids, ido, threads=32, self_check=True)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
