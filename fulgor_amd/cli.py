@@ -1,0 +1,69 @@
+"""`fulgor pseudoalign`-compatible command line (tools/pseudoalign.cpp:228-369): same flags, same exit
+codes, same summary lines; the index argument is a dump basename or an .fgidx container."""
+import argparse
+import sys
+import time
+
+from . import driver
+from .index import FULL_INTERSECTION, THRESHOLD_UNION, Index, pack_reads
+from .reads import parse_fastx
+
+
+def pseudoalign(argv):
+    ap = argparse.ArgumentParser(prog="fulgor pseudoalign", add_help=True)
+    ap.add_argument("-i", dest="index_filename", required=True, help="The Fulgor index (dump basename or .fgidx).")
+    ap.add_argument("-q", dest="query_filename", required=True, help="Query filename in FASTA/FASTQ format (optionally gzipped).")
+    ap.add_argument("-o", dest="output_filename", required=True, help="File where output will be written.")
+    ap.add_argument("-t", dest="num_threads", type=int, default=1, help="Accepted for compatibility; reads are batched on the GPU.")
+    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("-r", dest="threshold", type=float, default=None,
+                    help="Threshold for threshold_union algorithm. It must be a float in (0.0,1.0].")
+    ap.add_argument("--deduplicate", action="store_true")
+    ap.add_argument("--format", dest="format", default="ascii")
+    ap.add_argument("--device", type=int, default=0)
+    try:
+        a = ap.parse_args(argv)
+    except SystemExit:
+        return 1
+    algo = FULL_INTERSECTION
+    if a.threshold is not None:
+        if a.threshold <= 0.0 or a.threshold > 1.0:
+            print("threshold must be a float in (0.0,1.0]", file=sys.stderr)  # tools/pseudoalign.cpp:275-278
+            return 1
+        if a.deduplicate:
+            print("Deduplication not available for threshold < 1.0. Remove --deduplicate flag.", file=sys.stderr)
+            return 1
+        algo = THRESHOLD_UNION
+    if a.format not in ("ascii", "binary"):
+        # the compressed formatter (src/ps_utils.cpp:138-243) is not implemented yet
+        print("Unknown output format. Supported formats: ascii, binary.")
+        return 1
+    if a.verbose:
+        print(" ".join(["fulgor", "pseudoalign"] + list(argv)))
+    t0 = time.time()
+    try:
+        index = Index(a.index_filename, device=a.device)
+    except RuntimeError as e:
+        print(str(e), file=sys.stderr)
+        return 1
+    seqs = parse_fastx(a.query_filename)  # read id = 0-based file order (src/ps_utils.cpp:276,286)
+    bases, offs = pack_reads(seqs)
+    t1 = time.time()
+    with open(a.output_filename, "wb") as out:
+        # --deduplicate changes how work is scheduled in the reference, not the output; every read is
+        # answered directly here
+        n, mapped = driver.pseudoalign_reads(index, bases, offs, algo, a.threshold or 0.0, sink=out, fmt=a.format)
+    el = (time.time() - t1) * 1000.0
+    if a.verbose:  # tools/pseudoalign.cpp:79-88
+        print("processed %d reads" % n)
+        print("elapsed = %d millisec / %d sec / %d min / %g musec/read" % (el, el / 1000, el / 60000, el * 1000 / max(1, n)))
+        print("num_mapped_reads %d/%d (%g%%)" % (mapped, n, mapped * 100.0 / max(1, n)))
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv or argv[0] != "pseudoalign":
+        print("usage: python -m fulgor_amd pseudoalign -i <index> -q <reads> -o <out> [-r tau] [--format ascii|binary] [--verbose]")
+        return 1
+    return pseudoalign(argv[1:])

@@ -58,6 +58,8 @@ void upload(DevBuf& b, const std::vector<T>& v, hipStream_t s) {
     if (!v.empty()) HIP_TRY(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
 }
 
+constexpr size_t TICKET_BYTES = 3 * 8 * TICKET_STRIDE * sizeof(unsigned int);
+
 const char* KERNEL_NAMES[FGPU_K_COUNT] = {"k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits"};
 
 }  // namespace
@@ -122,7 +124,7 @@ struct fgpu_reads {
 struct fgpu_result {
     fgpu_index* ix = nullptr;
     DevBuf d_nids, d_npos, d_idoff, d_ids_pool, d_cnt_pool, d_cursor, d_bitmap, d_counts, d_offsets, d_block_sums,
-        d_block_mapped, d_totals, d_colors, d_acct, d_partial;
+        d_block_mapped, d_totals, d_colors, d_acct, d_partial, d_tickets;
     uint64_t* h_totals = nullptr;  // pinned {total colours, mapped reads, ids used}
     uint64_t n = 0, total = 0, mapped = 0, total_kmers = 0, total_bases = 0;
     uint32_t id_stride = 0;
@@ -183,6 +185,8 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     res->d_nids.ensure(count * 4 + 16);
     res->d_npos.ensure(count * 4 + 16);
     res->d_idoff.ensure(count * 8 + 16);
+    res->d_tickets.ensure(TICKET_BYTES);  // 8 padded work counters for each persistent launch of a pass
+    HIP_TRY(hipMemsetAsync(res->d_tickets.p, 0, TICKET_BYTES, s));
     const uint32_t stride = std::max<uint32_t>(1, rd->max_kmers);  // at most one id per k-mer
     res->id_stride = stride;
     res->d_ids_pool.ensure(count * (uint64_t)stride * 4 + 16);
@@ -196,12 +200,12 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
         hipLaunchKernelGGL(k1_lookup<128>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
                            rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
                            res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
-                           stride);
+                           stride, res->d_tickets.as<unsigned int>());
     } else {
         hipLaunchKernelGGL(k1_lookup<1024>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
                            rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
                            res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
-                           stride);
+                           stride, res->d_tickets.as<unsigned int>());
     }
     HIP_TRY(hipGetLastError());
     res->have_ids = true;
@@ -232,7 +236,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         Timed t(ix, FGPU_K_INTERSECT);
         hipLaunchKernelGGL(k2a_intersect, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_nids.as<uint32_t>(),
                            res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), n, res->d_bitmap.as<uint32_t>(),
-                           res->d_counts.as<uint32_t>());
+                           res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
         HIP_TRY(hipGetLastError());
     } else if (algo == FGPU_THRESHOLD_UNION) {
         const size_t per_wave = (size_t)W * 32 * 4 + wave_scratch_bytes();
@@ -241,7 +245,8 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         Timed t(ix, FGPU_K_UNION);
         hipLaunchKernelGGL(k3a_union, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_nids.as<uint32_t>(),
                            res->d_npos.as<uint32_t>(), res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(),
-                           res->d_cnt_pool.as<uint32_t>(), tau, n, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>());
+                           res->d_cnt_pool.as<uint32_t>(), tau, n, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
+                           res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
         HIP_TRY(hipGetLastError());
     } else {
         throw std::runtime_error("unknown algorithm");
@@ -265,7 +270,8 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         const uint32_t grid = resident_grid(k2b_expand, n, 4, ix->num_cus, 256, 0);
         Timed t(ix, FGPU_K_EXPAND);
         hipLaunchKernelGGL(k2b_expand, dim3(grid), dim3(256), 0, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
-                           res->d_offsets.as<uint64_t>(), n, W, res->d_colors.as<uint32_t>());
+                           res->d_offsets.as<uint64_t>(), n, W, res->d_colors.as<uint32_t>(),
+                           res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(s));
@@ -412,7 +418,7 @@ void fgpu_result_free(fgpu_result* r) {
     if (!r) return;
     (void)hipSetDevice(r->ix->device);
     for (DevBuf* b : {&r->d_nids, &r->d_npos, &r->d_idoff, &r->d_ids_pool, &r->d_cnt_pool, &r->d_cursor, &r->d_bitmap,
-                      &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct, &r->d_partial})
+                      &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct, &r->d_partial, &r->d_tickets})
         b->release();
     if (r->h_totals) (void)hipHostFree(r->h_totals);
     delete r;
@@ -612,6 +618,8 @@ int fgpu_intersect_ids(fgpu_index* ix, const uint32_t* ids, const uint64_t* id_o
             HIP_TRY(hipMemcpy(res->d_idoff.p, id_offs, n * 8, hipMemcpyHostToDevice));
         }
         if (id_offs[n]) HIP_TRY(hipMemcpy(res->d_ids_pool.p, ids, id_offs[n] * 4, hipMemcpyHostToDevice));
+        res->d_tickets.ensure(TICKET_BYTES);
+        HIP_TRY(hipMemsetAsync(res->d_tickets.p, 0, TICKET_BYTES, ix->stream));
         stage_colors(ix, FGPU_FULL_INTERSECTION, 0.0, res);
         uint64_t* o = (uint64_t*)malloc((n + 1) * 8);
         uint32_t* c = (uint32_t*)malloc(std::max<uint64_t>(1, res->total) * 4);

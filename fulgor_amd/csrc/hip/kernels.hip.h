@@ -72,6 +72,30 @@ __device__ __forceinline__ uint32_t mask_rank(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// Dynamic work distribution for the persistent one-wave-per-read kernels. The batch is cut into 8
+// static partitions (label = blockIdx & 7, which the dispatcher happens to place on one XCD each; only
+// speed depends on that) and every wave pulls `batch` reads at a time from its partition's
+// counter. No tail from uneven reads or from a grid larger than what is actually resident.
+constexpr uint32_t TICKET_STRIDE = 64;  // counters live 256 bytes apart (separate L2 channels)
+struct WorkQueue {
+    unsigned int* counters;  // 8 * TICKET_STRIDE words, zeroed before every launch
+    uint64_t n;
+    uint32_t batch;          // reads per pull
+    __device__ __forceinline__ bool pull(uint64_t& first, uint32_t& count) const {
+        const uint32_t parts = min(8u, gridDim.x);
+        const uint32_t part = blockIdx.x % parts;
+        const uint64_t per = (n + parts - 1) / parts;
+        const uint64_t lo = min(n, part * per), hi = min(n, lo + per);
+        unsigned int t = 0;
+        if (lane_id() == 0) t = atomicAdd(&counters[part * TICKET_STRIDE], batch);
+        t = __builtin_amdgcn_readfirstlane(t);
+        first = lo + t;
+        if (first >= hi) return false;
+        count = (uint32_t)min((uint64_t)batch, hi - first);
+        return true;
+    }
+};
+
 // bits [off, off+L) of the 128-bit value B:A (off in [0,63], L <= 32)
 __device__ __forceinline__ uint32_t extract128(uint64_t A, uint64_t B, uint32_t off, uint32_t L) {
     uint64_t v = off ? ((A >> off) | (B << (64 - off))) : A;
@@ -129,7 +153,7 @@ __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __res
                                                  const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
                                                  uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
                                                  uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
-                                                 uint32_t* __restrict__ cnt_pool, uint32_t stride) {
+                                                 uint32_t* __restrict__ cnt_pool, uint32_t stride, unsigned int* tickets) {
     __shared__ uint64_t s_hash[4][80];
     __shared__ uint32_t s_ids[4][KMAX];
     __shared__ uint32_t s_uid[4][KMAX];
@@ -140,9 +164,12 @@ __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __res
     uint32_t* uid = s_uid[wv];
     uint32_t* ucnt = s_ucnt[wv];
     const uint32_t k = d.k, m = d.m, W = k - m + 1;
-    const uint64_t total_waves = (uint64_t)gridDim.x * 4;
+    const WorkQueue wq{tickets, n_reads, 8};
+    uint64_t t_first;
+    uint32_t t_count;
 
-    for (uint64_t r = (uint64_t)blockIdx.x * 4 + wv; r < n_reads; r += total_waves) {
+    while (wq.pull(t_first, t_count))
+    for (uint64_t r = t_first; r < t_first + t_count; ++r) {
         const uint64_t rb = offs[first + r];
         const uint32_t len = (uint32_t)(offs[first + r + 1] - rb);
         const uint32_t nk = len >= k ? min(len - k + 1, (uint32_t)KMAX) : 0;  // host guarantees <= KMAX
@@ -193,32 +220,80 @@ __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __res
             loA = loB; hiA = hiB; nvA = nvB;
         }
 
-        // sort + unique + count by repeated minimum extraction (typically < 10 distinct ids per read)
-        uint32_t cnt = 0, positives = 0;
-        uint32_t last = 0;
-        bool have_last = false;
-        for (;;) {
-            uint32_t lm = NEG;
-            for (uint32_t i = lane; i < nk; i += 64) {
-                uint32_t v = ids[i];
-                if (v != NEG && (!have_last || v > last)) lm = min(lm, v);
+        // ---- sorted distinct ids + multiplicities -------------------------------------------------
+        // Consecutive k-mers mostly sit on the same unitig, so first compress runs: a "head" is a positive
+        // k-mer whose id differs from its left neighbour (or that starts a 64-lane chunk); heads and run
+        // lengths are compacted into LDS with ballot + mbcnt. Typically < 12 heads per read.
+        uint32_t H = 0, positives = 0;
+        for (uint32_t b0 = 0; b0 < nk; b0 += 64) {
+            const uint32_t i = b0 + lane;
+            const uint32_t clen = min(64u, nk - b0);
+            const uint32_t v = i < nk ? ids[i] : NEG;
+            const uint32_t pv = (lane > 0 && i < nk) ? ids[i - 1] : NEG;
+            const bool change = lane == 0 || v != pv || (uint32_t)lane >= clen;
+            const uint64_t C = __ballot(change);
+            const bool head = v != NEG && change;
+            const uint64_t Hm = __ballot(head);
+            positives += __popcll(__ballot(v != NEG));
+            const uint64_t rest = lane == 63 ? 0ull : (C >> (lane + 1));
+            const uint32_t next = rest ? (uint32_t)__builtin_ctzll(rest) + lane + 1 : 64u;
+            if (head && H + mask_rank(Hm) < (uint32_t)KMAX) {
+                uid[H + mask_rank(Hm)] = v;
+                ucnt[H + mask_rank(Hm)] = min(next, clen) - lane;
             }
-            const uint32_t wm = wave_min_u32(lm);
-            if (wm == NEG) break;
-            uint32_t c = 0;
-            for (uint32_t i = lane; i < nk; i += 64) c += (ids[i] == wm);
-            c = wave_sum_u32(c);
-            if (lane == 0) { uid[cnt] = wm; ucnt[cnt] = c; }
-            positives += c;
-            last = wm;
-            have_last = true;
-            ++cnt;
+            H += __popcll(Hm);
         }
         wave_lds_sync();
+        uint32_t cnt = 0;
         const uint64_t base = r * (uint64_t)stride;
-        for (uint32_t j = lane; j < cnt; j += 64) {
-            ids_pool[base + j] = uid[j];
-            cnt_pool[base + j] = ucnt[j];
+        if (H <= 64) {
+            // lane j owns head j: total multiplicity of its id, whether it is the first head with that id,
+            // and its rank among the distinct ids
+            const uint32_t vj = (uint32_t)lane < H ? uid[lane] : NEG;
+            uint32_t total = 0;
+            bool first = (uint32_t)lane < H;
+            for (uint32_t i = 0; i < H; ++i) {
+                const uint32_t vi = uid[i], li = ucnt[i];
+                if (vi == vj) {
+                    total += li;
+                    if (i < (uint32_t)lane) first = false;
+                }
+            }
+            uint64_t reps = __ballot(first);
+            cnt = __popcll(reps);
+            uint32_t pos = 0;
+            while (reps) {
+                const int i = __builtin_ctzll(reps);
+                reps &= reps - 1;
+                pos += uid[i] < vj;
+            }
+            if (first) {
+                ids_pool[base + pos] = vj;
+                cnt_pool[base + pos] = total;
+            }
+        } else {
+            // many heads (only possible for long or very fragmented reads): repeated minimum extraction
+            uint32_t last = 0;
+            bool have_last = false;
+            for (;;) {
+                uint32_t lm = NEG;
+                for (uint32_t i = lane; i < nk; i += 64) {
+                    uint32_t v = ids[i];
+                    if (v != NEG && (!have_last || v > last)) lm = min(lm, v);
+                }
+                const uint32_t wm = wave_min_u32(lm);
+                if (wm == NEG) break;
+                uint32_t c = 0;
+                for (uint32_t i = lane; i < nk; i += 64) c += (ids[i] == wm);
+                c = wave_sum_u32(c);
+                if (lane == 0) {
+                    ids_pool[base + cnt] = wm;
+                    cnt_pool[base + cnt] = c;
+                }
+                last = wm;
+                have_last = true;
+                ++cnt;
+            }
         }
         if (lane == 0) {
             nids[r] = cnt;
@@ -251,19 +326,38 @@ __device__ __forceinline__ uint32_t read_delta(const uint64_t* __restrict__ bits
     return (uint32_t)((body | (1ULL << len)) - 1ULL);
 }
 
-// Narrow form for indexes with fewer than 65536 colours: every value fits 16 bits, so a delta code is
-// at most 9 + 16 = 25 bits and a 32-bit window (one 8-byte load + v_alignbit) always holds it.
-// `base` points at the 32-bit word holding the first bit of the segment, `rel` is the bit offset from it.
-__device__ __forceinline__ uint32_t read_delta_narrow(const uint32_t* __restrict__ base, uint32_t& rel) {
-    const uint32_t* w = base + (rel >> 5);
-    const uint32_t v = __builtin_amdgcn_alignbit(w[1], w[0], rel & 31u);
-    const uint32_t z = (uint32_t)__builtin_ctz(v | 0x80000000u);
-    const uint32_t len = (__builtin_amdgcn_ubfe(v, z + 1, z) | (1u << z)) - 1u;
-    const uint32_t used = 2 * z + 1;
-    const uint32_t body = __builtin_amdgcn_ubfe(v, used, len);
-    rel += used + len;
-    return (body | (1u << len)) - 1u;
-}
+// Narrow form for indexes with fewer than 65536 colours: every value fits 16 bits, so a delta code is at
+// most 9 + 16 = 25 bits. The decoder keeps a 64-bit bit buffer in registers and refills it 32 bits at a
+// time from a word that was requested one refill earlier, so the load latency overlaps with decoding.
+struct NarrowReader {
+    const uint32_t* p;  // next word to request
+    uint64_t buf;
+    uint32_t have;      // valid bits in buf
+    uint32_t nxt;       // prefetched word (the one before p)
+    __device__ __forceinline__ void init(const uint32_t* __restrict__ bits32, uint64_t pos) {
+        const uint32_t* w = bits32 + (pos >> 5);
+        const uint32_t sh = (uint32_t)pos & 31u;
+        buf = (((uint64_t)w[1] << 32) | w[0]) >> sh;
+        have = 64 - sh;
+        nxt = w[2];
+        p = w + 3;
+    }
+    __device__ __forceinline__ uint32_t delta() {
+        if (have < 32) {
+            buf |= (uint64_t)nxt << have;
+            have += 32;
+            nxt = *p++;
+        }
+        const uint32_t v = (uint32_t)buf;
+        const uint32_t z = (uint32_t)__builtin_ctz(v | 0x80000000u);
+        const uint32_t len = (__builtin_amdgcn_ubfe(v, z + 1, z) | (1u << z)) - 1u;
+        const uint32_t used = 2 * z + 1;
+        const uint32_t body = __builtin_amdgcn_ubfe(v, used, len);
+        buf >>= used + len;
+        have -= used + len;
+        return (body | (1u << len)) - 1u;
+    }
+};
 
 struct ListHeader {
     uint64_t begin, body, soff;
@@ -297,10 +391,10 @@ __device__ __forceinline__ void decode_segment(const DevColors& c, uint64_t begi
     }
     const uint32_t nc = min(SAMPLE_STRIDE, ncodes - seg * SAMPLE_STRIDE);
     if (c.n < 65536u) {
-        const uint32_t* base = (const uint32_t*)c.bits + (pos >> 5);
-        uint32_t rel = (uint32_t)pos & 31u;
+        NarrowReader rd;
+        rd.init((const uint32_t*)c.bits, pos);
         for (uint32_t i = 0; i < nc; ++i) {
-            prev = prev + 1u + read_delta_narrow(base, rel);
+            prev = prev + 1u + rd.delta();
             f(prev);
         }
     } else {
@@ -365,7 +459,8 @@ __device__ __forceinline__ uint32_t bytes_equal_mask4(uint32_t x, uint32_t patte
 __global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint32_t* __restrict__ nids,
                                                      const uint64_t* __restrict__ idoff,
                                                      const uint32_t* __restrict__ ids_pool, uint64_t n_reads,
-                                                     uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count) {
+                                                     uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count,
+                                                     unsigned int* tickets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = c.w32;
@@ -373,13 +468,16 @@ __global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint32_t
     unsigned char* mine = smem + (size_t)wv * per_wave;
     WaveScratch sc = carve_scratch(mine);
     uint32_t* R = (uint32_t*)(mine + wave_scratch_bytes());
-    uint32_t* CNT = R + W;  // W*8 words: one byte counter per colour
-    const uint64_t total_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    uint32_t* CNT = R + W;  // W*8 words: one byte counter per colour, 8 planes of W words (conflict-free fold)
+    const WorkQueue wq{tickets, n_reads, 8};
+    uint64_t t_first;
+    uint32_t t_count;
 
     for (uint32_t w = lane; w < W * 8; w += 64) CNT[w] = 0;
     wave_lds_sync();
 
-    for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wv; r < n_reads; r += total_waves) {
+    while (wq.pull(t_first, t_count))
+    for (uint64_t r = t_first; r < t_first + t_count; ++r) {
         const uint32_t cnt = nids[r];
         const uint64_t off = idoff[r];
         uint32_t* bm = out_bitmap + r * W;
@@ -432,8 +530,10 @@ __global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint32_t
                         decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg,
                                        [&](uint32_t v) { atomicOr(&CNT[v >> 5], 1u << (v & 31)); });
                     else
-                        decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg,
-                                       [&](uint32_t v) { atomicAdd(&CNT[v >> 2], 1u << (8 * (v & 3))); });
+                        decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg, [&](uint32_t v) {
+                            // counter of colour v: byte (v & 3) of word ((v >> 2) & 7) * W + (v >> 5)
+                            atomicAdd(&CNT[((v >> 2) & 7u) * W + (v >> 5)], 1u << (8 * (v & 3)));
+                        });
                 }
             }
             wave_lds_sync();
@@ -448,9 +548,9 @@ __global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint32_t
                 for (uint32_t w = lane; w < W; w += 64) {
                     uint32_t m = 0;
 #pragma unroll
-                    for (uint32_t q = 0; q < 8; ++q) {
-                        m |= bytes_equal_mask4(CNT[w * 8 + q], pattern) << (4 * q);
-                        CNT[w * 8 + q] = 0;
+                    for (uint32_t q = 0; q < 8; ++q) {  // plane q holds colours 32w + 4q .. 32w + 4q + 3
+                        m |= bytes_equal_mask4(CNT[q * W + w], pattern) << (4 * q);
+                        CNT[q * W + w] = 0;
                     }
                     R[w] &= m;
                 }
@@ -479,7 +579,7 @@ __global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint32_t
 __global__ void k3a_union(DevColors c, const uint32_t* __restrict__ nids, const uint32_t* __restrict__ npos,
                           const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
                           const uint32_t* __restrict__ cnt_pool, double tau, uint64_t n_reads,
-                          uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count) {
+                          uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count, unsigned int* tickets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = c.w32;
@@ -488,10 +588,12 @@ __global__ void k3a_union(DevColors c, const uint32_t* __restrict__ nids, const 
     unsigned char* mine = smem + (size_t)wv * per_wave;
     WaveScratch sc = carve_scratch(mine);
     int32_t* scores = (int32_t*)(mine + wave_scratch_bytes());
-    const uint32_t waves_per_block = blockDim.x >> 6;
-    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_block;
+    const WorkQueue wq{tickets, n_reads, 8};
+    uint64_t t_first;
+    uint32_t t_count;
 
-    for (uint64_t r = (uint64_t)blockIdx.x * waves_per_block + wv; r < n_reads; r += total_waves) {
+    while (wq.pull(t_first, t_count))
+    for (uint64_t r = t_first; r < t_first + t_count; ++r) {
         const uint32_t cnt = nids[r];
         const uint64_t off = idoff[r];
         uint32_t* bm = out_bitmap + r * W;
@@ -654,11 +756,14 @@ __global__ __launch_bounds__(256) void scan_apply(const uint32_t* __restrict__ c
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k2b_expand(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
                                                   const uint64_t* __restrict__ out_off, uint64_t n_reads, uint32_t W,
-                                                  uint32_t* __restrict__ colors) {
+                                                  uint32_t* __restrict__ colors, unsigned int* tickets) {
     const int lane = lane_id();
-    const uint64_t total_waves = (uint64_t)gridDim.x * 4;
     const uint32_t W64 = W >> 1;
-    for (uint64_t r = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n_reads; r += total_waves) {
+    const WorkQueue wq{tickets, n_reads, 32};
+    uint64_t t_first;
+    uint32_t t_count;
+    while (wq.pull(t_first, t_count))
+    for (uint64_t r = t_first; r < t_first + t_count; ++r) {
         if (counts[r] == 0) continue;
         uint32_t* out = colors + out_off[r];
         const uint64_t* bm = (const uint64_t*)(bitmap + r * W);

@@ -211,3 +211,27 @@ def test_s4546_random_id_lists(s4546):
     go, gc = ix.intersect_ids_batch(ids, ido)
     oo, oc = orc.intersect_ids(ids, ido, threads=32, self_check=True)
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+
+
+def test_cli_output_is_byte_identical_to_reference_format(s10_gpu, s10_fgidx, tmp_path):
+    """`fulgor pseudoalign -i .. -q .. -o ..` drop-in: ascii output equals the golden file byte for byte
+    (single worker => file order), binary output decodes to the same lists"""
+    import os
+    from conftest import GOLDEN
+    from fulgor_amd import cli
+    q = os.path.join(GOLDEN, "s10_reads.fa")
+    out = tmp_path / "out.tsv"
+    assert cli.main(["pseudoalign", "-i", s10_fgidx, "-q", q, "-o", str(out), "--verbose"]) == 0
+    assert out.read_bytes() == open(os.path.join(GOLDEN, "s10_full_intersection.tsv"), "rb").read()
+    out2 = tmp_path / "out_tu.tsv"
+    assert cli.main(["pseudoalign", "-i", s10_fgidx, "-q", q, "-o", str(out2), "-r", "0.8"]) == 0
+    assert out2.read_bytes() == open(os.path.join(GOLDEN, "s10_threshold_union_0.8.tsv"), "rb").read()
+    out3 = tmp_path / "out.bin"
+    assert cli.main(["pseudoalign", "-i", s10_fgidx, "-q", q, "-o", str(out3), "--format", "binary"]) == 0
+    raw = np.frombuffer(out3.read_bytes(), dtype="<u4")
+    gold = load_golden_tsv("s10_full_intersection.tsv")
+    p = 0
+    for i, cols in enumerate(gold):
+        assert raw[p] == i and raw[p + 1] == len(cols) and raw[p + 2:p + 2 + len(cols)].tolist() == cols
+        p += 2 + len(cols)
+    assert p == len(raw)
