@@ -60,7 +60,7 @@ void upload(DevBuf& b, const std::vector<T>& v, hipStream_t s) {
 
 constexpr size_t TICKET_BYTES = 3 * 8 * TICKET_STRIDE * sizeof(unsigned int);
 
-const char* KERNEL_NAMES[FGPU_K_COUNT] = {"k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits"};
+const char* KERNEL_NAMES[FGPU_K_COUNT] = {"k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits", "k_desc"};
 
 }  // namespace
 
@@ -124,7 +124,8 @@ struct fgpu_reads {
 struct fgpu_result {
     fgpu_index* ix = nullptr;
     DevBuf d_nids, d_npos, d_idoff, d_ids_pool, d_cnt_pool, d_cursor, d_bitmap, d_counts, d_offsets, d_block_sums,
-        d_block_mapped, d_totals, d_colors, d_acct, d_partial, d_tickets;
+        d_block_mapped, d_totals, d_colors, d_acct, d_partial, d_tickets, d_idcsr, d_desc;
+    uint64_t total_ids = 0;
     uint64_t* h_totals = nullptr;  // pinned {total colours, mapped reads, ids used}
     uint64_t n = 0, total = 0, mapped = 0, total_kmers = 0, total_bases = 0;
     uint32_t id_stride = 0;
@@ -211,6 +212,45 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     res->have_ids = true;
 }
 
+// exclusive scan of n u32 sizes into n+1 u64 offsets; totals -> d_totals {sum, #nonzero}
+void run_scan(fgpu_index* ix, fgpu_result* res, const uint32_t* sizes, uint64_t n, uint64_t* offsets) {
+    hipStream_t s = ix->stream;
+    const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    res->d_block_sums.ensure(std::max<uint64_t>(1, nb) * 8);
+    res->d_block_mapped.ensure(std::max<uint64_t>(1, nb) * 8);
+    res->d_totals.ensure(32);
+    Timed t(ix, FGPU_K_SCAN);
+    hipLaunchKernelGGL(scan_block_sums, dim3((uint32_t)nb), dim3(256), 0, s, sizes, n, res->d_block_sums.as<uint64_t>(),
+                       res->d_block_mapped.as<uint64_t>());
+    hipLaunchKernelGGL(scan_top, dim3(1), dim3(256), 0, s, res->d_block_sums.as<uint64_t>(), res->d_block_mapped.as<uint64_t>(), nb,
+                       res->d_totals.as<uint64_t>());
+    hipLaunchKernelGGL(scan_apply, dim3((uint32_t)nb), dim3(256), 0, s, sizes, n, res->d_block_sums.as<uint64_t>(), offsets);
+    HIP_TRY(hipGetLastError());
+}
+
+// per-read id lists (nids + source offsets into ids/cnt arrays) -> compact CSR of resolved descriptors
+void stage_descriptors(fgpu_index* ix, fgpu_result* res, uint64_t max_total_ids) {
+    hipStream_t s = ix->stream;
+    const uint64_t n = res->n;
+    res->d_idcsr.ensure((n + 1) * 8 + 16);
+    res->total_ids = 0;
+    if (n == 0) return;
+    run_scan(ix, res, res->d_nids.as<uint32_t>(), n, res->d_idcsr.as<uint64_t>());
+    // size the descriptor array exactly (one small D2H copy) instead of by the k-mer upper bound
+    HIP_TRY(hipMemcpyAsync(res->h_totals, res->d_totals.p, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    res->total_ids = res->h_totals[0];
+    if (res->total_ids > max_total_ids) throw std::runtime_error("internal error: more colour-set ids than k-mers");
+    res->d_desc.ensure(std::max<uint64_t>(1, res->total_ids) * sizeof(ListDesc));
+    Timed t(ix, FGPU_K_DESC);
+    const uint64_t threads = n * 16;
+    hipLaunchKernelGGL(k_desc, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, ix->dc, res->d_nids.as<uint32_t>(),
+                       res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(),
+                       res->have_ids ? res->d_cnt_pool.as<uint32_t>() : (const uint32_t*)nullptr, res->d_idcsr.as<uint64_t>(), n,
+                       res->d_desc.as<ListDesc>());
+    HIP_TRY(hipGetLastError());
+}
+
 void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     hipStream_t s = ix->stream;
     const uint64_t n = res->n;
@@ -218,11 +258,6 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     res->d_bitmap.ensure(n * W * 4 + 16);
     res->d_counts.ensure(n * 4 + 16);
     res->d_offsets.ensure((n + 1) * 8 + 16);
-    const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-    res->d_block_sums.ensure(std::max<uint64_t>(1, nb) * 8);
-    res->d_block_mapped.ensure(std::max<uint64_t>(1, nb) * 8);
-    res->d_totals.ensure(32);
-    if (!res->h_totals) HIP_TRY(hipHostMalloc((void**)&res->h_totals, 32));
     res->total = res->mapped = 0;
     if (n == 0) {
         HIP_TRY(hipMemsetAsync(res->d_offsets.p, 0, 8, s));
@@ -234,33 +269,23 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         const uint32_t wpb = pick_waves(per_wave, (const void*)k2a_intersect);
         const uint32_t grid = resident_grid(k2a_intersect, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
         Timed t(ix, FGPU_K_INTERSECT);
-        hipLaunchKernelGGL(k2a_intersect, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_nids.as<uint32_t>(),
-                           res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), n, res->d_bitmap.as<uint32_t>(),
-                           res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
+        hipLaunchKernelGGL(k2a_intersect, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_idcsr.as<uint64_t>(),
+                           res->d_desc.as<ListDesc>(), n, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
+                           res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
         HIP_TRY(hipGetLastError());
     } else if (algo == FGPU_THRESHOLD_UNION) {
         const size_t per_wave = (size_t)W * 32 * 4 + wave_scratch_bytes();
         const uint32_t wpb = pick_waves(per_wave, (const void*)k3a_union);
         const uint32_t grid = resident_grid(k3a_union, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
         Timed t(ix, FGPU_K_UNION);
-        hipLaunchKernelGGL(k3a_union, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_nids.as<uint32_t>(),
-                           res->d_npos.as<uint32_t>(), res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(),
-                           res->d_cnt_pool.as<uint32_t>(), tau, n, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
-                           res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
+        hipLaunchKernelGGL(k3a_union, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_npos.as<uint32_t>(),
+                           res->d_idcsr.as<uint64_t>(), res->d_desc.as<ListDesc>(), tau, n, res->d_bitmap.as<uint32_t>(),
+                           res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
         HIP_TRY(hipGetLastError());
     } else {
         throw std::runtime_error("unknown algorithm");
     }
-    {
-        Timed t(ix, FGPU_K_SCAN);
-        hipLaunchKernelGGL(scan_block_sums, dim3((uint32_t)nb), dim3(256), 0, s, res->d_counts.as<uint32_t>(), n,
-                           res->d_block_sums.as<uint64_t>(), res->d_block_mapped.as<uint64_t>());
-        hipLaunchKernelGGL(scan_top, dim3(1), dim3(256), 0, s, res->d_block_sums.as<uint64_t>(),
-                           res->d_block_mapped.as<uint64_t>(), nb, res->d_totals.as<uint64_t>());
-        hipLaunchKernelGGL(scan_apply, dim3((uint32_t)nb), dim3(256), 0, s, res->d_counts.as<uint32_t>(), n,
-                           res->d_block_sums.as<uint64_t>(), res->d_offsets.as<uint64_t>());
-        HIP_TRY(hipGetLastError());
-    }
+    run_scan(ix, res, res->d_counts.as<uint32_t>(), n, res->d_offsets.as<uint64_t>());
     HIP_TRY(hipMemcpyAsync(res->h_totals, res->d_totals.p, 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     res->total = res->h_totals[0];
@@ -409,8 +434,15 @@ void fgpu_reads_free(fgpu_reads* rd) {
 int fgpu_result_create(fgpu_index* ix, fgpu_result** out) {
     if (!ix || !out) return fail(-EINVAL, "null argument");
     NEED_DEVICE(ix);
-    *out = new fgpu_result();
-    (*out)->ix = ix;
+    fgpu_result* r = new fgpu_result();
+    r->ix = ix;
+    int rc = guarded([&] {
+        HIP_TRY(hipSetDevice(ix->device));
+        HIP_TRY(hipHostMalloc((void**)&r->h_totals, 32));
+        r->d_totals.ensure(32);
+    });
+    if (rc) { delete r; return rc; }
+    *out = r;
     return 0;
 }
 
@@ -418,7 +450,7 @@ void fgpu_result_free(fgpu_result* r) {
     if (!r) return;
     (void)hipSetDevice(r->ix->device);
     for (DevBuf* b : {&r->d_nids, &r->d_npos, &r->d_idoff, &r->d_ids_pool, &r->d_cnt_pool, &r->d_cursor, &r->d_bitmap,
-                      &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct, &r->d_partial, &r->d_tickets})
+                      &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct, &r->d_partial, &r->d_tickets, &r->d_idcsr, &r->d_desc})
         b->release();
     if (r->h_totals) (void)hipHostFree(r->h_totals);
     delete r;
@@ -432,6 +464,7 @@ int fgpu_run(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t coun
     return guarded([&] {
         HIP_TRY(hipSetDevice(ix->device));
         stage_lookup(ix, rd, first, count, res);
+        stage_descriptors(ix, res, res->total_kmers);
         stage_colors(ix, algo, tau, res);
     });
 }
@@ -465,7 +498,7 @@ int fgpu_result_accumulate_hits(fgpu_index* ix, const fgpu_result* r, void* devi
             Timed t(ix, FGPU_K_HITS);
             hipLaunchKernelGGL(k_hits, dim3(grid), dim3(threads), 0, ix->stream, r->d_bitmap.as<uint32_t>(), r->n, W,
                                r->d_partial.as<uint32_t>());
-            hipLaunchKernelGGL(k_hits_reduce, dim3((ix->dc.n + 255) / 256), dim3(256), 0, ix->stream, r->d_partial.as<uint32_t>(),
+            hipLaunchKernelGGL(k_hits_reduce, dim3((ix->dc.n + 255) / 256, HITS_ROW_GROUPS), dim3(256), 0, ix->stream, r->d_partial.as<uint32_t>(),
                                grid, W, ix->dc.n, (unsigned long long*)device_u64_hits);
             hipLaunchKernelGGL(k_add_totals, dim3(1), dim3(64), 0, ix->stream, (unsigned long long*)device_u64_hits, ix->dc.n,
                                r->n, r->d_totals.as<uint64_t>());
@@ -485,9 +518,8 @@ int fgpu_result_algorithmic_bytes(const fgpu_result* r, uint64_t* list_bytes, ui
         if (r->n) {
             const_cast<fgpu_result*>(r)->d_acct.ensure(16);
             HIP_TRY(hipMemsetAsync(r->d_acct.p, 0, 16, ix->stream));
-            hipLaunchKernelGGL(k_account, dim3(1024), dim3(256), 0, ix->stream, ix->dc, r->d_nids.as<uint32_t>(),
-                               r->d_idoff.as<uint64_t>(), r->d_ids_pool.as<uint32_t>(), r->d_counts.as<uint32_t>(), r->n,
-                               r->d_acct.as<unsigned long long>());
+            hipLaunchKernelGGL(k_account, dim3(1024), dim3(256), 0, ix->stream, ix->dc, r->d_idcsr.as<uint64_t>(),
+                               r->d_desc.as<ListDesc>(), r->d_counts.as<uint32_t>(), r->n, r->d_acct.as<unsigned long long>());
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(acct, r->d_acct.p, 16, hipMemcpyDeviceToHost, ix->stream));
             HIP_TRY(hipStreamSynchronize(ix->stream));
@@ -620,6 +652,8 @@ int fgpu_intersect_ids(fgpu_index* ix, const uint32_t* ids, const uint64_t* id_o
         if (id_offs[n]) HIP_TRY(hipMemcpy(res->d_ids_pool.p, ids, id_offs[n] * 4, hipMemcpyHostToDevice));
         res->d_tickets.ensure(TICKET_BYTES);
         HIP_TRY(hipMemsetAsync(res->d_tickets.p, 0, TICKET_BYTES, ix->stream));
+        res->have_ids = false;
+        stage_descriptors(ix, res, id_offs[n]);
         stage_colors(ix, FGPU_FULL_INTERSECTION, 0.0, res);
         uint64_t* o = (uint64_t*)malloc((n + 1) * 8);
         uint32_t* c = (uint32_t*)malloc(std::max<uint64_t>(1, res->total) * 4);

@@ -378,6 +378,43 @@ __device__ __forceinline__ ListHeader read_header(const DevColors& c, uint32_t i
     return h;
 }
 
+// One resolved colour list of one read (32 bytes). Written by k_desc, a flat kernel with one thread per
+// (read, list) pair, so that the dependent chain id -> offsets -> header bits is walked with full
+// memory-level parallelism once instead of serially inside the per-read kernels.
+struct __attribute__((aligned(16))) ListDesc {
+    uint64_t begin;   // bit offset of the list
+    uint64_t soff;    // first restart sample
+    uint32_t ncodes;  // gap codes (0 for bitmap lists)
+    uint32_t meta;    // encoding | (body - begin) << 8
+    int32_t score;    // positive k-mers that produced this id (threshold-union)
+    uint32_t id;      // colour-set id
+};
+__device__ __forceinline__ int desc_type(const ListDesc& d) { return (int)(d.meta & 0xFFu); }
+__device__ __forceinline__ uint64_t desc_body(const ListDesc& d) { return d.begin + (d.meta >> 8); }
+
+__global__ __launch_bounds__(256) void k_desc(DevColors c, const uint32_t* __restrict__ nids,
+                                              const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ ids_src,
+                                              const uint32_t* __restrict__ cnt_src, const uint64_t* __restrict__ dst_off,
+                                              uint64_t n_reads, ListDesc* __restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t r = t >> 4;
+    if (r >= n_reads) return;
+    const uint32_t cnt = nids[r];
+    const uint64_t so = src_off[r], dso = dst_off[r];
+    for (uint32_t j = (uint32_t)t & 15u; j < cnt; j += 16) {
+        const uint32_t id = ids_src[so + j];
+        const ListHeader h = read_header(c, id);
+        ListDesc d;
+        d.begin = h.begin;
+        d.soff = h.soff;
+        d.ncodes = h.ncodes;
+        d.meta = (uint32_t)h.type | ((uint32_t)(h.body - h.begin) << 8);
+        d.score = cnt_src ? (int32_t)cnt_src[so + j] : 0;
+        d.id = id;
+        out[dso + j] = d;
+    }
+}
+
 // decode segment `seg` (SAMPLE_STRIDE codes) of a gap-coded list and feed every value to f
 template <typename F>
 __device__ __forceinline__ void decode_segment(const DevColors& c, uint64_t begin, uint64_t body, uint64_t soff,
@@ -456,9 +493,8 @@ __device__ __forceinline__ uint32_t bytes_equal_mask4(uint32_t x, uint32_t patte
     return ((t >> 7) * 0x00204081u >> 21) & 0xFu;
 }
 
-__global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint32_t* __restrict__ nids,
-                                                     const uint64_t* __restrict__ idoff,
-                                                     const uint32_t* __restrict__ ids_pool, uint64_t n_reads,
+__global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint64_t* __restrict__ id_csr,
+                                                     const ListDesc* __restrict__ desc, uint64_t n_reads,
                                                      uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count,
                                                      unsigned int* tickets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -478,8 +514,8 @@ __global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint32_t
 
     while (wq.pull(t_first, t_count))
     for (uint64_t r = t_first; r < t_first + t_count; ++r) {
-        const uint32_t cnt = nids[r];
-        const uint64_t off = idoff[r];
+        const uint64_t off = id_csr[r];
+        const uint32_t cnt = (uint32_t)(id_csr[r + 1] - off);
         uint32_t* bm = out_bitmap + r * W;
         if (cnt == 0) {
             for (uint32_t w = lane; w < W; w += 64) bm[w] = 0;
@@ -494,7 +530,10 @@ __global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint32_t
         for (uint32_t g = 0; g < cnt; g += 64) {
             ListHeader h;
             h.type = D_ENC_NONE; h.ncodes = 0; h.begin = h.body = h.soff = 0; h.size = 0;
-            if (g + lane < cnt) h = read_header(c, ids_pool[off + g + lane]);
+            if (g + lane < cnt) {
+                const ListDesc d = desc[off + g + lane];
+                h.type = desc_type(d); h.ncodes = d.ncodes; h.begin = d.begin; h.body = desc_body(d); h.soff = d.soff;
+            }
             const uint32_t nseg = (h.ncodes + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
             sc.h_begin[lane] = h.begin; sc.h_body[lane] = h.body; sc.h_soff[lane] = h.soff; sc.h_ncodes[lane] = h.ncodes;
             sc.h_score[lane] = h.type;
@@ -576,9 +615,8 @@ __global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint32_t
 // `merge` (ps_threshold_union.cpp:16-40): scores[c] += score for members of sparse/bitmap lists,
 // -= score for the missing colours of complemented lists while min_score is lowered by that score;
 // keep c iff scores[c] >= min_score. min_score = uint64(double(#positive k-mers) * tau) (:389).
-__global__ void k3a_union(DevColors c, const uint32_t* __restrict__ nids, const uint32_t* __restrict__ npos,
-                          const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
-                          const uint32_t* __restrict__ cnt_pool, double tau, uint64_t n_reads,
+__global__ void k3a_union(DevColors c, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
+                          const ListDesc* __restrict__ desc, double tau, uint64_t n_reads,
                           uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count, unsigned int* tickets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
@@ -594,8 +632,8 @@ __global__ void k3a_union(DevColors c, const uint32_t* __restrict__ nids, const 
 
     while (wq.pull(t_first, t_count))
     for (uint64_t r = t_first; r < t_first + t_count; ++r) {
-        const uint32_t cnt = nids[r];
-        const uint64_t off = idoff[r];
+        const uint64_t off = id_csr[r];
+        const uint32_t cnt = (uint32_t)(id_csr[r + 1] - off);
         uint32_t* bm = out_bitmap + r * W;
         if (cnt == 0) {
             for (uint32_t w = lane; w < W; w += 64) bm[w] = 0;
@@ -611,8 +649,9 @@ __global__ void k3a_union(DevColors c, const uint32_t* __restrict__ nids, const 
             h.type = D_ENC_NONE; h.ncodes = 0; h.begin = h.body = h.soff = 0; h.size = 0;
             int32_t score = 0;
             if (g + lane < cnt) {
-                h = read_header(c, ids_pool[off + g + lane]);
-                score = (int32_t)cnt_pool[off + g + lane];
+                const ListDesc d = desc[off + g + lane];
+                h.type = desc_type(d); h.ncodes = d.ncodes; h.begin = d.begin; h.body = desc_body(d); h.soff = d.soff;
+                score = d.score;
             }
             const uint32_t nseg = (h.ncodes + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
             sc.h_begin[lane] = h.begin; sc.h_body[lane] = h.body; sc.h_soff[lane] = h.soff; sc.h_ncodes[lane] = h.ncodes;
@@ -751,14 +790,17 @@ __global__ __launch_bounds__(256) void scan_apply(const uint32_t* __restrict__ c
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2b: bitmap -> ascending u32 colour list. 64 colours at a time: the bitmap word is the lane mask,
-// mbcnt gives each set lane its slot, one compacted store per word.
+// K2b: bitmap -> ascending u32 colour list. Lane = one 32-colour word of the bitmap: popcount, wave
+// prefix sum, every lane scatters the indices of its set bits into an LDS staging buffer at its prefix
+// (16-bit entries relative to the round's first colour), then the wave copies the staged run out with
+// full-width coalesced stores. 64 words (2048 colours) per round.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k2b_expand(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
                                                   const uint64_t* __restrict__ out_off, uint64_t n_reads, uint32_t W,
                                                   uint32_t* __restrict__ colors, unsigned int* tickets) {
+    __shared__ uint16_t s_stage[4][2048 + 64];
     const int lane = lane_id();
-    const uint32_t W64 = W >> 1;
+    uint16_t* stage = s_stage[threadIdx.x >> 6];
     const WorkQueue wq{tickets, n_reads, 32};
     uint64_t t_first;
     uint32_t t_count;
@@ -766,19 +808,25 @@ __global__ __launch_bounds__(256) void k2b_expand(const uint32_t* __restrict__ b
     for (uint64_t r = t_first; r < t_first + t_count; ++r) {
         if (counts[r] == 0) continue;
         uint32_t* out = colors + out_off[r];
-        const uint64_t* bm = (const uint64_t*)(bitmap + r * W);
-        uint32_t base = 0;
-        for (uint32_t wb = 0; wb < W64; wb += 64) {
-            const uint64_t mine = wb + lane < W64 ? bm[wb + lane] : 0ull;
-            const uint32_t nw = min(64u, W64 - wb);
-            for (uint32_t i = 0; i < nw; ++i) {
-                const uint32_t mlo = __builtin_amdgcn_readlane((uint32_t)mine, i);
-                const uint32_t mhi = __builtin_amdgcn_readlane((uint32_t)(mine >> 32), i);
-                const uint64_t M = ((uint64_t)mhi << 32) | mlo;
-                if (M == 0) continue;
-                if ((M >> lane) & 1) out[base + mask_rank(M)] = (wb + i) * 64 + lane;
-                base += __popcll(M);
+        const uint32_t* bm = bitmap + r * W;
+        for (uint32_t w0 = 0; w0 < W; w0 += 64) {
+            uint32_t x = w0 + lane < W ? bm[w0 + lane] : 0u;
+            const uint32_t pc = __popc(x);
+            const uint32_t incl = wave_incl_scan_u32(pc);
+            const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+            if (total == 0) continue;
+            uint32_t at = incl - pc;
+            const uint32_t rel = (uint32_t)lane * 32;
+            while (x) {  // slot i lives at i + i/32: dense words (prefix = 32 * lane) would otherwise share 2 banks
+                stage[at + (at >> 5)] = (uint16_t)(rel + __builtin_ctz(x));
+                ++at;
+                x &= x - 1;
             }
+            wave_lds_sync();
+            const uint32_t cbase = w0 * 32;
+            for (uint32_t i = lane; i < total; i += 64) out[i] = cbase + stage[i + (i >> 5)];
+            out += total;
+            wave_lds_sync();
         }
     }
 }
@@ -813,13 +861,23 @@ __global__ void k_hits(const uint32_t* __restrict__ bitmap, uint64_t n_reads, ui
     }
 }
 
+// grid = (ceil(n/256), HITS_ROW_GROUPS): each block sums every HITS_ROW_GROUPS-th partial row for 256
+// columns, then one u64 atomic per column
+constexpr uint32_t HITS_ROW_GROUPS = 32;
 __global__ void k_hits_reduce(const uint32_t* __restrict__ partial, uint32_t nblocks, uint32_t W, uint32_t n,
                               unsigned long long* __restrict__ hits) {
     const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= n) return;
+    const uint64_t row = (uint64_t)W * 32;
     unsigned long long s = 0;
-    for (uint32_t b = 0; b < nblocks; ++b) s += partial[(uint64_t)b * W * 32 + col];
-    hits[col] += s;
+    uint32_t b = blockIdx.y;
+    for (; b + 3 * HITS_ROW_GROUPS < nblocks; b += 4 * HITS_ROW_GROUPS) {
+        const uint32_t x0 = partial[b * row + col], x1 = partial[(b + HITS_ROW_GROUPS) * row + col],
+                       x2 = partial[(b + 2 * HITS_ROW_GROUPS) * row + col], x3 = partial[(b + 3 * HITS_ROW_GROUPS) * row + col];
+        s += (unsigned long long)x0 + x1 + x2 + x3;
+    }
+    for (; b < nblocks; b += HITS_ROW_GROUPS) s += partial[b * row + col];
+    if (s) atomicAdd(&hits[col], s);
 }
 
 __global__ void k_add_totals(unsigned long long* hits, uint32_t n, uint64_t num_reads, const uint64_t* totals) {
@@ -833,16 +891,15 @@ __global__ void k_add_totals(unsigned long long* hits, uint32_t n, uint64_t num_
 // algorithmic bytes of the colour-intersection stage:
 //   sum over reads of  sum_c ceil(list bits / 8) + 16|C| + 4|C| + 4|R| + 8
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_account(DevColors c, const uint32_t* __restrict__ nids,
-                                                 const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
-                                                 const uint32_t* __restrict__ counts, uint64_t n_reads,
-                                                 unsigned long long* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_account(DevColors c, const uint64_t* __restrict__ id_csr,
+                                                 const ListDesc* __restrict__ desc, const uint32_t* __restrict__ counts,
+                                                 uint64_t n_reads, unsigned long long* __restrict__ out) {
     uint64_t in_bytes = 0, out_bytes = 0;  // out[0]: list side (lists + offsets + ids), out[1]: result side
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t cnt = nids[r];
-        const uint64_t off = idoff[r];
+        const uint64_t off = id_csr[r];
+        const uint32_t cnt = (uint32_t)(id_csr[r + 1] - off);
         for (uint32_t i = 0; i < cnt; ++i) {
-            const uint32_t id = ids_pool[off + i];
+            const uint32_t id = desc[off + i].id;
             in_bytes += (c.offsets[id + 1] - c.offsets[id] + 7) / 8;
         }
         in_bytes += 20ull * cnt;

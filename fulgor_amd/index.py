@@ -14,7 +14,7 @@ from . import _native
 
 FULL_INTERSECTION = 0
 THRESHOLD_UNION = 1
-KERNELS = ("k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits")
+KERNELS = ("k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits", "k_desc")
 
 
 def pack_reads(reads):

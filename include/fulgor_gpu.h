@@ -95,7 +95,7 @@ int fgpu_result_algorithmic_bytes(const fgpu_result* res, uint64_t* list_bytes, 
 
 /* per-kernel HIP-event timing on the engine's stream */
 enum { FGPU_K_LOOKUP = 0, FGPU_K_INTERSECT = 1, FGPU_K_UNION = 2, FGPU_K_SCAN = 3, FGPU_K_EXPAND = 4,
-       FGPU_K_HITS = 5, FGPU_K_COUNT = 6 };
+       FGPU_K_HITS = 5, FGPU_K_DESC = 6, FGPU_K_COUNT = 7 };
 int fgpu_timing_enable(fgpu_index* idx, int on);
 int fgpu_timing_reset(fgpu_index* idx);
 int fgpu_timing_get(fgpu_index* idx, int kernel, double* total_ms, uint64_t* launches);
