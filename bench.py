@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default=os.environ.get("FULGOR_BENCH_WORKLOAD", "s10"))
+    ap.add_argument("--workload", default=os.environ.get("FULGOR_BENCH_WORKLOAD", "s4546syn"), choices=["s4546syn", "s10"])
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the BASELINE config size)")
     ap.add_argument("--algo", default="full-intersection", choices=["full-intersection", "threshold-union"])
     ap.add_argument("--tau", type=float, default=0.8)

@@ -31,6 +31,14 @@ FG_HD uint32_t base_code(uint8_t c) {
     }
 }
 
+// branch-free form of base_code for the device hot loops: (b >> 1) & 3 maps A,C,T,G -> 0,1,2,3; x ^ (x >> 1)
+// turns that into A0 C1 G2 T3; validity = letter range (0x40..0x7F) and bit (b & 31) of the set {A,C,G,T}
+FG_HD uint32_t base_code_fast(uint32_t b) {
+    const uint32_t x = (b >> 1) & 3u;
+    const uint32_t ok = (uint32_t)((b & 0xC0u) == 0x40u) & ((0x0010008Au >> (b & 31u)) & 1u);
+    return ok ? (x ^ (x >> 1)) : 0xFFu;
+}
+
 // ---- bit-plane L-mers (L <= 32) --------------------------------------------------------------
 // An L-mer is two 32-bit planes: lo = bit0 of every base, hi = bit1; base i (i=0 is the first /
 // leftmost base) lives at bit i of each plane.
@@ -77,7 +85,11 @@ FG_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a 
 constexpr uint32_t MIN_ORDER_SHIFT = 36;
 
 // ---- perfect hash over canonical minimizer keys ------------------------------------------------
-// bucket = fastrange(high32(h), num_buckets); slot = fastrange(low32(h) ^ (pilot * PHI32), num_slots)
+// Minimizers are the m-mers with the SMALLEST order hash, so mix64(key) itself is far from uniform
+// over the selected keys; the perfect hash therefore uses a second, seeded mix of it:
+//   h = phf_hash(mix64(key), seed); bucket = fastrange(high32(h), num_buckets);
+//   slot = fastrange(mix32(low32(h) ^ pilot * PHI32), num_slots)
+FG_HD uint64_t phf_hash(uint64_t h0, uint64_t seed) { return mix64(h0 ^ (seed * 0x9E3779B97F4A7C15ULL + 0x632BE59BD9B4E019ULL)); }
 constexpr uint32_t PHI32 = 0x9E3779B1u;
 FG_HD uint32_t phf_bucket(uint64_t h, uint32_t num_buckets) { return mulhi32((uint32_t)(h >> 32), num_buckets); }
 FG_HD uint32_t phf_slot(uint64_t h, uint32_t pilot, uint32_t num_slots) {

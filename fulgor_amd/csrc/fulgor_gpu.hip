@@ -147,8 +147,8 @@ void upload_index(fgpu_index* ix) {
     upload(ix->d_sample_off, h.sample_off, s);
     upload(ix->d_samples, h.samples, s);
     HIP_TRY(hipStreamSynchronize(s));
-    ix->dd = DevDict{ix->d_strings.as<uint64_t>(), ix->d_pilots.as<uint32_t>(), ix->d_slots.as<uint64_t>(),
-                     ix->d_overflow.as<uint64_t>(), d.num_buckets, d.num_slots, d.k, d.m};
+    ix->dd = DevDict{ix->d_strings.as<uint64_t>(), ix->d_pilots.as<uint16_t>(), ix->d_slots.as<uint64_t>(),
+                     ix->d_overflow.as<uint64_t>(), d.num_buckets, d.num_slots, d.k, d.m, d.seed};
     uint32_t w32 = (h.num_colors + 31) / 32;
     w32 += w32 & 1;
     ix->dc = DevColors{ix->d_bits.as<uint64_t>(), ix->d_offsets.as<uint64_t>(), ix->d_sample_off.as<uint64_t>(),
@@ -194,11 +194,18 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     res->d_cnt_pool.ensure(count * (uint64_t)stride * 4 + 16);
     if (count == 0) return;
     if (rd->max_kmers > 1024) throw std::runtime_error("reads with more than 1024 k-mers are not supported by this build");
-    const uint32_t grid = rd->max_kmers <= 128 ? resident_grid(k1_lookup<128>, count, 4, ix->num_cus, 256, 0)
-                                               : resident_grid(k1_lookup<1024>, count, 4, ix->num_cus, 256, 0);
+    const bool w13 = ix->dd.k - ix->dd.m == 12;
+    const uint32_t grid = rd->max_kmers > 128 ? resident_grid(k1_lookup<1024>, count, 4, ix->num_cus, 256, 0)
+                          : w13               ? resident_grid(k1_lookup_short<true>, count, 4, ix->num_cus, 256, 0)
+                                              : resident_grid(k1_lookup_short<false>, count, 4, ix->num_cus, 256, 0);
     Timed t(ix, FGPU_K_LOOKUP);
-    if (rd->max_kmers <= 128) {
-        hipLaunchKernelGGL(k1_lookup<128>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
+    if (rd->max_kmers <= 128 && w13) {
+        hipLaunchKernelGGL(k1_lookup_short<true>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
+                           rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
+                           res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
+                           stride, res->d_tickets.as<unsigned int>());
+    } else if (rd->max_kmers <= 128) {
+        hipLaunchKernelGGL(k1_lookup_short<false>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
                            rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
                            res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
                            stride, res->d_tickets.as<unsigned int>());
@@ -274,7 +281,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
                            res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
         HIP_TRY(hipGetLastError());
     } else if (algo == FGPU_THRESHOLD_UNION) {
-        const size_t per_wave = (size_t)W * 32 * 4 + wave_scratch_bytes();
+        const size_t per_wave = (size_t)W * 64 + wave_scratch_bytes();
         const uint32_t wpb = pick_waves(per_wave, (const void*)k3a_union);
         const uint32_t grid = resident_grid(k3a_union, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
         Timed t(ix, FGPU_K_UNION);

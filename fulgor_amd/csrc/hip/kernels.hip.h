@@ -20,10 +20,11 @@ namespace fg {
 
 struct DevDict {
     const uint64_t* strings;
-    const uint32_t* pilots;
+    const uint16_t* pilots;
     const uint64_t* slots;
     const uint64_t* overflow;
     uint32_t num_buckets, num_slots, k, m;
+    uint64_t seed;
 };
 
 struct DevColors {
@@ -116,8 +117,9 @@ __device__ __forceinline__ uint32_t try_record(const DevDict& d, uint64_t rec, u
 
 // Probe the bucket of minimizer hash h. A: query strand == unitig strand, minimizer at offset jA;
 // B: query is the reverse complement, minimizer at offset jB of the reverse-complemented k-mer.
-__device__ __forceinline__ uint32_t probe(const DevDict& d, uint64_t h, bool doA, bool doB, uint32_t jA, uint32_t jB,
+__device__ __forceinline__ uint32_t probe(const DevDict& d, uint64_t h0, bool doA, bool doB, uint32_t jA, uint32_t jB,
                                           uint32_t klo, uint32_t khi, uint32_t rlo, uint32_t rhi) {
+    const uint64_t h = phf_hash(h0, d.seed);
     const uint32_t pilot = d.pilots[phf_bucket(h, d.num_buckets)];
     uint64_t e = d.slots[phf_slot(h, pilot, d.num_slots)];
     const uint64_t* p = nullptr;
@@ -301,6 +303,266 @@ __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __res
             idoff[r] = base;
         }
         wave_lds_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 for short reads (at most 128 k-mers, i.e. <= 158 bases at k = 31): same results as k1_lookup, but
+// organised for memory-level parallelism: read offsets are fetched once per ticket, the bases of the
+// NEXT read are requested before the current one is processed, each lane owns two k-mers (i and i+64)
+// and the dependent probe steps are issued for both together: 2 pilots -> 2 slots -> 2 overflow pairs
+// -> up to 8 string fetches in flight.
+// ---------------------------------------------------------------------------------------------
+// W13 = true fixes the number of m-mers per k-mer at 13 (k - m = 12, e.g. k = 31, m = 19) so that the
+// minimizer scan unrolls completely. The probe section is written without branches: every load is issued
+// unconditionally from an in-bounds address (inactive candidates read word 0) and results are selected,
+// because on this kernel the scalar unit (exec-mask bookkeeping of divergent branches), not memory, was
+// the limiter.
+template <bool W13>
+__global__ __launch_bounds__(256) void k1_lookup_short(DevDict d, const uint8_t* __restrict__ bases,
+                                                       const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
+                                                       uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
+                                                       uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
+                                                       uint32_t* __restrict__ cnt_pool, uint32_t stride, unsigned int* tickets) {
+    constexpr int KMAX = 128;
+    __shared__ uint64_t s_hash[4][144];
+    __shared__ uint32_t s_ids[4][KMAX];
+    __shared__ uint32_t s_uid[4][KMAX];
+    __shared__ uint32_t s_ucnt[4][KMAX];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    uint64_t* hsh = s_hash[wv];
+    uint32_t* ids = s_ids[wv];
+    uint32_t* uid = s_uid[wv];
+    uint32_t* ucnt = s_ucnt[wv];
+    const uint32_t k = d.k, m = d.m, W = W13 ? 13u : k - m + 1;
+    const uint32_t km = k - m;
+    const WorkQueue wq{tickets, n_reads, 8};
+    uint64_t t_first;
+    uint32_t t_count;
+
+    while (wq.pull(t_first, t_count)) {
+        const uint64_t myoff = (uint32_t)lane <= t_count ? offs[first + t_first + lane] : 0;
+        uint64_t rb = __shfl(myoff, 0), re = __shfl(myoff, 1);
+        uint32_t len = (uint32_t)(re - rb);
+        const uint8_t* seq = bases + rb;
+        // reads are padded by the host buffer: positions past the read end are masked below, not branched on
+        uint32_t b0 = seq[lane], b1 = seq[lane + 64], b2 = seq[lane + 128];
+        for (uint32_t j = 0; j < t_count; ++j) {
+            const uint64_t r = t_first + j;
+            const uint32_t cur_len = len;
+            const uint32_t c0 = (uint32_t)lane < cur_len ? base_code_fast(b0) : 0xFFu;
+            const uint32_t c1 = (uint32_t)lane + 64 < cur_len ? base_code_fast(b1) : 0xFFu;
+            const uint32_t c2 = (uint32_t)lane + 128 < cur_len ? base_code_fast(b2) : 0xFFu;
+            if (j + 1 < t_count) {  // request the next read's bases now; they are consumed next iteration
+                rb = re;
+                re = __shfl(myoff, (int)j + 2);
+                len = (uint32_t)(re - rb);
+                seq = bases + rb;
+                b0 = seq[lane];
+                b1 = seq[lane + 64];
+                b2 = seq[lane + 128];
+            }
+            const uint32_t nk = cur_len >= k ? min(cur_len - k + 1, (uint32_t)KMAX) : 0;
+            const uint64_t loA = __ballot(c0 <= 3 && (c0 & 1)), hiA = __ballot(c0 <= 3 && (c0 & 2)), nvA = __ballot(c0 > 3);
+            const uint64_t loB = __ballot(c1 <= 3 && (c1 & 1)), hiB = __ballot(c1 <= 3 && (c1 & 2)), nvB = __ballot(c1 > 3);
+            const uint64_t loC = __ballot(c2 <= 3 && (c2 & 1)), hiC = __ballot(c2 <= 3 && (c2 & 2)), nvC = __ballot(c2 > 3);
+
+            hsh[lane] = mix64(canonical_key(extract128(loA, loB, lane, m), extract128(hiA, hiB, lane, m), m));
+            hsh[64 + lane] = mix64(canonical_key(extract128(loB, loC, lane, m), extract128(hiB, hiC, lane, m), m));
+            if (lane < 16)
+                hsh[128 + lane] = mix64(canonical_key((uint32_t)(loC >> lane) & low_mask32(m), (uint32_t)(hiC >> lane) & low_mask32(m), m));
+            wave_lds_sync();
+
+            bool valid[2];
+            uint32_t klo[2], khi[2], rlo[2], rhi[2], jL[2], jR[2], csid[2];
+            uint64_t hL[2], hR[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const uint64_t lx = a ? loB : loA, ly = a ? loC : loB, hx = a ? hiB : hiA, hy = a ? hiC : hiB;
+                const uint64_t nx = a ? nvB : nvA, ny = a ? nvC : nvB;
+                valid[a] = (uint32_t)(64 * a + lane) < nk && extract128(nx, ny, lane, k) == 0;
+                klo[a] = extract128(lx, ly, lane, k);
+                khi[a] = extract128(hx, hy, lane, k);
+                rlo[a] = rc_plane(klo[a], k);
+                rhi[a] = rc_plane(khi[a], k);
+            }
+            uint32_t bL[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, bR[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (W13) {
+#pragma unroll
+                for (uint32_t jj = 0; jj < 13; ++jj) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const uint32_t o = (uint32_t)(hsh[64 * a + lane + jj] >> MIN_ORDER_SHIFT) << 4;
+                        bL[a] = min(bL[a], o | jj);
+                        bR[a] = min(bR[a], o | (15u - jj));
+                    }
+                }
+            } else {
+                for (uint32_t jj = 0; jj < W; ++jj) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const uint32_t o = (uint32_t)(hsh[64 * a + lane + jj] >> MIN_ORDER_SHIFT) << 4;
+                        bL[a] = min(bL[a], o | jj);
+                        bR[a] = min(bR[a], o | (15u - jj));
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                jL[a] = bL[a] & 15u;
+                jR[a] = 15u - (bR[a] & 15u);
+                hL[a] = hsh[64 * a + lane + jL[a]];
+                hR[a] = hsh[64 * a + lane + jR[a]];
+            }
+            // ---- staged, branch-free probe of the leftmost-minimizer key for both k-mers ----
+            uint64_t hp[2], e[2], p0[2], p1[2];
+            uint32_t pil[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) hp[a] = phf_hash(hL[a], d.seed);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) pil[a] = d.pilots[phf_bucket(hp[a], d.num_buckets)];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) e[a] = d.slots[phf_slot(hp[a], pil[a], d.num_slots)];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const uint64_t* p = d.overflow + ((e[a] & REC_TAG) ? ovf_off(e[a]) : 0u);
+                p0[a] = p[0];
+                p1[a] = p[1];
+            }
+            uint64_t w0[2][4], w1[2][4];
+            uint32_t cs[2][4], csh[2][4];
+            bool con[2][4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const bool tag = (e[a] & REC_TAG) != 0;
+                const uint64_t r0 = tag ? p0[a] : e[a], r1 = tag ? p1[a] : REC_EMPTY;
+                const bool same = hL[a] == hR[a];
+                const uint32_t jB = km - jR[a];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint64_t rec = (q & 2) ? r1 : r0;
+                    const uint32_t jd = (q & 1) ? jB : jL[a];
+                    con[a][q] = valid[a] && ((q & 1) == 0 || same) && jd >= rec_jmin(rec) && jd <= rec_jmax(rec);
+                    const uint32_t sp = con[a][q] ? rec_pos(rec) - jd : 0u;
+                    csh[a][q] = sp & 31u;
+                    cs[a][q] = rec_csid(rec);
+                    const uint64_t* w = d.strings + (sp >> 5);
+                    w0[a][q] = w[0];
+                    w1[a][q] = w[1];
+                }
+            }
+            bool slow = false;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                uint32_t found = NEG;
+#pragma unroll
+                for (int q = 3; q >= 0; --q) {
+                    uint32_t lo, hi;
+                    string_lmer(w0[a][q], w1[a][q], csh[a][q], k, lo, hi);
+                    const bool hit = con[a][q] && lo == ((q & 1) ? rlo[a] : klo[a]) && hi == ((q & 1) ? rhi[a] : khi[a]);
+                    found = hit ? cs[a][q] : found;
+                }
+                csid[a] = found;
+                const bool more = (e[a] & REC_TAG) && ovf_cnt(e[a]) > 2;
+                slow |= valid[a] && found == NEG && (more || hL[a] != hR[a]);
+            }
+            // rare continuations: more than two records under the key, or a different rightmost key
+            if (__any(slow)) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    if (valid[a] && csid[a] == NEG) {
+                        const bool same = hL[a] == hR[a];
+                        const uint32_t jB = km - jR[a];
+                        if ((e[a] & REC_TAG) && ovf_cnt(e[a]) > 2) {
+                            const uint64_t* p = d.overflow + ovf_off(e[a]);
+                            for (uint32_t i = 2; i < ovf_cnt(e[a]) && csid[a] == NEG; ++i) {
+                                csid[a] = try_record(d, p[i], jL[a], klo[a], khi[a]);
+                                if (csid[a] == NEG && same) csid[a] = try_record(d, p[i], jB, rlo[a], rhi[a]);
+                            }
+                        }
+                        if (csid[a] == NEG && !same)
+                            csid[a] = probe(d, hR[a], false, true, jL[a], jB, klo[a], khi[a], rlo[a], rhi[a]);
+                    }
+                }
+            }
+            ids[lane] = (uint32_t)lane < nk ? csid[0] : NEG;
+            ids[64 + lane] = (uint32_t)(64 + lane) < nk ? csid[1] : NEG;
+            wave_lds_sync();
+
+            // ---- sorted distinct ids + multiplicities (run heads, see k1_lookup) ----
+            uint32_t H = 0, positives = 0;
+            for (uint32_t b0i = 0; b0i < nk; b0i += 64) {
+                const uint32_t i = b0i + lane;
+                const uint32_t clen = min(64u, nk - b0i);
+                const uint32_t v = ids[i];
+                const uint32_t pv = lane > 0 ? ids[i - 1] : NEG;
+                const bool change = lane == 0 || v != pv || (uint32_t)lane >= clen;
+                const uint64_t C = __ballot(change);
+                const bool head = v != NEG && change;
+                const uint64_t Hm = __ballot(head);
+                positives += __popcll(__ballot(v != NEG));
+                const uint64_t rest = lane == 63 ? 0ull : (C >> (lane + 1));
+                const uint32_t next = rest ? (uint32_t)__builtin_ctzll(rest) + lane + 1 : 64u;
+                if (head) {
+                    uid[H + mask_rank(Hm)] = v;
+                    ucnt[H + mask_rank(Hm)] = min(next, clen) - lane;
+                }
+                H += __popcll(Hm);
+            }
+            wave_lds_sync();
+            uint32_t cnt = 0;
+            const uint64_t base = r * (uint64_t)stride;
+            if (H <= 64) {
+                const uint32_t vj = (uint32_t)lane < H ? uid[lane] : NEG;
+                uint32_t total = 0;
+                bool firsth = (uint32_t)lane < H;
+                for (uint32_t i = 0; i < H; ++i) {
+                    const uint32_t vi = uid[i], li = ucnt[i];
+                    total += vi == vj ? li : 0u;
+                    firsth = firsth && !(vi == vj && i < (uint32_t)lane);
+                }
+                uint64_t reps = __ballot(firsth);
+                cnt = __popcll(reps);
+                uint32_t pos = 0;
+                while (reps) {
+                    const int i = __builtin_ctzll(reps);
+                    reps &= reps - 1;
+                    pos += uid[i] < vj;
+                }
+                if (firsth) {
+                    ids_pool[base + pos] = vj;
+                    cnt_pool[base + pos] = total;
+                }
+            } else {
+                uint32_t last = 0;
+                bool have_last = false;
+                for (;;) {
+                    uint32_t lm = NEG;
+                    for (uint32_t i = lane; i < nk; i += 64) {
+                        uint32_t v = ids[i];
+                        if (v != NEG && (!have_last || v > last)) lm = min(lm, v);
+                    }
+                    const uint32_t wm = wave_min_u32(lm);
+                    if (wm == NEG) break;
+                    uint32_t cc = 0;
+                    for (uint32_t i = lane; i < nk; i += 64) cc += (ids[i] == wm);
+                    cc = wave_sum_u32(cc);
+                    if (lane == 0) {
+                        ids_pool[base + cnt] = wm;
+                        cnt_pool[base + cnt] = cc;
+                    }
+                    last = wm;
+                    have_last = true;
+                    ++cnt;
+                }
+            }
+            if (lane == 0) {
+                nids[r] = cnt;
+                npos[r] = positives;
+                idoff[r] = base;
+            }
+            wave_lds_sync();
+        }
     }
 }
 
@@ -615,6 +877,9 @@ __global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint64_t
 // `merge` (ps_threshold_union.cpp:16-40): scores[c] += score for members of sparse/bitmap lists,
 // -= score for the missing colours of complemented lists while min_score is lowered by that score;
 // keep c iff scores[c] >= min_score. min_score = uint64(double(#positive k-mers) * tau) (:389).
+// Scores live in LDS as 16-bit counters biased by 0x8000 (|score| <= #k-mers <= 1024), two per word,
+// laid out in 16 planes of W words (colour c -> plane (c>>1)&15, word c>>5, half c&1) so that both the
+// per-word updates of bitmap lists and the final threshold pass are bank-conflict free.
 __global__ void k3a_union(DevColors c, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
                           const ListDesc* __restrict__ desc, double tau, uint64_t n_reads,
                           uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count, unsigned int* tickets) {
@@ -622,10 +887,10 @@ __global__ void k3a_union(DevColors c, const uint32_t* __restrict__ npos, const 
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = c.w32;
     const uint32_t n = c.n;
-    const uint32_t per_wave = W * 32 * 4 + wave_scratch_bytes();
+    const uint32_t per_wave = W * 64 + wave_scratch_bytes();
     unsigned char* mine = smem + (size_t)wv * per_wave;
     WaveScratch sc = carve_scratch(mine);
-    int32_t* scores = (int32_t*)(mine + wave_scratch_bytes());
+    uint32_t* SC = (uint32_t*)(mine + wave_scratch_bytes());  // 16 planes of W words
     const WorkQueue wq{tickets, n_reads, 8};
     uint64_t t_first;
     uint32_t t_count;
@@ -641,7 +906,7 @@ __global__ void k3a_union(DevColors c, const uint32_t* __restrict__ npos, const 
             continue;
         }
         const long long min_score = (long long)(unsigned long long)((double)npos[r] * tau);
-        for (uint32_t i = lane; i < W * 32; i += 64) scores[i] = 0;
+        for (uint32_t i = lane; i < W * 16; i += 64) SC[i] = 0x80008000u;
         long long comp_total = 0;
         wave_lds_sync();
         for (uint32_t g = 0; g < cnt; g += 64) {
@@ -667,14 +932,14 @@ __global__ void k3a_union(DevColors c, const uint32_t* __restrict__ npos, const 
                 const int src = __builtin_ctzll(mb);
                 mb &= mb - 1;
                 const uint64_t body = sc.h_body[src];
-                const int32_t s = sc.h_score[src];
+                const uint32_t s = (uint32_t)sc.h_score[src];
                 for (uint32_t w = lane; w * 32 < n; w += 64) {
                     uint32_t x = (uint32_t)bits_window(c.bits, body + 32ull * w);
                     if (n - w * 32 < 32) x &= (1u << (n - w * 32)) - 1u;
-                    while (x) {
-                        const uint32_t b = __builtin_ctz(x);
-                        x &= x - 1;
-                        scores[w * 32 + b] += s;  // a list holds distinct colours: no two lanes share a slot
+#pragma unroll
+                    for (uint32_t q = 0; q < 16; ++q) {  // colours 32w + 2q, 32w + 2q + 1 share a word; only this lane touches it
+                        const uint32_t add = ((x >> (2 * q)) & 1u) * s + (((x >> (2 * q + 1)) & 1u) * s << 16);
+                        if (add) SC[q * W + w] += add;
                     }
                 }
                 wave_lds_sync();
@@ -687,24 +952,33 @@ __global__ void k3a_union(DevColors c, const uint32_t* __restrict__ npos, const 
                     const uint32_t nc = sc.h_ncodes[i];
                     const uint32_t ns = (nc + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
                     const uint32_t seg = t - (sc.pref[i] - ns);
-                    const int32_t s = sc.h_score[i];
-                    decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg,
-                                   [&](uint32_t v) { atomicAdd(&scores[v], s); });
+                    const uint32_t sv = (uint32_t)sc.h_score[i];  // two's complement: adding it to one half never
+                                                                  // carries into the other thanks to the bias
+                    decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg, [&](uint32_t v) {
+                        atomicAdd(&SC[((v >> 1) & 15u) * W + (v >> 5)], (v & 1u) ? (sv << 16) : sv);
+                    });
                 }
             }
             wave_lds_sync();
         }
+        // colour c passes iff (half - 0x8000) + comp_total >= min_score  <=>  half >= thr
+        long long thr_ll = min_score - comp_total + 0x8000;
+        const uint32_t thr = thr_ll < 0 ? 0u : (thr_ll > 0x10000 ? 0x10000u : (uint32_t)thr_ll);
         uint32_t pc = 0;
-        for (uint32_t cb = 0; cb < W * 32; cb += 64) {
-            const uint32_t col = cb + lane;
-            const bool pass = col < n && ((long long)scores[col] + comp_total >= min_score);
-            const uint64_t M = __ballot(pass);
-            if (lane == 0) {
-                bm[cb >> 5] = (uint32_t)M;
-                if ((cb >> 5) + 1 < W) bm[(cb >> 5) + 1] = (uint32_t)(M >> 32);
+        for (uint32_t w = lane; w < W; w += 64) {
+            uint32_t m = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 16; ++q) {
+                const uint32_t x = SC[q * W + w];
+                m |= (uint32_t)((x & 0xFFFFu) >= thr) << (2 * q);
+                m |= (uint32_t)((x >> 16) >= thr) << (2 * q + 1);
             }
-            pc += __popcll(M);
+            const uint32_t lo = w * 32;
+            m &= lo >= n ? 0u : (n - lo >= 32 ? 0xFFFFFFFFu : ((1u << (n - lo)) - 1u));
+            bm[w] = m;
+            pc += __popc(m);
         }
+        pc = wave_sum_u32(pc);
         if (lane == 0) out_count[r] = pc;
         wave_lds_sync();
     }

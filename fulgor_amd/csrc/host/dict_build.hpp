@@ -134,55 +134,68 @@ inline void build_dict(Dict& d, uint32_t k, uint32_t m, const char* bases, uint6
     if (nkeys >= (1ULL << 31)) throw std::runtime_error("too many minimizers");
 
     d.num_slots = (uint32_t)std::max<uint64_t>(1, (uint64_t)(nkeys / 0.80) + 1);
-    d.num_buckets = (uint32_t)std::max<uint64_t>(1, (nkeys + 2) / 3);
-    d.seed = 0;
-    d.pilots.assign(d.num_buckets, 0);
-    d.slots.assign(d.num_slots, REC_EMPTY);
-    d.overflow.clear();
+    d.num_buckets = (uint32_t)std::max<uint64_t>(1, (nkeys + 5) / 6);  // ~6 keys per 16-bit pilot: table stays L2 resident
 
-    // keys are sorted by h0, and phf_bucket is monotone in high32(h0): buckets are contiguous runs
-    std::vector<uint32_t> bucket_begin(d.num_buckets + 1, 0);
-    for (uint64_t i = 0; i < nkeys; ++i) bucket_begin[phf_bucket(recs[key_begin[i]].h0, d.num_buckets) + 1]++;
-    for (uint32_t b = 0; b < d.num_buckets; ++b) bucket_begin[b + 1] += bucket_begin[b];
-    std::vector<uint32_t> order(d.num_buckets);
-    for (uint32_t b = 0; b < d.num_buckets; ++b) order[b] = b;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-        return bucket_begin[a + 1] - bucket_begin[a] > bucket_begin[b + 1] - bucket_begin[b];
-    });
-    std::vector<uint64_t> taken((d.num_slots + 63) / 64, 0);
-    std::vector<uint32_t> pos;
-    for (uint32_t b : order) {
-        const uint32_t kb = bucket_begin[b], ke = bucket_begin[b + 1];
-        if (kb == ke) continue;
-        pos.resize(ke - kb);
-        uint32_t pilot = 0;
-        for (;; ++pilot) {
-            if (pilot == 0xFFFFFFFFu) throw std::runtime_error("perfect hash construction failed");
-            bool ok = true;
-            for (uint32_t i = kb; i < ke && ok; ++i) {
-                uint32_t s = phf_slot(recs[key_begin[i]].h0, pilot, d.num_slots);
-                if ((taken[s >> 6] >> (s & 63)) & 1) ok = false;
-                for (uint32_t j = kb; j < i && ok; ++j)
-                    if (pos[j - kb] == s) ok = false;
-                pos[i - kb] = s;
-            }
-            if (ok) break;
+    std::vector<uint64_t> kh(nkeys);          // seeded hash of every key
+    std::vector<uint32_t> korder(nkeys);      // keys grouped by bucket
+    std::vector<uint32_t> bucket_begin, order, pos;
+    std::vector<uint64_t> taken;
+    bool built = false;
+    for (d.seed = 1; d.seed <= 16 && !built; ++d.seed) {
+        for (uint64_t i = 0; i < nkeys; ++i) kh[i] = phf_hash(recs[key_begin[i]].h0, d.seed);
+        bucket_begin.assign(d.num_buckets + 1, 0);
+        for (uint64_t i = 0; i < nkeys; ++i) bucket_begin[phf_bucket(kh[i], d.num_buckets) + 1]++;
+        for (uint32_t b = 0; b < d.num_buckets; ++b) bucket_begin[b + 1] += bucket_begin[b];
+        {
+            std::vector<uint32_t> fill(bucket_begin.begin(), bucket_begin.end() - 1);
+            for (uint64_t i = 0; i < nkeys; ++i) korder[fill[phf_bucket(kh[i], d.num_buckets)]++] = (uint32_t)i;
         }
-        d.pilots[b] = pilot;
-        for (uint32_t i = kb; i < ke; ++i) {
-            uint32_t s = pos[i - kb];
-            taken[s >> 6] |= 1ULL << (s & 63);
-            uint64_t rb = key_begin[i], re = key_begin[i + 1];
-            if (re - rb == 1) {
-                d.slots[s] = recs[rb].rec;
-            } else {
-                if (d.overflow.size() + (re - rb) >= (1ULL << 32)) throw std::runtime_error("overflow array too large");
-                d.slots[s] = ovf_pack((uint32_t)d.overflow.size(), (uint32_t)(re - rb));
-                for (uint64_t r = rb; r < re; ++r) d.overflow.push_back(recs[r].rec);
+        order.resize(d.num_buckets);
+        for (uint32_t b = 0; b < d.num_buckets; ++b) order[b] = b;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            return bucket_begin[a + 1] - bucket_begin[a] > bucket_begin[b + 1] - bucket_begin[b];
+        });
+        d.pilots.assign(d.num_buckets, 0);
+        d.slots.assign(d.num_slots, REC_EMPTY);
+        d.overflow.clear();
+        taken.assign((d.num_slots + 63) / 64, 0);
+        bool ok_all = true;
+        for (uint32_t b : order) {
+            const uint32_t kb = bucket_begin[b], ke = bucket_begin[b + 1];
+            if (kb == ke) continue;
+            pos.resize(ke - kb);
+            uint32_t pilot = 0;
+            for (;; ++pilot) {
+                if (pilot > 0xFFFFu) break;
+                bool ok = true;
+                for (uint32_t i = kb; i < ke && ok; ++i) {
+                    uint32_t sl = phf_slot(kh[korder[i]], pilot, d.num_slots);
+                    if ((taken[sl >> 6] >> (sl & 63)) & 1) ok = false;
+                    for (uint32_t j = kb; j < i && ok; ++j)
+                        if (pos[j - kb] == sl) ok = false;
+                    pos[i - kb] = sl;
+                }
+                if (ok) break;
+            }
+            if (pilot > 0xFFFFu) { ok_all = false; break; }  // retry with the next seed
+            d.pilots[b] = (uint16_t)pilot;
+            for (uint32_t i = kb; i < ke; ++i) {
+                const uint32_t sl = pos[i - kb];
+                taken[sl >> 6] |= 1ULL << (sl & 63);
+                const uint64_t rb = key_begin[korder[i]], re = key_begin[korder[i] + 1];
+                if (re - rb == 1) {
+                    d.slots[sl] = recs[rb].rec;
+                } else {
+                    if (d.overflow.size() + (re - rb) >= (1ULL << 32)) throw std::runtime_error("overflow array too large");
+                    d.slots[sl] = ovf_pack((uint32_t)d.overflow.size(), (uint32_t)(re - rb));
+                    for (uint64_t r = rb; r < re; ++r) d.overflow.push_back(recs[r].rec);
+                }
             }
         }
+        if (ok_all) { built = true; break; }
     }
-    if (d.overflow.empty()) d.overflow.push_back(REC_EMPTY);  // keep the device array non-empty
+    if (!built) throw std::runtime_error("perfect hash construction failed for 16 seeds");
+    d.overflow.push_back(REC_EMPTY);  // keep the device array non-empty and padded for paired reads
 }
 
 // Host walk of the same structure, used ONLY by the build-time self check (verify_dict below, the
@@ -208,7 +221,8 @@ inline uint32_t dict_lookup(const Dict& d, uint32_t klo, uint32_t khi) {
         string_lmer(d.strings[s >> 5], d.strings[(s >> 5) + 1], (uint32_t)(s & 31), k, lo, hi);
         return (lo == qlo && hi == qhi) ? rec_csid(r) : 0xFFFFFFFFu;
     };
-    auto probe = [&](uint64_t h, bool doA, bool doB) -> uint32_t {
+    auto probe = [&](uint64_t h0, bool doA, bool doB) -> uint32_t {
+        const uint64_t h = phf_hash(h0, d.seed);
         uint32_t pilot = d.pilots[phf_bucket(h, d.num_buckets)];
         uint64_t e = d.slots[phf_slot(h, pilot, d.num_slots)];
         const uint64_t* p = &e;

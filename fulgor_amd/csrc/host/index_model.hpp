@@ -39,7 +39,7 @@ struct Dict {
     std::vector<uint64_t> strings;  // bit-plane words, padded with 2 zero words
     uint64_t seed = 0;
     uint32_t num_buckets = 0, num_slots = 0;
-    std::vector<uint32_t> pilots;
+    std::vector<uint16_t> pilots;   // 16-bit displacement per bucket (~6 keys per bucket): the table stays L2 resident
     std::vector<uint64_t> slots;
     std::vector<uint64_t> overflow;
     // unitig table (export / u2c)
