@@ -606,6 +606,99 @@ struct Index {
     }
 };
 
+}  // namespace oracle
+#include "fulgor_oracle_codecs.hpp"
+namespace oracle {
+
+// index<ColorSets> for the four codecs (include/index_types.hpp): the k-mer side is shared, the colour
+// side is selected by `type` (index_t numbering of include/util.hpp:18: 0 hybrid, 1 diff, 2 meta, 3 meta-diff)
+struct AnyIndex : Index {
+    int type = 0;
+    MetaColors meta;
+    DiffColors diff;
+    MetaDiffColors mdiff;
+
+    std::vector<std::vector<uint32_t>> decode_all() const {
+        std::vector<std::vector<uint32_t>> sets(colors.num_sets());
+        for (uint64_t id = 0; id < colors.num_sets(); ++id) {
+            HybridCursor c = color_set(id);
+            for (uint32_t v = c.value(); v < colors.num_colors; c.next(), v = c.value()) sets[id].push_back(v);
+        }
+        return sets;
+    }
+    // re-encode the colour sets with another codec (same colour numbering, same colour-set ids)
+    void convert(int new_type, uint32_t psize, uint32_t csize) {
+        const auto sets = decode_all();
+        const uint32_t n = colors.num_colors;
+        if (new_type == 1) build_diff(diff, sets, n, csize);
+        else if (new_type == 2) build_meta(meta, sets, n, psize);
+        else if (new_type == 3) build_metadiff(mdiff, sets, n, psize, csize);
+        else if (new_type != 0) throw std::runtime_error("unknown index type");
+        type = new_type;
+    }
+
+    void any_full_intersection(const std::vector<uint32_t>& ids, std::vector<uint32_t>& out, std::vector<uint32_t>& tmp) const {
+        out.clear();
+        tmp.clear();
+        if (type == 0) { full_intersection(ids, out, tmp); return; }
+        if (type == 1) {
+            std::vector<DiffCursor> its;
+            for (uint32_t id : ids) its.push_back(diff_color_set(diff, id));
+            diff_intersect(its, out);
+        } else if (type == 2) {
+            std::vector<MetaCursor> its;
+            for (uint32_t id : ids) its.push_back(meta_color_set(meta, id));
+            meta_intersect<MetaCursor, false>(its, out, tmp);
+        } else {
+            std::vector<MetaDiffCursor> its;
+            for (uint32_t id : ids) its.push_back(metadiff_color_set(mdiff, id));
+            meta_intersect<MetaDiffCursor, true>(its, out, tmp);
+        }
+    }
+
+    // ps_threshold_union.cpp:320-402 for the non-hybrid codecs (the k-mer side is identical)
+    void any_threshold_union(const char* seq, uint64_t len, double threshold, std::vector<uint32_t>& out) const {
+        if (type == 0) { threshold_union(seq, len, threshold, out); return; }
+        if (len < k) return;
+        out.clear();
+        struct S { uint64_t item; uint32_t score; };
+        std::vector<S> unitigs;
+        uint64_t num_positive = 0, prev = (uint64_t)-1;
+        stream_kmers(seq, len, [&](uint64_t u) {
+            ++num_positive;
+            if (u != prev) { unitigs.push_back({u, 1}); prev = u; }
+            else ++unitigs.back().score;
+        });
+        std::sort(unitigs.begin(), unitigs.end(), [](const S& a, const S& b) { return a.item < b.item; });
+        std::vector<S> sets;
+        uint64_t pu = (uint64_t)-1;
+        for (auto& u : unitigs) {
+            if (u.item != pu) { sets.push_back({u2c(u.item), u.score}); pu = u.item; }
+            else sets.back().score += u.score;
+        }
+        std::sort(sets.begin(), sets.end(), [](const S& a, const S& b) { return a.item < b.item; });
+        std::vector<S> merged;
+        for (auto& s : sets) {
+            if (merged.empty() || merged.back().item != s.item) merged.push_back(s);
+            else merged.back().score += s.score;
+        }
+        const uint64_t min_score = (uint64_t)((double)num_positive * threshold);
+        if (type == 1) {
+            std::vector<Scored<DiffCursor>> its;
+            for (auto& s : merged) its.push_back({diff_color_set(diff, s.item), s.score});
+            merge_diff(its, out, min_score);
+        } else if (type == 2) {
+            std::vector<Scored<MetaCursor>> its;
+            for (auto& s : merged) its.push_back({meta_color_set(meta, s.item), s.score});
+            merge_meta(its, out, min_score);
+        } else {
+            std::vector<Scored<MetaDiffCursor>> its;
+            for (auto& s : merged) its.push_back({metadiff_color_set(mdiff, s.item), s.score});
+            merge_metadiff(its, out, min_score);
+        }
+    }
+};
+
 // util.hpp:245-261 + ps_utils.cpp:55-71: "<id>\t<count>[\t<c>...]\n"
 static inline void format_ascii(uint32_t query_id, const std::vector<uint32_t>& colors, std::string& out) {
     out += std::to_string(query_id);

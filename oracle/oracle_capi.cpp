@@ -18,7 +18,7 @@ const char* fo_last_error() { return g_err.c_str(); }
 
 void* fo_index_load_dump(const char* base) {
     try {
-        auto* ix = new Index();
+        auto* ix = new AnyIndex();
         ix->load_dump(base);
         return ix;
     } catch (std::exception& e) { g_err = e.what(); return nullptr; }
@@ -28,7 +28,7 @@ void* fo_index_from_arrays(uint32_t k, const char* unitig_bases, const uint64_t*
                            uint64_t num_unitigs, uint32_t num_colors, uint32_t sparse_thr, uint32_t dense_thr,
                            const uint64_t* words, uint64_t nbits, const uint64_t* offsets, uint64_t num_sets) {
     try {
-        auto* ix = new Index();
+        auto* ix = new AnyIndex();
         ix->k = k;
         ix->add_unitigs(unitig_bases, unitig_off, unitig_csid, num_unitigs);
         ix->set_colors(num_colors, sparse_thr, dense_thr, words, nbits, offsets, num_sets);
@@ -36,10 +36,10 @@ void* fo_index_from_arrays(uint32_t k, const char* unitig_bases, const uint64_t*
     } catch (std::exception& e) { g_err = e.what(); return nullptr; }
 }
 
-void fo_index_free(void* h) { delete static_cast<Index*>(h); }
+void fo_index_free(void* h) { delete static_cast<AnyIndex*>(h); }
 
 void fo_index_info(void* h, uint64_t* k, uint64_t* num_colors, uint64_t* num_sets, uint64_t* num_unitigs, uint64_t* nbits) {
-    auto* ix = static_cast<Index*>(h);
+    auto* ix = static_cast<AnyIndex*>(h);
     *k = ix->k;
     *num_colors = ix->colors.num_colors;
     *num_sets = ix->colors.num_sets();
@@ -47,10 +47,18 @@ void fo_index_info(void* h, uint64_t* k, uint64_t* num_colors, uint64_t* num_set
     *nbits = ix->colors.bits.n;
 }
 // encoded stream export (encoder parity against the product's encoder)
-const uint64_t* fo_colors_words(void* h) { return static_cast<Index*>(h)->colors.bits.w.data(); }
-const uint64_t* fo_colors_offsets(void* h) { return static_cast<Index*>(h)->colors.offsets.data(); }
+const uint64_t* fo_colors_words(void* h) { return static_cast<AnyIndex*>(h)->colors.bits.w.data(); }
+const uint64_t* fo_colors_offsets(void* h) { return static_cast<AnyIndex*>(h)->colors.offsets.data(); }
 
 void fo_free(void* p) { free(p); }
+
+// re-encode the colour sets with another codec: 1 differential, 2 meta, 3 meta-differential (0 = back to hybrid)
+int fo_index_convert(void* h, int type, uint32_t partition_size, uint32_t cluster_size) {
+    try {
+        static_cast<AnyIndex*>(h)->convert(type, partition_size, cluster_size);
+        return 0;
+    } catch (std::exception& e) { g_err = e.what(); return -1; }
+}
 
 }  // extern "C"
 
@@ -97,7 +105,7 @@ extern "C" {
 
 int fo_fetch_color_set_ids(void* h, const char* bases, const uint64_t* offs, uint64_t n, uint64_t** out_off,
                            uint32_t** out_ids, int nthreads) {
-    auto* ix = static_cast<Index*>(h);
+    auto* ix = static_cast<AnyIndex*>(h);
     return run_batch(n, nthreads, out_off, out_ids, [&](uint64_t r, std::vector<uint32_t>& out) {
         out.clear();  // callers clear first (ps_utils.cpp:277)
         ix->fetch_color_set_ids(bases + offs[r], offs[r + 1] - offs[r], out);
@@ -106,29 +114,32 @@ int fo_fetch_color_set_ids(void* h, const char* bases, const uint64_t* offs, uin
 
 int fo_full_intersection(void* h, const char* bases, const uint64_t* offs, uint64_t n, uint64_t** out_off,
                          uint32_t** out_colors, int nthreads, int self_check) {
-    auto* ix = static_cast<Index*>(h);
+    auto* ix = static_cast<AnyIndex*>(h);
     return run_batch(n, nthreads, out_off, out_colors, [&](uint64_t r, std::vector<uint32_t>& out) {
         std::vector<uint32_t> ids, tmp;
         ix->fetch_color_set_ids(bases + offs[r], offs[r + 1] - offs[r], ids);
-        ix->full_intersection(ids, out, tmp, self_check != 0);
+        if (ix->type == 0) ix->full_intersection(ids, out, tmp, self_check != 0);
+        else ix->any_full_intersection(ids, out, tmp);
     });
 }
 
 int fo_intersect_ids(void* h, const uint32_t* ids, const uint64_t* id_offs, uint64_t n, uint64_t** out_off,
                      uint32_t** out_colors, int nthreads, int self_check) {
-    auto* ix = static_cast<Index*>(h);
+    auto* ix = static_cast<AnyIndex*>(h);
     return run_batch(n, nthreads, out_off, out_colors, [&](uint64_t r, std::vector<uint32_t>& out) {
         std::vector<uint32_t> v(ids + id_offs[r], ids + id_offs[r + 1]), tmp;
-        ix->full_intersection(v, out, tmp, self_check != 0);
+        if (ix->type == 0) ix->full_intersection(v, out, tmp, self_check != 0);
+        else ix->any_full_intersection(v, out, tmp);
     });
 }
 
 int fo_threshold_union(void* h, const char* bases, const uint64_t* offs, uint64_t n, double tau, uint64_t** out_off,
                        uint32_t** out_colors, int nthreads, int self_check) {
-    auto* ix = static_cast<Index*>(h);
+    auto* ix = static_cast<AnyIndex*>(h);
     return run_batch(n, nthreads, out_off, out_colors, [&](uint64_t r, std::vector<uint32_t>& out) {
         out.clear();
-        ix->threshold_union(bases + offs[r], offs[r + 1] - offs[r], tau, out, self_check != 0);
+        if (ix->type == 0) ix->threshold_union(bases + offs[r], offs[r + 1] - offs[r], tau, out, self_check != 0);
+        else ix->any_threshold_union(bases + offs[r], offs[r + 1] - offs[r], tau, out);
     });
 }
 
@@ -137,7 +148,7 @@ int fo_threshold_union(void* h, const char* bases, const uint64_t* offs, uint64_
 // algo 0 = full-intersection, 1 = threshold-union. Returns wall seconds.
 double fo_time_pseudoalign(void* h, const char* bases, const uint64_t* offs, uint64_t n, int algo, double tau,
                            int nthreads, uint64_t* num_mapped, uint64_t* total_colors) {
-    auto* ix = static_cast<Index*>(h);
+    auto* ix = static_cast<AnyIndex*>(h);
     if (nthreads < 1) nthreads = 1;
     std::atomic<uint64_t> next{0}, mapped{0}, total{0};
     auto t0 = std::chrono::steady_clock::now();
@@ -152,8 +163,8 @@ double fo_time_pseudoalign(void* h, const char* bases, const uint64_t* offs, uin
                 ids.clear();
                 colors.clear();
                 ix->fetch_color_set_ids(bases + offs[r], offs[r + 1] - offs[r], ids);  // done for both algorithms (ps_utils.cpp:275-280)
-                if (algo == 0) ix->full_intersection(ids, colors, tmp);
-                else ix->threshold_union(bases + offs[r], offs[r + 1] - offs[r], tau, colors);
+                if (algo == 0) ix->any_full_intersection(ids, colors, tmp);
+                else ix->any_threshold_union(bases + offs[r], offs[r + 1] - offs[r], tau, colors);
                 if (!colors.empty()) ++m;
                 tc += colors.size();
             }

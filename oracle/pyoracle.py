@@ -32,6 +32,7 @@ def lib():
         L.fo_colors_words.argtypes = [vp]
         L.fo_colors_offsets.restype = C.POINTER(C.c_uint64)
         L.fo_colors_offsets.argtypes = [vp]
+        L.fo_index_convert.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32]
         L.fo_free.argtypes = [vp]
         L.fo_free.restype = None
         L.fo_fetch_color_set_ids.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.c_int]
@@ -79,6 +80,12 @@ class OracleIndex:
             int(ex["k"]), _ptr(ex["unitig_bases"]), _ptr(ex["unitig_off"]), _ptr(ex["unitig_csid"]),
             len(ex["unitig_csid"]), int(t[0]), int(t[1]), int(t[2]), _ptr(ex["color_words"]), int(ex["color_bits"]),
             _ptr(ex["color_offsets"]), len(ex["color_offsets"]) - 1))
+
+    def convert(self, index_type, partition_size=64, cluster_size=8):
+        """re-encode the colour sets: 0 hybrid, 1 differential, 2 meta, 3 meta-differential"""
+        if self._L.fo_index_convert(self._h, index_type, partition_size, cluster_size) != 0:
+            raise RuntimeError("oracle: %s" % self._L.fo_last_error().decode())
+        return self
 
     def info(self):
         v = [C.c_uint64() for _ in range(5)]

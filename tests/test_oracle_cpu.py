@@ -48,3 +48,19 @@ def test_oracle_strand_symmetry(s10_oracle):
     b2, o2 = pack_reads(rc)
     assert csr_to_lists(*s10_oracle.full_intersection(b1, o1)) == csr_to_lists(*s10_oracle.full_intersection(b2, o2))
     assert csr_to_lists(*s10_oracle.threshold_union(b1, o1, 0.8)) == csr_to_lists(*s10_oracle.threshold_union(b2, o2, 0.8))
+
+
+# ---- the other three codecs: same colour numbering and colour-set ids => same golden vectors -----------
+CODEC_CASES = [(1, 3, 4), (1, 10, 1), (2, 3, 4), (2, 4, 2), (2, 1, 16), (3, 3, 4), (3, 4, 2), (3, 10, 1), (3, 1, 16)]
+
+
+@pytest.mark.parametrize("index_type,psize,csize", CODEC_CASES)
+def test_oracle_meta_diff_metadiff_match_golden(s10_dump, index_type, psize, csize):
+    """meta / differential / meta-differential cursors + meta_intersect, diff_intersect, merge_meta,
+    merge_diff, merge_metadiff (restated) against the vectors of the independent k-mer oracle"""
+    from oracle.pyoracle import OracleIndex
+    orc = OracleIndex.from_dump(s10_dump).convert(index_type, psize, csize)
+    b, o = pack_reads(load_golden_reads())
+    assert csr_to_lists(*orc.full_intersection(b, o, threads=4)) == load_golden_tsv("s10_full_intersection.tsv")
+    for tau in (0.8, 1.0, 0.01):
+        assert csr_to_lists(*orc.threshold_union(b, o, tau, threads=4)) == load_golden_tsv("s10_threshold_union_%s.tsv" % tau)
