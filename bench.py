@@ -52,6 +52,10 @@ def main():
     ap.add_argument("--algo", default="full-intersection", choices=["full-intersection", "threshold-union"])
     ap.add_argument("--tau", type=float, default=0.8)
     ap.add_argument("--chunk", type=int, default=1 << 20, help="reads per kernel pass")
+    ap.add_argument("--index-type", default="hybrid", choices=["hybrid", "diff", "meta", "meta-diff"],
+                    help="colour-set codec (fur / dfur / mfur / mdfur of the reference)")
+    ap.add_argument("--partition-size", type=int, default=160)
+    ap.add_argument("--cluster-size", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -82,6 +86,11 @@ def main():
         fg, gen, desc = prepare_workload(args.workload, rank)
 
     ix = fulgor_amd.Index(fg, device=local_rank)
+    itype = {"hybrid": 0, "diff": 1, "meta": 2, "meta-diff": 3}[args.index_type]
+    if itype:
+        ix.convert(itype, args.partition_size, args.cluster_size)
+        desc += "; colour sets re-encoded as %s (partitions of %d colours, clusters of %d sets)" % (
+            args.index_type, args.partition_size, args.cluster_size)
     algo = fulgor_amd.FULL_INTERSECTION if args.algo == "full-intersection" else fulgor_amd.THRESHOLD_UNION
     bases, offs = gen.generate(rank * n_reads, n_reads, 150, 42)
     reads = ix.upload_reads(bases, offs)
@@ -175,18 +184,20 @@ def main():
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ix, bases, offs, algo, args.tau)
+            out["cpu_baseline"] = cpu_baseline(ix, bases, offs, algo, args.tau, itype, args.partition_size, args.cluster_size)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(ix, bases, offs, algo, tau):
+def cpu_baseline(ix, bases, offs, algo, tau, itype=0, psize=160, csize=16):
     """The oracle (CPU restatement of the reference, same worker-pool threading) timed on the host cores
     on a bounded prefix of the same reads; kind = "port" because the reference binary cannot be built."""
     from oracle.pyoracle import OracleIndex
     orc = OracleIndex.from_export(ix.export())
+    if itype:
+        orc.convert(itype, psize, csize)
     cores = os.cpu_count() or 1
     probe = min(len(offs) - 1, 20000)
     sec, _, _ = orc.time_pseudoalign(bases[:int(offs[probe])], offs[:probe + 1], algo, tau, cores)

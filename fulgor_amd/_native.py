@@ -46,6 +46,7 @@ def lib():
     L.fgpu_close.restype = None
     L.fgpu_save.argtypes = [vp, C.c_char_p]
     L.fgpu_selfcheck.argtypes = [vp, C.c_uint64]
+    L.fgpu_convert.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32]
     L.fgpu_info.argtypes = [vp, u64p, u64p, u64p, u64p, u64p, C.POINTER(C.c_int)]
     L.fgpu_free.argtypes = [vp]
     L.fgpu_free.restype = None

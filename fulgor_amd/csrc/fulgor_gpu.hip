@@ -70,8 +70,10 @@ struct fgpu_index {
     hipStream_t stream = nullptr;
     int num_cus = 256;
     DevBuf d_strings, d_pilots, d_slots, d_overflow, d_bits, d_offsets, d_sample_off, d_samples;
+    DevBuf d_gbits, d_gops, d_gset_ops_off, d_gset_ops, d_gsamples, d_gset_bytes;
     DevDict dd{};
     DevColors dc{};
+    DevGeneric dg{};
     // timing
     bool timing = false;
     double ms[FGPU_K_COUNT] = {0};
@@ -153,6 +155,22 @@ void upload_index(fgpu_index* ix) {
     w32 += w32 & 1;
     ix->dc = DevColors{ix->d_bits.as<uint64_t>(), ix->d_offsets.as<uint64_t>(), ix->d_sample_off.as<uint64_t>(),
                        ix->d_samples.as<uint64_t>(), h.num_colors, h.sparse_thr, h.dense_thr, w32};
+}
+
+static_assert(sizeof(SetOp) == sizeof(DevOp), "host and device op layouts must match");
+
+void upload_generic(fgpu_index* ix) {
+    const GenericSets& g = ix->host.generic;
+    hipStream_t s = ix->stream;
+    upload(ix->d_gbits, g.bits, s);
+    upload(ix->d_gops, g.ops, s);
+    upload(ix->d_gset_ops_off, g.set_ops_off, s);
+    upload(ix->d_gset_ops, g.set_ops, s);
+    upload(ix->d_gsamples, g.samples, s);
+    upload(ix->d_gset_bytes, g.set_bytes, s);
+    HIP_TRY(hipStreamSynchronize(s));
+    ix->dg = DevGeneric{ix->d_gbits.as<uint64_t>(), ix->d_gops.as<DevOp>(), ix->d_gset_ops_off.as<uint64_t>(),
+                        ix->d_gset_ops.as<uint32_t>(), ix->d_gsamples.as<uint64_t>(), g.num_colors, ix->dc.w32};
 }
 
 // waves per block such that the dynamic LDS request fits; throws if one wave does not fit a CU
@@ -254,7 +272,7 @@ void stage_descriptors(fgpu_index* ix, fgpu_result* res, uint64_t max_total_ids)
     hipLaunchKernelGGL(k_desc, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, ix->dc, res->d_nids.as<uint32_t>(),
                        res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(),
                        res->have_ids ? res->d_cnt_pool.as<uint32_t>() : (const uint32_t*)nullptr, res->d_idcsr.as<uint64_t>(), n,
-                       res->d_desc.as<ListDesc>());
+                       res->d_desc.as<ListDesc>(), ix->host.type == IDX_HYBRID ? 1 : 0);
     HIP_TRY(hipGetLastError());
 }
 
@@ -271,7 +289,25 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         HIP_TRY(hipStreamSynchronize(s));
         return;
     }
-    if (algo == FGPU_FULL_INTERSECTION) {
+    if (ix->host.type != IDX_HYBRID) {
+        const bool uni = algo == FGPU_THRESHOLD_UNION;
+        if (!uni && algo != FGPU_FULL_INTERSECTION) throw std::runtime_error("unknown algorithm");
+        const size_t per_wave = wave_scratch_bytes() + 64 * 8 + (size_t)W * 4 + (uni ? (size_t)W * 64 : (size_t)W * 4);
+        const void* kfn = uni ? (const void*)k_generic<true> : (const void*)k_generic<false>;
+        const uint32_t wpb = pick_waves(per_wave, kfn);
+        const uint32_t grid = uni ? resident_grid(k_generic<true>, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave)
+                                  : resident_grid(k_generic<false>, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
+        Timed t(ix, uni ? FGPU_K_UNION : FGPU_K_INTERSECT);
+        if (uni)
+            hipLaunchKernelGGL(k_generic<true>, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dg, res->d_npos.as<uint32_t>(),
+                               res->d_idcsr.as<uint64_t>(), res->d_desc.as<ListDesc>(), tau, n, res->d_bitmap.as<uint32_t>(),
+                               res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
+        else
+            hipLaunchKernelGGL(k_generic<false>, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dg, res->d_npos.as<uint32_t>(),
+                               res->d_idcsr.as<uint64_t>(), res->d_desc.as<ListDesc>(), tau, n, res->d_bitmap.as<uint32_t>(),
+                               res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
+        HIP_TRY(hipGetLastError());
+    } else if (algo == FGPU_FULL_INTERSECTION) {
         const size_t per_wave = (size_t)W * 4 + (size_t)W * 32 + wave_scratch_bytes();
         const uint32_t wpb = pick_waves(per_wave, (const void*)k2a_intersect);
         const uint32_t grid = resident_grid(k2a_intersect, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
@@ -342,7 +378,6 @@ int fgpu_open(const char* path, int device, fgpu_index** out) {
         }
         ix = new fgpu_index();
         open_index(path, ix->host);
-        if (ix->host.type != IDX_HYBRID) throw std::runtime_error("only hybrid (.fur-equivalent) indexes are supported by this build");
         ix->device = device;
         if (device == FGPU_HOST_ONLY) return;  // ingestion / export / save only; queries are refused
         HIP_TRY(hipSetDevice(device));
@@ -351,6 +386,7 @@ int fgpu_open(const char* path, int device, fgpu_index** out) {
         ix->num_cus = prop.multiProcessorCount;
         HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
         upload_index(ix);
+        if (ix->host.type != IDX_HYBRID) upload_generic(ix);
     });
     if (rc) { delete ix; return rc; }
     *out = ix;
@@ -362,7 +398,8 @@ void fgpu_close(fgpu_index* ix) {
     if (ix->device == FGPU_HOST_ONLY) { delete ix; return; }
     (void)hipSetDevice(ix->device);
     for (DevBuf* b : {&ix->d_strings, &ix->d_pilots, &ix->d_slots, &ix->d_overflow, &ix->d_bits, &ix->d_offsets,
-                      &ix->d_sample_off, &ix->d_samples})
+                      &ix->d_sample_off, &ix->d_samples, &ix->d_gbits, &ix->d_gops, &ix->d_gset_ops_off, &ix->d_gset_ops,
+                      &ix->d_gsamples, &ix->d_gset_bytes})
         b->release();
     for (auto e : ix->event_pool) (void)hipEventDestroy(e);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -387,6 +424,29 @@ int fgpu_info(const fgpu_index* ix, uint64_t* k, uint64_t* num_colors, uint64_t*
 }
 
 void fgpu_free(void* p) { free(p); }
+
+int fgpu_convert(fgpu_index* ix, int index_type, uint32_t partition_size, uint32_t cluster_size) {
+    if (!ix) return fail(-EINVAL, "null argument");
+    return guarded([&] {
+        if (index_type == IDX_HYBRID) {
+            ix->host.generic = GenericSets();
+        } else {
+            convert_sets(ix->host.hybrid, index_type, partition_size, cluster_size, ix->host.generic);
+            // every set must decode to the same colours through its ops (cheap sample: every 97th set)
+            std::vector<uint32_t> a, b;
+            for (uint64_t id = 0; id < ix->host.hybrid.num_sets(); id += 97) {
+                hybrid_decode(ix->host.hybrid, id, a);
+                generic_decode(ix->host.generic, id, b);
+                if (a != b) throw std::runtime_error("codec conversion self-check failed");
+            }
+        }
+        ix->host.type = index_type;
+        if (ix->device != FGPU_HOST_ONLY) {
+            HIP_TRY(hipSetDevice(ix->device));
+            if (index_type != IDX_HYBRID) upload_generic(ix);
+        }
+    });
+}
 
 int fgpu_selfcheck(const fgpu_index* ix, uint64_t unitig_stride) {
     if (!ix) return fail(-EINVAL, "null argument");
@@ -526,7 +586,8 @@ int fgpu_result_algorithmic_bytes(const fgpu_result* r, uint64_t* list_bytes, ui
             const_cast<fgpu_result*>(r)->d_acct.ensure(16);
             HIP_TRY(hipMemsetAsync(r->d_acct.p, 0, 16, ix->stream));
             hipLaunchKernelGGL(k_account, dim3(1024), dim3(256), 0, ix->stream, ix->dc, r->d_idcsr.as<uint64_t>(),
-                               r->d_desc.as<ListDesc>(), r->d_counts.as<uint32_t>(), r->n, r->d_acct.as<unsigned long long>());
+                               r->d_desc.as<ListDesc>(), r->d_counts.as<uint32_t>(), r->n, r->d_acct.as<unsigned long long>(),
+                               ix->host.type == IDX_HYBRID ? (const uint32_t*)nullptr : ix->d_gset_bytes.as<uint32_t>());
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(acct, r->d_acct.p, 16, hipMemcpyDeviceToHost, ix->stream));
             HIP_TRY(hipStreamSynchronize(ix->stream));

@@ -657,7 +657,7 @@ __device__ __forceinline__ uint64_t desc_body(const ListDesc& d) { return d.begi
 __global__ __launch_bounds__(256) void k_desc(DevColors c, const uint32_t* __restrict__ nids,
                                               const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ ids_src,
                                               const uint32_t* __restrict__ cnt_src, const uint64_t* __restrict__ dst_off,
-                                              uint64_t n_reads, ListDesc* __restrict__ out) {
+                                              uint64_t n_reads, ListDesc* __restrict__ out, int resolve_hybrid) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t r = t >> 4;
     if (r >= n_reads) return;
@@ -665,7 +665,9 @@ __global__ __launch_bounds__(256) void k_desc(DevColors c, const uint32_t* __res
     const uint64_t so = src_off[r], dso = dst_off[r];
     for (uint32_t j = (uint32_t)t & 15u; j < cnt; j += 16) {
         const uint32_t id = ids_src[so + j];
-        const ListHeader h = read_header(c, id);
+        ListHeader h;
+        h.begin = h.body = h.soff = 0; h.ncodes = h.size = 0; h.type = D_ENC_NONE;
+        if (resolve_hybrid) h = read_header(c, id);
         ListDesc d;
         d.begin = h.begin;
         d.soff = h.soff;
@@ -985,6 +987,202 @@ __global__ void k3a_union(DevColors c, const uint32_t* __restrict__ npos, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Generic colour-set kernel for the meta, differential and meta-differential codecs.
+// Every colour set is a short list of ops over ONE bit arena (host/codecs_build.hpp). Per read, per
+// colour set: T = 0; fills and bitmaps are applied wave-cooperatively; all 16-code segments of all gap
+// ops decode concurrently (OR / clear / XOR into T with LDS atomics); then
+//   full intersection (meta_intersect / diff_intersect, ps_full_intersection.cpp:129-332): R &= T
+//   threshold union   (merge_meta / merge_diff / merge_metadiff, ps_threshold_union.cpp:42-318):
+//                     score[c] += s for every c in T, keep c iff score[c] >= min_score
+// The reference reaches the same sets through partition/cluster shortcuts; the results are the sets.
+// ---------------------------------------------------------------------------------------------
+struct DevOp {
+    uint64_t body, soff;
+    uint32_t ncodes, kind, base, np;
+};
+struct DevGeneric {
+    const uint64_t* bits;
+    const DevOp* ops;
+    const uint64_t* set_ops_off;
+    const uint32_t* set_ops;
+    const uint64_t* samples;
+    uint32_t n, w32;
+};
+enum { G_OR_GAPS = 0, G_OR_BITMAP = 1, G_OR_COMP = 2, G_XOR_GAPS = 3 };
+
+// decode segment `seg` of a gap op (values are relative to the op's colour base)
+template <typename F>
+__device__ __forceinline__ void decode_op_segment(const DevGeneric& g, uint64_t body, uint64_t soff, uint32_t ncodes,
+                                                  uint32_t seg, F f) {
+    uint64_t pos = body;
+    uint32_t prev = 0xFFFFFFFFu;
+    if (seg) {
+        const uint64_t s = g.samples[soff + seg - 1];
+        pos = body + (uint32_t)s;
+        prev = (uint32_t)(s >> 32);
+    }
+    const uint32_t nc = min(SAMPLE_STRIDE, ncodes - seg * SAMPLE_STRIDE);
+    if (g.n < 65536u) {
+        NarrowReader rd;
+        rd.init((const uint32_t*)g.bits, pos);
+        for (uint32_t i = 0; i < nc; ++i) { prev = prev + 1u + rd.delta(); f(prev); }
+    } else {
+        for (uint32_t i = 0; i < nc; ++i) { prev = prev + 1u + read_delta(g.bits, pos); f(prev); }
+    }
+}
+
+template <bool UNION>
+__global__ void k_generic(DevGeneric g, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
+                          const ListDesc* __restrict__ desc, double tau, uint64_t n_reads,
+                          uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count, unsigned int* tickets) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t W = g.w32, n = g.n;
+    const uint32_t acc_bytes = UNION ? W * 64 : W * 4;
+    const uint32_t per_wave = wave_scratch_bytes() + 64 * 8 + W * 4 + acc_bytes;
+    unsigned char* mine = smem + (size_t)wv * per_wave;
+    WaveScratch sc = carve_scratch(mine);                              // h_begin = body, h_soff, h_ncodes, h_score = kind
+    uint32_t* o_base = (uint32_t*)(mine + wave_scratch_bytes());       // 64 words: colour base of each op
+    uint32_t* o_np = o_base + 64;                                      // 64 words
+    uint32_t* T = o_np + 64;
+    uint32_t* ACC = T + W;                                             // R (W words) or SC (16 planes of W words)
+    const WorkQueue wq{tickets, n_reads, 8};
+    uint64_t t_first;
+    uint32_t t_count;
+
+    while (wq.pull(t_first, t_count))
+    for (uint64_t r = t_first; r < t_first + t_count; ++r) {
+        const uint64_t off = id_csr[r];
+        const uint32_t cnt = (uint32_t)(id_csr[r + 1] - off);
+        uint32_t* bm = out_bitmap + r * W;
+        if (cnt == 0) {
+            for (uint32_t w = lane; w < W; w += 64) bm[w] = 0;
+            if (lane == 0) out_count[r] = 0;
+            continue;
+        }
+        if (UNION) {
+            for (uint32_t i = lane; i < W * 16; i += 64) ACC[i] = 0x80008000u;
+        } else {
+            for (uint32_t w = lane; w < W; w += 64) {
+                const uint32_t lo = w * 32;
+                ACC[w] = lo >= n ? 0u : (n - lo >= 32 ? 0xFFFFFFFFu : ((1u << (n - lo)) - 1u));
+            }
+        }
+        for (uint32_t li = 0; li < cnt; ++li) {
+            const ListDesc d = desc[off + li];
+            const uint64_t o0 = g.set_ops_off[d.id], o1 = g.set_ops_off[d.id + 1];
+            for (uint32_t w = lane; w < W; w += 64) T[w] = 0;
+            wave_lds_sync();
+            for (uint64_t og = o0; og < o1; og += 64) {
+                DevOp op;
+                op.body = op.soff = 0; op.ncodes = 0; op.kind = G_OR_BITMAP; op.base = 0; op.np = 0;
+                const bool have = og + lane < o1;
+                if (have) op = g.ops[g.set_ops[og + lane]];
+                const uint32_t nseg = (have && op.kind != G_OR_BITMAP) ? (op.ncodes + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE : 0u;
+                sc.h_begin[lane] = op.body; sc.h_soff[lane] = op.soff; sc.h_ncodes[lane] = op.ncodes;
+                sc.h_score[lane] = (int32_t)op.kind;
+                o_base[lane] = op.base; o_np[lane] = op.np;
+                const uint32_t incl = wave_incl_scan_u32(nseg);
+                sc.pref[lane] = incl;
+                const uint32_t total_seg = (uint32_t)__shfl((int)incl, 63);
+                wave_lds_sync();
+                // complemented hybrid lists: fill the partition's colour range first
+                uint64_t mc = __ballot(have && op.kind == G_OR_COMP);
+                while (mc) {
+                    const int src = __builtin_ctzll(mc);
+                    mc &= mc - 1;
+                    const uint32_t b = o_base[src], e = b + o_np[src];
+                    for (uint32_t w = (b >> 5) + lane; w * 32 < e; w += 64) {
+                        uint32_t m = 0xFFFFFFFFu;
+                        if (w * 32 < b) m &= 0xFFFFFFFFu << (b & 31);
+                        if (e - w * 32 < 32) m &= (1u << (e - w * 32)) - 1u;
+                        atomicOr(&T[w], m);
+                    }
+                }
+                // hybrid bitmaps: OR the np bits at `body` into T at colour `base`
+                uint64_t mb = __ballot(have && op.kind == G_OR_BITMAP && op.np != 0);
+                while (mb) {
+                    const int src = __builtin_ctzll(mb);
+                    mb &= mb - 1;
+                    const uint64_t body = sc.h_begin[src];
+                    const uint32_t b = o_base[src], np = o_np[src];
+                    for (uint32_t kk = lane; kk * 32 < np; kk += 64) {
+                        uint32_t v = (uint32_t)bits_window(g.bits, body + 32ull * kk);
+                        if (np - kk * 32 < 32) v &= (1u << (np - kk * 32)) - 1u;
+                        const uint32_t dpos = b + kk * 32, sh = dpos & 31u;
+                        atomicOr(&T[dpos >> 5], v << sh);
+                        if (sh && (v >> (32 - sh))) atomicOr(&T[(dpos >> 5) + 1], v >> (32 - sh));
+                    }
+                }
+                wave_lds_sync();
+                for (uint32_t t0 = 0; t0 < total_seg; t0 += 64) {
+                    const uint32_t t = t0 + lane;
+                    if (t < total_seg) {
+                        const uint32_t i = upper_slot(sc.pref, t);
+                        const uint32_t nc = sc.h_ncodes[i];
+                        const uint32_t ns = (nc + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
+                        const uint32_t seg = t - (sc.pref[i] - ns);
+                        const uint32_t kind = (uint32_t)sc.h_score[i], b = o_base[i];
+                        if (kind == G_OR_GAPS)
+                            decode_op_segment(g, sc.h_begin[i], sc.h_soff[i], nc, seg,
+                                              [&](uint32_t v) { atomicOr(&T[(b + v) >> 5], 1u << ((b + v) & 31)); });
+                        else if (kind == G_OR_COMP)
+                            decode_op_segment(g, sc.h_begin[i], sc.h_soff[i], nc, seg,
+                                              [&](uint32_t v) { atomicAnd(&T[(b + v) >> 5], ~(1u << ((b + v) & 31))); });
+                        else
+                            decode_op_segment(g, sc.h_begin[i], sc.h_soff[i], nc, seg,
+                                              [&](uint32_t v) { atomicXor(&T[(b + v) >> 5], 1u << ((b + v) & 31)); });
+                    }
+                }
+                wave_lds_sync();
+            }
+            if (UNION) {
+                const uint32_t s = (uint32_t)d.score;
+                for (uint32_t w = lane; w < W; w += 64) {
+                    const uint32_t x = T[w];
+#pragma unroll
+                    for (uint32_t q = 0; q < 16; ++q) {
+                        const uint32_t add = ((x >> (2 * q)) & 1u) * s + (((x >> (2 * q + 1)) & 1u) * s << 16);
+                        if (add) ACC[q * W + w] += add;
+                    }
+                }
+            } else {
+                for (uint32_t w = lane; w < W; w += 64) ACC[w] &= T[w];
+            }
+            wave_lds_sync();
+        }
+        uint32_t pc = 0;
+        if (UNION) {
+            const long long min_score = (long long)(unsigned long long)((double)npos[r] * tau);
+            const long long thr_ll = min_score + 0x8000;
+            const uint32_t thr = thr_ll > 0x10000 ? 0x10000u : (uint32_t)thr_ll;
+            for (uint32_t w = lane; w < W; w += 64) {
+                uint32_t m = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 16; ++q) {
+                    const uint32_t x = ACC[q * W + w];
+                    m |= (uint32_t)((x & 0xFFFFu) >= thr) << (2 * q);
+                    m |= (uint32_t)((x >> 16) >= thr) << (2 * q + 1);
+                }
+                const uint32_t lo = w * 32;
+                m &= lo >= n ? 0u : (n - lo >= 32 ? 0xFFFFFFFFu : ((1u << (n - lo)) - 1u));
+                bm[w] = m;
+                pc += __popc(m);
+            }
+        } else {
+            for (uint32_t w = lane; w < W; w += 64) {
+                const uint32_t x = ACC[w];
+                bm[w] = x;
+                pc += __popc(x);
+            }
+        }
+        pc = wave_sum_u32(pc);
+        if (lane == 0) out_count[r] = pc;
+        wave_lds_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // sizes -> CSR offsets (three small launches)
 // ---------------------------------------------------------------------------------------------
 constexpr int SCAN_ITEMS = 16;
@@ -1167,16 +1365,18 @@ __global__ void k_add_totals(unsigned long long* hits, uint32_t n, uint64_t num_
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_account(DevColors c, const uint64_t* __restrict__ id_csr,
                                                  const ListDesc* __restrict__ desc, const uint32_t* __restrict__ counts,
-                                                 uint64_t n_reads, unsigned long long* __restrict__ out) {
+                                                 uint64_t n_reads, unsigned long long* __restrict__ out,
+                                                 const uint32_t* __restrict__ set_bytes) {
     uint64_t in_bytes = 0, out_bytes = 0;  // out[0]: list side (lists + offsets + ids), out[1]: result side
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t off = id_csr[r];
         const uint32_t cnt = (uint32_t)(id_csr[r + 1] - off);
         for (uint32_t i = 0; i < cnt; ++i) {
             const uint32_t id = desc[off + i].id;
-            in_bytes += (c.offsets[id + 1] - c.offsets[id] + 7) / 8;
+            // hybrid: the list + two 8-byte offsets; other codecs: every list the set touches (+16 each)
+            in_bytes += set_bytes ? (uint64_t)set_bytes[id] : (c.offsets[id + 1] - c.offsets[id] + 7) / 8 + 16;
         }
-        in_bytes += 20ull * cnt;
+        in_bytes += 4ull * cnt;
         out_bytes += 4ull * counts[r] + 8;
     }
     for (int o = 32; o; o >>= 1) { in_bytes += __shfl_xor(in_bytes, o); out_bytes += __shfl_xor(out_bytes, o); }

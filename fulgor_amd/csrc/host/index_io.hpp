@@ -17,6 +17,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include "codecs_build.hpp"
 #include "dict_build.hpp"
 #include "hybrid_codec.hpp"
 
@@ -113,7 +114,7 @@ inline void load_dump(const std::string& base, HostIndex& idx, uint32_t m = 0, u
 
 // ---- own binary container ------------------------------------------------------------------------
 namespace detail {
-static const char FGIDX_MAGIC[8] = {'F', 'G', 'I', 'D', 'X', '0', '0', '3'};  // 003: 16-bit pilots; decoder samples rebuilt at load
+static const char FGIDX_MAGIC[8] = {'F', 'G', 'I', 'D', 'X', '0', '0', '3'};  // 003: 16-bit pilots; samples rebuilt at load; optional codec section
 template <typename T>
 void wr(std::ofstream& o, const T& v) { o.write(reinterpret_cast<const char*>(&v), sizeof(T)); }
 template <typename T>
@@ -153,6 +154,12 @@ inline void save_binary(const HostIndex& idx, const std::string& path) {
     const HybridSets& h = idx.hybrid;
     wr(o, h.num_colors); wr(o, h.sparse_thr); wr(o, h.dense_thr); wr(o, h.nbits);
     wrv(o, h.offsets); wrv(o, h.bits);  // restart samples are an acceleration structure: rebuilt at load
+    if (idx.type != IDX_HYBRID) {
+        const GenericSets& g = idx.generic;
+        wr(o, g.num_colors); wr(o, g.partition_size); wr(o, g.cluster_size); wr(o, g.num_partitions);
+        wr(o, g.num_partial_sets); wr(o, g.num_clusters); wr(o, g.nbits);
+        wrv(o, g.bits); wrv(o, g.ops); wrv(o, g.set_ops_off); wrv(o, g.set_ops); wrv(o, g.set_bytes);
+    }
     uint64_t nf = idx.filenames.size();
     wr(o, nf);
     for (auto& f : idx.filenames) {
@@ -181,6 +188,14 @@ inline void load_binary(const std::string& path, HostIndex& idx) {
     rd(i, h.num_colors); rd(i, h.sparse_thr); rd(i, h.dense_thr); rd(i, h.nbits);
     rdv(i, h.offsets); rdv(i, h.bits);
     hybrid_build_samples(h);
+    if (idx.type != IDX_HYBRID) {
+        GenericSets& g = idx.generic;
+        g.type = idx.type;
+        rd(i, g.num_colors); rd(i, g.partition_size); rd(i, g.cluster_size); rd(i, g.num_partitions);
+        rd(i, g.num_partial_sets); rd(i, g.num_clusters); rd(i, g.nbits);
+        rdv(i, g.bits); rdv(i, g.ops); rdv(i, g.set_ops_off); rdv(i, g.set_ops); rdv(i, g.set_bytes);
+        build_generic_samples(g);
+    }
     uint64_t nf;
     rd(i, nf);
     idx.filenames.clear();

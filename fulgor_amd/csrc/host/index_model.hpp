@@ -48,10 +48,38 @@ struct Dict {
     uint64_t num_unitigs() const { return unitig_csid.size(); }
 };
 
+// ---- meta / differential / meta-differential colour sets (see codecs_build.hpp) ----------------------
+enum OpKind : uint32_t { OP_OR_GAPS = 0, OP_OR_BITMAP = 1, OP_OR_COMP = 2, OP_XOR_GAPS = 3 };
+
+struct SetOp {         // 32 bytes, read as two 16-byte loads on the device
+    uint64_t body;     // bit position of the first gap code / of the bitmap
+    uint64_t soff;     // first restart sample (samples hold bit offsets relative to `body`)
+    uint32_t ncodes;   // gap codes (0 for bitmaps)
+    uint32_t kind;     // OpKind
+    uint32_t base;     // first colour of the partition (0 for differential)
+    uint32_t np;       // colours in the partition
+};
+
+struct GenericSets {
+    int type = IDX_META;
+    uint32_t num_colors = 0;
+    uint32_t partition_size = 0, cluster_size = 0, num_partitions = 0;
+    uint64_t num_partial_sets = 0, num_clusters = 0;
+    std::vector<uint64_t> bits;  // arena, padded with 2 words
+    uint64_t nbits = 0;
+    std::vector<SetOp> ops;
+    std::vector<uint64_t> set_ops_off;  // num_sets + 1
+    std::vector<uint32_t> set_ops;      // op indices
+    std::vector<uint64_t> samples;      // restart samples of all gap ops (acceleration, rebuilt at load)
+    std::vector<uint32_t> set_bytes;    // algorithmic bytes per colour set (accounting only)
+    uint64_t num_sets() const { return set_ops_off.empty() ? 0 : set_ops_off.size() - 1; }
+};
+
 struct HostIndex {
     int type = IDX_HYBRID;
     Dict dict;
-    HybridSets hybrid;
+    HybridSets hybrid;    // always present (ingestion format, export)
+    GenericSets generic;  // present when type != IDX_HYBRID: the codec the queries run on
     std::vector<std::string> filenames;
 };
 

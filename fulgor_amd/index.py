@@ -14,6 +14,7 @@ from . import _native
 
 FULL_INTERSECTION = 0
 THRESHOLD_UNION = 1
+HYBRID, DIFF, META, META_DIFF = 0, 1, 2, 3  # index_t, include/util.hpp:18
 KERNELS = ("k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits", "k_desc")
 
 
@@ -133,6 +134,12 @@ class Index:
 
     def save(self, path):
         _native.check(self._L.fgpu_save(self._h, str(path).encode()))
+
+    def convert(self, index_type, partition_size=128, cluster_size=16):
+        """re-encode the colour sets: 0 hybrid, 1 differential, 2 meta, 3 meta-differential (index_t, util.hpp:18)"""
+        _native.check(self._L.fgpu_convert(self._h, int(index_type), int(partition_size), int(cluster_size)))
+        self.index_type = int(index_type)
+        return self
 
     def selfcheck(self, unitig_stride=1):
         _native.check(self._L.fgpu_selfcheck(self._h, unitig_stride))

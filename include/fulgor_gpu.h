@@ -48,6 +48,13 @@ int fgpu_open(const char* path, int device, fgpu_index** out);
 /* build-time self check (the reference's `--check`, include/builders/builder.hpp:221-277): every k-mer
  * of every `unitig_stride`-th unitig must resolve to its unitig's colour-set id through the dictionary */
 int fgpu_selfcheck(const fgpu_index* idx, uint64_t unitig_stride);
+/* Re-encode the colour sets with another codec of the reference (index_types.hpp): FGPU_DIFF
+ * (differential.hpp), FGPU_META (meta.hpp), FGPU_META_DIFF (meta_differential.hpp), FGPU_HYBRID to go back.
+ * Stands in for `fulgor build --meta / --diff` + `fulgor permute` whose clustering heuristics are out of
+ * scope: partitions are colour ranges of `partition_size`, clusters are runs of `cluster_size` consecutive
+ * sets; colour numbering and colour-set ids are unchanged, so query results are identical across codecs.
+ * Subsequent queries (and fgpu_save) use the new codec. */
+int fgpu_convert(fgpu_index* idx, int index_type, uint32_t partition_size, uint32_t cluster_size);
 void fgpu_close(fgpu_index* idx);
 int fgpu_save(const fgpu_index* idx, const char* path);
 /* index::k / num_colors / num_color_sets / num_unitigs (include/index.hpp:64-68), ColorSets::type */

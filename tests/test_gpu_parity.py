@@ -235,3 +235,51 @@ def test_cli_output_is_byte_identical_to_reference_format(s10_gpu, s10_fgidx, tm
         assert raw[p] == i and raw[p + 1] == len(cols) and raw[p + 2:p + 2 + len(cols)].tolist() == cols
         p += 2 + len(cols)
     assert p == len(raw)
+
+
+# ---- meta / differential / meta-differential codecs ---------------------
+CODECS = [(fulgor_amd.DIFF, 10, 4), (fulgor_amd.DIFF, 10, 1), (fulgor_amd.META, 3, 1), (fulgor_amd.META, 4, 1),
+          (fulgor_amd.META_DIFF, 3, 4), (fulgor_amd.META_DIFF, 4, 2), (fulgor_amd.META_DIFF, 1, 16)]
+
+
+@pytest.mark.parametrize("index_type,psize,csize", CODECS)
+def test_gpu_codecs_match_golden_and_oracle(s10_fgidx, s10_dump, seeded_reads, index_type, psize, csize):
+    from oracle.pyoracle import OracleIndex
+    ix = fulgor_amd.Index(s10_fgidx, device=0).convert(index_type, psize, csize)
+    b, o = pack_reads(load_golden_reads())
+    assert csr_to_lists(*ix.pseudoalign_full_intersection_batch(b, o)) == load_golden_tsv("s10_full_intersection.tsv")
+    for tau in (0.8, 1.0, 0.01):
+        assert csr_to_lists(*ix.pseudoalign_threshold_union_batch(b, o, tau)) == load_golden_tsv("s10_threshold_union_%s.tsv" % tau)
+    # the oracle's own restatement of that codec (cursors + meta_intersect / diff_intersect / merge_*)
+    orc = OracleIndex.from_dump(s10_dump).convert(index_type, psize, csize)
+    b, o = seeded_reads
+    b, o = b[:150 * 20000], o[:20001]
+    for got, want in ((ix.pseudoalign_full_intersection_batch(b, o), orc.full_intersection(b, o)),
+                      (ix.pseudoalign_threshold_union_batch(b, o, 0.8), orc.threshold_union(b, o, 0.8))):
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    rng = np.random.default_rng(5)
+    ns = ix.num_color_sets()
+    lists = [np.unique(rng.integers(0, ns, size=l)).astype(np.uint32) for l in rng.integers(0, 30, size=1500)]
+    ido = np.zeros(len(lists) + 1, dtype=np.uint64)
+    ido[1:] = np.cumsum([len(l) for l in lists])
+    ids = np.concatenate(lists)
+    got, want = ix.intersect_ids_batch(ids, ido), orc.intersect_ids(ids, ido)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+@pytest.mark.parametrize("index_type,psize,csize", [(fulgor_amd.DIFF, 4546, 16), (fulgor_amd.META, 160, 1), (fulgor_amd.META_DIFF, 160, 16)])
+def test_s4546_codecs_equal_hybrid(s4546, index_type, psize, csize):
+    """4546 colours: the same colour sets under another codec must give the same answers as the hybrid
+    index (which is itself checked against the oracle above)"""
+    from conftest import DATA
+    from fulgor_amd import synth
+    ix, _, gen = s4546
+    b, o = gen.generate(200000, 30000, 150, 42)
+    want_fi = ix.pseudoalign_full_intersection_batch(b, o)
+    want_tu = ix.pseudoalign_threshold_union_batch(b, o, 0.8)
+    fg, _ = synth.ensure_s4546(DATA, S10_GENOMES)
+    iy = fulgor_amd.Index(fg, device=0).convert(index_type, psize, csize)
+    got_fi = iy.pseudoalign_full_intersection_batch(b, o)
+    got_tu = iy.pseudoalign_threshold_union_batch(b, o, 0.8)
+    assert np.array_equal(got_fi[0], want_fi[0]) and np.array_equal(got_fi[1], want_fi[1])
+    assert np.array_equal(got_tu[0], want_tu[0]) and np.array_equal(got_tu[1], want_tu[1])

@@ -103,3 +103,18 @@ def test_readgen_is_sliceable_and_seeded(built):
     assert not np.array_equal(b[:150000], b3)
     assert set(np.unique(b).tolist()) <= set(b"ACGT")
     assert o[-1] == 70000 * 150
+
+
+@pytest.mark.parametrize("index_type,psize,csize", [(1, 10, 4), (2, 3, 1), (3, 4, 2)])
+def test_codec_conversion_roundtrip_on_host(s10_fgidx, tmp_path, index_type, psize, csize):
+    """fgpu_convert re-encodes every colour set (self-checked against the hybrid decode inside the call);
+    the converted index survives the container and still refuses queries without a GPU"""
+    ix = fulgor_amd.Index(s10_fgidx, device=-1).convert(index_type, psize, csize)
+    p = tmp_path / "x.fgidx"
+    ix.save(p)
+    iy = fulgor_amd.Index(str(p), device=-1)
+    assert iy.index_type == index_type and iy.num_color_sets() == ix.num_color_sets()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        iy.pseudoalign_full_intersection([0, 1])
+    with pytest.raises(RuntimeError, match="unknown index type"):
+        ix.convert(7)
