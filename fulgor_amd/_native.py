@@ -68,6 +68,9 @@ def lib():
     L.fgpu_timing_enable.argtypes = [vp, C.c_int]
     L.fgpu_timing_reset.argtypes = [vp]
     L.fgpu_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), u64p]
+    L.fgpu_formatter_create.argtypes = [C.c_int, C.c_uint64, C.POINTER(vp), C.POINTER(vp), u64p]
+    L.fgpu_formatter_add.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint64, C.POINTER(vp), u64p]
+    L.fgpu_formatter_finish.argtypes = [vp, C.POINTER(vp), u64p]
     L.fgpu_export_sizes.argtypes = [vp, u64p, u64p, u64p, u64p, u64p]
     L.fgpu_export.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     _lib = L

@@ -34,9 +34,8 @@ def pseudoalign(argv):
             print("Deduplication not available for threshold < 1.0. Remove --deduplicate flag.", file=sys.stderr)
             return 1
         algo = THRESHOLD_UNION
-    if a.format not in ("ascii", "binary"):
-        # the compressed formatter (src/ps_utils.cpp:138-243) is not implemented yet
-        print("Unknown output format. Supported formats: ascii, binary.")
+    if a.format not in driver.FORMATS:
+        print("Unknown output format. Supported formats: ascii, binary, compressed.")  # tools/pseudoalign.cpp:317-320
         return 1
     if a.verbose:
         print(" ".join(["fulgor", "pseudoalign"] + list(argv)))

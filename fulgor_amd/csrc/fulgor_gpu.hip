@@ -11,6 +11,7 @@
 
 #include "../../include/fulgor_gpu.h"
 #include "hip/kernels.hip.h"
+#include "host/formatters.hpp"
 #include "host/index_io.hpp"
 
 using namespace fg;
@@ -732,6 +733,56 @@ int fgpu_intersect_ids(fgpu_index* ix, const uint32_t* ids, const uint64_t* id_o
         *out_colors = c;
     });
     fgpu_result_free(res);
+    return rc;
+}
+
+// ---- output formatters (host) ---------------------------------------------------------------------------
+struct fgpu_formatter {
+    int format;
+    CompressedFormatter comp;
+};
+
+int fgpu_formatter_create(int format, uint64_t num_colors, fgpu_formatter** out, char** header, uint64_t* header_len) {
+    if (!out || !header || !header_len) return fail(-EINVAL, "null argument");
+    if (format < FGPU_FMT_ASCII || format > FGPU_FMT_COMPRESSED)
+        return fail(-EINVAL, "Unknown output format. Supported formats: ascii, binary, compressed.");  // tools/pseudoalign.cpp:317-320
+    return guarded([&] {
+        auto* f = new fgpu_formatter();
+        f->format = format;
+        std::string h;
+        if (format == FGPU_FMT_COMPRESSED) f->comp.init((uint32_t)num_colors, h);
+        *header = (char*)malloc(std::max<size_t>(1, h.size()));
+        memcpy(*header, h.data(), h.size());
+        *header_len = h.size();
+        *out = f;
+    });
+}
+
+int fgpu_formatter_add(fgpu_formatter* f, uint32_t first_id, const uint64_t* offsets, const uint32_t* colors, uint64_t n,
+                       char** out, uint64_t* out_len) {
+    if (!f || !offsets || !out || !out_len) return fail(-EINVAL, "null argument");
+    return guarded([&] {
+        std::string s;
+        if (f->format == FGPU_FMT_ASCII) format_ascii(first_id, offsets, colors, n, s);
+        else if (f->format == FGPU_FMT_BINARY) format_binary(first_id, offsets, colors, n, s);
+        else f->comp.add_batch(first_id, offsets, colors, n, s);
+        *out = (char*)malloc(std::max<size_t>(1, s.size()));
+        if (!*out) throw std::bad_alloc();
+        memcpy(*out, s.data(), s.size());
+        *out_len = s.size();
+    });
+}
+
+int fgpu_formatter_finish(fgpu_formatter* f, char** out, uint64_t* out_len) {
+    if (!f || !out || !out_len) return fail(-EINVAL, "null argument");
+    int rc = guarded([&] {
+        std::string s;
+        if (f->format == FGPU_FMT_COMPRESSED) f->comp.finish(s);
+        *out = (char*)malloc(std::max<size_t>(1, s.size()));
+        memcpy(*out, s.data(), s.size());
+        *out_len = s.size();
+    });
+    delete f;
     return rc;
 }
 

@@ -2,8 +2,6 @@
 (tools/pseudoalign.cpp:12-89) with the per-read loop replaced by batched passes through the C ABI, the
 output formatters of src/ps_utils.cpp:48-136, and the multi-GPU sharding (reads are independent units:
 contiguous ranges per rank, index replicated, one all-reduce of the hit counters)."""
-import struct
-
 import numpy as np
 
 from .index import FULL_INTERSECTION, THRESHOLD_UNION, pack_reads  # noqa: F401
@@ -36,33 +34,55 @@ def all_reduce_hits(t):
     return t
 
 
-# ---- output formatters (src/ps_utils.cpp:48-136) -------------------------------------------------------
+# ---- output formatters (src/ps_utils.cpp:48-243): native, through the C ABI -----------------------------------
+FORMATS = {"ascii": 0, "binary": 1, "compressed": 2}
+
+
+class Formatter:
+    """formatter_buffer of one worker: add(first_id, offsets, colours) -> bytes; finish() -> trailing bytes"""
+
+    def __init__(self, fmt, num_colors):
+        import ctypes as C
+        from . import _native
+        self._C, self._N = C, _native
+        self._L = _native.lib()
+        if fmt not in FORMATS:
+            raise ValueError("Unknown output format. Supported formats: ascii, binary, compressed.")
+        h, p, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        _native.check(self._L.fgpu_formatter_create(FORMATS[fmt], int(num_colors), C.byref(h), C.byref(p), C.byref(n)))
+        self._h = h
+        self.header = self._take(p, n)
+
+    def _take(self, p, n):
+        b = self._C.string_at(p, n.value)
+        self._L.fgpu_free(p)
+        return b
+
+    def add(self, first_id, offsets, colors):
+        C = self._C
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        colors = np.ascontiguousarray(colors, dtype=np.uint32)
+        p, n = C.c_void_p(), C.c_uint64()
+        self._N.check(self._L.fgpu_formatter_add(self._h, int(first_id), offsets.ctypes.data_as(C.c_void_p),
+                                                 colors.ctypes.data_as(C.c_void_p), len(offsets) - 1, C.byref(p), C.byref(n)))
+        return self._take(p, n)
+
+    def finish(self):
+        C = self._C
+        p, n = C.c_void_p(), C.c_uint64()
+        self._N.check(self._L.fgpu_formatter_finish(self._h, C.byref(p), C.byref(n)))
+        self._h = None
+        return self._take(p, n)
+
+
 def format_ascii(first_id, offsets, colors):
-    """psa_ascii_formatter: "<id>\\t<count>[\\t<colour>...]\\n" for every read, mapped or not"""
-    offsets = np.asarray(offsets, dtype=np.int64)
-    out = []
-    cs = colors.astype(str) if len(colors) else colors
-    for i in range(len(offsets) - 1):
-        a, b = offsets[i], offsets[i + 1]
-        if b > a:
-            out.append("%d\t%d\t%s\n" % (first_id + i, b - a, "\t".join(cs[a:b])))
-        else:
-            out.append("%d\t0\n" % (first_id + i))
-    return "".join(out).encode()
+    f = Formatter("ascii", 0)
+    return f.add(first_id, offsets, colors) + f.finish()
 
 
 def format_binary(first_id, offsets, colors):
-    """psa_binary_formatter: u32 id, u32 count, u32 x count"""
-    offsets = np.asarray(offsets, dtype=np.int64)
-    out = []
-    for i in range(len(offsets) - 1):
-        a, b = offsets[i], offsets[i + 1]
-        out.append(struct.pack("<II", first_id + i, b - a))
-        out.append(colors[a:b].astype("<u4").tobytes())
-    return b"".join(out)
-
-
-FORMATTERS = {"ascii": format_ascii, "binary": format_binary}
+    f = Formatter("binary", 0)
+    return f.add(first_id, offsets, colors) + f.finish()
 
 
 def pseudoalign_reads(index, bases, offs, algo=FULL_INTERSECTION, threshold=0.0, chunk=1 << 20, first_id=0,
@@ -73,14 +93,19 @@ def pseudoalign_reads(index, bases, offs, algo=FULL_INTERSECTION, threshold=0.0,
     reads = index.upload_reads(bases, offs)
     res = index.new_result()
     mapped = 0
+    f = Formatter(fmt, index.num_colors()) if sink is not None else None
+    if f is not None:
+        sink.write(f.header)
     for a in range(0, n, chunk):
         cnt = min(chunk, n - a)
         index.run(reads, res, algo, threshold, a, cnt)
         _, _, m = res.sizes()
         mapped += m
-        if sink is not None:
+        if f is not None:
             o, c = res.download()
-            sink.write(FORMATTERS[fmt](first_id + a, o, c))
+            sink.write(f.add(first_id + a, o, c))
+    if f is not None:
+        sink.write(f.finish())
     res.close()
     reads.close()
     return n, mapped

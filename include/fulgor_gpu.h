@@ -108,6 +108,17 @@ int fgpu_timing_reset(fgpu_index* idx);
 int fgpu_timing_get(fgpu_index* idx, int kernel, double* total_ms, uint64_t* launches);
 const char* fgpu_kernel_name(int kernel);
 
+/* ---- output formatters (src/ps_utils.cpp:48-243): host side, one call per batch of CSR results ----------
+ * ascii "<id>\t<count>[\t<colour>...]\n"; binary u32 id, u32 count, u32 x count; compressed = the
+ * reference's bit-packed blocks (u64 num_colors header, then {u64 num_bits, words} blocks closed past 2^14
+ * bytes). Buffers are malloc'd: release with fgpu_free. fgpu_formatter_finish flushes and destroys. */
+typedef struct fgpu_formatter fgpu_formatter;
+enum { FGPU_FMT_ASCII = 0, FGPU_FMT_BINARY = 1, FGPU_FMT_COMPRESSED = 2 };
+int fgpu_formatter_create(int format, uint64_t num_colors, fgpu_formatter** out, char** header, uint64_t* header_len);
+int fgpu_formatter_add(fgpu_formatter* f, uint32_t first_id, const uint64_t* offsets, const uint32_t* colors, uint64_t n,
+                       char** out, uint64_t* out_len);
+int fgpu_formatter_finish(fgpu_formatter* f, char** out, uint64_t* out_len);
+
 /* ---- index export (lets tests hand the same encoded index to the oracle) -------------------------- */
 int fgpu_export_sizes(const fgpu_index* idx, uint64_t* unitig_bases, uint64_t* num_unitigs, uint64_t* color_words,
                       uint64_t* color_bits, uint64_t* num_sets);

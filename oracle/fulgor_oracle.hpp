@@ -708,4 +708,93 @@ static inline void format_ascii(uint32_t query_id, const std::vector<uint32_t>& 
     out += '\n';
 }
 
+// psa_compressed_formatter + formatter_buffer of ONE worker (src/ps_utils.cpp:27-46, 138-243): file =
+// u64 num_colors, then blocks {u64 num_bits, data}; a block is closed when the bytes added since the last
+// flush exceed 2^14 (checked after every record) and once more at the end (~formatter_buffer).
+static inline void format_compressed(uint32_t first_id, const uint64_t* off, const uint32_t* colors, uint64_t n,
+                                     uint32_t num_colors, std::string& out) {
+    const uint64_t hdr = num_colors;  // writes 8 bytes
+    out.append(reinterpret_cast<const char*>(&hdr), 8);
+    const uint32_t sparse_thr = (uint32_t)(0.25 * num_colors), dense_thr = (uint32_t)(0.75 * num_colors);
+    BitStream bv;
+    uint32_t num_bytes = 0;
+    auto flush = [&]() {
+        const uint64_t nb = bv.n;
+        out.append(reinterpret_cast<const char*>(&nb), 8);
+        out.append(reinterpret_cast<const char*>(bv.w.data()), num_bytes);
+        bv = BitStream();
+        num_bytes = 0;
+    };
+    for (uint64_t r = 0; r < n; ++r) {
+        const uint32_t* c = colors + off[r];
+        const uint32_t size = (uint32_t)(off[r + 1] - off[r]);
+        const size_t before = bv.w.size() * 8;
+        write_delta(bv, first_id + (uint32_t)r);
+        write_delta(bv, size);
+        if (size == 0) {
+        } else if (size < sparse_thr) {
+            write_delta(bv, c[0]);
+            for (uint32_t i = 1; i < size; ++i) write_delta(bv, c[i] - (c[i - 1] + 1));
+        } else if (size < dense_thr) {
+            std::vector<bool> bm(num_colors, false);
+            for (uint32_t i = 0; i < size; ++i) bm[c[i]] = true;
+            for (uint32_t v = 0; v < num_colors; ++v) bv.push_bit(bm[v]);
+        } else {
+            std::vector<bool> in(num_colors, false);
+            for (uint32_t i = 0; i < size; ++i) in[c[i]] = true;
+            int64_t prev = -1;
+            for (uint32_t v = 0; v < num_colors; ++v) {
+                if (in[v]) continue;
+                write_delta(bv, (uint64_t)(v - (prev + 1)));
+                prev = v;
+            }
+        }
+        num_bytes += (uint32_t)(bv.w.size() * 8 - before);
+        if (num_bytes > (1u << 14)) flush();
+    }
+    flush();
+}
+
+// inverse of format_compressed (test helper): (ids, CSR)
+static inline void parse_compressed(const std::string& file, std::vector<uint32_t>& ids, std::vector<uint64_t>& off,
+                                    std::vector<uint32_t>& colors) {
+    uint64_t num_colors;
+    memcpy(&num_colors, file.data(), 8);
+    const uint32_t n = (uint32_t)num_colors, sparse_thr = (uint32_t)(0.25 * n), dense_thr = (uint32_t)(0.75 * n);
+    size_t p = 8;
+    off.assign(1, 0);
+    while (p < file.size()) {
+        uint64_t nbits;
+        memcpy(&nbits, file.data() + p, 8);
+        p += 8;
+        BitStream bv;
+        bv.w.assign((nbits + 63) / 64, 0);
+        memcpy(bv.w.data(), file.data() + p, bv.w.size() * 8);
+        bv.n = nbits;
+        bv.seal();
+        p += (nbits + 63) / 64 * 8;
+        BitCursor c(&bv, 0);
+        while (c.position() < nbits) {
+            ids.push_back((uint32_t)read_delta(c));
+            const uint32_t size = (uint32_t)read_delta(c);
+            if (size == 0) {
+            } else if (size < sparse_thr) {
+                uint32_t v = (uint32_t)read_delta(c);
+                colors.push_back(v);
+                for (uint32_t i = 1; i < size; ++i) { v += (uint32_t)read_delta(c) + 1; colors.push_back(v); }
+            } else if (size < dense_thr) {
+                for (uint32_t v = 0; v < n; ++v)
+                    if (c.take(1)) colors.push_back(v);
+            } else {
+                std::vector<bool> missing(n, false);
+                int64_t prev = -1;
+                for (uint32_t i = 0; i < n - size; ++i) { prev = prev + 1 + (int64_t)read_delta(c); missing[prev] = true; }
+                for (uint32_t v = 0; v < n; ++v)
+                    if (!missing[v]) colors.push_back(v);
+            }
+            off.push_back(colors.size());
+        }
+    }
+}
+
 }  // namespace oracle

@@ -195,4 +195,31 @@ char* fo_format_ascii(const uint64_t* off, const uint32_t* colors, uint64_t n, u
     return p;
 }
 
+char* fo_format_compressed(const uint64_t* off, const uint32_t* colors, uint64_t n, uint32_t first_id, uint32_t num_colors,
+                           uint64_t* out_len) {
+    std::string s;
+    format_compressed(first_id, off, colors, n, num_colors, s);
+    char* p = (char*)malloc(s.size() + 1);
+    memcpy(p, s.data(), s.size());
+    *out_len = s.size();
+    return p;
+}
+
+// parses a compressed output file back into (ids, CSR); buffers are malloc'd
+int fo_parse_compressed(const char* file, uint64_t len, uint64_t* n_out, uint32_t** ids, uint64_t** off, uint32_t** colors) {
+    try {
+        std::vector<uint32_t> vi, vc;
+        std::vector<uint64_t> vo;
+        parse_compressed(std::string(file, len), vi, vo, vc);
+        *n_out = vi.size();
+        *ids = (uint32_t*)malloc(std::max<size_t>(1, vi.size()) * 4);
+        *off = (uint64_t*)malloc(vo.size() * 8);
+        *colors = (uint32_t*)malloc(std::max<size_t>(1, vc.size()) * 4);
+        memcpy(*ids, vi.data(), vi.size() * 4);
+        memcpy(*off, vo.data(), vo.size() * 8);
+        memcpy(*colors, vc.data(), vc.size() * 4);
+        return 0;
+    } catch (std::exception& e) { g_err = e.what(); return -1; }
+}
+
 }  // extern "C"

@@ -42,6 +42,9 @@ def lib():
         L.fo_time_pseudoalign.restype = C.c_double
         L.fo_time_pseudoalign.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, C.c_double, C.c_int,
                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.fo_format_compressed.restype = vp
+        L.fo_format_compressed.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.fo_parse_compressed.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
         L.fo_format_ascii.restype = vp
         L.fo_format_ascii.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
         _lib = L
@@ -59,6 +62,34 @@ def _take(L, n, po, pv):
     L.fo_free(po)
     L.fo_free(pv)
     return offs, vals
+
+
+def format_compressed(offs, colors, num_colors, first_id=0):
+    """psa_compressed_formatter of one worker (src/ps_utils.cpp:138-243) over a whole CSR result"""
+    L = lib()
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    colors = np.ascontiguousarray(colors, dtype=np.uint32)
+    ln = C.c_uint64()
+    p = L.fo_format_compressed(_ptr(offs), _ptr(colors), len(offs) - 1, first_id, num_colors, C.byref(ln))
+    s = C.string_at(p, ln.value)
+    L.fo_free(p)
+    return s
+
+
+def parse_compressed(data):
+    """inverse of format_compressed -> (ids, offsets, colours)"""
+    L = lib()
+    n = C.c_uint64()
+    pi, po, pc = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    if L.fo_parse_compressed(data, len(data), C.byref(n), C.byref(pi), C.byref(po), C.byref(pc)) != 0:
+        raise RuntimeError("oracle: %s" % L.fo_last_error().decode())
+    ids = np.ctypeslib.as_array(C.cast(pi, C.POINTER(C.c_uint32)), shape=(max(n.value, 1),))[:n.value].copy()
+    offs = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), shape=(n.value + 1,)).copy()
+    tot = int(offs[-1])
+    cols = np.ctypeslib.as_array(C.cast(pc, C.POINTER(C.c_uint32)), shape=(max(tot, 1),))[:tot].copy()
+    for q in (pi, po, pc):
+        L.fo_free(q)
+    return ids, offs, cols
 
 
 class OracleIndex:

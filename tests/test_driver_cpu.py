@@ -30,6 +30,36 @@ def test_ascii_formatter_matches_reference_formatter(s10_oracle):
     assert driver.format_ascii(0, offs, cols) == b"".join(want)
 
 
+def test_compressed_formatter_matches_oracle_and_roundtrips(s10_oracle):
+    """byte-identical with the restated psa_compressed_formatter, across block boundaries and batches,
+    for n = 10 and for a 4546-colour universe (all three record encodings)"""
+    from oracle import pyoracle
+    reads = load_golden_reads()
+    b, o = pack_reads(reads)
+    offs, cols = s10_oracle.full_intersection(b, o)
+    f = driver.Formatter("compressed", 10)
+    half = 400
+    o1 = offs[:half + 1]
+    o2 = offs[half:] - offs[half]
+    got = f.header + f.add(0, o1, cols[:int(offs[half])]) + f.add(half, o2, cols[int(offs[half]):]) + f.finish()
+    assert got == pyoracle.format_compressed(offs, cols, 10)
+    ids, po, pc = pyoracle.parse_compressed(got)
+    assert ids.tolist() == list(range(len(reads))) and np.array_equal(po, offs) and np.array_equal(pc, cols)
+    rng = np.random.default_rng(1)
+    sizes = np.concatenate([rng.integers(0, 40, 300), rng.integers(1200, 3300, 40), rng.integers(3500, 4547, 40), [0, 4546]])
+    rng.shuffle(sizes)
+    lists = [np.sort(rng.choice(4546, size=s, replace=False)).astype(np.uint32) for s in sizes]
+    offs = np.zeros(len(lists) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(sizes)
+    cols = np.concatenate(lists)
+    f = driver.Formatter("compressed", 4546)
+    got = f.header + f.add(7, offs, cols) + f.finish()
+    assert got == pyoracle.format_compressed(offs, cols, 4546, first_id=7)
+    ids, po, pc = pyoracle.parse_compressed(got)
+    assert ids.tolist() == list(range(7, 7 + len(lists))) and np.array_equal(po, offs) and np.array_equal(pc, cols)
+    assert got.count(b"") and len(got) > (1 << 14)  # several blocks
+
+
 def test_binary_formatter_layout():
     offs = np.array([0, 2, 2], dtype=np.uint64)
     cols = np.array([5, 9], dtype=np.uint32)
@@ -82,4 +112,6 @@ def test_cli_argument_errors():
     assert cli.main(["pseudoalign", "-i", "x", "-q", "y", "-o", "z", "-r", "0.5", "--deduplicate"]) == 1
     assert cli.main(["pseudoalign", "-i", "x", "-q", "y", "-o", "z", "--format", "weird"]) == 1
     assert cli.main(["pseudoalign", "-i", "x"]) == 1
+    with pytest.raises(ValueError):
+        driver.Formatter("weird", 10)
     assert cli.main(["build"]) == 1

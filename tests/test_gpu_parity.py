@@ -235,6 +235,11 @@ def test_cli_output_is_byte_identical_to_reference_format(s10_gpu, s10_fgidx, tm
         assert raw[p] == i and raw[p + 1] == len(cols) and raw[p + 2:p + 2 + len(cols)].tolist() == cols
         p += 2 + len(cols)
     assert p == len(raw)
+    out4 = tmp_path / "out.cmp"
+    assert cli.main(["pseudoalign", "-i", s10_fgidx, "-q", q, "-o", str(out4), "--format", "compressed"]) == 0
+    from oracle import pyoracle
+    ids, po, pc = pyoracle.parse_compressed(out4.read_bytes())
+    assert ids.tolist() == list(range(len(gold))) and csr_to_lists(po, pc) == gold
 
 
 # ---- meta / differential / meta-differential codecs ---------------------
