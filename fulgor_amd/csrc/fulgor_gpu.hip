@@ -122,7 +122,13 @@ struct fgpu_reads {
     std::vector<uint64_t> cum_kmers;  // prefix sums of max(0, len-k+1)
     std::vector<uint64_t> h_offs;
     uint32_t max_kmers = 0;
+    // reads with more than SEG_KMERS k-mers are cut into overlapping segments (k-1 shared bases) that the
+    // lookup kernel treats as units; seg_first[r] = first segment of read r (n + 1 entries)
+    bool has_long = false;
+    std::vector<uint64_t> seg_first, seg_start, seg_end;
+    DevBuf d_seg_start, d_seg_end;
 };
+constexpr uint32_t SEG_KMERS = 1024;
 
 struct fgpu_result {
     fgpu_index* ix = nullptr;
@@ -199,43 +205,90 @@ uint32_t resident_grid(K kernel, uint64_t units, uint32_t per_block, int num_cus
 
 void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t count, fgpu_result* res) {
     hipStream_t s = ix->stream;
-    res->n = count;
     res->total_kmers = rd->cum_kmers[first + count] - rd->cum_kmers[first];
     res->total_bases = rd->h_offs[first + count] - rd->h_offs[first];
-    res->d_nids.ensure(count * 4 + 16);
-    res->d_npos.ensure(count * 4 + 16);
-    res->d_idoff.ensure(count * 8 + 16);
+    // units = reads, or segments when the batch holds reads longer than SEG_KMERS k-mers
+    const bool seg = rd->has_long;
+    const uint64_t u_first = seg ? rd->seg_first[first] : first;
+    const uint64_t units = seg ? rd->seg_first[first + count] - u_first : count;
+    res->n = count;
+    res->d_nids.ensure(units * 4 + 16);
+    res->d_npos.ensure(units * 4 + 16);
+    res->d_idoff.ensure(units * 8 + 16);
     res->d_tickets.ensure(TICKET_BYTES);  // 8 padded work counters for each persistent launch of a pass
     HIP_TRY(hipMemsetAsync(res->d_tickets.p, 0, TICKET_BYTES, s));
     const uint32_t stride = std::max<uint32_t>(1, rd->max_kmers);  // at most one id per k-mer
     res->id_stride = stride;
-    res->d_ids_pool.ensure(count * (uint64_t)stride * 4 + 16);
-    res->d_cnt_pool.ensure(count * (uint64_t)stride * 4 + 16);
-    if (count == 0) return;
-    if (rd->max_kmers > 1024) throw std::runtime_error("reads with more than 1024 k-mers are not supported by this build");
-    const bool w13 = ix->dd.k - ix->dd.m == 12;
-    const uint32_t grid = rd->max_kmers > 128 ? resident_grid(k1_lookup<1024>, count, 4, ix->num_cus, 256, 0)
-                          : w13               ? resident_grid(k1_lookup_short<true>, count, 4, ix->num_cus, 256, 0)
-                                              : resident_grid(k1_lookup_short<false>, count, 4, ix->num_cus, 256, 0);
-    Timed t(ix, FGPU_K_LOOKUP);
-    if (rd->max_kmers <= 128 && w13) {
-        hipLaunchKernelGGL(k1_lookup_short<true>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
-                           rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
-                           res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
-                           stride, res->d_tickets.as<unsigned int>());
-    } else if (rd->max_kmers <= 128) {
-        hipLaunchKernelGGL(k1_lookup_short<false>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
-                           rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
-                           res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
-                           stride, res->d_tickets.as<unsigned int>());
-    } else {
-        hipLaunchKernelGGL(k1_lookup<1024>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
-                           rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
-                           res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
-                           stride, res->d_tickets.as<unsigned int>());
-    }
-    HIP_TRY(hipGetLastError());
+    res->d_ids_pool.ensure(units * (uint64_t)stride * 4 + 16);
+    res->d_cnt_pool.ensure(units * (uint64_t)stride * 4 + 16);
     res->have_ids = true;
+    if (units == 0) return;
+    const bool w13 = ix->dd.k - ix->dd.m == 12;
+    const bool short_reads = rd->max_kmers <= 128 && !seg;
+    const uint32_t grid = !short_reads ? resident_grid(k1_lookup<1024>, units, 4, ix->num_cus, 256, 0)
+                          : w13        ? resident_grid(k1_lookup_short<true>, units, 4, ix->num_cus, 256, 0)
+                                       : resident_grid(k1_lookup_short<false>, units, 4, ix->num_cus, 256, 0);
+    {
+        Timed t(ix, FGPU_K_LOOKUP);
+        if (short_reads && w13) {
+            hipLaunchKernelGGL(k1_lookup_short<true>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
+                               rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
+                               res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
+                               stride, res->d_tickets.as<unsigned int>());
+        } else if (short_reads) {
+            hipLaunchKernelGGL(k1_lookup_short<false>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
+                               rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
+                               res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
+                               stride, res->d_tickets.as<unsigned int>());
+        } else {
+            hipLaunchKernelGGL(k1_lookup<1024>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
+                               seg ? rd->d_seg_start.as<uint64_t>() : rd->d_offs.as<uint64_t>(),
+                               seg ? rd->d_seg_end.as<uint64_t>() : (const uint64_t*)nullptr, u_first, units,
+                               res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(), res->d_idoff.as<uint64_t>(),
+                               res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(), stride,
+                               res->d_tickets.as<unsigned int>());
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    if (!seg) return;
+    // long-read path (rare): merge the per-segment id lists of every read on the host. Sorted unique ids,
+    // summed multiplicities, summed positive counts — what one pass over the whole read would have produced
+    // (fetch_color_set_ids sorts + deduplicates over the whole read: ps_full_intersection.cpp:361-373).
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<uint32_t> s_nids(units), s_npos(units), s_ids(units * stride), s_cnt(units * stride);
+    HIP_TRY(hipMemcpy(s_nids.data(), res->d_nids.p, units * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(s_npos.data(), res->d_npos.p, units * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(s_ids.data(), res->d_ids_pool.p, units * (uint64_t)stride * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(s_cnt.data(), res->d_cnt_pool.p, units * (uint64_t)stride * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> r_nids(count), r_npos(count), r_ids, r_cnt;
+    std::vector<uint64_t> r_off(count);
+    std::vector<std::pair<uint32_t, uint32_t>> tmp;
+    for (uint64_t r = 0; r < count; ++r) {
+        tmp.clear();
+        uint32_t pos = 0;
+        for (uint64_t u = rd->seg_first[first + r] - u_first; u < rd->seg_first[first + r + 1] - u_first; ++u) {
+            pos += s_npos[u];
+            for (uint32_t j = 0; j < s_nids[u]; ++j) tmp.push_back({s_ids[u * stride + j], s_cnt[u * stride + j]});
+        }
+        std::sort(tmp.begin(), tmp.end());
+        r_off[r] = r_ids.size();
+        for (size_t i = 0; i < tmp.size(); ++i) {
+            if (i && tmp[i].first == tmp[i - 1].first) r_cnt.back() += tmp[i].second;
+            else { r_ids.push_back(tmp[i].first); r_cnt.push_back(tmp[i].second); }
+        }
+        r_nids[r] = (uint32_t)(r_ids.size() - r_off[r]);
+        r_npos[r] = pos;
+    }
+    res->d_ids_pool.ensure(r_ids.size() * 4 + 16);
+    res->d_cnt_pool.ensure(r_cnt.size() * 4 + 16);
+    HIP_TRY(hipMemcpy(res->d_nids.p, r_nids.data(), count * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(res->d_npos.p, r_npos.data(), count * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(res->d_idoff.p, r_off.data(), count * 8, hipMemcpyHostToDevice));
+    if (!r_ids.empty()) {
+        HIP_TRY(hipMemcpy(res->d_ids_pool.p, r_ids.data(), r_ids.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(res->d_cnt_pool.p, r_cnt.data(), r_cnt.size() * 4, hipMemcpyHostToDevice));
+    }
+    res->id_stride = 0;  // ids are a compact CSR now (d_idoff holds the offsets)
 }
 
 // exclusive scan of n u32 sizes into n+1 u64 offsets; totals -> d_totals {sum, #nonzero}
@@ -475,9 +528,28 @@ int fgpu_reads_upload(fgpu_index* ix, const char* bases, const uint64_t* offs, u
             if (offs[i + 1] < offs[i]) throw std::runtime_error("read offsets are not monotone");
             uint64_t len = offs[i + 1] - offs[i];
             uint64_t nk = len >= k ? len - k + 1 : 0;
-            if (nk > 1024) throw std::runtime_error("reads with more than 1024 k-mers are not supported by this build");
-            rd->max_kmers = std::max<uint32_t>(rd->max_kmers, (uint32_t)nk);
+            if (nk > SEG_KMERS) rd->has_long = true;
+            rd->max_kmers = std::max<uint32_t>(rd->max_kmers, (uint32_t)std::min<uint64_t>(nk, SEG_KMERS));
             rd->cum_kmers[i + 1] = rd->cum_kmers[i] + nk;
+        }
+        if (rd->has_long) {
+            rd->seg_first.assign(1, 0);
+            for (uint64_t i = 0; i < n; ++i) {
+                const uint64_t len = offs[i + 1] - offs[i];
+                const uint64_t nk = len >= k ? len - k + 1 : 0;
+                if (nk <= SEG_KMERS) {
+                    rd->seg_start.push_back(offs[i]);
+                    rd->seg_end.push_back(offs[i + 1]);
+                } else {
+                    for (uint64_t s0 = 0; s0 < nk; s0 += SEG_KMERS) {
+                        rd->seg_start.push_back(offs[i] + s0);
+                        rd->seg_end.push_back(offs[i] + std::min(nk, s0 + SEG_KMERS) + k - 1);
+                    }
+                }
+                rd->seg_first.push_back(rd->seg_start.size());
+            }
+            upload(rd->d_seg_start, rd->seg_start, ix->stream);
+            upload(rd->d_seg_end, rd->seg_end, ix->stream);
         }
         const uint64_t nb = offs[n];
         rd->d_bases.ensure(nb + 256);
@@ -496,6 +568,8 @@ void fgpu_reads_free(fgpu_reads* rd) {
     (void)hipSetDevice(rd->ix->device);
     rd->d_bases.release();
     rd->d_offs.release();
+    rd->d_seg_start.release();
+    rd->d_seg_end.release();
     delete rd;
 }
 
@@ -667,20 +741,20 @@ int fgpu_fetch_color_set_ids(fgpu_index* ix, const char* bases, const uint64_t* 
         HIP_TRY(hipStreamSynchronize(ix->stream));
         if (ix->timing) ix->collect_timing();
         std::vector<uint32_t> nids(n);
-        const uint64_t stride = res->id_stride;
-        std::vector<uint32_t> pool(n * stride);
-        if (n) {
-            HIP_TRY(hipMemcpy(nids.data(), res->d_nids.p, n * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(pool.data(), res->d_ids_pool.p, n * stride * 4, hipMemcpyDeviceToHost));
-        }
+        if (n) HIP_TRY(hipMemcpy(nids.data(), res->d_nids.p, n * 4, hipMemcpyDeviceToHost));
         uint64_t used = 0;
         for (uint64_t r = 0; r < n; ++r) used += nids[r];
+        const uint64_t stride = res->id_stride ? res->id_stride : 0;
+        std::vector<uint32_t> pool(stride ? n * stride : used);
+        if (!pool.empty()) HIP_TRY(hipMemcpy(pool.data(), res->d_ids_pool.p, pool.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<uint64_t> src(n);
+        if (!stride && n) HIP_TRY(hipMemcpy(src.data(), res->d_idoff.p, n * 8, hipMemcpyDeviceToHost));
         uint64_t* o = (uint64_t*)malloc((n + 1) * 8);
         uint32_t* v = (uint32_t*)malloc(std::max<uint64_t>(1, used) * 4);
         if (!o || !v) { free(o); free(v); throw std::bad_alloc(); }
         o[0] = 0;
         for (uint64_t r = 0; r < n; ++r) {
-            memcpy(v + o[r], pool.data() + r * stride, (size_t)nids[r] * 4);
+            memcpy(v + o[r], pool.data() + (stride ? r * stride : src[r]), (size_t)nids[r] * 4);
             o[r + 1] = o[r] + nids[r];
         }
         *out_offsets = o;

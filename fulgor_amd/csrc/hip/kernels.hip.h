@@ -152,7 +152,8 @@ __device__ __forceinline__ uint32_t probe(const DevDict& d, uint64_t h0, bool do
 // positive k-mers had each id.
 template <int KMAX>
 __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __restrict__ bases,
-                                                 const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
+                                                 const uint64_t* __restrict__ offs, const uint64_t* __restrict__ ends,
+                                                 uint64_t first, uint64_t n_reads,
                                                  uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
                                                  uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
                                                  uint32_t* __restrict__ cnt_pool, uint32_t stride, unsigned int* tickets) {
@@ -173,7 +174,8 @@ __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __res
     while (wq.pull(t_first, t_count))
     for (uint64_t r = t_first; r < t_first + t_count; ++r) {
         const uint64_t rb = offs[first + r];
-        const uint32_t len = (uint32_t)(offs[first + r + 1] - rb);
+        // `ends` is given when the units are overlapping segments of long reads (host-side split)
+        const uint32_t len = (uint32_t)((ends ? ends[first + r] : offs[first + r + 1]) - rb);
         const uint32_t nk = len >= k ? min(len - k + 1, (uint32_t)KMAX) : 0;  // host guarantees <= KMAX
         const uint8_t* seq = bases + rb;
 

@@ -96,18 +96,27 @@ def test_gpu_edge_batches(s10_gpu):
         s10_gpu.pseudoalign_threshold_union_batch(b, o, 1.5)
 
 
-def test_gpu_long_reads_up_to_1024_kmers(s10_gpu, s10_oracle):
+def test_gpu_reads_of_any_length(s10_gpu, s10_oracle):
+    """ragged batch: 31 bp .. 60 kbp. Reads above 1024 k-mers are cut into overlapping segments by the host
+    and their id lists merged; answers must not depend on that."""
     from oracle.kmer_oracle import read_fasta
     src = max(read_fasta(S10_GENOMES[5]), key=len)
-    reads = [src[i * 1000:i * 1000 + l] for i, l in enumerate([1054, 700, 300, 151, 1000, 31, 64, 95, 96, 159])]
+    lens = [1054, 700, 300, 151, 1000, 31, 64, 95, 96, 159, 1055, 2078, 5000, 60000, 30, 0, 1100]
+    reads = [src[i * 1000:i * 1000 + l] for i, l in enumerate(lens)]
+    reads.append(src[200000:203000].replace(b"A", b"N", 3))  # long read with invalid windows
     b, o = pack_reads(reads)
     for got, want in ((s10_gpu.pseudoalign_full_intersection_batch(b, o), s10_oracle.full_intersection(b, o)),
                       (s10_gpu.pseudoalign_threshold_union_batch(b, o, 0.8), s10_oracle.threshold_union(b, o, 0.8)),
+                      (s10_gpu.pseudoalign_threshold_union_batch(b, o, 1.0), s10_oracle.threshold_union(b, o, 1.0)),
                       (s10_gpu.fetch_color_set_ids_batch(b, o), s10_oracle.fetch_color_set_ids(b, o))):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
-    b, o = pack_reads([src[:1100]])
-    with pytest.raises(RuntimeError, match="1024 k-mers"):
-        s10_gpu.pseudoalign_full_intersection_batch(b, o)
+    # the same batch through the device-resident API in two passes
+    rd = s10_gpu.upload_reads(b, o)
+    res = s10_gpu.new_result()
+    s10_gpu.run(rd, res, fulgor_amd.FULL_INTERSECTION, first=10, count=6)
+    go, gc = res.download()
+    wo, wc = s10_oracle.full_intersection(b[int(o[10]):int(o[16])], o[10:17] - o[10])
+    assert np.array_equal(go, wo) and np.array_equal(gc, wc)
 
 
 def test_gpu_config_size_1M_reads_bit_exact_and_properties(s10_gpu, s10_oracle, built):
