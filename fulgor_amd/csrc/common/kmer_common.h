@@ -101,7 +101,11 @@ FG_HD uint32_t phf_slot(uint64_t h, uint32_t pilot, uint32_t num_slots) {
 }
 
 // ---- 8-byte super-k-mer record -----------------------------------------------------------------
-// bits  0..31  pos   : absolute base offset of the minimizer occurrence in the concatenated unitigs
+// bits  0..30  pos   : absolute base offset of the minimizer occurrence in the concatenated unitigs
+// bit   31     fwd   : the m-mer at pos, read in unitig orientation, is its own canonical form (key(fwd) <=
+//                      key(rc)). A query whose minimizer m-mer has the same flag lies on the unitig's strand,
+//                      otherwise on the opposite one (m-mers of odd length are never palindromes), so only
+//                      ONE orientation has to be compared against the string.
 // bits 32..35  jmin  : smallest offset (minimizer start - k-mer start) of a k-mer of this super-k-mer
 // bits 36..39  jmax  : largest such offset                       (requires k - m <= 15)
 // bits 40..62  csid  : colour-set id of the unitig (u2c folded in; index.hpp:37 in the reference)
@@ -111,10 +115,16 @@ constexpr uint32_t REC_MAX_CSID = (1u << 23) - 1;
 // empty slot: jmin=15 > jmax=0 never matches
 constexpr uint64_t REC_EMPTY = (15ULL << 32);
 
-FG_HD uint64_t rec_pack(uint32_t pos, uint32_t jmin, uint32_t jmax, uint32_t csid) {
-    return (uint64_t)pos | ((uint64_t)jmin << 32) | ((uint64_t)jmax << 36) | ((uint64_t)csid << 40);
+FG_HD uint64_t rec_pack(uint32_t pos, bool fwd_canonical, uint32_t jmin, uint32_t jmax, uint32_t csid) {
+    return (uint64_t)(pos & 0x7FFFFFFFu) | ((uint64_t)fwd_canonical << 31) | ((uint64_t)jmin << 32) | ((uint64_t)jmax << 36) |
+           ((uint64_t)csid << 40);
 }
-FG_HD uint32_t rec_pos(uint64_t r) { return (uint32_t)r; }
+FG_HD uint32_t rec_pos(uint64_t r) { return (uint32_t)r & 0x7FFFFFFFu; }
+FG_HD bool rec_fwd(uint64_t r) { return (r >> 31) & 1u; }
+// is the L-mer its own canonical form?
+FG_HD bool is_fwd_canonical(uint32_t lo, uint32_t hi, uint32_t L) {
+    return lmer_key(lo, hi) <= lmer_key(rc_plane(lo, L), rc_plane(hi, L));
+}
 FG_HD uint32_t rec_jmin(uint64_t r) { return (uint32_t)(r >> 32) & 15u; }
 FG_HD uint32_t rec_jmax(uint64_t r) { return (uint32_t)(r >> 36) & 15u; }
 FG_HD uint32_t rec_csid(uint64_t r) { return (uint32_t)(r >> 40) & REC_MAX_CSID; }

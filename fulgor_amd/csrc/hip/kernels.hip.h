@@ -431,20 +431,33 @@ __global__ __launch_bounds__(256) void k1_lookup_short(DevDict d, const uint8_t*
                 p0[a] = p[0];
                 p1[a] = p[1];
             }
-            uint64_t w0[2][4], w1[2][4];
-            uint32_t cs[2][4], csh[2][4];
-            bool con[2][4];
+            // one candidate per record: the strand bit of the record against the canonical flag of the
+            // query's minimizer tells whether the k-mer (offset jL) or its reverse complement (offset jB)
+            // can sit on that super-k-mer
+            uint64_t w0[2][2], w1[2][2];
+            uint32_t cs[2][2], csh[2][2];
+            bool con[2][2], rcq[2][2];
+            bool slow[2] = {false, false};
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const bool tag = (e[a] & REC_TAG) != 0;
                 const uint64_t r0 = tag ? p0[a] : e[a], r1 = tag ? p1[a] : REC_EMPTY;
                 const bool same = hL[a] == hR[a];
                 const uint32_t jB = km - jR[a];
+                const uint32_t mlo = (klo[a] >> jL[a]) & low_mask32(m), mhi = (khi[a] >> jL[a]) & low_mask32(m);
+                const uint64_t kf = lmer_key(mlo, mhi), kr = lmer_key(rc_plane(mlo, m), rc_plane(mhi, m));
+                const bool qfwd = kf <= kr;
+                // leave to the slow path: a palindromic minimizer (even m only), distinct tied minimizers, or the
+                // same canonical m-mer occurring twice in the k-mer (then jL != jR and the two occurrences may
+                // have opposite orientations, so one flag cannot decide the strand)
+                const bool simple = same && kf != kr && jL[a] == jR[a];
+                slow[a] = valid[a] && !simple;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint64_t rec = (q & 2) ? r1 : r0;
-                    const uint32_t jd = (q & 1) ? jB : jL[a];
-                    con[a][q] = valid[a] && ((q & 1) == 0 || same) && jd >= rec_jmin(rec) && jd <= rec_jmax(rec);
+                for (int q = 0; q < 2; ++q) {
+                    const uint64_t rec = q ? r1 : r0;
+                    rcq[a][q] = rec_fwd(rec) != qfwd;  // opposite strand: compare the reverse complement
+                    const uint32_t jd = rcq[a][q] ? jB : jL[a];
+                    con[a][q] = valid[a] && simple && jd >= rec_jmin(rec) && jd <= rec_jmax(rec);
                     const uint32_t sp = con[a][q] ? rec_pos(rec) - jd : 0u;
                     csh[a][q] = sp & 31u;
                     cs[a][q] = rec_csid(rec);
@@ -453,35 +466,28 @@ __global__ __launch_bounds__(256) void k1_lookup_short(DevDict d, const uint8_t*
                     w1[a][q] = w[1];
                 }
             }
-            bool slow = false;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 uint32_t found = NEG;
 #pragma unroll
-                for (int q = 3; q >= 0; --q) {
+                for (int q = 1; q >= 0; --q) {
                     uint32_t lo, hi;
                     string_lmer(w0[a][q], w1[a][q], csh[a][q], k, lo, hi);
-                    const bool hit = con[a][q] && lo == ((q & 1) ? rlo[a] : klo[a]) && hi == ((q & 1) ? rhi[a] : khi[a]);
+                    const bool hit = con[a][q] && lo == (rcq[a][q] ? rlo[a] : klo[a]) && hi == (rcq[a][q] ? rhi[a] : khi[a]);
                     found = hit ? cs[a][q] : found;
                 }
                 csid[a] = found;
                 const bool more = (e[a] & REC_TAG) && ovf_cnt(e[a]) > 2;
-                slow |= valid[a] && found == NEG && (more || hL[a] != hR[a]);
+                slow[a] = slow[a] || (valid[a] && found == NEG && more);
             }
             // rare continuations: more than two records under the key, or a different rightmost key
-            if (__any(slow)) {
+            if (__any(slow[0] || slow[1])) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    if (valid[a] && csid[a] == NEG) {
+                    if (slow[a] && csid[a] == NEG) {  // the generic probe tries both orientations on every record
                         const bool same = hL[a] == hR[a];
                         const uint32_t jB = km - jR[a];
-                        if ((e[a] & REC_TAG) && ovf_cnt(e[a]) > 2) {
-                            const uint64_t* p = d.overflow + ovf_off(e[a]);
-                            for (uint32_t i = 2; i < ovf_cnt(e[a]) && csid[a] == NEG; ++i) {
-                                csid[a] = try_record(d, p[i], jL[a], klo[a], khi[a]);
-                                if (csid[a] == NEG && same) csid[a] = try_record(d, p[i], jB, rlo[a], rhi[a]);
-                            }
-                        }
+                        csid[a] = probe(d, hL[a], true, same, jL[a], jB, klo[a], khi[a], rlo[a], rhi[a]);
                         if (csid[a] == NEG && !same)
                             csid[a] = probe(d, hR[a], false, true, jL[a], jB, klo[a], khi[a], rlo[a], rhi[a]);
                     }

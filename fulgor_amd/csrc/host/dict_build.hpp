@@ -42,7 +42,7 @@ inline void build_dict(Dict& d, uint32_t k, uint32_t m, const char* bases, uint6
                        unsigned nthreads = 0) {
     if (k < 2 || k > 31) throw std::runtime_error("k must be in [2,31]");
     if (m < 1 || m > k || k - m > 15) throw std::runtime_error("need m <= k and k - m <= 15");
-    if (total_bases >= (1ULL << 32)) throw std::runtime_error("unitig strings exceed 2^32 bases");
+    if (total_bases >= (1ULL << 31)) throw std::runtime_error("unitig strings exceed 2^31 bases");
     if (nthreads == 0) nthreads = std::max(1u, std::thread::hardware_concurrency());
     d.k = k;
     d.m = m;
@@ -68,6 +68,7 @@ inline void build_dict(Dict& d, uint32_t k, uint32_t m, const char* bases, uint6
         for (unsigned t = 0; t < nthreads; ++t) {
             th.emplace_back([&, t]() {
                 std::vector<uint64_t> hh;
+                std::vector<uint8_t> fw;
                 auto& out = parts[t];
                 for (uint64_t u = cut[t]; u < cut[t + 1]; ++u) {
                     const uint64_t b = unitig_off[u], e = unitig_off[u + 1];
@@ -76,11 +77,13 @@ inline void build_dict(Dict& d, uint32_t k, uint32_t m, const char* bases, uint6
                     if (unitig_csid[u] > REC_MAX_CSID) throw std::runtime_error("colour-set id exceeds record width");
                     const uint64_t nm = len - m + 1;
                     hh.resize(nm);
+                    fw.resize(nm);
                     for (uint64_t i = 0; i < nm; ++i) {
                         uint64_t s = b + i;
                         uint32_t lo, hi;
                         string_lmer(d.strings[s >> 5], d.strings[(s >> 5) + 1], (uint32_t)(s & 31), m, lo, hi);
                         hh[i] = mix64(canonical_key(lo, hi, m));
+                        fw[i] = is_fwd_canonical(lo, hi, m);
                     }
                     const uint64_t nk = len - k + 1;
                     nk_parts[t] += nk;
@@ -98,7 +101,7 @@ inline void build_dict(Dict& d, uint32_t k, uint32_t m, const char* bases, uint6
                         if (p != run_p) {
                             if (run_p != ~0ULL) {
                                 uint64_t s_last = s - 1;
-                                out.push_back({hh[run_p], rec_pack((uint32_t)(b + run_p), (uint32_t)(run_p - s_last),
+                                out.push_back({hh[run_p], rec_pack((uint32_t)(b + run_p), fw[run_p] != 0, (uint32_t)(run_p - s_last),
                                                                    (uint32_t)(run_p - run_first), unitig_csid[u])});
                             }
                             run_p = p;
