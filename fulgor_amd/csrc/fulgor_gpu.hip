@@ -362,7 +362,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
                                res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
         HIP_TRY(hipGetLastError());
     } else if (algo == FGPU_FULL_INTERSECTION) {
-        const size_t per_wave = (size_t)W * 4 + (size_t)W * 32 + wave_scratch_bytes();
+        const size_t per_wave = (size_t)(1 + SPARSE_PLANES) * W * 4 + wave_scratch_bytes();
         const uint32_t wpb = pick_waves(per_wave, (const void*)k2a_intersect);
         const uint32_t grid = resident_grid(k2a_intersect, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
         Timed t(ix, FGPU_K_INTERSECT);

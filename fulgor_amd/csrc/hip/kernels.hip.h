@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __res
 // because on this kernel the scalar unit (exec-mask bookkeeping of divergent branches), not memory, was
 // the limiter.
 template <bool W13>
-__global__ __launch_bounds__(256) void k1_lookup_short(DevDict d, const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(256, 6) void k1_lookup_short(DevDict d, const uint8_t* __restrict__ bases,
                                                        const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
                                                        uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
                                                        uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
@@ -749,39 +749,32 @@ __device__ __forceinline__ uint32_t upper_slot(const uint32_t* pref, uint32_t t)
 // K2a: full intersection of hybrid colour sets -> bitmap + cardinality
 // ---------------------------------------------------------------------------------------------
 // Semantics of `intersect` (ps_full_intersection.cpp:32-127): the result is the set intersection of the
-// given lists. Here, per read (one wave):
-//   R = all colours (n-bit bitmap in LDS)
-//   bitmap lists      : R &= list, word-wise
-//   complemented lists: every missing colour clears its bit in R            (ds_and)
-//   sparse lists      : every member bumps a per-colour byte counter        (ds_add); afterwards
-//                       R &= {c : counter[c] == number of sparse lists}
-// All gap-coded lists of a read are cut into SAMPLE_STRIDE-code segments (restart samples built at
-// load) and ALL segments of ALL lists are decoded concurrently, one segment per lane.
-__device__ __forceinline__ uint32_t bytes_equal_mask4(uint32_t x, uint32_t pattern) {
-    // 4 byte lanes of x compared with the same lanes of pattern -> 4-bit mask (bit b = byte b equal)
-    const uint32_t y = x ^ pattern;
-    uint32_t t = (y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
-    t = ~(t | y | 0x7F7F7F7Fu);            // 0x80 in every byte of y that is zero
-    return ((t >> 7) * 0x00204081u >> 21) & 0xFu;
-}
+// given lists. Per read (one wave) the kernel builds an EXCLUSION bitmap in LDS and returns its complement:
+//   bitmap lists      : EXCL |= ~list, word-wise
+//   complemented lists: every missing colour sets its bit in EXCL
+//   sparse lists      : list p (up to 8 per round) sets bits in its own plane T_p; afterwards EXCL |= ~T_p
+// so EVERY gap code of every list does the same thing — OR one bit into a bitmap chosen per lane — and all
+// 16-code segments of all lists run through ONE decode loop, one segment per lane (restart samples built at
+// load), without divergence between list kinds.
+constexpr uint32_t SPARSE_PLANES = 3;
 
-__global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint64_t* __restrict__ id_csr,
+__global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint64_t* __restrict__ id_csr,
                                                      const ListDesc* __restrict__ desc, uint64_t n_reads,
                                                      uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count,
                                                      unsigned int* tickets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = c.w32;
-    const uint32_t per_wave = W * 4 + W * 32 + wave_scratch_bytes();
+    const uint32_t per_wave = (1 + SPARSE_PLANES) * W * 4 + wave_scratch_bytes();
     unsigned char* mine = smem + (size_t)wv * per_wave;
     WaveScratch sc = carve_scratch(mine);
-    uint32_t* R = (uint32_t*)(mine + wave_scratch_bytes());
-    uint32_t* CNT = R + W;  // W*8 words: one byte counter per colour, 8 planes of W words (conflict-free fold)
+    uint32_t* EXCL = (uint32_t*)(mine + wave_scratch_bytes());
+    uint32_t* T = EXCL + W;  // SPARSE_PLANES planes of W words, all zero between reads
     const WorkQueue wq{tickets, n_reads, 8};
     uint64_t t_first;
     uint32_t t_count;
 
-    for (uint32_t w = lane; w < W * 8; w += 64) CNT[w] = 0;
+    for (uint32_t w = lane; w < W * SPARSE_PLANES; w += 64) T[w] = 0;
     wave_lds_sync();
 
     while (wq.pull(t_first, t_count))
@@ -794,11 +787,10 @@ __global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint64_t
             if (lane == 0) out_count[r] = 0;
             continue;
         }
-        for (uint32_t w = lane; w < W; w += 64) {
+        for (uint32_t w = lane; w < W; w += 64) {  // colours >= n start excluded
             const uint32_t lo = w * 32;
-            R[w] = lo >= c.n ? 0u : (c.n - lo >= 32 ? 0xFFFFFFFFu : ((1u << (c.n - lo)) - 1u));
+            EXCL[w] = lo >= c.n ? 0xFFFFFFFFu : (c.n - lo >= 32 ? 0u : ~((1u << (c.n - lo)) - 1u));
         }
-        uint32_t sparse_pending = 0;  // sparse lists counted in CNT and not yet folded into R
         for (uint32_t g = 0; g < cnt; g += 64) {
             ListHeader h;
             h.type = D_ENC_NONE; h.ncodes = 0; h.begin = h.body = h.soff = 0; h.size = 0;
@@ -807,71 +799,62 @@ __global__ __launch_bounds__(256) void k2a_intersect(DevColors c, const uint64_t
                 h.type = desc_type(d); h.ncodes = d.ncodes; h.begin = d.begin; h.body = desc_body(d); h.soff = d.soff;
             }
             const uint32_t nseg = (h.ncodes + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
+            const uint64_t sparse_mask = __ballot(h.type == D_ENC_DELTA_GAPS);
+            const uint32_t nsparse = __popcll(sparse_mask);
+            const uint32_t srank = mask_rank(sparse_mask);
             sc.h_begin[lane] = h.begin; sc.h_body[lane] = h.body; sc.h_soff[lane] = h.soff; sc.h_ncodes[lane] = h.ncodes;
-            sc.h_score[lane] = h.type;
-            const uint32_t incl = wave_incl_scan_u32(nseg);  // bitmap lists have ncodes = 0
-            sc.pref[lane] = incl;
-            const uint32_t total_seg = (uint32_t)__shfl((int)incl, 63);
-            const uint32_t sparse_here = __popcll(__ballot(h.type == D_ENC_DELTA_GAPS));
-            // exactly one sparse list in the whole read: a plain bitmap T (aliasing the counters) is enough
-            const bool single_sparse = sparse_here == 1 && sparse_pending == 0 && g + 64 >= cnt;
-            if (!single_sparse) sparse_pending += sparse_here;
             wave_lds_sync();
 
+            // bitmap lists: exclude what they do not contain
             uint64_t mb = __ballot(h.type == D_ENC_BITMAP);
             while (mb) {
                 const int src = __builtin_ctzll(mb);
                 mb &= mb - 1;
                 const uint64_t body = sc.h_body[src];
-                for (uint32_t w = lane; w < W; w += 64) R[w] &= (uint32_t)bits_window(c.bits, body + 32ull * w);
+                for (uint32_t w = lane; w * 32 < c.n; w += 64) EXCL[w] |= ~(uint32_t)bits_window(c.bits, body + 32ull * w);
             }
             wave_lds_sync();
 
-            for (uint32_t t0 = 0; t0 < total_seg; t0 += 64) {
-                const uint32_t t = t0 + lane;
-                if (t < total_seg) {
-                    const uint32_t i = upper_slot(sc.pref, t);
-                    const uint32_t nc = sc.h_ncodes[i];
-                    const uint32_t ns = (nc + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
-                    const uint32_t seg = t - (sc.pref[i] - ns);
-                    if (sc.h_score[i] == D_ENC_COMPLEMENT)
-                        decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg,
-                                       [&](uint32_t v) { atomicAnd(&R[v >> 5], ~(1u << (v & 31))); });
-                    else if (single_sparse)
-                        decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg,
-                                       [&](uint32_t v) { atomicOr(&CNT[v >> 5], 1u << (v & 31)); });
-                    else
-                        decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg, [&](uint32_t v) {
-                            // counter of colour v: byte (v & 3) of word ((v >> 2) & 7) * W + (v >> 5)
-                            atomicAdd(&CNT[((v >> 2) & 7u) * W + (v >> 5)], 1u << (8 * (v & 3)));
-                        });
-                }
-            }
-            wave_lds_sync();
-            if (single_sparse) {
-                for (uint32_t w = lane; w < W; w += 64) { R[w] &= CNT[w]; CNT[w] = 0; }
+            // rounds of up to SPARSE_PLANES sparse lists; complemented lists ride along in the first round
+            for (uint32_t rb = 0; rb == 0 || rb < nsparse; rb += SPARSE_PLANES) {
+                const bool mine_now = (h.type == D_ENC_COMPLEMENT && rb == 0) ||
+                                      (h.type == D_ENC_DELTA_GAPS && srank >= rb && srank < rb + SPARSE_PLANES);
+                // LDS word offset of the bitmap this list ORs into
+                sc.h_score[lane] = h.type == D_ENC_COMPLEMENT ? 0 : (int32_t)((1 + (srank - rb)) * W);
+                const uint32_t incl = wave_incl_scan_u32(mine_now ? nseg : 0u);
+                sc.pref[lane] = incl;
+                const uint32_t total_seg = (uint32_t)__shfl((int)incl, 63);
                 wave_lds_sync();
-            }
-
-            // fold the byte counters into R before they could overflow, and at the end
-            if (sparse_pending && (g + 64 >= cnt || sparse_pending > 255 - 64)) {
-                const uint32_t pattern = sparse_pending * 0x01010101u;
-                for (uint32_t w = lane; w < W; w += 64) {
-                    uint32_t m = 0;
-#pragma unroll
-                    for (uint32_t q = 0; q < 8; ++q) {  // plane q holds colours 32w + 4q .. 32w + 4q + 3
-                        m |= bytes_equal_mask4(CNT[q * W + w], pattern) << (4 * q);
-                        CNT[q * W + w] = 0;
+                for (uint32_t t0 = 0; t0 < total_seg; t0 += 64) {
+                    const uint32_t t = t0 + lane;
+                    if (t < total_seg) {
+                        const uint32_t i = upper_slot(sc.pref, t);
+                        const uint32_t nc = sc.h_ncodes[i];
+                        const uint32_t ns = (nc + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
+                        const uint32_t seg = t - (sc.pref[i] - ns);
+                        uint32_t* dst = EXCL + sc.h_score[i];
+                        decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg,
+                                       [&](uint32_t v) { atomicOr(&dst[v >> 5], 1u << (v & 31)); });
                     }
-                    R[w] &= m;
                 }
-                sparse_pending = 0;
                 wave_lds_sync();
+                const uint32_t np = min(SPARSE_PLANES, nsparse > rb ? nsparse - rb : 0u);
+                if (np) {  // a colour absent from any of these sparse lists is excluded; planes go back to zero
+                    for (uint32_t w = lane; w < W; w += 64) {
+                        uint32_t all = 0xFFFFFFFFu;
+                        for (uint32_t p = 0; p < np; ++p) {
+                            all &= T[p * W + w];
+                            T[p * W + w] = 0;
+                        }
+                        EXCL[w] |= ~all;
+                    }
+                    wave_lds_sync();
+                }
             }
         }
         uint32_t pc = 0;
         for (uint32_t w = lane; w < W; w += 64) {
-            const uint32_t x = R[w];
+            const uint32_t x = ~EXCL[w];
             bm[w] = x;
             pc += __popc(x);
         }
