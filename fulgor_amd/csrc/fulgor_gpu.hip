@@ -122,6 +122,7 @@ struct fgpu_reads {
     std::vector<uint64_t> cum_kmers;  // prefix sums of max(0, len-k+1)
     std::vector<uint64_t> h_offs;
     uint32_t max_kmers = 0;
+    uint64_t max_total_kmers = 0;  // longest read, in k-mers (not capped by segmentation)
     // reads with more than SEG_KMERS k-mers are cut into overlapping segments (k-1 shared bases) that the
     // lookup kernel treats as units; seg_first[r] = first segment of read r (n + 1 entries)
     bool has_long = false;
@@ -138,6 +139,7 @@ struct fgpu_result {
     uint64_t* h_totals = nullptr;  // pinned {total colours, mapped reads, ids used}
     uint64_t n = 0, total = 0, mapped = 0, total_kmers = 0, total_bases = 0;
     uint32_t id_stride = 0;
+    uint32_t max_kmers_in_batch = 0xFFFFFFFFu;  // bound on #positive k-mers of any read (unknown for id-only calls)
     bool have_ids = false;
 };
 
@@ -212,6 +214,7 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     const uint64_t u_first = seg ? rd->seg_first[first] : first;
     const uint64_t units = seg ? rd->seg_first[first + count] - u_first : count;
     res->n = count;
+    res->max_kmers_in_batch = (uint32_t)std::min<uint64_t>(rd->max_total_kmers, 0xFFFFFFFFull);
     res->d_nids.ensure(units * 4 + 16);
     res->d_npos.ensure(units * 4 + 16);
     res->d_idoff.ensure(units * 8 + 16);
@@ -371,14 +374,21 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
                            res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
         HIP_TRY(hipGetLastError());
     } else if (algo == FGPU_THRESHOLD_UNION) {
-        const size_t per_wave = (size_t)W * 64 + wave_scratch_bytes();
-        const uint32_t wpb = pick_waves(per_wave, (const void*)k3a_union);
-        const uint32_t grid = resident_grid(k3a_union, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
-        Timed t(ix, FGPU_K_UNION);
-        hipLaunchKernelGGL(k3a_union, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_npos.as<uint32_t>(),
-                           res->d_idcsr.as<uint64_t>(), res->d_desc.as<ListDesc>(), tau, n, res->d_bitmap.as<uint32_t>(),
-                           res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
-        HIP_TRY(hipGetLastError());
+        // score counter width from the longest read of the batch: 8 bits up to 127 k-mers, 16 up to 32767, else 32
+        const int bits = res->max_kmers_in_batch <= 127 ? 8 : (res->max_kmers_in_batch <= 32767 ? 16 : 32);
+        const size_t per_wave = (size_t)W * 4 * bits + wave_scratch_bytes();
+        auto launch = [&](auto kernel) {
+            const uint32_t wpb = pick_waves(per_wave, (const void*)kernel);
+            const uint32_t grid = resident_grid(kernel, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
+            Timed t(ix, FGPU_K_UNION);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_npos.as<uint32_t>(),
+                               res->d_idcsr.as<uint64_t>(), res->d_desc.as<ListDesc>(), tau, n, res->d_bitmap.as<uint32_t>(),
+                               res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
+            HIP_TRY(hipGetLastError());
+        };
+        if (bits == 8) launch(k3a_union<8>);
+        else if (bits == 16) launch(k3a_union<16>);
+        else launch(k3a_union<32>);
     } else {
         throw std::runtime_error("unknown algorithm");
     }
@@ -529,6 +539,7 @@ int fgpu_reads_upload(fgpu_index* ix, const char* bases, const uint64_t* offs, u
             uint64_t len = offs[i + 1] - offs[i];
             uint64_t nk = len >= k ? len - k + 1 : 0;
             if (nk > SEG_KMERS) rd->has_long = true;
+            rd->max_total_kmers = std::max(rd->max_total_kmers, nk);
             rd->max_kmers = std::max<uint32_t>(rd->max_kmers, (uint32_t)std::min<uint64_t>(nk, SEG_KMERS));
             rd->cum_kmers[i + 1] = rd->cum_kmers[i] + nk;
         }

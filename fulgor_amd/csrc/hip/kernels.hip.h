@@ -870,20 +870,31 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint6
 // `merge` (ps_threshold_union.cpp:16-40): scores[c] += score for members of sparse/bitmap lists,
 // -= score for the missing colours of complemented lists while min_score is lowered by that score;
 // keep c iff scores[c] >= min_score. min_score = uint64(double(#positive k-mers) * tau) (:389).
-// Scores live in LDS as 16-bit counters biased by 0x8000 (|score| <= #k-mers <= 1024), two per word,
-// laid out in 16 planes of W words (colour c -> plane (c>>1)&15, word c>>5, half c&1) so that both the
-// per-word updates of bitmap lists and the final threshold pass are bank-conflict free.
-__global__ void k3a_union(DevColors c, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
-                          const ListDesc* __restrict__ desc, double tau, uint64_t n_reads,
-                          uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count, unsigned int* tickets) {
+// Scores live in LDS as small biased counters: BITS = 8 for reads of at most 127 k-mers (4 per word, 8
+// planes of W words), 16 up to 32767 k-mers (2 per word, 16 planes), 32 beyond; colour c -> plane (c / PER) % PLANES, word
+// c / 32, field c % PER: bitmap lists and the final pass touch every plane conflict-free. The counters
+// start at HALF - min_score + (total score of complemented lists), so that
+//     score[c] >= min_score   <=>   counter[c] >= HALF   <=>   top bit of the field set,
+// and they never leave [0, 2*HALF) because 0 <= min_score <= #positive k-mers < HALF. A signed score is
+// added as a 32-bit two's complement shifted to the field: fields cannot borrow from each other.
+template <int BITS>
+__global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a_union(DevColors c, const uint32_t* __restrict__ npos,
+                                                                  const uint64_t* __restrict__ id_csr,
+                                                                  const ListDesc* __restrict__ desc, double tau, uint64_t n_reads,
+                                                                  uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count,
+                                                                  unsigned int* tickets) {
+    constexpr uint32_t PER = 32 / BITS;            // counters per word
+    constexpr uint32_t PLANES = 32 / PER;          // planes (one result word = PLANES counter words)
+    constexpr uint32_t HALF = 1u << (BITS - 1);
+    constexpr uint32_t ONES = BITS == 8 ? 0x01010101u : (BITS == 16 ? 0x00010001u : 1u);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = c.w32;
     const uint32_t n = c.n;
-    const uint32_t per_wave = W * 64 + wave_scratch_bytes();
+    const uint32_t per_wave = W * PLANES * 4 + wave_scratch_bytes();
     unsigned char* mine = smem + (size_t)wv * per_wave;
     WaveScratch sc = carve_scratch(mine);
-    uint32_t* SC = (uint32_t*)(mine + wave_scratch_bytes());  // 16 planes of W words
+    uint32_t* SC = (uint32_t*)(mine + wave_scratch_bytes());
     const WorkQueue wq{tickets, n_reads, 8};
     uint64_t t_first;
     uint32_t t_count;
@@ -898,9 +909,18 @@ __global__ void k3a_union(DevColors c, const uint32_t* __restrict__ npos, const 
             if (lane == 0) out_count[r] = 0;
             continue;
         }
-        const long long min_score = (long long)(unsigned long long)((double)npos[r] * tau);
-        for (uint32_t i = lane; i < W * 16; i += 64) SC[i] = 0x80008000u;
-        long long comp_total = 0;
+        const uint32_t min_score = (uint32_t)(unsigned long long)((double)npos[r] * tau);
+        uint32_t comp_total = 0;
+        for (uint32_t g = 0; g < cnt; g += 64) {
+            uint32_t cs = 0;
+            if (g + lane < cnt) {
+                const ListDesc d = desc[off + g + lane];
+                cs = desc_type(d) == D_ENC_COMPLEMENT ? (uint32_t)d.score : 0u;
+            }
+            comp_total += wave_sum_u32(cs);
+        }
+        const uint32_t start = (HALF - min_score + comp_total) * ONES;
+        for (uint32_t i = lane; i < W * PLANES; i += 64) SC[i] = start;
         wave_lds_sync();
         for (uint32_t g = 0; g < cnt; g += 64) {
             ListHeader h;
@@ -914,7 +934,6 @@ __global__ void k3a_union(DevColors c, const uint32_t* __restrict__ npos, const 
             const uint32_t nseg = (h.ncodes + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
             sc.h_begin[lane] = h.begin; sc.h_body[lane] = h.body; sc.h_soff[lane] = h.soff; sc.h_ncodes[lane] = h.ncodes;
             sc.h_score[lane] = h.type == D_ENC_COMPLEMENT ? -score : score;
-            comp_total += (long long)wave_sum_u32(h.type == D_ENC_COMPLEMENT ? (uint32_t)score : 0u);
             const uint32_t incl = wave_incl_scan_u32(nseg);  // gap-coded lists of both kinds
             sc.pref[lane] = incl;
             const uint32_t total_seg = (uint32_t)__shfl((int)incl, 63);
@@ -930,9 +949,12 @@ __global__ void k3a_union(DevColors c, const uint32_t* __restrict__ npos, const 
                     uint32_t x = (uint32_t)bits_window(c.bits, body + 32ull * w);
                     if (n - w * 32 < 32) x &= (1u << (n - w * 32)) - 1u;
 #pragma unroll
-                    for (uint32_t q = 0; q < 16; ++q) {  // colours 32w + 2q, 32w + 2q + 1 share a word; only this lane touches it
-                        const uint32_t add = ((x >> (2 * q)) & 1u) * s + (((x >> (2 * q + 1)) & 1u) * s << 16);
-                        if (add) SC[q * W + w] += add;
+                    for (uint32_t q = 0; q < PLANES; ++q) {  // only this lane touches these words
+                        uint32_t spread;
+                        if (BITS == 8) spread = ((((x >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u) * s;
+                        else if (BITS == 16) spread = ((x >> (2 * q)) & 1u) * s + ((((x >> (2 * q + 1)) & 1u) * s) << 16);
+                        else spread = ((x >> q) & 1u) * s;
+                        SC[q * W + w] += spread;
                     }
                 }
                 wave_lds_sync();
@@ -945,26 +967,23 @@ __global__ void k3a_union(DevColors c, const uint32_t* __restrict__ npos, const 
                     const uint32_t nc = sc.h_ncodes[i];
                     const uint32_t ns = (nc + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
                     const uint32_t seg = t - (sc.pref[i] - ns);
-                    const uint32_t sv = (uint32_t)sc.h_score[i];  // two's complement: adding it to one half never
-                                                                  // carries into the other thanks to the bias
+                    const uint32_t sv = (uint32_t)sc.h_score[i];
                     decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg, [&](uint32_t v) {
-                        atomicAdd(&SC[((v >> 1) & 15u) * W + (v >> 5)], (v & 1u) ? (sv << 16) : sv);
+                        atomicAdd(&SC[((v / PER) % PLANES) * W + (v >> 5)], sv << ((BITS & 31) * (v % PER)));
                     });
                 }
             }
             wave_lds_sync();
         }
-        // colour c passes iff (half - 0x8000) + comp_total >= min_score  <=>  half >= thr
-        long long thr_ll = min_score - comp_total + 0x8000;
-        const uint32_t thr = thr_ll < 0 ? 0u : (thr_ll > 0x10000 ? 0x10000u : (uint32_t)thr_ll);
         uint32_t pc = 0;
         for (uint32_t w = lane; w < W; w += 64) {
             uint32_t m = 0;
 #pragma unroll
-            for (uint32_t q = 0; q < 16; ++q) {
+            for (uint32_t q = 0; q < PLANES; ++q) {
                 const uint32_t x = SC[q * W + w];
-                m |= (uint32_t)((x & 0xFFFFu) >= thr) << (2 * q);
-                m |= (uint32_t)((x >> 16) >= thr) << (2 * q + 1);
+                if (BITS == 8) m |= ((((x >> 7) & 0x01010101u) * 0x00204081u >> 21) & 0xFu) << (4 * q);
+                else if (BITS == 16) m |= (((x >> 15) & 1u) | ((x >> 30) & 2u)) << (2 * q);
+                else m |= (x >> 31) << q;
             }
             const uint32_t lo = w * 32;
             m &= lo >= n ? 0u : (n - lo >= 32 ? 0xFFFFFFFFu : ((1u << (n - lo)) - 1u));
