@@ -1042,7 +1042,7 @@ __device__ __forceinline__ void decode_op_segment(const DevGeneric& g, uint64_t 
 }
 
 template <bool UNION>
-__global__ void k_generic(DevGeneric g, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
+__global__ __launch_bounds__(256, UNION ? 4 : 8) void k_generic(DevGeneric g, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
                           const ListDesc* __restrict__ desc, double tau, uint64_t n_reads,
                           uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count, unsigned int* tickets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1132,16 +1132,12 @@ __global__ void k_generic(DevGeneric g, const uint32_t* __restrict__ npos, const
                         const uint32_t nc = sc.h_ncodes[i];
                         const uint32_t ns = (nc + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
                         const uint32_t seg = t - (sc.pref[i] - ns);
-                        const uint32_t kind = (uint32_t)sc.h_score[i], b = o_base[i];
-                        if (kind == G_OR_GAPS)
-                            decode_op_segment(g, sc.h_begin[i], sc.h_soff[i], nc, seg,
-                                              [&](uint32_t v) { atomicOr(&T[(b + v) >> 5], 1u << ((b + v) & 31)); });
-                        else if (kind == G_OR_COMP)
-                            decode_op_segment(g, sc.h_begin[i], sc.h_soff[i], nc, seg,
-                                              [&](uint32_t v) { atomicAnd(&T[(b + v) >> 5], ~(1u << ((b + v) & 31))); });
-                        else
-                            decode_op_segment(g, sc.h_begin[i], sc.h_soff[i], nc, seg,
-                                              [&](uint32_t v) { atomicXor(&T[(b + v) >> 5], 1u << ((b + v) & 31)); });
+                        // every gap op is a toggle: sparse members flip 0 -> 1 (partitions are disjoint and a
+                        // list holds distinct colours), missing colours of a complemented list flip the filled
+                        // range 1 -> 0, representative and differential lists XOR by definition
+                        const uint32_t b = o_base[i];
+                        decode_op_segment(g, sc.h_begin[i], sc.h_soff[i], nc, seg,
+                                          [&](uint32_t v) { atomicXor(&T[(b + v) >> 5], 1u << ((b + v) & 31)); });
                     }
                 }
                 wave_lds_sync();
