@@ -139,6 +139,7 @@ struct fgpu_result {
     uint64_t* h_totals = nullptr;  // pinned {total colours, mapped reads, ids used}
     uint64_t n = 0, total = 0, mapped = 0, total_kmers = 0, total_bases = 0;
     uint32_t id_stride = 0;
+    uint32_t hit_rows = 0;  // rows of d_partial filled by the last expand launch (0: no colours, nothing to add)
     uint32_t max_kmers_in_batch = 0xFFFFFFFFu;  // bound on #positive k-mers of any read (unknown for id-only calls)
     bool have_ids = false;
 };
@@ -341,6 +342,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     res->d_counts.ensure(n * 4 + 16);
     res->d_offsets.ensure((n + 1) * 8 + 16);
     res->total = res->mapped = 0;
+    res->hit_rows = 0;
     if (n == 0) {
         HIP_TRY(hipMemsetAsync(res->d_offsets.p, 0, 8, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -399,11 +401,16 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     res->mapped = res->h_totals[1];
     res->d_colors.ensure(res->total * 4 + 16);
     if (res->total) {
-        const uint32_t grid = resident_grid(k2b_expand, n, 4, ix->num_cus, 256, 0);
+        const size_t lds = 4 * (2048 + 64) * 2 + (size_t)W * 64;
+        if (lds > 64 * 1024) throw std::runtime_error("colour count too large for the expand kernel's LDS histogram");
+        // a block must see fewer than 65536 reads (16-bit hit counters): true for any resident grid >= n / 65535
+        const uint32_t grid = std::max<uint32_t>(resident_grid(k2b_expand, n, 4, ix->num_cus, 256, lds), (uint32_t)(n / 60000 + 1));
+        res->d_partial.ensure((size_t)grid * W * 32 * 4);
+        res->hit_rows = grid;
         Timed t(ix, FGPU_K_EXPAND);
-        hipLaunchKernelGGL(k2b_expand, dim3(grid), dim3(256), 0, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
+        hipLaunchKernelGGL(k2b_expand, dim3(grid), dim3(256), lds, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
                            res->d_offsets.as<uint64_t>(), n, W, res->d_colors.as<uint32_t>(),
-                           res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE);
+                           res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE, res->d_partial.as<uint32_t>());
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(s));
@@ -645,14 +652,11 @@ int fgpu_result_accumulate_hits(fgpu_index* ix, const fgpu_result* r, void* devi
         HIP_TRY(hipSetDevice(ix->device));
         if (r->n) {
             const uint32_t W = ix->dc.w32;
-            const uint32_t threads = std::min<uint32_t>(256, ((W + 63) / 64) * 64);
-            const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ix->num_cus * 8, (r->n + 63) / 64));
-            const_cast<fgpu_result*>(r)->d_partial.ensure((size_t)grid * W * 32 * 4);
             Timed t(ix, FGPU_K_HITS);
-            hipLaunchKernelGGL(k_hits, dim3(grid), dim3(threads), 0, ix->stream, r->d_bitmap.as<uint32_t>(), r->n, W,
-                               r->d_partial.as<uint32_t>());
-            hipLaunchKernelGGL(k_hits_reduce, dim3((ix->dc.n + 255) / 256, HITS_ROW_GROUPS), dim3(256), 0, ix->stream, r->d_partial.as<uint32_t>(),
-                               grid, W, ix->dc.n, (unsigned long long*)device_u64_hits);
+            // the expand kernel left one row of per-colour counts per block; sum the rows into the totals
+            if (r->hit_rows)
+                hipLaunchKernelGGL(k_hits_reduce, dim3((ix->dc.n + 255) / 256, HITS_ROW_GROUPS), dim3(256), 0, ix->stream,
+                                   r->d_partial.as<uint32_t>(), r->hit_rows, W, ix->dc.n, (unsigned long long*)device_u64_hits);
             hipLaunchKernelGGL(k_add_totals, dim3(1), dim3(64), 0, ix->stream, (unsigned long long*)device_u64_hits, ix->dc.n,
                                r->n, r->d_totals.as<uint64_t>());
             HIP_TRY(hipGetLastError());

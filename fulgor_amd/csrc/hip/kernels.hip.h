@@ -1275,10 +1275,20 @@ __global__ __launch_bounds__(256) void scan_apply(const uint32_t* __restrict__ c
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k2b_expand(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
                                                   const uint64_t* __restrict__ out_off, uint64_t n_reads, uint32_t W,
-                                                  uint32_t* __restrict__ colors, unsigned int* tickets) {
-    __shared__ uint16_t s_stage[4][2048 + 64];
+                                                  uint32_t* __restrict__ colors, unsigned int* tickets,
+                                                  uint32_t* __restrict__ hit_partial) {
+    // hit_partial != nullptr: also count, per colour, the reads of this launch that contain it. Each block
+    // keeps 16-bit counters in LDS (a block sees far fewer than 65536 reads) and stores them as one row of
+    // hit_partial[gridDim.x][W*32] at the end; k_hits_reduce sums the rows.
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_x[];
+    uint16_t* stage_all = (uint16_t*)smem_x;                        // 4 x (2048 + 64) entries
+    uint32_t* hist = (uint32_t*)(smem_x + 4 * (2048 + 64) * 2);     // W*16 words (two counters per word)
     const int lane = lane_id();
-    uint16_t* stage = s_stage[threadIdx.x >> 6];
+    uint16_t* stage = stage_all + (threadIdx.x >> 6) * (2048 + 64);
+    if (hit_partial) {
+        for (uint32_t i = threadIdx.x; i < W * 16; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+    }
     const WorkQueue wq{tickets, n_reads, 32};
     uint64_t t_first;
     uint32_t t_count;
@@ -1302,9 +1312,22 @@ __global__ __launch_bounds__(256) void k2b_expand(const uint32_t* __restrict__ b
             }
             wave_lds_sync();
             const uint32_t cbase = w0 * 32;
-            for (uint32_t i = lane; i < total; i += 64) out[i] = cbase + stage[i + (i >> 5)];
+            for (uint32_t i = lane; i < total; i += 64) {
+                const uint32_t col = cbase + stage[i + (i >> 5)];
+                out[i] = col;
+                if (hit_partial) atomicAdd(&hist[col >> 1], 1u << (16 * (col & 1)));
+            }
             out += total;
             wave_lds_sync();
+        }
+    }
+    if (hit_partial) {
+        __syncthreads();
+        uint32_t* row = hit_partial + (uint64_t)blockIdx.x * W * 32;
+        for (uint32_t i = threadIdx.x; i < W * 16; i += blockDim.x) {
+            const uint32_t v = hist[i];
+            row[2 * i] = v & 0xFFFFu;
+            row[2 * i + 1] = v >> 16;
         }
     }
 }
