@@ -53,20 +53,23 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     for (int o = 32; o; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
     return v;
 }
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
-    return v;
-}
-// inclusive prefix sum across the 64 lanes
+// inclusive prefix sum across the 64 lanes with DPP adds (pure VALU, no LDS crossbar round trips):
+// row_shr 1,2,3 of the input, then row_shr 4 / 8 of the partial sums inside each 16-lane row, then the last
+// lane of row 0/2 broadcast into row 1/3 (row_bcast:15) and lane 31 into rows 2,3 (row_bcast:31).
+// Lanes masked off by row/bank masks and lanes without a source receive 0.
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = (uint32_t)__shfl_up((int)v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
+    uint32_t r = v;
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xF, 0xF, true);  // row_shr:3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x114, 0xF, 0xE, true);  // row_shr:4, banks 1-3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x118, 0xF, 0xC, true);  // row_shr:8, banks 2-3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x142, 0xA, 0xF, true);  // row_bcast:15 -> rows 1,3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x143, 0xC, 0xF, true);  // row_bcast:31 -> rows 2,3
+    return r;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), 63);
 }
 // number of set bits of a wave-uniform 64-bit mask below this lane
 __device__ __forceinline__ uint32_t mask_rank(uint64_t m) {
@@ -823,7 +826,7 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint6
                 sc.h_score[lane] = h.type == D_ENC_COMPLEMENT ? 0 : (int32_t)((1 + (srank - rb)) * W);
                 const uint32_t incl = wave_incl_scan_u32(mine_now ? nseg : 0u);
                 sc.pref[lane] = incl;
-                const uint32_t total_seg = (uint32_t)__shfl((int)incl, 63);
+                const uint32_t total_seg = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 wave_lds_sync();
                 for (uint32_t t0 = 0; t0 < total_seg; t0 += 64) {
                     const uint32_t t = t0 + lane;
@@ -936,7 +939,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
             sc.h_score[lane] = h.type == D_ENC_COMPLEMENT ? -score : score;
             const uint32_t incl = wave_incl_scan_u32(nseg);  // gap-coded lists of both kinds
             sc.pref[lane] = incl;
-            const uint32_t total_seg = (uint32_t)__shfl((int)incl, 63);
+            const uint32_t total_seg = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             wave_lds_sync();
 
             uint64_t mb = __ballot(h.type == D_ENC_BITMAP);
@@ -1094,7 +1097,7 @@ __global__ __launch_bounds__(256, UNION ? 4 : 8) void k_generic(DevGeneric g, co
                 o_base[lane] = op.base; o_np[lane] = op.np;
                 const uint32_t incl = wave_incl_scan_u32(nseg);
                 sc.pref[lane] = incl;
-                const uint32_t total_seg = (uint32_t)__shfl((int)incl, 63);
+                const uint32_t total_seg = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 wave_lds_sync();
                 // complemented hybrid lists: fill the partition's colour range first
                 uint64_t mc = __ballot(have && op.kind == G_OR_COMP);
@@ -1301,7 +1304,7 @@ __global__ __launch_bounds__(256) void k2b_expand(const uint32_t* __restrict__ b
             uint32_t x = w0 + lane < W ? bm[w0 + lane] : 0u;
             const uint32_t pc = __popc(x);
             const uint32_t incl = wave_incl_scan_u32(pc);
-            const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             if (total == 0) continue;
             uint32_t at = incl - pc;
             const uint32_t rel = (uint32_t)lane * 32;
