@@ -71,9 +71,17 @@ def main():
     import fulgor_amd  # binds libfulgor_gpu.so to torch's HIP runtime (fulgor_amd/_native.py)
     import torch
     import torch.distributed as dist
+    # FULGOR_BENCH_SHARE_GPU=1 (test only): all ranks use cuda:0 and gloo, to exercise the multi-rank control
+    # flow on a single-GPU box; the real path is one GPU per rank over RCCL ("nccl" backend on ROCm)
+    share = os.environ.get("FULGOR_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist.barrier()
 
     default_reads = {"s10": 1_000_000, "s4546syn": 10_000_000}
@@ -105,8 +113,13 @@ def main():
             cnt = min(args.chunk, n_reads - first)
             ix.run(reads, res, algo, args.tau, first, cnt)
             res.accumulate_hits(hits.data_ptr())
-        if world > 1:
-            dist.all_reduce(hits)  # RCCL: per-colour hit counts + {reads, mapped}
+        if world > 1:  # RCCL: per-colour hit counts + {reads, mapped}
+            if share:
+                h_cpu = hits.cpu()
+                dist.all_reduce(h_cpu)
+                hits.copy_(h_cpu)
+            else:
+                dist.all_reduce(hits)
 
     for _ in range(args.warmup):
         step()
@@ -125,7 +138,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda:%d" % local_rank)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -49,9 +49,8 @@ def pseudoalign(argv):
     bases, offs = pack_reads(seqs)
     t1 = time.time()
     with open(a.output_filename, "wb") as out:
-        # --deduplicate changes how work is scheduled in the reference, not the output; every read is
-        # answered directly here
-        n, mapped = driver.pseudoalign_reads(index, bases, offs, algo, a.threshold or 0.0, sink=out, fmt=a.format)
+        n, mapped = driver.pseudoalign_reads(index, bases, offs, algo, a.threshold or 0.0, sink=out, fmt=a.format,
+                                             deduplicate=a.deduplicate)
     el = (time.time() - t1) * 1000.0
     if a.verbose:  # tools/pseudoalign.cpp:79-88
         print("processed %d reads" % n)

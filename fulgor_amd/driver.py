@@ -85,17 +85,65 @@ def format_binary(first_id, offsets, colors):
     return f.add(first_id, offsets, colors) + f.finish()
 
 
+def deduplicated_full_intersection(index, bases, offs):
+    """--deduplicate (tools/pseudoalign.cpp:91-226): fetch the colour-set ids of every read, collapse
+    identical id lists, intersect each distinct list once, fan the results back out. Same answers as the
+    direct path; the intersection kernel sees only distinct id lists. Returns CSR (offsets, colours)."""
+    ido, ids = index.fetch_color_set_ids_batch(bases, offs)
+    ido = ido.astype(np.int64)
+    n = len(ido) - 1
+    lens = np.diff(ido)
+    maxlen = int(lens.max()) if n else 0
+    if n == 0 or maxlen == 0:
+        return np.zeros(n + 1, dtype=np.uint64), np.zeros(0, dtype=np.uint32)
+    # exact grouping: pad the lists to a rectangle (0xFFFFFFFF is not a valid id) and take unique rows
+    pad = np.full((n, maxlen), 0xFFFFFFFF, dtype=np.uint32)
+    cols = np.arange(len(ids), dtype=np.int64) - np.repeat(ido[:-1], lens)
+    pad[np.repeat(np.arange(n), lens), cols] = ids
+    uniq, inv = np.unique(pad, axis=0, return_inverse=True)
+    inv = np.asarray(inv).reshape(-1)
+    ulens = (uniq != 0xFFFFFFFF).sum(axis=1)
+    u_off = np.zeros(len(uniq) + 1, dtype=np.uint64)
+    u_off[1:] = np.cumsum(ulens)
+    u_ids = uniq[uniq != 0xFFFFFFFF]  # row-major order keeps every list contiguous and sorted
+    ro, rc = index.intersect_ids_batch(u_ids, u_off)
+    ro = ro.astype(np.int64)
+    rsz = np.diff(ro)
+    sizes = rsz[inv]
+    out_off = np.zeros(n + 1, dtype=np.uint64)
+    out_off[1:] = np.cumsum(sizes)
+    total = int(out_off[-1])
+    # gather: element j of read r comes from rc[ro[inv[r]] + j]
+    src = np.repeat(ro[inv], sizes) + (np.arange(total, dtype=np.int64) - np.repeat(out_off[:-1].astype(np.int64), sizes))
+    return out_off, rc[src] if total else np.zeros(0, dtype=np.uint32)
+
+
 def pseudoalign_reads(index, bases, offs, algo=FULL_INTERSECTION, threshold=0.0, chunk=1 << 20, first_id=0,
-                      sink=None, fmt="ascii"):
+                      sink=None, fmt="ascii", deduplicate=False):
     """the worker loop over one read set: upload once, one pass per chunk, format + write each chunk.
     returns (num_reads, num_mapped_reads)"""
     n = len(offs) - 1
-    reads = index.upload_reads(bases, offs)
-    res = index.new_result()
-    mapped = 0
     f = Formatter(fmt, index.num_colors()) if sink is not None else None
     if f is not None:
         sink.write(f.header)
+    if deduplicate:
+        if algo != FULL_INTERSECTION:
+            raise ValueError("Deduplication not available for threshold < 1.0. Remove --deduplicate flag.")
+        mapped = 0
+        offs = np.asarray(offs, dtype=np.uint64)
+        for a in range(0, n, chunk):
+            cnt = min(chunk, n - a)
+            lo, hi = int(offs[a]), int(offs[a + cnt])
+            o, c = deduplicated_full_intersection(index, bases[lo:hi], offs[a:a + cnt + 1] - offs[a])
+            mapped += int((np.diff(o.astype(np.int64)) > 0).sum())
+            if f is not None:
+                sink.write(f.add(first_id + a, o, c))
+        if f is not None:
+            sink.write(f.finish())
+        return n, mapped
+    reads = index.upload_reads(bases, offs)
+    res = index.new_result()
+    mapped = 0
     for a in range(0, n, chunk):
         cnt = min(chunk, n - a)
         index.run(reads, res, algo, threshold, a, cnt)

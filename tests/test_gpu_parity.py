@@ -244,6 +244,9 @@ def test_cli_output_is_byte_identical_to_reference_format(s10_gpu, s10_fgidx, tm
         assert raw[p] == i and raw[p + 1] == len(cols) and raw[p + 2:p + 2 + len(cols)].tolist() == cols
         p += 2 + len(cols)
     assert p == len(raw)
+    out5 = tmp_path / "out_dedup.tsv"
+    assert cli.main(["pseudoalign", "-i", s10_fgidx, "-q", q, "-o", str(out5), "--deduplicate"]) == 0
+    assert out5.read_bytes() == out.read_bytes()
     out4 = tmp_path / "out.cmp"
     assert cli.main(["pseudoalign", "-i", s10_fgidx, "-q", q, "-o", str(out4), "--format", "compressed"]) == 0
     from oracle import pyoracle
@@ -297,3 +300,12 @@ def test_s4546_codecs_equal_hybrid(s4546, index_type, psize, csize):
     got_tu = iy.pseudoalign_threshold_union_batch(b, o, 0.8)
     assert np.array_equal(got_fi[0], want_fi[0]) and np.array_equal(got_fi[1], want_fi[1])
     assert np.array_equal(got_tu[0], want_tu[0]) and np.array_equal(got_tu[1], want_tu[1])
+
+
+def test_deduplicated_path_equals_direct_path(s4546):
+    from fulgor_amd import driver
+    ix, _, gen = s4546
+    b, o = gen.generate(500000, 40000, 150, 42)
+    want = ix.pseudoalign_full_intersection_batch(b, o)
+    got = driver.deduplicated_full_intersection(ix, b, o)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
