@@ -52,6 +52,8 @@ def lib():
     L.fgpu_free.restype = None
     for name in ("fgpu_fetch_color_set_ids", "fgpu_full_intersection"):
         getattr(L, name).argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp)]
+    L.fgpu_kmer_color_set_ids.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp)]
+    L.fgpu_kmer_matches.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp)]
     L.fgpu_threshold_union.argtypes = [vp, vp, vp, C.c_uint64, C.c_double, C.POINTER(vp), C.POINTER(vp)]
     L.fgpu_intersect_ids.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp)]
     L.fgpu_reads_upload.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp)]

@@ -134,7 +134,8 @@ constexpr uint32_t SEG_KMERS = 1024;
 struct fgpu_result {
     fgpu_index* ix = nullptr;
     DevBuf d_nids, d_npos, d_idoff, d_ids_pool, d_cnt_pool, d_cursor, d_bitmap, d_counts, d_offsets, d_block_sums,
-        d_block_mapped, d_totals, d_colors, d_acct, d_partial, d_tickets, d_idcsr, d_desc;
+        d_block_mapped, d_totals, d_colors, d_acct, d_partial, d_tickets, d_idcsr, d_desc, d_kmer_ids, d_scores;
+    bool want_kmer_ids = false, want_scores = false;
     uint64_t total_ids = 0;
     uint64_t* h_totals = nullptr;  // pinned {total colours, mapped reads, ids used}
     uint64_t n = 0, total = 0, mapped = 0, total_kmers = 0, total_bases = 0;
@@ -226,6 +227,11 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     res->d_ids_pool.ensure(units * (uint64_t)stride * 4 + 16);
     res->d_cnt_pool.ensure(units * (uint64_t)stride * 4 + 16);
     res->have_ids = true;
+    uint32_t* kmer_out = nullptr;
+    if (res->want_kmer_ids) {
+        res->d_kmer_ids.ensure(units * (uint64_t)stride * 4 + 16);
+        kmer_out = res->d_kmer_ids.as<uint32_t>();
+    }
     if (units == 0) return;
     const bool w13 = ix->dd.k - ix->dd.m == 12;
     const bool short_reads = rd->max_kmers <= 128 && !seg;
@@ -238,19 +244,19 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
             hipLaunchKernelGGL(k1_lookup_short<true>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
                                rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
                                res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
-                               stride, res->d_tickets.as<unsigned int>());
+                               stride, res->d_tickets.as<unsigned int>(), kmer_out);
         } else if (short_reads) {
             hipLaunchKernelGGL(k1_lookup_short<false>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
                                rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
                                res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
-                               stride, res->d_tickets.as<unsigned int>());
+                               stride, res->d_tickets.as<unsigned int>(), kmer_out);
         } else {
             hipLaunchKernelGGL(k1_lookup<1024>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
                                seg ? rd->d_seg_start.as<uint64_t>() : rd->d_offs.as<uint64_t>(),
                                seg ? rd->d_seg_end.as<uint64_t>() : (const uint64_t*)nullptr, u_first, units,
                                res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(), res->d_idoff.as<uint64_t>(),
                                res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(), stride,
-                               res->d_tickets.as<unsigned int>());
+                               res->d_tickets.as<unsigned int>(), kmer_out);
         }
         HIP_TRY(hipGetLastError());
     }
@@ -383,9 +389,14 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
             const uint32_t wpb = pick_waves(per_wave, (const void*)kernel);
             const uint32_t grid = resident_grid(kernel, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
             Timed t(ix, FGPU_K_UNION);
+            uint32_t* scores_out = nullptr;
+            if (res->want_scores) {
+                res->d_scores.ensure(n * (uint64_t)ix->dc.n * 4 + 16);
+                scores_out = res->d_scores.as<uint32_t>();
+            }
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_npos.as<uint32_t>(),
                                res->d_idcsr.as<uint64_t>(), res->d_desc.as<ListDesc>(), tau, n, res->d_bitmap.as<uint32_t>(),
-                               res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
+                               res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, scores_out);
             HIP_TRY(hipGetLastError());
         };
         if (bits == 8) launch(k3a_union<8>);
@@ -610,7 +621,7 @@ void fgpu_result_free(fgpu_result* r) {
     if (!r) return;
     (void)hipSetDevice(r->ix->device);
     for (DevBuf* b : {&r->d_nids, &r->d_npos, &r->d_idoff, &r->d_ids_pool, &r->d_cnt_pool, &r->d_cursor, &r->d_bitmap,
-                      &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct, &r->d_partial, &r->d_tickets, &r->d_idcsr, &r->d_desc})
+                      &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct, &r->d_partial, &r->d_tickets, &r->d_idcsr, &r->d_desc, &r->d_kmer_ids, &r->d_scores})
         b->release();
     if (r->h_totals) (void)hipHostFree(r->h_totals);
     delete r;
@@ -822,6 +833,77 @@ int fgpu_intersect_ids(fgpu_index* ix, const uint32_t* ids, const uint64_t* id_o
         *out_colors = c;
     });
     fgpu_result_free(res);
+    return rc;
+}
+
+// ---- k-mer level queries --------------------------------------------------------------------
+int fgpu_kmer_color_set_ids(fgpu_index* ix, const char* bases, const uint64_t* offs, uint64_t n, uint64_t** out_offsets,
+                            uint32_t** out_ids) {
+    if (!ix || !out_offsets || !out_ids) return fail(-EINVAL, "null argument");
+    NEED_DEVICE(ix);
+    *out_offsets = nullptr;
+    *out_ids = nullptr;
+    fgpu_reads* rd = nullptr;
+    fgpu_result* res = nullptr;
+    int rc = fgpu_reads_upload(ix, bases, offs, n, &rd);
+    if (!rc) rc = fgpu_result_create(ix, &res);
+    if (!rc) rc = guarded([&] {
+        HIP_TRY(hipSetDevice(ix->device));
+        res->want_kmer_ids = true;
+        stage_lookup(ix, rd, 0, n, res);
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+        if (ix->timing) ix->collect_timing();
+        const uint32_t k = ix->host.dict.k;
+        const uint64_t stride = std::max<uint32_t>(1, rd->max_kmers);
+        const uint64_t units = rd->has_long ? rd->seg_first[n] : n;
+        std::vector<uint32_t> raw(units * stride);
+        if (units) HIP_TRY(hipMemcpy(raw.data(), res->d_kmer_ids.p, units * stride * 4, hipMemcpyDeviceToHost));
+        uint64_t* o = (uint64_t*)malloc((n + 1) * 8);
+        uint32_t* v = (uint32_t*)malloc(std::max<uint64_t>(1, rd->cum_kmers[n]) * 4);
+        if (!o || !v) { free(o); free(v); throw std::bad_alloc(); }
+        for (uint64_t r = 0; r <= n; ++r) o[r] = rd->cum_kmers[r];
+        for (uint64_t r = 0; r < n; ++r) {
+            // segments of a long read hold consecutive, non-overlapping k-mer ranges
+            const uint64_t u0 = rd->has_long ? rd->seg_first[r] : r, u1 = rd->has_long ? rd->seg_first[r + 1] : r + 1;
+            uint64_t at = o[r];
+            for (uint64_t u = u0; u < u1; ++u) {
+                const uint64_t len = rd->has_long ? rd->seg_end[u] - rd->seg_start[u] : offs[r + 1] - offs[r];
+                const uint64_t nk = len >= k ? len - k + 1 : 0;
+                memcpy(v + at, raw.data() + u * stride, nk * 4);
+                at += nk;
+            }
+        }
+        *out_offsets = o;
+        *out_ids = v;
+    });
+    fgpu_result_free(res);
+    fgpu_reads_free(rd);
+    return rc;
+}
+
+int fgpu_kmer_matches(fgpu_index* ix, const char* bases, const uint64_t* offs, uint64_t n, uint32_t** out_counts) {
+    if (!ix || !out_counts) return fail(-EINVAL, "null argument");
+    NEED_DEVICE(ix);
+    *out_counts = nullptr;
+    if (ix->host.type != IDX_HYBRID) return fail(-ENOTSUP, "kmer_matches is implemented for the hybrid codec only");
+    fgpu_reads* rd = nullptr;
+    fgpu_result* res = nullptr;
+    int rc = fgpu_reads_upload(ix, bases, offs, n, &rd);
+    if (!rc) rc = fgpu_result_create(ix, &res);
+    if (!rc) rc = guarded([&] {
+        HIP_TRY(hipSetDevice(ix->device));
+        res->want_scores = true;
+        stage_lookup(ix, rd, 0, n, res);
+        stage_descriptors(ix, res, res->total_kmers);
+        stage_colors(ix, FGPU_THRESHOLD_UNION, 1.0, res);  // the threshold only shapes the (discarded) bitmap
+        const uint64_t nc = ix->dc.n;
+        uint32_t* c = (uint32_t*)malloc(std::max<uint64_t>(1, n * nc) * 4);
+        if (!c) throw std::bad_alloc();
+        if (n) HIP_TRY(hipMemcpy(c, res->d_scores.p, n * nc * 4, hipMemcpyDeviceToHost));
+        *out_counts = c;
+    });
+    fgpu_result_free(res);
+    fgpu_reads_free(rd);
     return rc;
 }
 

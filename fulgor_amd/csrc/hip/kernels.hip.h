@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __res
                                                  uint64_t first, uint64_t n_reads,
                                                  uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
                                                  uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
-                                                 uint32_t* __restrict__ cnt_pool, uint32_t stride, unsigned int* tickets) {
+                                                 uint32_t* __restrict__ cnt_pool, uint32_t stride, unsigned int* tickets,
+                                                 uint32_t* __restrict__ kmer_out) {
     __shared__ uint64_t s_hash[4][80];
     __shared__ uint32_t s_ids[4][KMAX];
     __shared__ uint32_t s_uid[4][KMAX];
@@ -227,6 +228,10 @@ __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __res
             loA = loB; hiA = hiB; nvA = nvB;
         }
 
+        // optional: colour-set id of every k-mer (0xFFFFFFFF = negative), the input of the reference's
+        // kmer_conservation / kmer_matches queries (src/kmer_conservation.cpp:7-54, src/kmer_matches.cpp:7-30)
+        if (kmer_out)
+            for (uint32_t i = lane; i < nk; i += 64) kmer_out[r * (uint64_t)stride + i] = ids[i];
         // ---- sorted distinct ids + multiplicities -------------------------------------------------
         // Consecutive k-mers mostly sit on the same unitig, so first compress runs: a "head" is a positive
         // k-mer whose id differs from its left neighbour (or that starts a 64-lane chunk); heads and run
@@ -328,7 +333,8 @@ __global__ __launch_bounds__(256, 6) void k1_lookup_short(DevDict d, const uint8
                                                        const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
                                                        uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
                                                        uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
-                                                       uint32_t* __restrict__ cnt_pool, uint32_t stride, unsigned int* tickets) {
+                                                       uint32_t* __restrict__ cnt_pool, uint32_t stride, unsigned int* tickets,
+                                                       uint32_t* __restrict__ kmer_out) {
     constexpr int KMAX = 128;
     __shared__ uint64_t s_hash[4][144];
     __shared__ uint32_t s_ids[4][KMAX];
@@ -498,6 +504,10 @@ __global__ __launch_bounds__(256, 6) void k1_lookup_short(DevDict d, const uint8
             }
             ids[lane] = (uint32_t)lane < nk ? csid[0] : NEG;
             ids[64 + lane] = (uint32_t)(64 + lane) < nk ? csid[1] : NEG;
+            if (kmer_out) {
+                if ((uint32_t)lane < nk) kmer_out[r * (uint64_t)stride + lane] = csid[0];
+                if ((uint32_t)(64 + lane) < nk) kmer_out[r * (uint64_t)stride + 64 + lane] = csid[1];
+            }
             wave_lds_sync();
 
             // ---- sorted distinct ids + multiplicities (run heads, see k1_lookup) ----
@@ -885,7 +895,9 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
                                                                   const uint64_t* __restrict__ id_csr,
                                                                   const ListDesc* __restrict__ desc, double tau, uint64_t n_reads,
                                                                   uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count,
-                                                                  unsigned int* tickets) {
+                                                                  unsigned int* tickets, uint32_t* __restrict__ scores_out) {
+    // scores_out != nullptr: also store score[c] (= #positive k-mers of the read whose colour set contains c,
+    // the `counts` of index::kmer_matches, src/kmer_matches.cpp:7-30) for every colour: n u32 per read
     constexpr uint32_t PER = 32 / BITS;            // counters per word
     constexpr uint32_t PLANES = 32 / PER;          // planes (one result word = PLANES counter words)
     constexpr uint32_t HALF = 1u << (BITS - 1);
@@ -910,6 +922,8 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
         if (cnt == 0) {
             for (uint32_t w = lane; w < W; w += 64) bm[w] = 0;
             if (lane == 0) out_count[r] = 0;
+            if (scores_out)
+                for (uint32_t cc = lane; cc < n; cc += 64) scores_out[r * (uint64_t)n + cc] = 0;
             continue;
         }
         const uint32_t min_score = (uint32_t)(unsigned long long)((double)npos[r] * tau);
@@ -977,6 +991,13 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
                 }
             }
             wave_lds_sync();
+        }
+        if (scores_out) {  // counter = HALF - min_score + score  =>  score = counter - HALF + min_score
+            for (uint32_t cc = lane; cc < n; cc += 64) {
+                const uint32_t x = SC[((cc / PER) % PLANES) * W + (cc >> 5)];
+                const uint32_t field = BITS == 32 ? x : ((x >> ((BITS & 31) * (cc % PER))) & ((1u << (BITS & 31)) - 1u));
+                scores_out[r * (uint64_t)n + cc] = field - HALF + min_score;
+            }
         }
         uint32_t pc = 0;
         for (uint32_t w = lane; w < W; w += 64) {

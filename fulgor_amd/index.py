@@ -28,6 +28,16 @@ def pack_reads(reads):
     return np.ascontiguousarray(bases), offs
 
 
+def conservation_triples(kmer_ids):
+    """run-length encoding of per-k-mer colour-set ids; negative k-mers (0xFFFFFFFF) break runs"""
+    ids = np.asarray(kmer_ids, dtype=np.uint32)
+    if len(ids) == 0:
+        return []
+    change = np.flatnonzero(np.concatenate(([True], ids[1:] != ids[:-1])))
+    ends = np.concatenate((change[1:], [len(ids)]))
+    return [(int(a), int(b - a), int(ids[a])) for a, b in zip(change, ends) if ids[a] != 0xFFFFFFFF]
+
+
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -169,6 +179,29 @@ class Index:
 
     def pseudoalign_threshold_union_batch(self, bases, offs, threshold):
         return self._call(self._L.fgpu_threshold_union, bases, offs, C.c_double(threshold))
+
+    def kmer_color_set_ids_batch(self, bases, offs):
+        """colour-set id of every k-mer of every read (0xFFFFFFFF = negative) as CSR"""
+        return self._call(self._L.fgpu_kmer_color_set_ids, bases, offs)
+
+    def kmer_matches_batch(self, bases, offs):
+        """index::kmer_matches for a batch: (positive k-mer flags as CSR of 0/1, counts[n_reads, num_colors])"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n = len(offs) - 1
+        p = C.c_void_p()
+        _native.check(self._L.fgpu_kmer_matches(self._h, _ptr(bases), _ptr(offs), n, C.byref(p)))
+        nc = self._num_colors
+        counts = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(max(1, n * nc),))[:n * nc].copy().reshape(n, nc)
+        self._L.fgpu_free(p)
+        ko, ki = self.kmer_color_set_ids_batch(bases, offs)
+        return ko, (ki != 0xFFFFFFFF).astype(np.uint8), counts
+
+    def kmer_conservation(self, sequence):
+        """index::kmer_conservation (src/kmer_conservation.cpp:7-54): list of (start_pos_in_query, num_kmers, color_set_id)"""
+        b, o = pack_reads([sequence])
+        _, ids = self.kmer_color_set_ids_batch(b, o)
+        return conservation_triples(ids)
 
     def intersect_ids_batch(self, ids, id_offs):
         ids = np.ascontiguousarray(ids, dtype=np.uint32)

@@ -76,6 +76,16 @@ int fgpu_threshold_union(fgpu_index* idx, const char* bases, const uint64_t* off
  * way, src/ps_utils.cpp:307-415) */
 int fgpu_intersect_ids(fgpu_index* idx, const uint32_t* ids, const uint64_t* id_offs, uint64_t n,
                        uint64_t** out_offsets, uint32_t** out_colors);
+/* ---- k-mer level queries on the same lookup kernel (the reference's other two query tools) ----------
+ * colour-set id of EVERY k-mer of every read (0xFFFFFFFF = k-mer absent or containing a non-ACGT base):
+ * out_offsets[r+1]-out_offsets[r] = max(0, len_r - k + 1). Run-length encoding these ids gives
+ * index::kmer_conservation's (start, num_kmers, color_set_id) triples (src/kmer_conservation.cpp:7-54); the
+ * id != 0xFFFFFFFF flags are kmer_matches' positive-k-mer bit vector. */
+int fgpu_kmer_color_set_ids(fgpu_index* idx, const char* bases, const uint64_t* offs, uint64_t n,
+                            uint64_t** out_offsets, uint32_t** out_ids);
+/* index::kmer_matches counts (src/kmer_matches.cpp:7-30): out_counts[r * num_colors + c] = number of positive
+ * k-mers of read r whose colour set contains c (all zero for reads shorter than k). Dense: size n by num_colors. */
+int fgpu_kmer_matches(fgpu_index* idx, const char* bases, const uint64_t* offs, uint64_t n, uint32_t** out_counts);
 void fgpu_free(void* p);
 
 /* ---- device-resident calls (what the driver loop and bench.py use) -------------------------------- */

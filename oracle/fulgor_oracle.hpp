@@ -449,6 +449,67 @@ struct Index {
         }
     }
 
+    // one answer per k-mer window, in order: f(position, unitig id or -1). Same lookups as stream_kmers.
+    template <typename F>
+    void lookup_every_kmer(const char* s, uint64_t len, F f) const {
+        if (len < k) return;
+        std::vector<int64_t> ans(len - k + 1, -1);
+        const uint64_t km = (1ULL << (2 * k)) - 1;
+        uint64_t fw = 0, rv = 0;
+        uint32_t run = 0;
+        for (uint64_t i = 0; i < len; ++i) {
+            const int c = nuc(s[i]);
+            if (c < 0) { run = 0; continue; }
+            fw = ((fw << 2) | (uint64_t)c) & km;
+            rv = (rv >> 2) | ((uint64_t)(3 - c) << (2 * (k - 1)));
+            if (++run < k) continue;
+            const int64_t sl = k2u.slot(fw < rv ? fw : rv);
+            if (sl >= 0) ans[i + 1 - k] = (int64_t)(k2u.vals[sl] >> 32);
+        }
+        for (uint64_t p = 0; p < ans.size(); ++p) f(p, ans[p]);
+    }
+
+    struct Triple { uint32_t start_pos_in_query, num_kmers, color_set_id; };  // kmer_conservation_triple, util.hpp:74-78
+
+    // src/kmer_conservation.cpp:7-54
+    void kmer_conservation(const char* seq, uint64_t len, std::vector<Triple>& out) const {
+        if (len < k) return;
+        out.clear();
+        const uint64_t invalid = (uint64_t)-1;
+        Triple kct = {0, 0, 0};
+        uint64_t prev = invalid;
+        auto push = [&]() {
+            if (prev != invalid) { kct.color_set_id = (uint32_t)prev; out.push_back(kct); }
+        };
+        lookup_every_kmer(seq, len, [&](uint64_t i, int64_t unitig) {
+            if (unitig >= 0) {
+                const uint64_t cs = u2c((uint64_t)unitig);
+                if (prev != cs) { push(); kct.num_kmers = 0; kct.start_pos_in_query = (uint32_t)i; }
+                kct.num_kmers += 1;
+                prev = cs;
+            } else {
+                push();
+                prev = invalid;
+            }
+        });
+        push();
+    }
+
+    // src/kmer_matches.cpp:7-30 (hybrid colour sets)
+    void kmer_matches(const char* seq, uint64_t len, std::vector<uint8_t>& positive, std::vector<uint32_t>& counts) const {
+        std::fill(counts.begin(), counts.end(), 0);
+        positive.clear();
+        if (len < k) return;
+        positive.assign(len - k + 1, 0);
+        lookup_every_kmer(seq, len, [&](uint64_t i, int64_t unitig) {
+            if (unitig < 0) return;
+            positive[i] = 1;
+            HybridCursor it = color_set(u2c((uint64_t)unitig));
+            const uint32_t sz = it.size();
+            for (uint32_t j = 0; j != sz; ++j, it.next()) counts[it.value()] += 1;
+        });
+    }
+
     void add_unitigs(const char* bases, const uint64_t* off, const uint32_t* csid, uint64_t nu) {
         ubases.assign(bases, off[nu]);
         uoff.assign(off, off + nu + 1);

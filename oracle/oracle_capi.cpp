@@ -222,4 +222,30 @@ int fo_parse_compressed(const char* file, uint64_t len, uint64_t* n_out, uint32_
     } catch (std::exception& e) { g_err = e.what(); return -1; }
 }
 
+// index::kmer_conservation for one read: malloc'd array of (start, num_kmers, color_set_id) triples
+int fo_kmer_conservation(void* h, const char* seq, uint64_t len, uint64_t* n_out, uint32_t** triples) {
+    auto* ix = static_cast<AnyIndex*>(h);
+    std::vector<Index::Triple> t;
+    ix->kmer_conservation(seq, len, t);
+    *n_out = t.size();
+    *triples = (uint32_t*)malloc(std::max<size_t>(1, t.size()) * 12);
+    for (size_t i = 0; i < t.size(); ++i) {
+        (*triples)[3 * i] = t[i].start_pos_in_query;
+        (*triples)[3 * i + 1] = t[i].num_kmers;
+        (*triples)[3 * i + 2] = t[i].color_set_id;
+    }
+    return 0;
+}
+
+// index::kmer_matches for one read: positive[num_kmers] (caller buffer, len - k + 1 bytes) and counts[num_colors]
+int fo_kmer_matches(void* h, const char* seq, uint64_t len, uint8_t* positive, uint32_t* counts) {
+    auto* ix = static_cast<AnyIndex*>(h);
+    std::vector<uint8_t> p;
+    std::vector<uint32_t> c(ix->colors.num_colors, 0);
+    ix->kmer_matches(seq, len, p, c);
+    if (!p.empty()) memcpy(positive, p.data(), p.size());
+    memcpy(counts, c.data(), c.size() * 4);
+    return 0;
+}
+
 }  // extern "C"

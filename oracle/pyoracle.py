@@ -45,6 +45,8 @@ def lib():
         L.fo_format_compressed.restype = vp
         L.fo_format_compressed.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
         L.fo_parse_compressed.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+        L.fo_kmer_conservation.argtypes = [vp, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(vp)]
+        L.fo_kmer_matches.argtypes = [vp, C.c_char_p, C.c_uint64, vp, vp]
         L.fo_format_ascii.restype = vp
         L.fo_format_ascii.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
         _lib = L
@@ -177,6 +179,25 @@ class OracleIndex:
                                       int(self_check)) != 0:
             raise RuntimeError("oracle: %s" % self._L.fo_last_error().decode())
         return _take(self._L, n, po, pv)
+
+    def kmer_conservation(self, seq):
+        """index::kmer_conservation -> list of (start_pos_in_query, num_kmers, color_set_id)"""
+        seq = bytes(seq)
+        n, p = C.c_uint64(), C.c_void_p()
+        self._L.fo_kmer_conservation(self._h, seq, len(seq), C.byref(n), C.byref(p))
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(max(1, 3 * n.value),))[:3 * n.value].copy()
+        self._L.fo_free(p)
+        return [tuple(int(x) for x in a[3 * i:3 * i + 3]) for i in range(n.value)]
+
+    def kmer_matches(self, seq):
+        """index::kmer_matches -> (positive flags per k-mer, counts per colour)"""
+        seq = bytes(seq)
+        i = self.info()
+        nk = max(0, len(seq) - i["k"] + 1)
+        pos = np.zeros(max(1, nk), dtype=np.uint8)
+        cnt = np.zeros(i["num_colors"], dtype=np.uint32)
+        self._L.fo_kmer_matches(self._h, seq, len(seq), _ptr(pos), _ptr(cnt))
+        return pos[:nk], cnt
 
     def time_pseudoalign(self, bases, offs, algo=0, tau=0.8, threads=8):
         """returns (seconds, mapped reads, total colours) for the reference-style worker loop"""

@@ -82,3 +82,16 @@ def load_golden_tsv(name):
 def csr_to_lists(offs, vals):
     offs = np.asarray(offs, dtype=np.int64)
     return [vals[offs[i]:offs[i + 1]].tolist() for i in range(len(offs) - 1)]
+
+
+def load_golden_kmer_level():
+    """read id -> (positive flags, counts per colour, [(start, num_kmers, colour mask)])"""
+    out = {}
+    with open(os.path.join(GOLDEN, "s10_kmer_level.tsv")) as f:
+        for line in f:
+            t = line.rstrip("\n").split("\t")
+            flags = np.array([int(c) for c in t[1]], dtype=np.uint8)
+            counts = np.array([int(x) for x in t[2].split(",")], dtype=np.uint32) if t[2] else np.zeros(10, dtype=np.uint32)
+            runs = [tuple(int(x) for x in r.split(":")) for r in t[3].split(",")] if t[3] else []
+            out[int(t[0])] = (flags, counts, runs)
+    return out

@@ -4,7 +4,8 @@ container; the outputs next to this script are what the tests read).
 Inputs : tests/data/salmonella_10/*.fasta.gz  (the reference's own test_data/salmonella_10, colour id =
          position in the sorted filename list), k = 31
 Reads  : 1000 synthetic 150 bp reads (seed 42, fulgor_amd/csrc/tools/readgen.cpp) + hand-made edge cases
-Outputs: s10_reads.fa, s10_full_intersection.tsv, s10_threshold_union_0.8.tsv, s10_threshold_union_1.0.tsv,
+Outputs: s10_reads.fa, s10_kmer_level.tsv (positive flags / per-colour counts / equal-mask runs),
+         s10_full_intersection.tsv, s10_threshold_union_0.8.tsv, s10_threshold_union_1.0.tsv,
          s10_threshold_union_0.01.tsv in the reference's ascii output format "<id>\t<count>[\t<colour>...]"
          (src/ps_utils.cpp:55-71)
 Oracle : oracle/kmer_oracle.py — per-k-mer colour masks computed directly from the genomes; shares no
@@ -59,6 +60,33 @@ def main():
     dump("s10_full_intersection.tsv", orc.full_intersection)
     for tau in (0.8, 1.0, 0.01):
         dump("s10_threshold_union_%s.tsv" % tau, lambda r, t=tau: orc.threshold_union(r, t))
+    # k-mer level golden vectors (kmer_matches / kmer_conservation): for a subset of reads, the positive flags,
+    # the per-colour counts and the runs of consecutive positive k-mers with the same colour mask
+    import numpy as np
+    from oracle.kmer_oracle import canonical_kmers
+    sel = list(range(0, 40)) + list(range(1000, 1010))
+    with open(os.path.join(HERE, "s10_kmer_level.tsv"), "w") as f:
+        for i in sel:
+            km, ok = canonical_kmers(reads[i], 31)
+            if len(km) == 0:
+                f.write("%d\t\t\t\n" % i)
+                continue
+            idx = np.searchsorted(orc.keys, km)
+            idx[idx >= len(orc.keys)] = 0
+            hit = ok & (orc.keys[idx] == km)
+            masks = np.where(hit, orc.masks[idx], np.uint64(0))
+            counts = [int(((masks >> np.uint64(c)) & np.uint64(1)).sum()) for c in range(orc.n)]
+            runs, p = [], 0
+            while p < len(masks):
+                if not hit[p]:
+                    p += 1
+                    continue
+                q = p
+                while q < len(masks) and hit[q] and masks[q] == masks[p]:
+                    q += 1
+                runs.append("%d:%d:%d" % (p, q - p, int(masks[p])))
+                p = q
+            f.write("%d\t%s\t%s\t%s\n" % (i, "".join("1" if h else "0" for h in hit), ",".join(map(str, counts)), ",".join(runs)))
     print("distinct canonical 31-mers:", len(orc.keys))
 
 

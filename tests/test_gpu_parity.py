@@ -309,3 +309,43 @@ def test_deduplicated_path_equals_direct_path(s4546):
     want = ix.pseudoalign_full_intersection_batch(b, o)
     got = driver.deduplicated_full_intersection(ix, b, o)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+def test_gpu_kmer_conservation_and_matches(s10_gpu, s10_oracle):
+    """the reference's two other query tools on the same lookup kernel: per-k-mer colour-set ids ->
+    kmer_conservation triples (src/kmer_conservation.cpp:7-54); un-thresholded union scores -> kmer_matches
+    counts (src/kmer_matches.cpp:7-30). Checked against the oracle restatement and, for the counts, against
+    the independent k-mer masks of the golden generator's oracle."""
+    from fulgor_amd.index import conservation_triples
+    reads = load_golden_reads()
+    sel = list(range(0, 60)) + list(range(1000, 1010))
+    sub = [reads[i] for i in sel]
+    b, o = pack_reads(sub)
+    ko, ki = s10_gpu.kmer_color_set_ids_batch(b, o)
+    mo, pos, counts = s10_gpu.kmer_matches_batch(b, o)
+    assert np.array_equal(ko, mo)
+    for j, r in enumerate(sub):
+        ids = ki[int(ko[j]):int(ko[j + 1])]
+        assert len(ids) == max(0, len(r) - 31 + 1)
+        assert conservation_triples(ids) == s10_oracle.kmer_conservation(r)
+        opos, ocnt = s10_oracle.kmer_matches(r)
+        assert np.array_equal(pos[int(ko[j]):int(ko[j + 1])], opos)
+        assert np.array_equal(counts[j], ocnt)
+    assert s10_gpu.kmer_conservation(sub[3]) == s10_oracle.kmer_conservation(sub[3])
+    # independent golden vectors (per-k-mer colour masks straight from the genomes)
+    from conftest import load_golden_kmer_level
+    gold = load_golden_kmer_level()
+    for j, rid in enumerate(sel):
+        if rid not in gold:
+            continue
+        flags, gcounts, runs = gold[rid]
+        assert np.array_equal(pos[int(ko[j]):int(ko[j + 1])], flags)
+        assert np.array_equal(counts[j], gcounts)
+        tr = conservation_triples(ki[int(ko[j]):int(ko[j + 1])])
+        assert [(s_, n_) for s_, n_, _ in tr] == [(s_, n_) for s_, n_, _ in runs]
+        for (_, _, cs), (_, _, mask) in zip(tr, runs):
+            assert sum(1 << c for c in s10_gpu.pseudoalign_full_intersection([cs])) == mask
+    # a long read (segmented lookup) keeps per-k-mer order
+    from oracle.kmer_oracle import read_fasta
+    src = max(read_fasta(S10_GENOMES[2]), key=len)[50000:53000]
+    assert s10_gpu.kmer_conservation(src) == s10_oracle.kmer_conservation(src)

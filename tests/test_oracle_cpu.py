@@ -64,3 +64,19 @@ def test_oracle_meta_diff_metadiff_match_golden(s10_dump, index_type, psize, csi
     assert csr_to_lists(*orc.full_intersection(b, o, threads=4)) == load_golden_tsv("s10_full_intersection.tsv")
     for tau in (0.8, 1.0, 0.01):
         assert csr_to_lists(*orc.threshold_union(b, o, tau, threads=4)) == load_golden_tsv("s10_threshold_union_%s.tsv" % tau)
+
+
+def _mask_of_set(orc, csid):
+    o, c = orc.intersect_ids(np.array([csid], dtype=np.uint32), np.array([0, 1], dtype=np.uint64), threads=1)
+    return sum(1 << int(x) for x in c)
+
+
+def test_oracle_kmer_level_queries_match_golden(s10_oracle):
+    """kmer_matches / kmer_conservation restatements against per-k-mer colour masks computed from the genomes"""
+    from conftest import load_golden_kmer_level
+    reads = load_golden_reads()
+    for rid, (flags, counts, runs) in load_golden_kmer_level().items():
+        pos, cnt = s10_oracle.kmer_matches(reads[rid])
+        assert np.array_equal(pos, flags) and np.array_equal(cnt, counts if len(flags) else np.zeros(10, np.uint32)), rid
+        got = [(s, n, _mask_of_set(s10_oracle, cs)) for s, n, cs in s10_oracle.kmer_conservation(reads[rid])]
+        assert got == runs, rid
