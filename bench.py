@@ -56,6 +56,8 @@ def main():
                     help="colour-set codec (fur / dfur / mfur / mdfur of the reference)")
     ap.add_argument("--partition-size", type=int, default=160)
     ap.add_argument("--cluster-size", type=int, default=16)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="passes in flight per GPU: chunk i runs on stream i %% streams (own result buffers, own host thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -102,17 +104,29 @@ def main():
     algo = fulgor_amd.FULL_INTERSECTION if args.algo == "full-intersection" else fulgor_amd.THRESHOLD_UNION
     bases, offs = gen.generate(rank * n_reads, n_reads, 150, 42)
     reads = ix.upload_reads(bases, offs)
-    res = ix.new_result()
+    results = [ix.new_result() for _ in range(max(1, args.streams))]
+    res = results[0]
     ncol = ix.num_colors()
     hits = torch.zeros(ncol + 2, dtype=torch.int64, device="cuda:%d" % local_rank)
+    chunks = [(first, min(args.chunk, n_reads - first)) for first in range(0, n_reads, args.chunk)]
+
+    def worker(w):
+        for i in range(w, len(chunks), len(results)):
+            ix.run(reads, results[w], algo, args.tau, chunks[i][0], chunks[i][1])
+            results[w].accumulate_hits(hits.data_ptr())
 
     def step():
         hits.zero_()
         torch.cuda.synchronize()
-        for first in range(0, n_reads, args.chunk):
-            cnt = min(args.chunk, n_reads - first)
-            ix.run(reads, res, algo, args.tau, first, cnt)
-            res.accumulate_hits(hits.data_ptr())
+        if len(results) == 1:
+            worker(0)
+        else:  # the C ABI calls release the GIL; every result owns its HIP stream
+            import threading
+            ts = [threading.Thread(target=worker, args=(w,)) for w in range(len(results))]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
         if world > 1:  # RCCL: per-colour hit counts + {reads, mapped}
             if share:
                 h_cpu = hits.cpu()
@@ -184,7 +198,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s, %s, %d synthetic 150 bp reads per GPU (seed 42), k=31, chunk %d reads/pass"
                                    % (desc, args.algo + (" tau=%g" % args.tau if algo else ""), n_reads, args.chunk),
-                       "index_replicated": True, "reads_per_gpu": n_reads,
+                       "index_replicated": True, "reads_per_gpu": n_reads, "streams": len(results),
                        "mapped_fraction": round(mapped_job / max(1, total_reads_job), 4),
                        "avg_colours_per_read": round(total_colors / n_reads, 2)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

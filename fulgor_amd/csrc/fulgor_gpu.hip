@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -82,15 +83,19 @@ struct fgpu_index {
     struct Pending { int kernel; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
+    std::mutex tmu;  // results on different streams may be driven from different host threads
 
     hipEvent_t get_event() {
+        std::lock_guard<std::mutex> g(tmu);
         if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
         return e;
     }
-    void collect_timing() {
-        for (auto& p : pending) {
+    // call only after the recording streams have been synchronised
+    void collect_timing(std::vector<Pending>& mine) {
+        std::lock_guard<std::mutex> g(tmu);
+        for (auto& p : mine) {
             float t = 0;
             HIP_TRY(hipEventElapsedTime(&t, p.a, p.b));
             ms[p.kernel] += t;
@@ -98,20 +103,21 @@ struct fgpu_index {
             event_pool.push_back(p.a);
             event_pool.push_back(p.b);
         }
-        pending.clear();
+        mine.clear();
     }
 };
 
 // RAII bracket: records HIP events around a kernel on the engine's stream
+struct fgpu_result;
 struct Timed {
     fgpu_index* ix;
     int kernel;
+    hipStream_t stream;
+    std::vector<fgpu_index::Pending>* sink;
     hipEvent_t a = nullptr, b = nullptr;
-    Timed(fgpu_index* i, int k) : ix(i), kernel(k) {
-        if (ix->timing) { a = ix->get_event(); b = ix->get_event(); HIP_TRY(hipEventRecord(a, ix->stream)); }
-    }
+    Timed(fgpu_index* i, fgpu_result* r, int k);
     ~Timed() {
-        if (ix->timing) { (void)hipEventRecord(b, ix->stream); ix->pending.push_back({kernel, a, b}); }
+        if (ix->timing) { (void)hipEventRecord(b, stream); sink->push_back({kernel, a, b}); }
     }
 };
 
@@ -133,6 +139,8 @@ constexpr uint32_t SEG_KMERS = 1024;
 
 struct fgpu_result {
     fgpu_index* ix = nullptr;
+    hipStream_t stream = nullptr;                 // every result owns a stream: passes on different results overlap
+    std::vector<fgpu_index::Pending> pending;     // timing events recorded on that stream
     DevBuf d_nids, d_npos, d_idoff, d_ids_pool, d_cnt_pool, d_cursor, d_bitmap, d_counts, d_offsets, d_block_sums,
         d_block_mapped, d_totals, d_colors, d_acct, d_partial, d_tickets, d_idcsr, d_desc, d_kmer_ids, d_scores;
     bool want_kmer_ids = false, want_scores = false;
@@ -144,6 +152,10 @@ struct fgpu_result {
     uint32_t max_kmers_in_batch = 0xFFFFFFFFu;  // bound on #positive k-mers of any read (unknown for id-only calls)
     bool have_ids = false;
 };
+
+Timed::Timed(fgpu_index* i, fgpu_result* r, int k) : ix(i), kernel(k), stream(r->stream), sink(&r->pending) {
+    if (ix->timing) { a = ix->get_event(); b = ix->get_event(); HIP_TRY(hipEventRecord(a, stream)); }
+}
 
 namespace {
 
@@ -208,7 +220,7 @@ uint32_t resident_grid(K kernel, uint64_t units, uint32_t per_block, int num_cus
 }
 
 void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t count, fgpu_result* res) {
-    hipStream_t s = ix->stream;
+    hipStream_t s = res->stream;
     res->total_kmers = rd->cum_kmers[first + count] - rd->cum_kmers[first];
     res->total_bases = rd->h_offs[first + count] - rd->h_offs[first];
     // units = reads, or segments when the batch holds reads longer than SEG_KMERS k-mers
@@ -239,7 +251,7 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
                           : w13        ? resident_grid(k1_lookup_short<true>, units, 4, ix->num_cus, 256, 0)
                                        : resident_grid(k1_lookup_short<false>, units, 4, ix->num_cus, 256, 0);
     {
-        Timed t(ix, FGPU_K_LOOKUP);
+        Timed t(ix, res, FGPU_K_LOOKUP);
         if (short_reads && w13) {
             hipLaunchKernelGGL(k1_lookup_short<true>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
                                rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
@@ -303,12 +315,12 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
 
 // exclusive scan of n u32 sizes into n+1 u64 offsets; totals -> d_totals {sum, #nonzero}
 void run_scan(fgpu_index* ix, fgpu_result* res, const uint32_t* sizes, uint64_t n, uint64_t* offsets) {
-    hipStream_t s = ix->stream;
+    hipStream_t s = res->stream;
     const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     res->d_block_sums.ensure(std::max<uint64_t>(1, nb) * 8);
     res->d_block_mapped.ensure(std::max<uint64_t>(1, nb) * 8);
     res->d_totals.ensure(32);
-    Timed t(ix, FGPU_K_SCAN);
+    Timed t(ix, res, FGPU_K_SCAN);
     hipLaunchKernelGGL(scan_block_sums, dim3((uint32_t)nb), dim3(256), 0, s, sizes, n, res->d_block_sums.as<uint64_t>(),
                        res->d_block_mapped.as<uint64_t>());
     hipLaunchKernelGGL(scan_top, dim3(1), dim3(256), 0, s, res->d_block_sums.as<uint64_t>(), res->d_block_mapped.as<uint64_t>(), nb,
@@ -319,7 +331,7 @@ void run_scan(fgpu_index* ix, fgpu_result* res, const uint32_t* sizes, uint64_t 
 
 // per-read id lists (nids + source offsets into ids/cnt arrays) -> compact CSR of resolved descriptors
 void stage_descriptors(fgpu_index* ix, fgpu_result* res, uint64_t max_total_ids) {
-    hipStream_t s = ix->stream;
+    hipStream_t s = res->stream;
     const uint64_t n = res->n;
     res->d_idcsr.ensure((n + 1) * 8 + 16);
     res->total_ids = 0;
@@ -331,7 +343,7 @@ void stage_descriptors(fgpu_index* ix, fgpu_result* res, uint64_t max_total_ids)
     res->total_ids = res->h_totals[0];
     if (res->total_ids > max_total_ids) throw std::runtime_error("internal error: more colour-set ids than k-mers");
     res->d_desc.ensure(std::max<uint64_t>(1, res->total_ids) * sizeof(ListDesc));
-    Timed t(ix, FGPU_K_DESC);
+    Timed t(ix, res, FGPU_K_DESC);
     const uint64_t threads = n * 16;
     hipLaunchKernelGGL(k_desc, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, ix->dc, res->d_nids.as<uint32_t>(),
                        res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(),
@@ -341,7 +353,7 @@ void stage_descriptors(fgpu_index* ix, fgpu_result* res, uint64_t max_total_ids)
 }
 
 void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
-    hipStream_t s = ix->stream;
+    hipStream_t s = res->stream;
     const uint64_t n = res->n;
     const uint32_t W = ix->dc.w32;
     res->d_bitmap.ensure(n * W * 4 + 16);
@@ -362,7 +374,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         const uint32_t wpb = pick_waves(per_wave, kfn);
         const uint32_t grid = uni ? resident_grid(k_generic<true>, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave)
                                   : resident_grid(k_generic<false>, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
-        Timed t(ix, uni ? FGPU_K_UNION : FGPU_K_INTERSECT);
+        Timed t(ix, res, uni ? FGPU_K_UNION : FGPU_K_INTERSECT);
         if (uni)
             hipLaunchKernelGGL(k_generic<true>, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dg, res->d_npos.as<uint32_t>(),
                                res->d_idcsr.as<uint64_t>(), res->d_desc.as<ListDesc>(), tau, n, res->d_bitmap.as<uint32_t>(),
@@ -376,7 +388,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         const size_t per_wave = (size_t)(1 + SPARSE_PLANES) * W * 4 + wave_scratch_bytes();
         const uint32_t wpb = pick_waves(per_wave, (const void*)k2a_intersect);
         const uint32_t grid = resident_grid(k2a_intersect, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
-        Timed t(ix, FGPU_K_INTERSECT);
+        Timed t(ix, res, FGPU_K_INTERSECT);
         hipLaunchKernelGGL(k2a_intersect, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_idcsr.as<uint64_t>(),
                            res->d_desc.as<ListDesc>(), n, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
                            res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
@@ -388,7 +400,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         auto launch = [&](auto kernel) {
             const uint32_t wpb = pick_waves(per_wave, (const void*)kernel);
             const uint32_t grid = resident_grid(kernel, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
-            Timed t(ix, FGPU_K_UNION);
+            Timed t(ix, res, FGPU_K_UNION);
             uint32_t* scores_out = nullptr;
             if (res->want_scores) {
                 res->d_scores.ensure(n * (uint64_t)ix->dc.n * 4 + 16);
@@ -418,14 +430,14 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         const uint32_t grid = std::max<uint32_t>(resident_grid(k2b_expand, n, 4, ix->num_cus, 256, lds), (uint32_t)(n / 60000 + 1));
         res->d_partial.ensure((size_t)grid * W * 32 * 4);
         res->hit_rows = grid;
-        Timed t(ix, FGPU_K_EXPAND);
+        Timed t(ix, res, FGPU_K_EXPAND);
         hipLaunchKernelGGL(k2b_expand, dim3(grid), dim3(256), lds, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
                            res->d_offsets.as<uint64_t>(), n, W, res->d_colors.as<uint32_t>(),
                            res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE, res->d_partial.as<uint32_t>());
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(s));
-    if (ix->timing) ix->collect_timing();
+    if (ix->timing) ix->collect_timing(res->pending);
 }
 
 template <typename F>
@@ -610,6 +622,7 @@ int fgpu_result_create(fgpu_index* ix, fgpu_result** out) {
     int rc = guarded([&] {
         HIP_TRY(hipSetDevice(ix->device));
         HIP_TRY(hipHostMalloc((void**)&r->h_totals, 32));
+        HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
         r->d_totals.ensure(32);
     });
     if (rc) { delete r; return rc; }
@@ -624,6 +637,8 @@ void fgpu_result_free(fgpu_result* r) {
                       &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct, &r->d_partial, &r->d_tickets, &r->d_idcsr, &r->d_desc, &r->d_kmer_ids, &r->d_scores})
         b->release();
     if (r->h_totals) (void)hipHostFree(r->h_totals);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    for (auto& p : r->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     delete r;
 }
 
@@ -663,17 +678,17 @@ int fgpu_result_accumulate_hits(fgpu_index* ix, const fgpu_result* r, void* devi
         HIP_TRY(hipSetDevice(ix->device));
         if (r->n) {
             const uint32_t W = ix->dc.w32;
-            Timed t(ix, FGPU_K_HITS);
+            Timed t(ix, const_cast<fgpu_result*>(r), FGPU_K_HITS);
             // the expand kernel left one row of per-colour counts per block; sum the rows into the totals
             if (r->hit_rows)
-                hipLaunchKernelGGL(k_hits_reduce, dim3((ix->dc.n + 255) / 256, HITS_ROW_GROUPS), dim3(256), 0, ix->stream,
+                hipLaunchKernelGGL(k_hits_reduce, dim3((ix->dc.n + 255) / 256, HITS_ROW_GROUPS), dim3(256), 0, r->stream,
                                    r->d_partial.as<uint32_t>(), r->hit_rows, W, ix->dc.n, (unsigned long long*)device_u64_hits);
-            hipLaunchKernelGGL(k_add_totals, dim3(1), dim3(64), 0, ix->stream, (unsigned long long*)device_u64_hits, ix->dc.n,
+            hipLaunchKernelGGL(k_add_totals, dim3(1), dim3(64), 0, r->stream, (unsigned long long*)device_u64_hits, ix->dc.n,
                                r->n, r->d_totals.as<uint64_t>());
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipStreamSynchronize(ix->stream));
-        if (ix->timing) ix->collect_timing();
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        if (ix->timing) ix->collect_timing(const_cast<fgpu_result*>(r)->pending);
     });
 }
 
@@ -685,13 +700,13 @@ int fgpu_result_algorithmic_bytes(const fgpu_result* r, uint64_t* list_bytes, ui
         uint64_t acct[2] = {0, 0};
         if (r->n) {
             const_cast<fgpu_result*>(r)->d_acct.ensure(16);
-            HIP_TRY(hipMemsetAsync(r->d_acct.p, 0, 16, ix->stream));
-            hipLaunchKernelGGL(k_account, dim3(1024), dim3(256), 0, ix->stream, ix->dc, r->d_idcsr.as<uint64_t>(),
+            HIP_TRY(hipMemsetAsync(r->d_acct.p, 0, 16, r->stream));
+            hipLaunchKernelGGL(k_account, dim3(1024), dim3(256), 0, r->stream, ix->dc, r->d_idcsr.as<uint64_t>(),
                                r->d_desc.as<ListDesc>(), r->d_counts.as<uint32_t>(), r->n, r->d_acct.as<unsigned long long>(),
                                ix->host.type == IDX_HYBRID ? (const uint32_t*)nullptr : ix->d_gset_bytes.as<uint32_t>());
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync(acct, r->d_acct.p, 16, hipMemcpyDeviceToHost, ix->stream));
-            HIP_TRY(hipStreamSynchronize(ix->stream));
+            HIP_TRY(hipMemcpyAsync(acct, r->d_acct.p, 16, hipMemcpyDeviceToHost, r->stream));
+            HIP_TRY(hipStreamSynchronize(r->stream));
         }
         if (list_bytes) *list_bytes = acct[0];
         if (output_bytes) *output_bytes = acct[1];
@@ -764,8 +779,8 @@ int fgpu_fetch_color_set_ids(fgpu_index* ix, const char* bases, const uint64_t* 
     if (!rc) rc = guarded([&] {
         HIP_TRY(hipSetDevice(ix->device));
         stage_lookup(ix, rd, 0, n, res);
-        HIP_TRY(hipStreamSynchronize(ix->stream));
-        if (ix->timing) ix->collect_timing();
+        HIP_TRY(hipStreamSynchronize(res->stream));
+        if (ix->timing) ix->collect_timing(res->pending);
         std::vector<uint32_t> nids(n);
         if (n) HIP_TRY(hipMemcpy(nids.data(), res->d_nids.p, n * 4, hipMemcpyDeviceToHost));
         uint64_t used = 0;
@@ -820,7 +835,7 @@ int fgpu_intersect_ids(fgpu_index* ix, const uint32_t* ids, const uint64_t* id_o
         }
         if (id_offs[n]) HIP_TRY(hipMemcpy(res->d_ids_pool.p, ids, id_offs[n] * 4, hipMemcpyHostToDevice));
         res->d_tickets.ensure(TICKET_BYTES);
-        HIP_TRY(hipMemsetAsync(res->d_tickets.p, 0, TICKET_BYTES, ix->stream));
+        HIP_TRY(hipMemsetAsync(res->d_tickets.p, 0, TICKET_BYTES, res->stream));
         res->have_ids = false;
         stage_descriptors(ix, res, id_offs[n]);
         stage_colors(ix, FGPU_FULL_INTERSECTION, 0.0, res);
@@ -851,8 +866,8 @@ int fgpu_kmer_color_set_ids(fgpu_index* ix, const char* bases, const uint64_t* o
         HIP_TRY(hipSetDevice(ix->device));
         res->want_kmer_ids = true;
         stage_lookup(ix, rd, 0, n, res);
-        HIP_TRY(hipStreamSynchronize(ix->stream));
-        if (ix->timing) ix->collect_timing();
+        HIP_TRY(hipStreamSynchronize(res->stream));
+        if (ix->timing) ix->collect_timing(res->pending);
         const uint32_t k = ix->host.dict.k;
         const uint64_t stride = std::max<uint32_t>(1, rd->max_kmers);
         const uint64_t units = rd->has_long ? rd->seg_first[n] : n;

@@ -1407,8 +1407,8 @@ __global__ void k_hits_reduce(const uint32_t* __restrict__ partial, uint32_t nbl
 
 __global__ void k_add_totals(unsigned long long* hits, uint32_t n, uint64_t num_reads, const uint64_t* totals) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        hits[n] += num_reads;
-        hits[n + 1] += totals[1];
+        atomicAdd(&hits[n], (unsigned long long)num_reads);  // several streams may add to the same vector
+        atomicAdd(&hits[n + 1], (unsigned long long)totals[1]);
     }
 }
 
