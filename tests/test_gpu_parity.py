@@ -349,3 +349,52 @@ def test_gpu_kmer_conservation_and_matches(s10_gpu, s10_oracle):
     from oracle.kmer_oracle import read_fasta
     src = max(read_fasta(S10_GENOMES[2]), key=len)[50000:53000]
     assert s10_gpu.kmer_conservation(src) == s10_oracle.kmer_conservation(src)
+
+
+def _fuzz_reads(gen, rng, n):
+    """ragged, dirty reads: lengths 0..420, N runs, lower case, homopolymers, low-complexity repeats"""
+    b, o = gen.generate(int(rng.integers(0, 1 << 30)), n, 150, int(rng.integers(1, 1000)))
+    base = [bytes(b[int(o[i]):int(o[i + 1])]) for i in range(n)]
+    out = []
+    for i, r in enumerate(base):
+        kind = rng.integers(0, 10)
+        if kind == 0:
+            r = r[:int(rng.integers(0, 60))]
+        elif kind == 1:
+            r = r + base[(i + 1) % n] + base[(i + 2) % n][:int(rng.integers(0, 120))]
+        elif kind == 2:
+            p = int(rng.integers(0, len(r)))
+            r = r[:p] + b"N" * int(rng.integers(1, 40)) + r[p:]
+        elif kind == 3:
+            r = r.lower()
+        elif kind == 4:
+            r = bytes([b"ACGT"[int(rng.integers(0, 4))]]) * int(rng.integers(1, 200))
+        elif kind == 5:
+            unit = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, 7))).astype(np.uint8))
+            r = (unit * 80)[:int(rng.integers(31, 300))]
+        elif kind == 6:
+            r = r[:75] + bytes([rng.choice(list(b"RYKMSWn-*"))]) + r[76:]
+        out.append(r)
+    return out
+
+
+@pytest.mark.parametrize("which", ["s10", "s4546"])
+def test_fuzz_dirty_ragged_reads(which, s10_gpu, s10_oracle, s4546, built):
+    from fulgor_amd.reads import ReadGenerator
+    rng = np.random.default_rng(2026)
+    if which == "s10":
+        ix, orc, gen = s10_gpu, s10_oracle, ReadGenerator(S10_GENOMES)
+    else:
+        ix, orc, gen = s4546
+    for rep in range(3):
+        reads = _fuzz_reads(gen, rng, 6000)
+        b, o = pack_reads(reads)
+        for got, want in ((ix.fetch_color_set_ids_batch(b, o), orc.fetch_color_set_ids(b, o, threads=32)),
+                          (ix.pseudoalign_full_intersection_batch(b, o), orc.full_intersection(b, o, threads=32)),
+                          (ix.pseudoalign_threshold_union_batch(b, o, float(rng.choice([0.3, 0.8, 1.0]))), None)):
+            if want is None:
+                continue
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        tau = float(rng.choice([0.25, 0.8, 1.0]))
+        got, want = ix.pseudoalign_threshold_union_batch(b, o, tau), orc.threshold_union(b, o, tau, threads=32)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
