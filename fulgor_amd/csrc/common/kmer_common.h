@@ -79,17 +79,24 @@ FG_HD uint64_t mix64(uint64_t x) {
 
 FG_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 
-// Minimizer order: smaller (hash >> 36) first; ties are broken by position (leftmost in the
-// orientation in which the window is read), so that reading the same window on the other strand
-// selects the rightmost tie. 28 bits leave room for a 4-bit position in a packed u32 min.
-constexpr uint32_t MIN_ORDER_SHIFT = 36;
+// Minimizer order: a cheap 24-bit multiplicative hash of the canonical m-mer key, smaller first; ties are
+// broken by position (leftmost in the orientation in which the window is read), so that reading the same
+// window on the other strand selects the rightmost tie. Packed as (order << 4 | position) in a u32 min.
+// (The order only has to be the same on host and device and reasonably random; the perfect hash below is
+// keyed by the canonical key itself through the 64-bit mixer.)
+FG_HD uint32_t order24(uint64_t canonical) {
+    uint32_t x = (uint32_t)canonical * 0x9E3779B1u ^ (uint32_t)(canonical >> 32) * 0x85EBCA77u;
+    x ^= x >> 15;
+    x *= 0x2C1B3C6Du;
+    return x >> 8;
+}
 
 // ---- perfect hash over canonical minimizer keys ------------------------------------------------
 // Minimizers are the m-mers with the SMALLEST order hash, so mix64(key) itself is far from uniform
 // over the selected keys; the perfect hash therefore uses a second, seeded mix of it:
-//   h = phf_hash(mix64(key), seed); bucket = fastrange(high32(h), num_buckets);
+//   h = phf_hash(canonical key, seed); bucket = fastrange(high32(h), num_buckets);
 //   slot = fastrange(mix32(low32(h) ^ pilot * PHI32), num_slots)
-FG_HD uint64_t phf_hash(uint64_t h0, uint64_t seed) { return mix64(h0 ^ (seed * 0x9E3779B97F4A7C15ULL + 0x632BE59BD9B4E019ULL)); }
+FG_HD uint64_t phf_hash(uint64_t key, uint64_t seed) { return mix64(key ^ (seed * 0x9E3779B97F4A7C15ULL + 0x632BE59BD9B4E019ULL)); }
 constexpr uint32_t PHI32 = 0x9E3779B1u;
 FG_HD uint32_t phf_bucket(uint64_t h, uint32_t num_buckets) { return mulhi32((uint32_t)(h >> 32), num_buckets); }
 FG_HD uint32_t phf_slot(uint64_t h, uint32_t pilot, uint32_t num_slots) {
@@ -136,10 +143,16 @@ FG_HD uint32_t ovf_cnt(uint64_t r) { return (uint32_t)(r >> 32) & 0x7FFFFFFFu; }
 // word w holds bases [32w, 32w+32): low 32 bits = lo plane, high 32 bits = hi plane.
 // extract an L-mer (L<=32) starting at base s from two consecutive words
 FG_HD void string_lmer(uint64_t w0, uint64_t w1, uint32_t sh, uint32_t L, uint32_t& lo, uint32_t& hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // sh <= 31: one v_alignbit (funnel shift) per plane
+    lo = __builtin_amdgcn_alignbit((uint32_t)w1, (uint32_t)w0, sh) & low_mask32(L);
+    hi = __builtin_amdgcn_alignbit((uint32_t)(w1 >> 32), (uint32_t)(w0 >> 32), sh) & low_mask32(L);
+#else
     uint64_t l = ((uint64_t)(uint32_t)w1 << 32) | (uint32_t)w0;
     uint64_t h = (w1 & 0xFFFFFFFF00000000ULL) | (w0 >> 32);
     lo = (uint32_t)(l >> sh) & low_mask32(L);
     hi = (uint32_t)(h >> sh) & low_mask32(L);
+#endif
 }
 
 // ---- colour-list skip samples --------------------------------------------------------------------

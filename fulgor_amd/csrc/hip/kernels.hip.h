@@ -199,10 +199,10 @@ __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __res
             const uint64_t nvB = __ballot(c1 > 3);
 
             // hash of the canonical m-mer starting at every base of the window (+ k-m extra on the right)
-            hsh[lane] = mix64(canonical_key(extract128(loA, loB, lane, m), extract128(hiA, hiB, lane, m), m));
+            hsh[lane] = canonical_key(extract128(loA, loB, lane, m), extract128(hiA, hiB, lane, m), m);
             if ((uint32_t)lane < k - m) {
                 uint32_t l2 = (uint32_t)(loB >> lane) & low_mask32(m), h2 = (uint32_t)(hiB >> lane) & low_mask32(m);
-                hsh[64 + lane] = mix64(canonical_key(l2, h2, m));
+                hsh[64 + lane] = canonical_key(l2, h2, m);
             }
             wave_lds_sync();
 
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __res
                 const uint32_t klo = extract128(loA, loB, lane, k), khi = extract128(hiA, hiB, lane, k);
                 uint32_t bestL = 0xFFFFFFFFu, bestR = 0xFFFFFFFFu;
                 for (uint32_t j = 0; j < W; ++j) {
-                    const uint32_t o = (uint32_t)(hsh[lane + j] >> MIN_ORDER_SHIFT) << 4;
+                    const uint32_t o = order24(hsh[lane + j]) << 4;
                     bestL = min(bestL, o | j);          // leftmost smallest
                     bestR = min(bestR, o | (15u - j));  // rightmost smallest
                 }
@@ -336,12 +336,12 @@ __global__ __launch_bounds__(256, 6) void k1_lookup_short(DevDict d, const uint8
                                                        uint32_t* __restrict__ cnt_pool, uint32_t stride, unsigned int* tickets,
                                                        uint32_t* __restrict__ kmer_out) {
     constexpr int KMAX = 128;
-    __shared__ uint64_t s_hash[4][144];
+    __shared__ uint32_t s_ord[4][144];  // (24-bit order << 4) of the canonical m-mer at every base
     __shared__ uint32_t s_ids[4][KMAX];
     __shared__ uint32_t s_uid[4][KMAX];
     __shared__ uint32_t s_ucnt[4][KMAX];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    uint64_t* hsh = s_hash[wv];
+    uint32_t* ord = s_ord[wv];
     uint32_t* ids = s_ids[wv];
     uint32_t* uid = s_uid[wv];
     uint32_t* ucnt = s_ucnt[wv];
@@ -378,10 +378,10 @@ __global__ __launch_bounds__(256, 6) void k1_lookup_short(DevDict d, const uint8
             const uint64_t loB = __ballot(c1 <= 3 && (c1 & 1)), hiB = __ballot(c1 <= 3 && (c1 & 2)), nvB = __ballot(c1 > 3);
             const uint64_t loC = __ballot(c2 <= 3 && (c2 & 1)), hiC = __ballot(c2 <= 3 && (c2 & 2)), nvC = __ballot(c2 > 3);
 
-            hsh[lane] = mix64(canonical_key(extract128(loA, loB, lane, m), extract128(hiA, hiB, lane, m), m));
-            hsh[64 + lane] = mix64(canonical_key(extract128(loB, loC, lane, m), extract128(hiB, hiC, lane, m), m));
+            ord[lane] = order24(canonical_key(extract128(loA, loB, lane, m), extract128(hiA, hiB, lane, m), m)) << 4;
+            ord[64 + lane] = order24(canonical_key(extract128(loB, loC, lane, m), extract128(hiB, hiC, lane, m), m)) << 4;
             if (lane < 16)
-                hsh[128 + lane] = mix64(canonical_key((uint32_t)(loC >> lane) & low_mask32(m), (uint32_t)(hiC >> lane) & low_mask32(m), m));
+                ord[128 + lane] = order24(canonical_key((uint32_t)(loC >> lane) & low_mask32(m), (uint32_t)(hiC >> lane) & low_mask32(m), m)) << 4;
             wave_lds_sync();
 
             bool valid[2];
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 6) void k1_lookup_short(DevDict d, const uint8
                 for (uint32_t jj = 0; jj < 13; ++jj) {
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
-                        const uint32_t o = (uint32_t)(hsh[64 * a + lane + jj] >> MIN_ORDER_SHIFT) << 4;
+                        const uint32_t o = ord[64 * a + lane + jj];
                         bL[a] = min(bL[a], o | jj);
                         bR[a] = min(bR[a], o | (15u - jj));
                     }
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256, 6) void k1_lookup_short(DevDict d, const uint8
                 for (uint32_t jj = 0; jj < W; ++jj) {
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
-                        const uint32_t o = (uint32_t)(hsh[64 * a + lane + jj] >> MIN_ORDER_SHIFT) << 4;
+                        const uint32_t o = ord[64 * a + lane + jj];
                         bL[a] = min(bL[a], o | jj);
                         bR[a] = min(bR[a], o | (15u - jj));
                     }
@@ -422,8 +422,10 @@ __global__ __launch_bounds__(256, 6) void k1_lookup_short(DevDict d, const uint8
             for (int a = 0; a < 2; ++a) {
                 jL[a] = bL[a] & 15u;
                 jR[a] = 15u - (bR[a] & 15u);
-                hL[a] = hsh[64 * a + lane + jL[a]];
-                hR[a] = hsh[64 * a + lane + jR[a]];
+                // canonical keys of the leftmost / rightmost smallest m-mer, cut out of the k-mer itself
+                hL[a] = canonical_key((klo[a] >> jL[a]) & low_mask32(m), (khi[a] >> jL[a]) & low_mask32(m), m);
+                hR[a] = jR[a] == jL[a] ? hL[a]
+                                       : canonical_key((klo[a] >> jR[a]) & low_mask32(m), (khi[a] >> jR[a]) & low_mask32(m), m);
             }
             // ---- staged, branch-free probe of the leftmost-minimizer key for both k-mers ----
             uint64_t hp[2], e[2], p0[2], p1[2];

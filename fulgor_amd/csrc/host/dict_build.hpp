@@ -82,7 +82,7 @@ inline void build_dict(Dict& d, uint32_t k, uint32_t m, const char* bases, uint6
                         uint64_t s = b + i;
                         uint32_t lo, hi;
                         string_lmer(d.strings[s >> 5], d.strings[(s >> 5) + 1], (uint32_t)(s & 31), m, lo, hi);
-                        hh[i] = mix64(canonical_key(lo, hi, m));
+                        hh[i] = canonical_key(lo, hi, m);
                         fw[i] = is_fwd_canonical(lo, hi, m);
                     }
                     const uint64_t nk = len - k + 1;
@@ -93,7 +93,7 @@ inline void build_dict(Dict& d, uint32_t k, uint32_t m, const char* bases, uint6
                         if (s < nk) {
                             uint32_t best = 0xFFFFFFFFu;
                             for (uint32_t j = 0; j < W; ++j) {  // leftmost smallest order
-                                uint32_t pk = (uint32_t)((hh[s + j] >> MIN_ORDER_SHIFT) << 4) | j;
+                                uint32_t pk = (order24(hh[s + j]) << 4) | j;
                                 best = pk < best ? pk : best;
                             }
                             p = s + (best & 15u);
@@ -210,8 +210,8 @@ inline uint32_t dict_lookup(const Dict& d, uint32_t klo, uint32_t khi) {
     uint64_t hs[16];
     for (uint32_t j = 0; j < W; ++j) {
         uint32_t lo = (klo >> j) & low_mask32(m), hi = (khi >> j) & low_mask32(m);
-        hs[j] = mix64(canonical_key(lo, hi, m));
-        uint32_t o = (uint32_t)(hs[j] >> MIN_ORDER_SHIFT) << 4;
+        hs[j] = canonical_key(lo, hi, m);
+        uint32_t o = order24(hs[j]) << 4;
         bestL = std::min(bestL, o | j);
         bestR = std::min(bestR, o | (15u - j));
     }

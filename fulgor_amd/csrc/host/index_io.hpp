@@ -114,7 +114,7 @@ inline void load_dump(const std::string& base, HostIndex& idx, uint32_t m = 0, u
 
 // ---- own binary container ------------------------------------------------------------------------
 namespace detail {
-static const char FGIDX_MAGIC[8] = {'F', 'G', 'I', 'D', 'X', '0', '0', '4'};  // 004: strand bit in records, 16-bit pilots, optional codec section
+static const char FGIDX_MAGIC[8] = {'F', 'G', 'I', 'D', 'X', '0', '0', '5'};  // 005: 24-bit multiplicative minimizer order, PHF keyed by the canonical key
 template <typename T>
 void wr(std::ofstream& o, const T& v) { o.write(reinterpret_cast<const char*>(&v), sizeof(T)); }
 template <typename T>
