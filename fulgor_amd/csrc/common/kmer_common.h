@@ -155,9 +155,33 @@ FG_HD void string_lmer(uint64_t w0, uint64_t w1, uint32_t sh, uint32_t L, uint32
 #endif
 }
 
-// ---- colour-list skip samples --------------------------------------------------------------------
-// One sample every SAMPLE_STRIDE codes of a gap-coded list: {prev value:32 | bit offset from the
-// start of the list:32}. Sample j is the decoder state after (j+1)*SAMPLE_STRIDE codes.
+// ---- colour-list skip samples (meta / differential codecs) -----------------------------------------
+// One sample every SAMPLE_STRIDE codes of a gap-coded op: {prev value:32 | bit offset from the
+// start of the op:32}. Sample j is the decoder state after (j+1)*SAMPLE_STRIDE codes.
 constexpr uint32_t SAMPLE_STRIDE = 16;
+
+// ---- packed blocks of the hybrid gap-coded lists --------------------------------------------------
+// A block holds up to 64 consecutive values v_0 < v_1 < ... of one list as `width`-bit offsets from
+// `start` (= previous value + 1, or 0 for the first block): v_i = start + field_i. Header word:
+//   start:27 | width:5 | count-1:6 | first data word, relative to the list's first data word:26
+// (so num_colors <= 2^27; a list owns fewer than n/4 codes, hence fewer than 2^26 data words).
+constexpr uint32_t BLK_VALUES = 64;
+constexpr uint32_t BLK_MAX_COLORS = 1u << 27;
+FG_HD uint64_t blk_pack(uint32_t start, uint32_t width, uint32_t count, uint32_t rel_word) {
+    return (uint64_t)start | ((uint64_t)width << 27) | ((uint64_t)(count - 1) << 32) | ((uint64_t)rel_word << 38);
+}
+FG_HD uint32_t blk_start(uint64_t h) { return (uint32_t)h & 0x7FFFFFFu; }
+FG_HD uint32_t blk_width(uint64_t h) { return ((uint32_t)h >> 27) & 31u; }
+FG_HD uint32_t blk_count(uint64_t h) { return ((uint32_t)(h >> 32) & 63u) + 1u; }
+FG_HD uint32_t blk_rel_word(uint64_t h) { return (uint32_t)(h >> 38); }
+// bits of the Elias-delta code of x (gamma(len+1) then len bits, len = floor(log2(x+1)))
+FG_HD uint32_t delta_code_bits(uint32_t x) {
+    const uint64_t y = (uint64_t)x + 1;
+    uint32_t len = 0;
+    while ((y >> (len + 1)) != 0) ++len;
+    uint32_t z = 0;
+    while (((len + 1) >> (z + 1)) != 0) ++z;
+    return 2 * z + 1 + len;
+}
 
 }  // namespace fg

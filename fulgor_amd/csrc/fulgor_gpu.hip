@@ -71,7 +71,7 @@ struct fgpu_index {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 256;
-    DevBuf d_strings, d_pilots, d_slots, d_overflow, d_bits, d_offsets, d_sample_off, d_samples;
+    DevBuf d_strings, d_pilots, d_slots, d_overflow, d_bits, d_offsets, d_set_size, d_blk_first, d_blk_wbase, d_blk_hdr, d_blk_words;
     DevBuf d_gbits, d_gops, d_gset_ops_off, d_gset_ops, d_gsamples, d_gset_bytes;
     DevDict dd{};
     DevColors dc{};
@@ -169,15 +169,19 @@ void upload_index(fgpu_index* ix) {
     upload(ix->d_overflow, d.overflow, s);
     upload(ix->d_bits, h.bits, s);
     upload(ix->d_offsets, h.offsets, s);
-    upload(ix->d_sample_off, h.sample_off, s);
-    upload(ix->d_samples, h.samples, s);
+    upload(ix->d_set_size, h.set_size, s);
+    upload(ix->d_blk_first, h.blk_first, s);
+    upload(ix->d_blk_wbase, h.blk_wbase, s);
+    upload(ix->d_blk_hdr, h.blk_hdr, s);
+    upload(ix->d_blk_words, h.blk_words, s);
     HIP_TRY(hipStreamSynchronize(s));
     ix->dd = DevDict{ix->d_strings.as<uint64_t>(), ix->d_pilots.as<uint16_t>(), ix->d_slots.as<uint64_t>(),
                      ix->d_overflow.as<uint64_t>(), d.num_buckets, d.num_slots, d.k, d.m, d.seed};
     uint32_t w32 = (h.num_colors + 31) / 32;
     w32 += w32 & 1;
-    ix->dc = DevColors{ix->d_bits.as<uint64_t>(), ix->d_offsets.as<uint64_t>(), ix->d_sample_off.as<uint64_t>(),
-                       ix->d_samples.as<uint64_t>(), h.num_colors, h.sparse_thr, h.dense_thr, w32};
+    ix->dc = DevColors{ix->d_bits.as<uint64_t>(), ix->d_offsets.as<uint64_t>(), ix->d_set_size.as<uint32_t>(),
+                       ix->d_blk_first.as<uint64_t>(), ix->d_blk_wbase.as<uint64_t>(), ix->d_blk_hdr.as<uint64_t>(),
+                       ix->d_blk_words.as<uint32_t>(), h.num_colors, h.sparse_thr, h.dense_thr, w32};
 }
 
 static_assert(sizeof(SetOp) == sizeof(DevOp), "host and device op layouts must match");
@@ -385,7 +389,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
                                res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
         HIP_TRY(hipGetLastError());
     } else if (algo == FGPU_FULL_INTERSECTION) {
-        const size_t per_wave = (size_t)(1 + SPARSE_PLANES) * W * 4 + wave_scratch_bytes();
+        const size_t per_wave = (size_t)2 * W * 4 + wave_scratch_bytes();
         const uint32_t wpb = pick_waves(per_wave, (const void*)k2a_intersect);
         const uint32_t grid = resident_grid(k2a_intersect, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
         Timed t(ix, res, FGPU_K_INTERSECT);
@@ -492,7 +496,7 @@ void fgpu_close(fgpu_index* ix) {
     if (ix->device == FGPU_HOST_ONLY) { delete ix; return; }
     (void)hipSetDevice(ix->device);
     for (DevBuf* b : {&ix->d_strings, &ix->d_pilots, &ix->d_slots, &ix->d_overflow, &ix->d_bits, &ix->d_offsets,
-                      &ix->d_sample_off, &ix->d_samples, &ix->d_gbits, &ix->d_gops, &ix->d_gset_ops_off, &ix->d_gset_ops,
+                      &ix->d_set_size, &ix->d_blk_first, &ix->d_blk_wbase, &ix->d_blk_hdr, &ix->d_blk_words, &ix->d_gbits, &ix->d_gops, &ix->d_gset_ops_off, &ix->d_gset_ops,
                       &ix->d_gsamples, &ix->d_gset_bytes})
         b->release();
     for (auto e : ix->event_pool) (void)hipEventDestroy(e);

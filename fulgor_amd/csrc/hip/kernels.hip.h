@@ -28,10 +28,13 @@ struct DevDict {
 };
 
 struct DevColors {
-    const uint64_t* bits;
+    const uint64_t* bits;       // the hybrid bit stream (bitmap lists are read from it)
     const uint64_t* offsets;
-    const uint64_t* sample_off;
-    const uint64_t* samples;
+    const uint32_t* set_size;   // list sizes
+    const uint64_t* blk_first;  // packed blocks of the gap-coded lists (host/hybrid_codec.hpp)
+    const uint64_t* blk_wbase;
+    const uint64_t* blk_hdr;
+    const uint32_t* blk_words;
     uint32_t n, sparse_thr, dense_thr;
     uint32_t w32;  // 32-bit words per result bitmap, rounded up to an even number
 };
@@ -644,22 +647,33 @@ struct NarrowReader {
     }
 };
 
+__device__ __forceinline__ uint32_t delta_code_bits_fast(uint32_t x) {  // = delta_code_bits(x), x < 2^32 - 1
+    const uint32_t len = 31u - (uint32_t)__builtin_clz(x + 1u);
+    const uint32_t z = 31u - (uint32_t)__builtin_clz(len + 1u);
+    return 2 * z + 1 + len;
+}
+
 struct ListHeader {
-    uint64_t begin, body, soff;
+    uint64_t begin, body, soff;  // bitmap list: bit offsets of the list / of its bitmap. Gap-coded list: begin = first
+                                 // data word in blk_words, soff = first block header
     uint32_t ncodes, size;
     int type;
 };
 
 __device__ __forceinline__ ListHeader read_header(const DevColors& c, uint32_t id) {
     ListHeader h;
-    h.begin = c.offsets[id];
-    uint64_t pos = h.begin;
-    h.size = read_delta(c.bits, pos);
-    h.body = pos;
-    h.soff = c.sample_off[id];
+    h.size = c.set_size[id];
+    h.begin = h.body = h.soff = 0;
     if (h.size < c.sparse_thr) { h.type = D_ENC_DELTA_GAPS; h.ncodes = h.size; }
     else if (h.size < c.dense_thr) { h.type = D_ENC_BITMAP; h.ncodes = 0; }
     else { h.type = D_ENC_COMPLEMENT; h.ncodes = c.n - h.size; }
+    if (h.type == D_ENC_BITMAP) {
+        h.begin = c.offsets[id];
+        h.body = h.begin + delta_code_bits_fast(h.size);
+    } else {
+        h.begin = h.body = c.blk_wbase[id];
+        h.soff = c.blk_first[id];
+    }
     return h;
 }
 
@@ -667,9 +681,9 @@ __device__ __forceinline__ ListHeader read_header(const DevColors& c, uint32_t i
 // (read, list) pair, so that the dependent chain id -> offsets -> header bits is walked with full
 // memory-level parallelism once instead of serially inside the per-read kernels.
 struct __attribute__((aligned(16))) ListDesc {
-    uint64_t begin;   // bit offset of the list
-    uint64_t soff;    // first restart sample
-    uint32_t ncodes;  // gap codes (0 for bitmap lists)
+    uint64_t begin;   // bitmap list: bit offset of the list; gap-coded list: first data word in blk_words
+    uint64_t soff;    // gap-coded list: first block header
+    uint32_t ncodes;  // values of a gap-coded list (0 for bitmap lists)
     uint32_t meta;    // encoding | (body - begin) << 8
     int32_t score;    // positive k-mers that produced this id (threshold-union)
     uint32_t id;      // colour-set id
@@ -702,30 +716,85 @@ __global__ __launch_bounds__(256) void k_desc(DevColors c, const uint32_t* __res
     }
 }
 
-// decode segment `seg` (SAMPLE_STRIDE codes) of a gap-coded list and feed every value to f
-template <typename F>
-__device__ __forceinline__ void decode_segment(const DevColors& c, uint64_t begin, uint64_t body, uint64_t soff,
-                                               uint32_t ncodes, uint32_t seg, F f) {
-    uint64_t pos = body;
-    uint32_t prev = 0xFFFFFFFFu;
-    if (seg) {
-        const uint64_t s = c.samples[soff + seg - 1];
-        pos = begin + (uint32_t)s;
-        prev = (uint32_t)(s >> 32);
+// ---------------------------------------------------------------------------------------------
+// Packed blocks: wave-parallel decode
+// ---------------------------------------------------------------------------------------------
+// The gap-coded lists of one read are flattened into one sequence of 64-value blocks. Lane s of the wave
+// resolves block s (its list by a search over the inclusive block counts `pref`, then its header), and the
+// wave then walks the blocks one per step: the step's parameters come out of lane q with v_readlane (so
+// they are scalars), lane i extracts value i with one funnel shift, and the data words of the next two
+// blocks are already in flight while a block is consumed.
+struct BlockLane {      // per lane: the flattened block this lane resolved
+    uint32_t a_lo, a_hi;  // address of its first data word
+    uint32_t start;       // value of field 0 (plus a caller-defined bias, e.g. an LDS plane offset in bits)
+    uint32_t meta;        // width | (count-1) << 5 | caller flags << 11
+    uint32_t extra;       // caller-defined (the list's score for the threshold union)
+};
+
+// first i in [0,64) with pref[i] > t (pref non-decreasing, pref[63] > t)
+__device__ __forceinline__ uint32_t upper_slot(const uint32_t* pref, uint32_t t) {
+    uint32_t lo = 0, hi = 63;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (pref[mid] > t) hi = mid; else lo = mid + 1;
     }
-    const uint32_t nc = min(SAMPLE_STRIDE, ncodes - seg * SAMPLE_STRIDE);
-    if (c.n < 65536u) {
-        NarrowReader rd;
-        rd.init((const uint32_t*)c.bits, pos);
-        for (uint32_t i = 0; i < nc; ++i) {
-            prev = prev + 1u + rd.delta();
-            f(prev);
-        }
-    } else {
-        for (uint32_t i = 0; i < nc; ++i) {
-            prev = prev + 1u + read_delta(c.bits, pos);
-            f(prev);
-        }
+    return lo;
+}
+
+// list owning flattened block s, given the inclusive block counts of the (at most 64) lists in the lanes:
+// the last list whose exclusive count is <= s. Lists are few (5 on average), so a scalar walk beats a search.
+// (`excl` must have been computed by all lanes: v_readlane reads lanes that are masked off here.)
+__device__ __forceinline__ uint32_t owner_list(uint32_t excl, uint32_t nlists, uint32_t s) {
+    uint32_t owner = 0;
+    for (uint32_t i = 1; i < nlists; ++i) {
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)excl, i);
+        owner = s >= e ? i : owner;
+    }
+    return owner;
+}
+
+// Every lane requests the two words that hold its field of block q. The request is unconditional (lanes past
+// the block's count read inside the 64 padding words of blk_words) so that the number of loads in flight is
+// known at compile time and the wait before a block is consumed leaves the two younger requests outstanding.
+__device__ __forceinline__ uint2 block_fetch(const BlockLane& b, uint32_t q, int lane) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)b.a_lo, q), hi = (uint32_t)__builtin_amdgcn_readlane((int)b.a_hi, q);
+    const uint32_t width = (uint32_t)__builtin_amdgcn_readlane((int)b.meta, q) & 31u;
+    typedef const uint32_t __attribute__((address_space(1))) * global_words;  // keeps the request a global_load (vmcnt only)
+    const global_words p = (global_words)((((uint64_t)hi << 32) | lo) + ((__umul24((uint32_t)lane, width) >> 3) & ~3u));
+    return make_uint2(p[0], p[1]);
+}
+
+template <typename F, typename G>
+__device__ __forceinline__ void block_consume(const BlockLane& b, uint32_t q, int lane, uint2 w, F& per_value, G& after_block) {
+    const uint32_t mt = (uint32_t)__builtin_amdgcn_readlane((int)b.meta, q);
+    const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)b.start, q);
+    const uint32_t ex = (uint32_t)__builtin_amdgcn_readlane((int)b.extra, q);
+    const uint32_t width = mt & 31u;
+    // the field is cut out by all lanes (not only count of them) so that the wait for `w` is unconditional
+    uint32_t f = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(w.y, w.x, __umul24((uint32_t)lane, width)), 0, width);
+    asm volatile("" : "+v"(f));  // (keeps the compiler from sinking the extraction into the branch below)
+    if ((uint32_t)lane <= ((mt >> 5) & 63u)) per_value(st + f, ex);
+    after_block(mt >> 11);
+}
+
+// per_value(v, extra of the block) for every value of blocks [0, steps) held by the lanes of `b` (steps >= 1);
+// after_block(flags) once per block (wave-uniform). Three register pairs rotate by unrolling, not by moves,
+// so a block is consumed while the requests of the next two are in flight.
+template <typename F, typename G>
+__device__ __forceinline__ void run_blocks(const BlockLane& b, uint32_t steps, int lane, F per_value, G after_block) {
+    const uint32_t last = steps - 1;
+    uint2 c0 = block_fetch(b, 0, lane), c1 = block_fetch(b, min(1u, last), lane), c2;
+    uint32_t q = 0;
+    while (true) {
+        c2 = block_fetch(b, min(q + 2, last), lane);
+        block_consume(b, q, lane, c0, per_value, after_block);
+        if (++q > last) break;
+        c0 = block_fetch(b, min(q + 2, last), lane);
+        block_consume(b, q, lane, c1, per_value, after_block);
+        if (++q > last) break;
+        c1 = block_fetch(b, min(q + 2, last), lane);
+        block_consume(b, q, lane, c2, per_value, after_block);
+        if (++q > last) break;
     }
 }
 
@@ -750,16 +819,6 @@ __device__ __forceinline__ WaveScratch carve_scratch(unsigned char* p) {
     return s;
 }
 
-// first i in [0,64) with pref[i] > t (pref non-decreasing, pref[63] > t)
-__device__ __forceinline__ uint32_t upper_slot(const uint32_t* pref, uint32_t t) {
-    uint32_t lo = 0, hi = 63;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (pref[mid] > t) hi = mid; else lo = mid + 1;
-    }
-    return lo;
-}
-
 // ---------------------------------------------------------------------------------------------
 // K2a: full intersection of hybrid colour sets -> bitmap + cardinality
 // ---------------------------------------------------------------------------------------------
@@ -767,12 +826,9 @@ __device__ __forceinline__ uint32_t upper_slot(const uint32_t* pref, uint32_t t)
 // given lists. Per read (one wave) the kernel builds an EXCLUSION bitmap in LDS and returns its complement:
 //   bitmap lists      : EXCL |= ~list, word-wise
 //   complemented lists: every missing colour sets its bit in EXCL
-//   sparse lists      : list p (up to 8 per round) sets bits in its own plane T_p; afterwards EXCL |= ~T_p
-// so EVERY gap code of every list does the same thing — OR one bit into a bitmap chosen per lane — and all
-// 16-code segments of all lists run through ONE decode loop, one segment per lane (restart samples built at
-// load), without divergence between list kinds.
-constexpr uint32_t SPARSE_PLANES = 3;
-
+//   sparse lists      : the list sets its bits in the plane T; after its last block EXCL |= ~T and T = 0
+// so every value of every gap-coded list ORs one bit into LDS, and all blocks of all lists of the read run
+// through one loop (run_blocks), one block of up to 64 values per step.
 __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint64_t* __restrict__ id_csr,
                                                      const ListDesc* __restrict__ desc, uint64_t n_reads,
                                                      uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count,
@@ -780,16 +836,16 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint6
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = c.w32;
-    const uint32_t per_wave = (1 + SPARSE_PLANES) * W * 4 + wave_scratch_bytes();
+    const uint32_t per_wave = 2 * W * 4 + wave_scratch_bytes();
     unsigned char* mine = smem + (size_t)wv * per_wave;
     WaveScratch sc = carve_scratch(mine);
     uint32_t* EXCL = (uint32_t*)(mine + wave_scratch_bytes());
-    uint32_t* T = EXCL + W;  // SPARSE_PLANES planes of W words, all zero between reads
+    uint32_t* T = EXCL + W;  // all zero between sparse lists
     const WorkQueue wq{tickets, n_reads, 8};
     uint64_t t_first;
     uint32_t t_count;
 
-    for (uint32_t w = lane; w < W * SPARSE_PLANES; w += 64) T[w] = 0;
+    for (uint32_t w = lane; w < W; w += 64) T[w] = 0;
     wave_lds_sync();
 
     while (wq.pull(t_first, t_count))
@@ -813,11 +869,13 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint6
                 const ListDesc d = desc[off + g + lane];
                 h.type = desc_type(d); h.ncodes = d.ncodes; h.begin = d.begin; h.body = desc_body(d); h.soff = d.soff;
             }
-            const uint32_t nseg = (h.ncodes + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
-            const uint64_t sparse_mask = __ballot(h.type == D_ENC_DELTA_GAPS);
-            const uint32_t nsparse = __popcll(sparse_mask);
-            const uint32_t srank = mask_rank(sparse_mask);
-            sc.h_begin[lane] = h.begin; sc.h_body[lane] = h.body; sc.h_soff[lane] = h.soff; sc.h_ncodes[lane] = h.ncodes;
+            const uint32_t nblk = (h.ncodes + BLK_VALUES - 1) / BLK_VALUES;  // 0 for bitmap lists
+            const uint32_t incl = wave_incl_scan_u32(nblk);
+            const uint32_t excl = incl - nblk;
+            const uint32_t total_blk = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            sc.h_begin[lane] = h.begin; sc.h_body[lane] = h.body; sc.h_soff[lane] = h.soff;
+            sc.h_ncodes[lane] = nblk | (h.type == D_ENC_DELTA_GAPS ? 0x80000000u : 0u);
+            sc.pref[lane] = incl;
             wave_lds_sync();
 
             // bitmap lists: exclude what they do not contain
@@ -830,42 +888,36 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint6
             }
             wave_lds_sync();
 
-            // rounds of up to SPARSE_PLANES sparse lists; complemented lists ride along in the first round
-            for (uint32_t rb = 0; rb == 0 || rb < nsparse; rb += SPARSE_PLANES) {
-                const bool mine_now = (h.type == D_ENC_COMPLEMENT && rb == 0) ||
-                                      (h.type == D_ENC_DELTA_GAPS && srank >= rb && srank < rb + SPARSE_PLANES);
-                // LDS word offset of the bitmap this list ORs into
-                sc.h_score[lane] = h.type == D_ENC_COMPLEMENT ? 0 : (int32_t)((1 + (srank - rb)) * W);
-                const uint32_t incl = wave_incl_scan_u32(mine_now ? nseg : 0u);
-                sc.pref[lane] = incl;
-                const uint32_t total_seg = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                wave_lds_sync();
-                for (uint32_t t0 = 0; t0 < total_seg; t0 += 64) {
-                    const uint32_t t = t0 + lane;
-                    if (t < total_seg) {
-                        const uint32_t i = upper_slot(sc.pref, t);
-                        const uint32_t nc = sc.h_ncodes[i];
-                        const uint32_t ns = (nc + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
-                        const uint32_t seg = t - (sc.pref[i] - ns);
-                        uint32_t* dst = EXCL + sc.h_score[i];
-                        decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg,
-                                       [&](uint32_t v) { atomicOr(&dst[v >> 5], 1u << (v & 31)); });
-                    }
+            for (uint32_t s0 = 0; s0 < total_blk; s0 += 64) {
+                BlockLane bl{0u, 0u, 0u, 0u, 0u};
+                const uint32_t s = s0 + lane;
+                if (s < total_blk) {
+                    const uint32_t i = owner_list(excl, min(64u, cnt - g), s);
+                    const uint32_t nb = sc.h_ncodes[i];
+                    const uint32_t j = s - (sc.pref[i] - (nb & 0x7FFFFFFFu));
+                    const uint64_t hd = c.blk_hdr[sc.h_soff[i] + j];
+                    const uint64_t a = (uint64_t)(c.blk_words + sc.h_begin[i] + blk_rel_word(hd));
+                    const bool sparse = (nb >> 31) != 0;
+                    bl.a_lo = (uint32_t)a;
+                    bl.a_hi = (uint32_t)(a >> 32);
+                    bl.start = blk_start(hd) + (sparse ? W * 32u : 0u);  // bit index relative to EXCL
+                    bl.meta = blk_width(hd) | ((blk_count(hd) - 1u) << 5) |
+                              ((sparse && j + 1 == (nb & 0x7FFFFFFFu)) ? 1u << 11 : 0u);
                 }
-                wave_lds_sync();
-                const uint32_t np = min(SPARSE_PLANES, nsparse > rb ? nsparse - rb : 0u);
-                if (np) {  // a colour absent from any of these sparse lists is excluded; planes go back to zero
-                    for (uint32_t w = lane; w < W; w += 64) {
-                        uint32_t all = 0xFFFFFFFFu;
-                        for (uint32_t p = 0; p < np; ++p) {
-                            all &= T[p * W + w];
-                            T[p * W + w] = 0;
-                        }
-                        EXCL[w] |= ~all;
-                    }
-                    wave_lds_sync();
-                }
+                run_blocks(bl, min(64u, total_blk - s0), lane,
+                           [&](uint32_t v, uint32_t) { atomicOr(&EXCL[v >> 5], 1u << (v & 31)); },
+                           [&](uint32_t last_of_sparse) {
+                               if (last_of_sparse) {  // a colour absent from this sparse list is excluded; T goes back to zero
+                                   wave_lds_sync();
+                                   for (uint32_t w = lane; w < W; w += 64) {
+                                       EXCL[w] |= ~T[w];
+                                       T[w] = 0;
+                                   }
+                                   wave_lds_sync();
+                               }
+                           });
             }
+            wave_lds_sync();
         }
         uint32_t pc = 0;
         for (uint32_t w = lane; w < W; w += 64) {
@@ -950,12 +1002,13 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
                 h.type = desc_type(d); h.ncodes = d.ncodes; h.begin = d.begin; h.body = desc_body(d); h.soff = d.soff;
                 score = d.score;
             }
-            const uint32_t nseg = (h.ncodes + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
-            sc.h_begin[lane] = h.begin; sc.h_body[lane] = h.body; sc.h_soff[lane] = h.soff; sc.h_ncodes[lane] = h.ncodes;
+            const uint32_t nblk = (h.ncodes + BLK_VALUES - 1) / BLK_VALUES;  // gap-coded lists of both kinds
+            sc.h_begin[lane] = h.begin; sc.h_body[lane] = h.body; sc.h_soff[lane] = h.soff; sc.h_ncodes[lane] = nblk;
             sc.h_score[lane] = h.type == D_ENC_COMPLEMENT ? -score : score;
-            const uint32_t incl = wave_incl_scan_u32(nseg);  // gap-coded lists of both kinds
+            const uint32_t incl = wave_incl_scan_u32(nblk);
+            const uint32_t excl = incl - nblk;
             sc.pref[lane] = incl;
-            const uint32_t total_seg = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t total_blk = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             wave_lds_sync();
 
             uint64_t mb = __ballot(h.type == D_ENC_BITMAP);
@@ -979,18 +1032,25 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
                 wave_lds_sync();
             }
 
-            for (uint32_t t0 = 0; t0 < total_seg; t0 += 64) {
-                const uint32_t t = t0 + lane;
-                if (t < total_seg) {
-                    const uint32_t i = upper_slot(sc.pref, t);
-                    const uint32_t nc = sc.h_ncodes[i];
-                    const uint32_t ns = (nc + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
-                    const uint32_t seg = t - (sc.pref[i] - ns);
-                    const uint32_t sv = (uint32_t)sc.h_score[i];
-                    decode_segment(c, sc.h_begin[i], sc.h_body[i], sc.h_soff[i], nc, seg, [&](uint32_t v) {
-                        atomicAdd(&SC[((v / PER) % PLANES) * W + (v >> 5)], sv << ((BITS & 31) * (v % PER)));
-                    });
+            for (uint32_t s0 = 0; s0 < total_blk; s0 += 64) {
+                BlockLane bl{0u, 0u, 0u, 0u, 0u};
+                const uint32_t s = s0 + lane;
+                if (s < total_blk) {
+                    const uint32_t i = owner_list(excl, min(64u, cnt - g), s);
+                    const uint32_t j = s - (sc.pref[i] - sc.h_ncodes[i]);
+                    const uint64_t hd = c.blk_hdr[sc.h_soff[i] + j];
+                    const uint64_t a = (uint64_t)(c.blk_words + sc.h_begin[i] + blk_rel_word(hd));
+                    bl.a_lo = (uint32_t)a;
+                    bl.a_hi = (uint32_t)(a >> 32);
+                    bl.start = blk_start(hd);
+                    bl.meta = blk_width(hd) | ((blk_count(hd) - 1u) << 5);
+                    bl.extra = (uint32_t)sc.h_score[i];
                 }
+                run_blocks(bl, min(64u, total_blk - s0), lane,
+                           [&](uint32_t v, uint32_t sv) {
+                               atomicAdd(&SC[((v / PER) % PLANES) * W + (v >> 5)], sv << ((BITS & 31) * (v % PER)));
+                           },
+                           [](uint32_t) {});
             }
             wave_lds_sync();
         }

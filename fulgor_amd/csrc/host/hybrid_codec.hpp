@@ -1,4 +1,4 @@
-// Encoder for the hybrid colour-set codec + decoder restart samples.
+// Encoder for the hybrid colour-set codec + the packed-block form the device decodes.
 //
 // Produces exactly the bit stream hybrid::builder::encode_color_set does in the reference
 // (include/color_sets/hybrid.hpp:37-95): delta(size), then
@@ -6,6 +6,7 @@
 //   size <  dense_thr  : raw bitmap of num_colors bits
 //   else               : delta(first missing), delta(gap-1)... over the num_colors-size missing colours
 #pragma once
+#include <stdexcept>
 #include <thread>
 #include "bits.hpp"
 #include "index_model.hpp"
@@ -75,7 +76,7 @@ inline int hybrid_header(const HybridSets& h, uint64_t id, uint32_t& size, uint3
     return ENC_COMPLEMENT;
 }
 
-// decode a whole set (host utility, used for export and samples)
+// decode a whole set (host utility)
 inline void hybrid_decode(const HybridSets& h, uint64_t id, std::vector<uint32_t>& out) {
     out.clear();
     uint32_t size, ncodes; uint64_t body;
@@ -102,19 +103,15 @@ inline void hybrid_decode(const HybridSets& h, uint64_t id, std::vector<uint32_t
     }
 }
 
-// restart samples for every gap-coded list (multi-threaded over lists)
-inline void hybrid_build_samples(HybridSets& h, unsigned nthreads = 0) {
+// packed 64-value blocks for every gap-coded list (multi-threaded over lists); see common/kmer_common.h
+inline void hybrid_build_blocks(HybridSets& h, unsigned nthreads = 0) {
     const uint64_t ns = h.num_sets();
-    h.sample_off.assign(ns + 1, 0);
+    if (h.num_colors > BLK_MAX_COLORS) throw std::runtime_error("more than 2^27 colours are not supported");
+    h.set_size.assign(ns, 0);
+    h.blk_first.assign(ns + 1, 0);
+    h.blk_wbase.assign(ns, 0);
+    std::vector<uint64_t> nwords(ns + 1, 0);
     if (nthreads == 0) nthreads = std::max(1u, std::thread::hardware_concurrency());
-    // pass 1: counts
-    auto count_range = [&](uint64_t a, uint64_t b) {
-        for (uint64_t id = a; id < b; ++id) {
-            uint32_t size, ncodes; uint64_t body;
-            hybrid_header(h, id, size, ncodes, body);
-            h.sample_off[id + 1] = ncodes ? (ncodes - 1) / SAMPLE_STRIDE : 0;
-        }
-    };
     auto run = [&](auto fn) {
         std::vector<std::thread> th;
         uint64_t chunk = (ns + nthreads - 1) / nthreads;
@@ -124,25 +121,52 @@ inline void hybrid_build_samples(HybridSets& h, unsigned nthreads = 0) {
         }
         for (auto& x : th) x.join();
     };
-    run(count_range);
-    for (uint64_t i = 0; i < ns; ++i) h.sample_off[i + 1] += h.sample_off[i];
-    h.samples.assign(h.sample_off[ns], 0);
-    auto fill_range = [&](uint64_t a, uint64_t b) {
-        for (uint64_t id = a; id < b; ++id) {
-            uint32_t size, ncodes; uint64_t body;
-            hybrid_header(h, id, size, ncodes, body);
-            if (ncodes <= SAMPLE_STRIDE) continue;
-            BitReader r(h.bits.data(), body);
-            uint32_t prev = 0xFFFFFFFFu;
-            uint64_t* dst = h.samples.data() + h.sample_off[id];
-            for (uint32_t i = 0; i < ncodes; ++i) {
-                prev = prev + 1 + (uint32_t)r.delta();
-                if ((i + 1) % SAMPLE_STRIDE == 0 && i + 1 < ncodes)
-                    *dst++ = ((uint64_t)prev << 32) | (uint32_t)(r.pos - h.offsets[id]);
-            }
+    // walks the blocks of one list: emit(start, width, count, values of the block)
+    auto walk = [&](uint64_t id, auto emit) {
+        uint32_t size, ncodes; uint64_t body;
+        hybrid_header(h, id, size, ncodes, body);
+        h.set_size[id] = size;
+        if (!ncodes) return;
+        BitReader r(h.bits.data(), body);
+        uint32_t prev = 0xFFFFFFFFu, vals[BLK_VALUES];
+        for (uint32_t done = 0; done < ncodes;) {
+            const uint32_t cnt = std::min(BLK_VALUES, ncodes - done), start = prev + 1;
+            for (uint32_t i = 0; i < cnt; ++i) { prev = prev + 1 + (uint32_t)r.delta(); vals[i] = prev; }
+            const uint32_t span = prev - start;
+            uint32_t width = 0;
+            while (width < 32 && (span >> width) != 0) ++width;
+            emit(start, width, cnt, vals);
+            done += cnt;
         }
     };
-    run(fill_range);
+    run([&](uint64_t a, uint64_t b) {
+        for (uint64_t id = a; id < b; ++id)
+            walk(id, [&](uint32_t, uint32_t width, uint32_t cnt, const uint32_t*) {
+                ++h.blk_first[id + 1];
+                nwords[id + 1] += ((uint64_t)cnt * width + 31) / 32;
+            });
+    });
+    for (uint64_t i = 0; i < ns; ++i) { h.blk_first[i + 1] += h.blk_first[i]; nwords[i + 1] += nwords[i]; }
+    for (uint64_t i = 0; i < ns; ++i) h.blk_wbase[i] = nwords[i];
+    h.blk_hdr.assign(h.blk_first[ns], 0);
+    h.blk_words.assign(nwords[ns] + 64, 0);  // a wave reads up to 64 * 27 bits + 1 word past a block's start
+    run([&](uint64_t a, uint64_t b) {
+        for (uint64_t id = a; id < b; ++id) {
+            uint64_t* hdr = h.blk_hdr.data() + h.blk_first[id];
+            uint32_t* base = h.blk_words.data() + h.blk_wbase[id];
+            uint64_t rel = 0;
+            walk(id, [&](uint32_t start, uint32_t width, uint32_t cnt, const uint32_t* vals) {
+                *hdr++ = blk_pack(start, width, cnt, (uint32_t)rel);
+                uint32_t* w = base + rel;
+                for (uint32_t i = 0; i < cnt && width; ++i) {
+                    const uint64_t f = (uint64_t)(vals[i] - start) << ((i * width) & 31);
+                    w[(i * width) >> 5] |= (uint32_t)f;
+                    if (f >> 32) w[((i * width) >> 5) + 1] |= (uint32_t)(f >> 32);
+                }
+                rel += ((uint64_t)cnt * width + 31) / 32;
+            });
+        }
+    });
 }
 
 }  // namespace fg

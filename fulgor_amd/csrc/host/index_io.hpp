@@ -82,7 +82,7 @@ inline void load_dump(const std::string& base, HostIndex& idx, uint32_t m = 0, u
             enc.encode(v.data(), v.size());
         }
         enc.finish(idx.hybrid);
-        hybrid_build_samples(idx.hybrid, nthreads);
+        hybrid_build_blocks(idx.hybrid, nthreads);
     }
     // unitigs
     std::string bases;
@@ -187,7 +187,7 @@ inline void load_binary(const std::string& path, HostIndex& idx) {
     HybridSets& h = idx.hybrid;
     rd(i, h.num_colors); rd(i, h.sparse_thr); rd(i, h.dense_thr); rd(i, h.nbits);
     rdv(i, h.offsets); rdv(i, h.bits);
-    hybrid_build_samples(h);
+    hybrid_build_blocks(h);
     if (idx.type != IDX_HYBRID) {
         GenericSets& g = idx.generic;
         g.type = idx.type;

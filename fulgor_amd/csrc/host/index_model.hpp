@@ -26,9 +26,14 @@ struct HybridSets {  // fulgor::hybrid, include/color_sets/hybrid.hpp:338-352
     std::vector<uint64_t> offsets;  // num_sets + 1 bit offsets into `bits`
     std::vector<uint64_t> bits;     // the bit vector, padded with 2 zero words
     uint64_t nbits = 0;
-    // acceleration structure built at load: decoder restart points every SAMPLE_STRIDE codes
-    std::vector<uint64_t> sample_off;  // num_sets + 1 indices into `samples`
-    std::vector<uint64_t> samples;     // {prev value : 32 | bit offset from list start : 32}
+    // Device-side form of the gap-coded lists, built at load (hybrid_build_blocks): every list is cut into
+    // blocks of 64 values, each stored as 64 fixed-width offsets from the block's first candidate value, so
+    // that one wavefront decodes a block in one step (lane i -> value i) instead of walking a universal code.
+    std::vector<uint32_t> set_size;    // num_sets: list sizes (the delta(size) header, decoded once)
+    std::vector<uint64_t> blk_first;   // num_sets + 1: first block header of every set (bitmap sets own none)
+    std::vector<uint64_t> blk_wbase;   // num_sets: first 32-bit word of the set's block data in blk_words
+    std::vector<uint64_t> blk_hdr;     // see blk_pack() in common/kmer_common.h
+    std::vector<uint32_t> blk_words;   // packed offsets, every block starts on a 32-bit word; 64 padding words
     uint64_t num_sets() const { return offsets.empty() ? 0 : offsets.size() - 1; }
 };
 

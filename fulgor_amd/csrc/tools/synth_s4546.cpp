@@ -254,9 +254,10 @@ int main(int argc, char** argv) {
             enc.encode(v.data(), v.size());
         }
         enc.finish(idx.hybrid);
-        hybrid_build_samples(idx.hybrid);
-        fprintf(stderr, "colour stream: %.1f MB, %.1f M integers, %zu samples\n", idx.hybrid.nbits / 8e6, ints / 1e6,
-                idx.hybrid.samples.size());
+        hybrid_build_blocks(idx.hybrid);
+        fprintf(stderr, "colour stream: %.1f MB, %.1f M integers; packed gap blocks: %zu blocks, %.1f MB\n",
+                idx.hybrid.nbits / 8e6, ints / 1e6, idx.hybrid.blk_hdr.size(),
+                (idx.hybrid.blk_hdr.size() * 8.0 + idx.hybrid.blk_words.size() * 4.0) / 1e6);
     }
     {
         std::vector<uint32_t> order(unitigs.size());
