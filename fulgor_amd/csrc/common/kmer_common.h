@@ -165,7 +165,13 @@ constexpr uint32_t SAMPLE_STRIDE = 16;
 // `start` (= previous value + 1, or 0 for the first block): v_i = start + field_i. Header word:
 //   start:27 | width:5 | count-1:6 | first data word, relative to the list's first data word:26
 // (so num_colors <= 2^27; a list owns fewer than n/4 codes, hence fewer than 2^26 data words).
+// Where a list is dense — its next 64 values fall within BLK_CHUNK_SPAN colours — the block is instead a
+// plain bitmap chunk: width = BLK_CHUNK_WIDTH, start = first colour rounded down to a multiple of 32,
+// count = number of 32-bit words (<= 64), holding ALL values of the list below start + BLK_CHUNK_SPAN.
+// A chunk is ORed into the result word-wise, one word per lane: no per-value work at all.
 constexpr uint32_t BLK_VALUES = 64;
+constexpr uint32_t BLK_CHUNK_WIDTH = 31;
+constexpr uint32_t BLK_CHUNK_SPAN = 64 * 32;
 constexpr uint32_t BLK_MAX_COLORS = 1u << 27;
 FG_HD uint64_t blk_pack(uint32_t start, uint32_t width, uint32_t count, uint32_t rel_word) {
     return (uint64_t)start | ((uint64_t)width << 27) | ((uint64_t)(count - 1) << 32) | ((uint64_t)rel_word << 38);

@@ -670,9 +670,10 @@ __device__ __forceinline__ ListHeader read_header(const DevColors& c, uint32_t i
     if (h.type == D_ENC_BITMAP) {
         h.begin = c.offsets[id];
         h.body = h.begin + delta_code_bits_fast(h.size);
-    } else {
+    } else {  // gap-coded on the host, packed blocks here: ncodes = number of blocks
         h.begin = h.body = c.blk_wbase[id];
         h.soff = c.blk_first[id];
+        h.ncodes = (uint32_t)(c.blk_first[id + 1] - h.soff);
     }
     return h;
 }
@@ -683,7 +684,7 @@ __device__ __forceinline__ ListHeader read_header(const DevColors& c, uint32_t i
 struct __attribute__((aligned(16))) ListDesc {
     uint64_t begin;   // bitmap list: bit offset of the list; gap-coded list: first data word in blk_words
     uint64_t soff;    // gap-coded list: first block header
-    uint32_t ncodes;  // values of a gap-coded list (0 for bitmap lists)
+    uint32_t ncodes;  // blocks of a gap-coded list (0 for bitmap lists)
     uint32_t meta;    // encoding | (body - begin) << 8
     int32_t score;    // positive k-mers that produced this id (threshold-union)
     uint32_t id;      // colour-set id
@@ -753,47 +754,55 @@ __device__ __forceinline__ uint32_t owner_list(uint32_t excl, uint32_t nlists, u
     return owner;
 }
 
-// Every lane requests the two words that hold its field of block q. The request is unconditional (lanes past
-// the block's count read inside the 64 padding words of blk_words) so that the number of loads in flight is
-// known at compile time and the wait before a block is consumed leaves the two younger requests outstanding.
+// Every lane requests the two words that hold its field of block q (word `lane` of a bitmap chunk). The
+// request is unconditional (lanes past the block's count read inside the 64 padding words of blk_words) so
+// that the number of loads in flight is known at compile time and the wait before a block is consumed leaves
+// the two younger requests outstanding.
 __device__ __forceinline__ uint2 block_fetch(const BlockLane& b, uint32_t q, int lane) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)b.a_lo, q), hi = (uint32_t)__builtin_amdgcn_readlane((int)b.a_hi, q);
-    const uint32_t width = (uint32_t)__builtin_amdgcn_readlane((int)b.meta, q) & 31u;
+    uint32_t width = (uint32_t)__builtin_amdgcn_readlane((int)b.meta, q) & 31u;
+    width += width == BLK_CHUNK_WIDTH;  // a chunk is read as 32-bit fields
     typedef const uint32_t __attribute__((address_space(1))) * global_words;  // keeps the request a global_load (vmcnt only)
     const global_words p = (global_words)((((uint64_t)hi << 32) | lo) + ((__umul24((uint32_t)lane, width) >> 3) & ~3u));
     return make_uint2(p[0], p[1]);
 }
 
-template <typename F, typename G>
-__device__ __forceinline__ void block_consume(const BlockLane& b, uint32_t q, int lane, uint2 w, F& per_value, G& after_block) {
+template <typename F, typename H, typename G>
+__device__ __forceinline__ void block_consume(const BlockLane& b, uint32_t q, int lane, uint2 w, F& per_value, H& per_word,
+                                              G& after_block) {
     const uint32_t mt = (uint32_t)__builtin_amdgcn_readlane((int)b.meta, q);
     const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)b.start, q);
     const uint32_t ex = (uint32_t)__builtin_amdgcn_readlane((int)b.extra, q);
     const uint32_t width = mt & 31u;
     // the field is cut out by all lanes (not only count of them) so that the wait for `w` is unconditional
     uint32_t f = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(w.y, w.x, __umul24((uint32_t)lane, width)), 0, width);
-    asm volatile("" : "+v"(f));  // (keeps the compiler from sinking the extraction into the branch below)
-    if ((uint32_t)lane <= ((mt >> 5) & 63u)) per_value(st + f, ex);
+    uint32_t x = w.x;
+    asm volatile("" : "+v"(f), "+v"(x));  // (keeps the compiler from sinking the extraction into the branches below)
+    if ((uint32_t)lane <= ((mt >> 5) & 63u)) {
+        if (width == BLK_CHUNK_WIDTH) per_word((st >> 5) + (uint32_t)lane, x, ex);
+        else per_value(st + f, ex);
+    }
     after_block(mt >> 11);
 }
 
-// per_value(v, extra of the block) for every value of blocks [0, steps) held by the lanes of `b` (steps >= 1);
+// per_value(v, extra of the block) for every value of the offset blocks, per_word(word index, bits, extra) for
+// every word of the bitmap chunks among blocks [0, steps) held by the lanes of `b` (steps >= 1);
 // after_block(flags) once per block (wave-uniform). Three register pairs rotate by unrolling, not by moves,
 // so a block is consumed while the requests of the next two are in flight.
-template <typename F, typename G>
-__device__ __forceinline__ void run_blocks(const BlockLane& b, uint32_t steps, int lane, F per_value, G after_block) {
+template <typename F, typename H, typename G>
+__device__ __forceinline__ void run_blocks(const BlockLane& b, uint32_t steps, int lane, F per_value, H per_word, G after_block) {
     const uint32_t last = steps - 1;
     uint2 c0 = block_fetch(b, 0, lane), c1 = block_fetch(b, min(1u, last), lane), c2;
     uint32_t q = 0;
     while (true) {
         c2 = block_fetch(b, min(q + 2, last), lane);
-        block_consume(b, q, lane, c0, per_value, after_block);
+        block_consume(b, q, lane, c0, per_value, per_word, after_block);
         if (++q > last) break;
         c0 = block_fetch(b, min(q + 2, last), lane);
-        block_consume(b, q, lane, c1, per_value, after_block);
+        block_consume(b, q, lane, c1, per_value, per_word, after_block);
         if (++q > last) break;
         c1 = block_fetch(b, min(q + 2, last), lane);
-        block_consume(b, q, lane, c2, per_value, after_block);
+        block_consume(b, q, lane, c2, per_value, per_word, after_block);
         if (++q > last) break;
     }
 }
@@ -869,7 +878,7 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint6
                 const ListDesc d = desc[off + g + lane];
                 h.type = desc_type(d); h.ncodes = d.ncodes; h.begin = d.begin; h.body = desc_body(d); h.soff = d.soff;
             }
-            const uint32_t nblk = (h.ncodes + BLK_VALUES - 1) / BLK_VALUES;  // 0 for bitmap lists
+            const uint32_t nblk = h.ncodes;  // 0 for bitmap lists
             const uint32_t incl = wave_incl_scan_u32(nblk);
             const uint32_t excl = incl - nblk;
             const uint32_t total_blk = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -906,6 +915,7 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint6
                 }
                 run_blocks(bl, min(64u, total_blk - s0), lane,
                            [&](uint32_t v, uint32_t) { atomicOr(&EXCL[v >> 5], 1u << (v & 31)); },
+                           [&](uint32_t wi, uint32_t x, uint32_t) { atomicOr(&EXCL[wi], x); },
                            [&](uint32_t last_of_sparse) {
                                if (last_of_sparse) {  // a colour absent from this sparse list is excluded; T goes back to zero
                                    wave_lds_sync();
@@ -1002,7 +1012,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
                 h.type = desc_type(d); h.ncodes = d.ncodes; h.begin = d.begin; h.body = desc_body(d); h.soff = d.soff;
                 score = d.score;
             }
-            const uint32_t nblk = (h.ncodes + BLK_VALUES - 1) / BLK_VALUES;  // gap-coded lists of both kinds
+            const uint32_t nblk = h.ncodes;  // gap-coded lists of both kinds
             sc.h_begin[lane] = h.begin; sc.h_body[lane] = h.body; sc.h_soff[lane] = h.soff; sc.h_ncodes[lane] = nblk;
             sc.h_score[lane] = h.type == D_ENC_COMPLEMENT ? -score : score;
             const uint32_t incl = wave_incl_scan_u32(nblk);
@@ -1049,6 +1059,16 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
                 run_blocks(bl, min(64u, total_blk - s0), lane,
                            [&](uint32_t v, uint32_t sv) {
                                atomicAdd(&SC[((v / PER) % PLANES) * W + (v >> 5)], sv << ((BITS & 31) * (v % PER)));
+                           },
+                           [&](uint32_t wi, uint32_t x, uint32_t sv) {  // only this lane touches these words
+#pragma unroll
+                               for (uint32_t q = 0; q < PLANES; ++q) {
+                                   uint32_t spread;
+                                   if (BITS == 8) spread = ((((x >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u) * sv;
+                                   else if (BITS == 16) spread = ((x >> (2 * q)) & 1u) * sv + ((((x >> (2 * q + 1)) & 1u) * sv) << 16);
+                                   else spread = ((x >> q) & 1u) * sv;
+                                   SC[q * W + wi] += spread;
+                               }
                            },
                            [](uint32_t) {});
             }

@@ -121,29 +121,40 @@ inline void hybrid_build_blocks(HybridSets& h, unsigned nthreads = 0) {
         }
         for (auto& x : th) x.join();
     };
-    // walks the blocks of one list: emit(start, width, count, values of the block)
-    auto walk = [&](uint64_t id, auto emit) {
+    // walks the blocks of one list: emit(start, width, count, nwords, values of the block, number of values)
+    auto walk = [&](uint64_t id, std::vector<uint32_t>& vals, auto emit) {
         uint32_t size, ncodes; uint64_t body;
         hybrid_header(h, id, size, ncodes, body);
         h.set_size[id] = size;
         if (!ncodes) return;
         BitReader r(h.bits.data(), body);
-        uint32_t prev = 0xFFFFFFFFu, vals[BLK_VALUES];
-        for (uint32_t done = 0; done < ncodes;) {
-            const uint32_t cnt = std::min(BLK_VALUES, ncodes - done), start = prev + 1;
-            for (uint32_t i = 0; i < cnt; ++i) { prev = prev + 1 + (uint32_t)r.delta(); vals[i] = prev; }
-            const uint32_t span = prev - start;
-            uint32_t width = 0;
-            while (width < 32 && (span >> width) != 0) ++width;
-            emit(start, width, cnt, vals);
-            done += cnt;
+        vals.resize(ncodes);
+        uint32_t prev = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < ncodes; ++i) { prev = prev + 1 + (uint32_t)r.delta(); vals[i] = prev; }
+        for (uint32_t i = 0; i < ncodes;) {
+            const uint32_t cnt = std::min(BLK_VALUES, ncodes - i);
+            const uint32_t origin = vals[i] & ~31u;
+            if (vals[i + cnt - 1] - origin < BLK_CHUNK_SPAN) {  // dense here: bitmap chunk
+                uint32_t j = i + cnt;
+                while (j < ncodes && vals[j] - origin < BLK_CHUNK_SPAN) ++j;
+                const uint32_t nw = ((vals[j - 1] - origin) >> 5) + 1;
+                emit(origin, BLK_CHUNK_WIDTH, nw, nw, vals.data() + i, j - i);
+                i = j;
+            } else {
+                const uint32_t start = i ? vals[i - 1] + 1 : 0u, span = vals[i + cnt - 1] - start;
+                uint32_t width = 0;
+                while ((span >> width) != 0) ++width;
+                emit(start, width, cnt, (uint32_t)(((uint64_t)cnt * width + 31) / 32), vals.data() + i, cnt);
+                i += cnt;
+            }
         }
     };
     run([&](uint64_t a, uint64_t b) {
+        std::vector<uint32_t> vals;
         for (uint64_t id = a; id < b; ++id)
-            walk(id, [&](uint32_t, uint32_t width, uint32_t cnt, const uint32_t*) {
+            walk(id, vals, [&](uint32_t, uint32_t, uint32_t, uint32_t nw, const uint32_t*, uint32_t) {
                 ++h.blk_first[id + 1];
-                nwords[id + 1] += ((uint64_t)cnt * width + 31) / 32;
+                nwords[id + 1] += nw;
             });
     });
     for (uint64_t i = 0; i < ns; ++i) { h.blk_first[i + 1] += h.blk_first[i]; nwords[i + 1] += nwords[i]; }
@@ -151,19 +162,24 @@ inline void hybrid_build_blocks(HybridSets& h, unsigned nthreads = 0) {
     h.blk_hdr.assign(h.blk_first[ns], 0);
     h.blk_words.assign(nwords[ns] + 64, 0);  // a wave reads up to 64 * 27 bits + 1 word past a block's start
     run([&](uint64_t a, uint64_t b) {
+        std::vector<uint32_t> vals;
         for (uint64_t id = a; id < b; ++id) {
             uint64_t* hdr = h.blk_hdr.data() + h.blk_first[id];
             uint32_t* base = h.blk_words.data() + h.blk_wbase[id];
             uint64_t rel = 0;
-            walk(id, [&](uint32_t start, uint32_t width, uint32_t cnt, const uint32_t* vals) {
+            walk(id, vals, [&](uint32_t start, uint32_t width, uint32_t cnt, uint32_t nw, const uint32_t* v, uint32_t nv) {
                 *hdr++ = blk_pack(start, width, cnt, (uint32_t)rel);
                 uint32_t* w = base + rel;
-                for (uint32_t i = 0; i < cnt && width; ++i) {
-                    const uint64_t f = (uint64_t)(vals[i] - start) << ((i * width) & 31);
-                    w[(i * width) >> 5] |= (uint32_t)f;
-                    if (f >> 32) w[((i * width) >> 5) + 1] |= (uint32_t)(f >> 32);
+                if (width == BLK_CHUNK_WIDTH) {
+                    for (uint32_t i = 0; i < nv; ++i) w[(v[i] - start) >> 5] |= 1u << ((v[i] - start) & 31);
+                } else {
+                    for (uint32_t i = 0; i < nv && width; ++i) {
+                        const uint64_t f = (uint64_t)(v[i] - start) << ((i * width) & 31);
+                        w[(i * width) >> 5] |= (uint32_t)f;
+                        if (f >> 32) w[((i * width) >> 5) + 1] |= (uint32_t)(f >> 32);
+                    }
                 }
-                rel += ((uint64_t)cnt * width + 31) / 32;
+                rel += nw;
             });
         }
     });
