@@ -177,8 +177,7 @@ void upload_index(fgpu_index* ix) {
     HIP_TRY(hipStreamSynchronize(s));
     ix->dd = DevDict{ix->d_strings.as<uint64_t>(), ix->d_pilots.as<uint16_t>(), ix->d_slots.as<uint64_t>(),
                      ix->d_overflow.as<uint64_t>(), d.num_buckets, d.num_slots, d.k, d.m, d.seed};
-    uint32_t w32 = (h.num_colors + 31) / 32;
-    w32 += w32 & 1;
+    const uint32_t w32 = ((h.num_colors + 31) / 32 + 3) & ~3u;  // result bitmaps move as 128-bit groups
     ix->dc = DevColors{ix->d_bits.as<uint64_t>(), ix->d_offsets.as<uint64_t>(), ix->d_set_size.as<uint32_t>(),
                        ix->d_blk_first.as<uint64_t>(), ix->d_blk_wbase.as<uint64_t>(), ix->d_blk_hdr.as<uint64_t>(),
                        ix->d_blk_words.as<uint32_t>(), h.num_colors, h.sparse_thr, h.dense_thr, w32};

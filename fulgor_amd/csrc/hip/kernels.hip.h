@@ -36,7 +36,7 @@ struct DevColors {
     const uint64_t* blk_hdr;
     const uint32_t* blk_words;
     uint32_t n, sparse_thr, dense_thr;
-    uint32_t w32;  // 32-bit words per result bitmap, rounded up to an even number
+    uint32_t w32;  // 32-bit words per result bitmap, rounded up to a multiple of 4
 };
 
 constexpr uint32_t NEG = 0xFFFFFFFFu;
@@ -838,106 +838,140 @@ __device__ __forceinline__ WaveScratch carve_scratch(unsigned char* p) {
 //   sparse lists      : the list sets its bits in the plane T; after its last block EXCL |= ~T and T = 0
 // so every value of every gap-coded list ORs one bit into LDS, and all blocks of all lists of the read run
 // through one loop (run_blocks), one block of up to 64 values per step.
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t src) {  // src wave-uniform
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+}
+__device__ __forceinline__ uint4 or_not(uint4 e, uint4 x) { return make_uint4(e.x | ~x.x, e.y | ~x.y, e.z | ~x.z, e.w | ~x.w); }
+
 __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint64_t* __restrict__ id_csr,
                                                      const ListDesc* __restrict__ desc, uint64_t n_reads,
                                                      uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count,
                                                      unsigned int* tickets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    const uint32_t W = c.w32;
+    const uint32_t W = c.w32, W4 = W >> 2;  // W is a multiple of 4: the bitmaps move as 128-bit groups
     const uint32_t per_wave = 2 * W * 4 + wave_scratch_bytes();
     unsigned char* mine = smem + (size_t)wv * per_wave;
     WaveScratch sc = carve_scratch(mine);
     uint32_t* EXCL = (uint32_t*)(mine + wave_scratch_bytes());
-    uint32_t* T = EXCL + W;  // all zero between sparse lists
-    const WorkQueue wq{tickets, n_reads, 8};
+    uint4* EX4 = (uint4*)EXCL;
+    uint4* T4 = EX4 + W4;  // the plane T, all zero between sparse lists
+    constexpr uint32_t BATCH = 8;
+    const WorkQueue wq{tickets, n_reads, BATCH};
     uint64_t t_first;
     uint32_t t_count;
+    const uint32_t n = c.n, tail_word = n >> 5, tail_mask = ~((1u << (n & 31u)) - 1u);
+    const ListDesc none{0, 0, 0, (uint32_t)D_ENC_NONE & 0xFFu, 0, 0};
 
-    for (uint32_t w = lane; w < W; w += 64) T[w] = 0;
+    for (uint32_t g4 = lane; g4 < W4; g4 += 64) T4[g4] = make_uint4(0u, 0u, 0u, 0u);
     wave_lds_sync();
 
-    while (wq.pull(t_first, t_count))
-    for (uint64_t r = t_first; r < t_first + t_count; ++r) {
-        const uint64_t off = id_csr[r];
-        const uint32_t cnt = (uint32_t)(id_csr[r + 1] - off);
-        uint32_t* bm = out_bitmap + r * W;
-        if (cnt == 0) {
-            for (uint32_t w = lane; w < W; w += 64) bm[w] = 0;
-            if (lane == 0) out_count[r] = 0;
-            continue;
-        }
-        for (uint32_t w = lane; w < W; w += 64) {  // colours >= n start excluded
-            const uint32_t lo = w * 32;
-            EXCL[w] = lo >= c.n ? 0xFFFFFFFFu : (c.n - lo >= 32 ? 0u : ~((1u << (c.n - lo)) - 1u));
-        }
-        for (uint32_t g = 0; g < cnt; g += 64) {
-            ListHeader h;
-            h.type = D_ENC_NONE; h.ncodes = 0; h.begin = h.body = h.soff = 0; h.size = 0;
-            if (g + lane < cnt) {
-                const ListDesc d = desc[off + g + lane];
-                h.type = desc_type(d); h.ncodes = d.ncodes; h.begin = d.begin; h.body = desc_body(d); h.soff = d.soff;
-            }
-            const uint32_t nblk = h.ncodes;  // 0 for bitmap lists
-            const uint32_t incl = wave_incl_scan_u32(nblk);
-            const uint32_t excl = incl - nblk;
-            const uint32_t total_blk = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            sc.h_begin[lane] = h.begin; sc.h_body[lane] = h.body; sc.h_soff[lane] = h.soff;
-            sc.h_ncodes[lane] = nblk | (h.type == D_ENC_DELTA_GAPS ? 0x80000000u : 0u);
-            sc.pref[lane] = incl;
-            wave_lds_sync();
-
-            // bitmap lists: exclude what they do not contain
-            uint64_t mb = __ballot(h.type == D_ENC_BITMAP);
-            while (mb) {
-                const int src = __builtin_ctzll(mb);
-                mb &= mb - 1;
-                const uint64_t body = sc.h_body[src];
-                for (uint32_t w = lane; w * 32 < c.n; w += 64) EXCL[w] |= ~(uint32_t)bits_window(c.bits, body + 32ull * w);
-            }
-            wave_lds_sync();
-
-            for (uint32_t s0 = 0; s0 < total_blk; s0 += 64) {
-                BlockLane bl{0u, 0u, 0u, 0u, 0u};
-                const uint32_t s = s0 + lane;
-                if (s < total_blk) {
-                    const uint32_t i = owner_list(excl, min(64u, cnt - g), s);
-                    const uint32_t nb = sc.h_ncodes[i];
-                    const uint32_t j = s - (sc.pref[i] - (nb & 0x7FFFFFFFu));
-                    const uint64_t hd = c.blk_hdr[sc.h_soff[i] + j];
-                    const uint64_t a = (uint64_t)(c.blk_words + sc.h_begin[i] + blk_rel_word(hd));
-                    const bool sparse = (nb >> 31) != 0;
-                    bl.a_lo = (uint32_t)a;
-                    bl.a_hi = (uint32_t)(a >> 32);
-                    bl.start = blk_start(hd) + (sparse ? W * 32u : 0u);  // bit index relative to EXCL
-                    bl.meta = blk_width(hd) | ((blk_count(hd) - 1u) << 5) |
-                              ((sparse && j + 1 == (nb & 0x7FFFFFFFu)) ? 1u << 11 : 0u);
+    while (wq.pull(t_first, t_count)) {
+        // id_csr[t_first ...] in the lanes; the descriptors of a read are requested one read ahead
+        const uint64_t csr_l = id_csr[min(t_first + (uint64_t)lane, n_reads)];
+        uint64_t off = readlane_u64(csr_l, 0), nxt = readlane_u64(csr_l, 1);
+        ListDesc dcur = none;
+        if ((uint64_t)lane < nxt - off) dcur = desc[off + lane];
+        for (uint32_t ri = 0; ri < t_count; ++ri) {
+            const uint64_t r = t_first + ri;
+            const uint32_t cnt = (uint32_t)(nxt - off);
+            const uint64_t nxt2 = readlane_u64(csr_l, ri + 2);  // (== nxt past the last read)
+            ListDesc dnext = none;
+            if ((uint64_t)lane < nxt2 - nxt) dnext = desc[nxt + lane];
+            uint4* bm4 = (uint4*)(out_bitmap + r * W);
+            if (cnt == 0) {
+                for (uint32_t g4 = lane; g4 < W4; g4 += 64) bm4[g4] = make_uint4(0u, 0u, 0u, 0u);
+                if (lane == 0) out_count[r] = 0;
+            } else {
+                for (uint32_t g4 = lane; g4 < W4; g4 += 64) {  // colours >= n start excluded
+                    const uint32_t w = 4 * g4;
+                    EX4[g4] = make_uint4(w < tail_word ? 0u : (w == tail_word ? tail_mask : 0xFFFFFFFFu),
+                                         w + 1 < tail_word ? 0u : (w + 1 == tail_word ? tail_mask : 0xFFFFFFFFu),
+                                         w + 2 < tail_word ? 0u : (w + 2 == tail_word ? tail_mask : 0xFFFFFFFFu),
+                                         w + 3 < tail_word ? 0u : (w + 3 == tail_word ? tail_mask : 0xFFFFFFFFu));
                 }
-                run_blocks(bl, min(64u, total_blk - s0), lane,
-                           [&](uint32_t v, uint32_t) { atomicOr(&EXCL[v >> 5], 1u << (v & 31)); },
-                           [&](uint32_t wi, uint32_t x, uint32_t) { atomicOr(&EXCL[wi], x); },
-                           [&](uint32_t last_of_sparse) {
-                               if (last_of_sparse) {  // a colour absent from this sparse list is excluded; T goes back to zero
-                                   wave_lds_sync();
-                                   for (uint32_t w = lane; w < W; w += 64) {
-                                       EXCL[w] |= ~T[w];
-                                       T[w] = 0;
-                                   }
-                                   wave_lds_sync();
-                               }
-                           });
+                for (uint32_t g = 0; g < cnt; g += 64) {
+                    ListDesc d = dcur;
+                    if (g) {
+                        d = none;
+                        if (g + lane < cnt) d = desc[off + g + lane];
+                    }
+                    const int type = (int)(int8_t)(d.meta & 0xFFu);
+                    const uint32_t nblk = d.ncodes;  // 0 for bitmap lists
+                    const uint32_t incl = wave_incl_scan_u32(nblk);
+                    const uint32_t excl = incl - nblk;
+                    const uint32_t total_blk = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    sc.h_begin[lane] = d.begin; sc.h_body[lane] = desc_body(d); sc.h_soff[lane] = d.soff;
+                    sc.h_ncodes[lane] = nblk | (type == D_ENC_DELTA_GAPS ? 0x80000000u : 0u);
+                    sc.pref[lane] = incl;
+                    wave_lds_sync();
+
+                    // bitmap lists: exclude what they do not contain (lane = 128 bits of the list)
+                    uint64_t mb = __ballot(type == D_ENC_BITMAP);
+                    while (mb) {
+                        const int src = __builtin_ctzll(mb);
+                        mb &= mb - 1;
+                        const uint64_t body = sc.h_body[src];
+                        const uint32_t* words = (const uint32_t*)c.bits + (body >> 5);
+                        const uint32_t sh = (uint32_t)body & 31u;
+                        for (uint32_t g4 = lane; g4 * 128 < n; g4 += 64) {
+                            const uint32_t* p = words + 4 * g4;  // (c.bits carries 256 padding bits)
+                            const uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4];
+                            const uint4 x = make_uint4(__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh),
+                                                       __builtin_amdgcn_alignbit(w3, w2, sh), __builtin_amdgcn_alignbit(w4, w3, sh));
+                            EX4[g4] = or_not(EX4[g4], x);
+                        }
+                    }
+                    wave_lds_sync();
+
+                    for (uint32_t s0 = 0; s0 < total_blk; s0 += 64) {
+                        BlockLane bl{0u, 0u, 0u, 0u, 0u};
+                        const uint32_t s = s0 + lane;
+                        if (s < total_blk) {
+                            const uint32_t i = owner_list(excl, min(64u, cnt - g), s);
+                            const uint32_t nb = sc.h_ncodes[i];
+                            const uint32_t j = s - (sc.pref[i] - (nb & 0x7FFFFFFFu));
+                            const uint64_t hd = c.blk_hdr[sc.h_soff[i] + j];
+                            const uint64_t a = (uint64_t)(c.blk_words + sc.h_begin[i] + blk_rel_word(hd));
+                            const bool sparse = (nb >> 31) != 0;
+                            bl.a_lo = (uint32_t)a;
+                            bl.a_hi = (uint32_t)(a >> 32);
+                            bl.start = blk_start(hd) + (sparse ? W * 32u : 0u);  // bit index relative to EXCL
+                            bl.meta = blk_width(hd) | ((blk_count(hd) - 1u) << 5) |
+                                      ((sparse && j + 1 == (nb & 0x7FFFFFFFu)) ? 1u << 11 : 0u);
+                        }
+                        run_blocks(bl, min(64u, total_blk - s0), lane,
+                                   [&](uint32_t v, uint32_t) { atomicOr(&EXCL[v >> 5], 1u << (v & 31)); },
+                                   [&](uint32_t wi, uint32_t x, uint32_t) { atomicOr(&EXCL[wi], x); },
+                                   [&](uint32_t last_of_sparse) {
+                                       if (last_of_sparse) {  // a colour absent from this sparse list is excluded; T goes back to zero
+                                           wave_lds_sync();
+                                           for (uint32_t g4 = lane; g4 < W4; g4 += 64) {
+                                               EX4[g4] = or_not(EX4[g4], T4[g4]);
+                                               T4[g4] = make_uint4(0u, 0u, 0u, 0u);
+                                           }
+                                           wave_lds_sync();
+                                       }
+                                   });
+                    }
+                    wave_lds_sync();
+                }
+                uint32_t pc = 0;
+                for (uint32_t g4 = lane; g4 < W4; g4 += 64) {
+                    const uint4 e = EX4[g4];
+                    const uint4 x = make_uint4(~e.x, ~e.y, ~e.z, ~e.w);
+                    bm4[g4] = x;
+                    pc += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
+                }
+                pc = wave_sum_u32(pc);
+                if (lane == 0) out_count[r] = pc;
+                wave_lds_sync();
             }
-            wave_lds_sync();
+            off = nxt;
+            nxt = nxt2;
+            dcur = dnext;
         }
-        uint32_t pc = 0;
-        for (uint32_t w = lane; w < W; w += 64) {
-            const uint32_t x = ~EXCL[w];
-            bm[w] = x;
-            pc += __popc(x);
-        }
-        pc = wave_sum_u32(pc);
-        if (lane == 0) out_count[r] = pc;
-        wave_lds_sync();
     }
 }
 

@@ -60,7 +60,7 @@ struct HybridEncoder {
         h.offsets.swap(offsets);
         h.nbits = bw.nbits;
         h.bits.swap(bw.words);
-        h.bits.resize((h.nbits + 63) / 64 + 2, 0);
+        h.bits.resize((h.nbits + 63) / 64 + 4, 0);
     }
 };
 

@@ -187,6 +187,7 @@ inline void load_binary(const std::string& path, HostIndex& idx) {
     HybridSets& h = idx.hybrid;
     rd(i, h.num_colors); rd(i, h.sparse_thr); rd(i, h.dense_thr); rd(i, h.nbits);
     rdv(i, h.offsets); rdv(i, h.bits);
+    h.bits.resize((h.nbits + 63) / 64 + 4, 0);  // the device reads up to 256 bits past a bitmap list
     hybrid_build_blocks(h);
     if (idx.type != IDX_HYBRID) {
         GenericSets& g = idx.generic;

@@ -24,7 +24,7 @@ struct HybridSets {  // fulgor::hybrid, include/color_sets/hybrid.hpp:338-352
     uint32_t sparse_thr = 0;  // m_sparse_set_threshold_size      = u32(0.25 * n)
     uint32_t dense_thr = 0;   // m_very_dense_set_threshold_size  = u32(0.75 * n)
     std::vector<uint64_t> offsets;  // num_sets + 1 bit offsets into `bits`
-    std::vector<uint64_t> bits;     // the bit vector, padded with 2 zero words
+    std::vector<uint64_t> bits;     // the bit vector, padded with 4 zero words
     uint64_t nbits = 0;
     // Device-side form of the gap-coded lists, built at load (hybrid_build_blocks): every list is cut into
     // blocks of 64 values, each stored as 64 fixed-width offsets from the block's first candidate value, so
