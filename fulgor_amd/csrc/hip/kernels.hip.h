@@ -982,12 +982,23 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint6
 // -= score for the missing colours of complemented lists while min_score is lowered by that score;
 // keep c iff scores[c] >= min_score. min_score = uint64(double(#positive k-mers) * tau) (:389).
 // Scores live in LDS as small biased counters: BITS = 8 for reads of at most 127 k-mers (4 per word, 8
-// planes of W words), 16 up to 32767 k-mers (2 per word, 16 planes), 32 beyond; colour c -> plane (c / PER) % PLANES, word
-// c / 32, field c % PER: bitmap lists and the final pass touch every plane conflict-free. The counters
+// planes of W words), 16 up to 32767 k-mers (2 per word, 16 planes), 32 beyond; colour c -> plane c % PLANES, word
+// c / 32, field (c % 32) / PLANES: the colours of bitmap word x that live in plane q are (x >> q) & ONES, one
+// shift and one mask without any multiply, and the result bits of plane q go back as (sign bits) << q. The counters
 // start at HALF - min_score + (total score of complemented lists), so that
 //     score[c] >= min_score   <=>   counter[c] >= HALF   <=>   top bit of the field set,
 // and they never leave [0, 2*HALF) because 0 <= min_score <= #positive k-mers < HALF. A signed score is
 // added as a 32-bit two's complement shifted to the field: fields cannot borrow from each other.
+// score `mag` (negated when neg = ~0) for the colours of bitmap word x that live in counter plane q
+template <int BITS>
+__device__ __forceinline__ uint32_t counter_spread(uint32_t x, uint32_t q, uint32_t mag, uint32_t neg) {
+    constexpr uint32_t ONES = BITS == 8 ? 0x01010101u : (BITS == 16 ? 0x00010001u : 1u);
+    const uint32_t t = (x >> q) & ONES;                                            // one flag per field
+    const uint32_t full = BITS == 32 ? 0u - t : (t << (BITS & 31)) - t;            // all-ones fields where flagged
+    const uint32_t v = full & (mag * ONES);
+    return (v ^ neg) - neg;
+}
+
 template <int BITS>
 __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a_union(DevColors c, const uint32_t* __restrict__ npos,
                                                                   const uint64_t* __restrict__ id_csr,
@@ -1065,13 +1076,8 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
                     uint32_t x = (uint32_t)bits_window(c.bits, body + 32ull * w);
                     if (n - w * 32 < 32) x &= (1u << (n - w * 32)) - 1u;
 #pragma unroll
-                    for (uint32_t q = 0; q < PLANES; ++q) {  // only this lane touches these words
-                        uint32_t spread;
-                        if (BITS == 8) spread = ((((x >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u) * s;
-                        else if (BITS == 16) spread = ((x >> (2 * q)) & 1u) * s + ((((x >> (2 * q + 1)) & 1u) * s) << 16);
-                        else spread = ((x >> q) & 1u) * s;
-                        SC[q * W + w] += spread;
-                    }
+                    for (uint32_t q = 0; q < PLANES; ++q)  // only this lane touches these words
+                        atomicAdd(&SC[q * W + w], counter_spread<BITS>(x, q, s, 0u));
                 }
                 wave_lds_sync();
             }
@@ -1092,17 +1098,12 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
                 }
                 run_blocks(bl, min(64u, total_blk - s0), lane,
                            [&](uint32_t v, uint32_t sv) {
-                               atomicAdd(&SC[((v / PER) % PLANES) * W + (v >> 5)], sv << ((BITS & 31) * (v % PER)));
+                               atomicAdd(&SC[(v % PLANES) * W + (v >> 5)], sv << ((BITS & 31) * ((v & 31u) / PLANES)));
                            },
                            [&](uint32_t wi, uint32_t x, uint32_t sv) {  // only this lane touches these words
+                               const uint32_t neg = (uint32_t)((int32_t)sv >> 31), mag = (sv ^ neg) - neg;
 #pragma unroll
-                               for (uint32_t q = 0; q < PLANES; ++q) {
-                                   uint32_t spread;
-                                   if (BITS == 8) spread = ((((x >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u) * sv;
-                                   else if (BITS == 16) spread = ((x >> (2 * q)) & 1u) * sv + ((((x >> (2 * q + 1)) & 1u) * sv) << 16);
-                                   else spread = ((x >> q) & 1u) * sv;
-                                   SC[q * W + wi] += spread;
-                               }
+                               for (uint32_t q = 0; q < PLANES; ++q) atomicAdd(&SC[q * W + wi], counter_spread<BITS>(x, q, mag, neg));
                            },
                            [](uint32_t) {});
             }
@@ -1110,8 +1111,8 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
         }
         if (scores_out) {  // counter = HALF - min_score + score  =>  score = counter - HALF + min_score
             for (uint32_t cc = lane; cc < n; cc += 64) {
-                const uint32_t x = SC[((cc / PER) % PLANES) * W + (cc >> 5)];
-                const uint32_t field = BITS == 32 ? x : ((x >> ((BITS & 31) * (cc % PER))) & ((1u << (BITS & 31)) - 1u));
+                const uint32_t x = SC[(cc % PLANES) * W + (cc >> 5)];
+                const uint32_t field = BITS == 32 ? x : ((x >> ((BITS & 31) * ((cc & 31u) / PLANES))) & ((1u << (BITS & 31)) - 1u));
                 scores_out[r * (uint64_t)n + cc] = field - HALF + min_score;
             }
         }
@@ -1119,12 +1120,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
         for (uint32_t w = lane; w < W; w += 64) {
             uint32_t m = 0;
 #pragma unroll
-            for (uint32_t q = 0; q < PLANES; ++q) {
-                const uint32_t x = SC[q * W + w];
-                if (BITS == 8) m |= ((((x >> 7) & 0x01010101u) * 0x00204081u >> 21) & 0xFu) << (4 * q);
-                else if (BITS == 16) m |= (((x >> 15) & 1u) | ((x >> 30) & 2u)) << (2 * q);
-                else m |= (x >> 31) << q;
-            }
+            for (uint32_t q = 0; q < PLANES; ++q) m |= ((SC[q * W + w] >> (BITS - 1)) & ONES) << q;
             const uint32_t lo = w * 32;
             m &= lo >= n ? 0u : (n - lo >= 32 ? 0xFFFFFFFFu : ((1u << (n - lo)) - 1u));
             bm[w] = m;
