@@ -339,16 +339,21 @@ __global__ __launch_bounds__(256, 6) void k1_lookup_short(DevDict d, const uint8
                                                        uint32_t* __restrict__ cnt_pool, uint32_t stride, unsigned int* tickets,
                                                        uint32_t* __restrict__ kmer_out) {
     constexpr int KMAX = 128;
-    __shared__ uint32_t s_ord[4][144];  // (24-bit order << 4) of the canonical m-mer at every base
+    // sliding-window minima by doubling: entry p = (24-bit order << 8 | tie-break position) of the best m-mer in
+    // [p, p + span), span = 1, 2, 4, 8; L breaks ties to the left (position p), R to the right (255 - p)
+    __shared__ uint32_t s_minL[4][152];
+    __shared__ uint32_t s_minR[4][152];
     __shared__ uint32_t s_ids[4][KMAX];
     __shared__ uint32_t s_uid[4][KMAX];
     __shared__ uint32_t s_ucnt[4][KMAX];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    uint32_t* ord = s_ord[wv];
+    uint32_t* mL = s_minL[wv];
+    uint32_t* mR = s_minR[wv];
     uint32_t* ids = s_ids[wv];
     uint32_t* uid = s_uid[wv];
     uint32_t* ucnt = s_ucnt[wv];
     const uint32_t k = d.k, m = d.m, W = W13 ? 13u : k - m + 1;
+    const uint32_t span = W13 ? 8u : 1u << (31 - __builtin_clz(W));  // largest power of two <= W (W <= 16)
     const uint32_t km = k - m;
     const WorkQueue wq{tickets, n_reads, 8};
     uint64_t t_first;
@@ -381,11 +386,36 @@ __global__ __launch_bounds__(256, 6) void k1_lookup_short(DevDict d, const uint8
             const uint64_t loB = __ballot(c1 <= 3 && (c1 & 1)), hiB = __ballot(c1 <= 3 && (c1 & 2)), nvB = __ballot(c1 > 3);
             const uint64_t loC = __ballot(c2 <= 3 && (c2 & 1)), hiC = __ballot(c2 <= 3 && (c2 & 2)), nvC = __ballot(c2 > 3);
 
-            ord[lane] = order24(canonical_key(extract128(loA, loB, lane, m), extract128(hiA, hiB, lane, m), m)) << 4;
-            ord[64 + lane] = order24(canonical_key(extract128(loB, loC, lane, m), extract128(hiB, hiC, lane, m), m)) << 4;
-            if (lane < 16)
-                ord[128 + lane] = order24(canonical_key((uint32_t)(loC >> lane) & low_mask32(m), (uint32_t)(hiC >> lane) & low_mask32(m), m)) << 4;
+            // window minima of the m-mer order over [i, i + W): W - 1 comparisons per k-mer become log2(span) + 1
+            uint32_t l0, l1, l2 = 0, r0, r1, r2 = 0;
+            {
+                const uint32_t o0 = order24(canonical_key(extract128(loA, loB, lane, m), extract128(hiA, hiB, lane, m), m)) << 8;
+                const uint32_t o1 = order24(canonical_key(extract128(loB, loC, lane, m), extract128(hiB, hiC, lane, m), m)) << 8;
+                l0 = o0 | (uint32_t)lane; r0 = o0 | (255u - lane);
+                l1 = o1 | (64u + lane); r1 = o1 | (191u - lane);
+                mL[lane] = l0; mR[lane] = r0;
+                mL[64 + lane] = l1; mR[64 + lane] = r1;
+                if (lane < 16) {
+                    const uint32_t o2 = order24(canonical_key((uint32_t)(loC >> lane) & low_mask32(m), (uint32_t)(hiC >> lane) & low_mask32(m), m)) << 8;
+                    l2 = o2 | (128u + lane); r2 = o2 | (127u - lane);
+                    mL[128 + lane] = l2; mR[128 + lane] = r2;
+                }
+            }
             wave_lds_sync();
+#pragma unroll
+            for (uint32_t st = 1; st < span; st <<= 1) {  // in place: every lane reads before any lane writes
+                const uint32_t a0 = mL[lane + st], a1 = mL[64 + lane + st], b0 = mR[lane + st], b1 = mR[64 + lane + st];
+                uint32_t a2 = 0, b2 = 0;
+                if (lane < 16) { a2 = mL[128 + lane + st]; b2 = mR[128 + lane + st]; }
+                l0 = min(l0, a0); l1 = min(l1, a1); r0 = min(r0, b0); r1 = min(r1, b1);
+                mL[lane] = l0; mR[lane] = r0;
+                mL[64 + lane] = l1; mR[64 + lane] = r1;
+                if (lane < 16) {
+                    l2 = min(l2, a2); r2 = min(r2, b2);
+                    mL[128 + lane] = l2; mR[128 + lane] = r2;
+                }
+                wave_lds_sync();
+            }
 
             bool valid[2];
             uint32_t klo[2], khi[2], rlo[2], rhi[2], jL[2], jR[2], csid[2];
@@ -400,31 +430,17 @@ __global__ __launch_bounds__(256, 6) void k1_lookup_short(DevDict d, const uint8
                 rlo[a] = rc_plane(klo[a], k);
                 rhi[a] = rc_plane(khi[a], k);
             }
-            uint32_t bL[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, bR[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-            if (W13) {
-#pragma unroll
-                for (uint32_t jj = 0; jj < 13; ++jj) {
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        const uint32_t o = ord[64 * a + lane + jj];
-                        bL[a] = min(bL[a], o | jj);
-                        bR[a] = min(bR[a], o | (15u - jj));
-                    }
-                }
-            } else {
-                for (uint32_t jj = 0; jj < W; ++jj) {
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        const uint32_t o = ord[64 * a + lane + jj];
-                        bL[a] = min(bL[a], o | jj);
-                        bR[a] = min(bR[a], o | (15u - jj));
-                    }
-                }
+            {
+                const uint32_t tail = W - span;  // [i, i + span) and [i + W - span, i + W) cover the window
+                const uint32_t bL0 = min(l0, mL[lane + tail]), bL1 = min(l1, mL[64 + lane + tail]);
+                const uint32_t bR0 = min(r0, mR[lane + tail]), bR1 = min(r1, mR[64 + lane + tail]);
+                jL[0] = (bL0 & 255u) - (uint32_t)lane;
+                jL[1] = (bL1 & 255u) - (64u + lane);
+                jR[0] = (255u - (bR0 & 255u)) - (uint32_t)lane;
+                jR[1] = (255u - (bR1 & 255u)) - (64u + lane);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                jL[a] = bL[a] & 15u;
-                jR[a] = 15u - (bR[a] & 15u);
                 // canonical keys of the leftmost / rightmost smallest m-mer, cut out of the k-mer itself
                 hL[a] = canonical_key((klo[a] >> jL[a]) & low_mask32(m), (khi[a] >> jL[a]) & low_mask32(m), m);
                 hR[a] = jR[a] == jL[a] ? hL[a]
