@@ -71,7 +71,7 @@ struct fgpu_index {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 256;
-    DevBuf d_strings, d_pilots, d_slots, d_overflow, d_bits, d_offsets, d_set_size, d_blk_first, d_blk_wbase, d_blk_hdr, d_blk_words;
+    DevBuf d_strings, d_pilots, d_slots, d_overflow, d_bits, d_offsets, d_set_desc, d_blk_hdr, d_blk_words;
     DevBuf d_gbits, d_gops, d_gset_ops_off, d_gset_ops, d_gsamples, d_gset_bytes;
     DevDict dd{};
     DevColors dc{};
@@ -169,18 +169,36 @@ void upload_index(fgpu_index* ix) {
     upload(ix->d_overflow, d.overflow, s);
     upload(ix->d_bits, h.bits, s);
     upload(ix->d_offsets, h.offsets, s);
-    upload(ix->d_set_size, h.set_size, s);
-    upload(ix->d_blk_first, h.blk_first, s);
-    upload(ix->d_blk_wbase, h.blk_wbase, s);
+    {  // one resolved descriptor per colour set: everything a kernel needs about a list behind one gather
+        std::vector<ListDesc> sd(h.num_sets());
+        for (uint64_t id = 0; id < sd.size(); ++id) {
+            const uint32_t size = h.set_size[id];
+            ListDesc& d = sd[id];
+            d.score = 0;
+            d.id = (uint32_t)id;
+            if (size >= h.sparse_thr && size < h.dense_thr) {  // bitmap list: bit offsets into the stream
+                d.begin = h.offsets[id];
+                d.soff = 0;
+                d.ncodes = 0;
+                d.meta = (uint32_t)D_ENC_BITMAP | (delta_code_bits(size) << 8);
+            } else {  // gap-coded on the host, packed blocks here
+                d.begin = h.blk_wbase[id];
+                d.soff = h.blk_first[id];
+                d.ncodes = (uint32_t)(h.blk_first[id + 1] - h.blk_first[id]);
+                d.meta = (uint32_t)(size < h.sparse_thr ? D_ENC_DELTA_GAPS : D_ENC_COMPLEMENT);
+            }
+        }
+        upload(ix->d_set_desc, sd, s);
+        HIP_TRY(hipStreamSynchronize(s));  // sd is released at the end of this block
+    }
     upload(ix->d_blk_hdr, h.blk_hdr, s);
     upload(ix->d_blk_words, h.blk_words, s);
     HIP_TRY(hipStreamSynchronize(s));
     ix->dd = DevDict{ix->d_strings.as<uint64_t>(), ix->d_pilots.as<uint16_t>(), ix->d_slots.as<uint64_t>(),
                      ix->d_overflow.as<uint64_t>(), d.num_buckets, d.num_slots, d.k, d.m, d.seed};
     const uint32_t w32 = ((h.num_colors + 31) / 32 + 3) & ~3u;  // result bitmaps move as 128-bit groups
-    ix->dc = DevColors{ix->d_bits.as<uint64_t>(), ix->d_offsets.as<uint64_t>(), ix->d_set_size.as<uint32_t>(),
-                       ix->d_blk_first.as<uint64_t>(), ix->d_blk_wbase.as<uint64_t>(), ix->d_blk_hdr.as<uint64_t>(),
-                       ix->d_blk_words.as<uint32_t>(), h.num_colors, h.sparse_thr, h.dense_thr, w32};
+    ix->dc = DevColors{ix->d_bits.as<uint64_t>(), ix->d_offsets.as<uint64_t>(), ix->d_set_desc.as<ListDesc>(),
+                       ix->d_blk_hdr.as<uint64_t>(), ix->d_blk_words.as<uint32_t>(), h.num_colors, h.sparse_thr, h.dense_thr, w32};
 }
 
 static_assert(sizeof(SetOp) == sizeof(DevOp), "host and device op layouts must match");
@@ -333,7 +351,10 @@ void run_scan(fgpu_index* ix, fgpu_result* res, const uint32_t* sizes, uint64_t 
 }
 
 // per-read id lists (nids + source offsets into ids/cnt arrays) -> compact CSR of resolved descriptors
-void stage_descriptors(fgpu_index* ix, fgpu_result* res, uint64_t max_total_ids) {
+// Per-read descriptor lists for the threshold union and the generic codecs. The hybrid full intersection
+// gathers DevColors::set_desc itself (no scan, no descriptor array, no host round trip), so it skips this.
+void stage_descriptors(fgpu_index* ix, fgpu_result* res, uint64_t max_total_ids, int algo) {
+    if (ix->host.type == IDX_HYBRID && algo == FGPU_FULL_INTERSECTION) return;
     hipStream_t s = res->stream;
     const uint64_t n = res->n;
     res->d_idcsr.ensure((n + 1) * 8 + 16);
@@ -392,9 +413,9 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         const uint32_t wpb = pick_waves(per_wave, (const void*)k2a_intersect);
         const uint32_t grid = resident_grid(k2a_intersect, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
         Timed t(ix, res, FGPU_K_INTERSECT);
-        hipLaunchKernelGGL(k2a_intersect, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_idcsr.as<uint64_t>(),
-                           res->d_desc.as<ListDesc>(), n, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
-                           res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
+        hipLaunchKernelGGL(k2a_intersect, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_nids.as<uint32_t>(),
+                           res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), n, res->d_bitmap.as<uint32_t>(),
+                           res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
         HIP_TRY(hipGetLastError());
     } else if (algo == FGPU_THRESHOLD_UNION) {
         // score counter width from the longest read of the batch: 8 bits up to 127 k-mers, 16 up to 32767, else 32
@@ -495,7 +516,7 @@ void fgpu_close(fgpu_index* ix) {
     if (ix->device == FGPU_HOST_ONLY) { delete ix; return; }
     (void)hipSetDevice(ix->device);
     for (DevBuf* b : {&ix->d_strings, &ix->d_pilots, &ix->d_slots, &ix->d_overflow, &ix->d_bits, &ix->d_offsets,
-                      &ix->d_set_size, &ix->d_blk_first, &ix->d_blk_wbase, &ix->d_blk_hdr, &ix->d_blk_words, &ix->d_gbits, &ix->d_gops, &ix->d_gset_ops_off, &ix->d_gset_ops,
+                      &ix->d_set_desc, &ix->d_blk_hdr, &ix->d_blk_words, &ix->d_gbits, &ix->d_gops, &ix->d_gset_ops_off, &ix->d_gset_ops,
                       &ix->d_gsamples, &ix->d_gset_bytes})
         b->release();
     for (auto e : ix->event_pool) (void)hipEventDestroy(e);
@@ -653,7 +674,7 @@ int fgpu_run(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t coun
     return guarded([&] {
         HIP_TRY(hipSetDevice(ix->device));
         stage_lookup(ix, rd, first, count, res);
-        stage_descriptors(ix, res, res->total_kmers);
+        stage_descriptors(ix, res, res->total_kmers, algo);
         stage_colors(ix, algo, tau, res);
     });
 }
@@ -704,8 +725,9 @@ int fgpu_result_algorithmic_bytes(const fgpu_result* r, uint64_t* list_bytes, ui
         if (r->n) {
             const_cast<fgpu_result*>(r)->d_acct.ensure(16);
             HIP_TRY(hipMemsetAsync(r->d_acct.p, 0, 16, r->stream));
-            hipLaunchKernelGGL(k_account, dim3(1024), dim3(256), 0, r->stream, ix->dc, r->d_idcsr.as<uint64_t>(),
-                               r->d_desc.as<ListDesc>(), r->d_counts.as<uint32_t>(), r->n, r->d_acct.as<unsigned long long>(),
+            hipLaunchKernelGGL(k_account, dim3(1024), dim3(256), 0, r->stream, ix->dc, r->d_nids.as<uint32_t>(),
+                               r->d_idoff.as<uint64_t>(), r->d_ids_pool.as<uint32_t>(), r->d_counts.as<uint32_t>(), r->n,
+                               r->d_acct.as<unsigned long long>(),
                                ix->host.type == IDX_HYBRID ? (const uint32_t*)nullptr : ix->d_gset_bytes.as<uint32_t>());
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(acct, r->d_acct.p, 16, hipMemcpyDeviceToHost, r->stream));
@@ -840,7 +862,7 @@ int fgpu_intersect_ids(fgpu_index* ix, const uint32_t* ids, const uint64_t* id_o
         res->d_tickets.ensure(TICKET_BYTES);
         HIP_TRY(hipMemsetAsync(res->d_tickets.p, 0, TICKET_BYTES, res->stream));
         res->have_ids = false;
-        stage_descriptors(ix, res, id_offs[n]);
+        stage_descriptors(ix, res, id_offs[n], FGPU_FULL_INTERSECTION);
         stage_colors(ix, FGPU_FULL_INTERSECTION, 0.0, res);
         uint64_t* o = (uint64_t*)malloc((n + 1) * 8);
         uint32_t* c = (uint32_t*)malloc(std::max<uint64_t>(1, res->total) * 4);
@@ -912,7 +934,7 @@ int fgpu_kmer_matches(fgpu_index* ix, const char* bases, const uint64_t* offs, u
         HIP_TRY(hipSetDevice(ix->device));
         res->want_scores = true;
         stage_lookup(ix, rd, 0, n, res);
-        stage_descriptors(ix, res, res->total_kmers);
+        stage_descriptors(ix, res, res->total_kmers, FGPU_THRESHOLD_UNION);
         stage_colors(ix, FGPU_THRESHOLD_UNION, 1.0, res);  // the threshold only shapes the (discarded) bitmap
         const uint64_t nc = ix->dc.n;
         uint32_t* c = (uint32_t*)malloc(std::max<uint64_t>(1, n * nc) * 4);

@@ -30,10 +30,8 @@ struct DevDict {
 struct DevColors {
     const uint64_t* bits;       // the hybrid bit stream (bitmap lists are read from it)
     const uint64_t* offsets;
-    const uint32_t* set_size;   // list sizes
-    const uint64_t* blk_first;  // packed blocks of the gap-coded lists (host/hybrid_codec.hpp)
-    const uint64_t* blk_wbase;
-    const uint64_t* blk_hdr;
+    const struct ListDesc* set_desc;  // one resolved descriptor per colour set (built at upload)
+    const uint64_t* blk_hdr;          // packed blocks of the gap-coded lists (host/hybrid_codec.hpp)
     const uint32_t* blk_words;
     uint32_t n, sparse_thr, dense_thr;
     uint32_t w32;  // 32-bit words per result bitmap, rounded up to a multiple of 4
@@ -663,12 +661,6 @@ struct NarrowReader {
     }
 };
 
-__device__ __forceinline__ uint32_t delta_code_bits_fast(uint32_t x) {  // = delta_code_bits(x), x < 2^32 - 1
-    const uint32_t len = 31u - (uint32_t)__builtin_clz(x + 1u);
-    const uint32_t z = 31u - (uint32_t)__builtin_clz(len + 1u);
-    return 2 * z + 1 + len;
-}
-
 struct ListHeader {
     uint64_t begin, body, soff;  // bitmap list: bit offsets of the list / of its bitmap. Gap-coded list: begin = first
                                  // data word in blk_words, soff = first block header
@@ -676,27 +668,10 @@ struct ListHeader {
     int type;
 };
 
-__device__ __forceinline__ ListHeader read_header(const DevColors& c, uint32_t id) {
-    ListHeader h;
-    h.size = c.set_size[id];
-    h.begin = h.body = h.soff = 0;
-    if (h.size < c.sparse_thr) { h.type = D_ENC_DELTA_GAPS; h.ncodes = h.size; }
-    else if (h.size < c.dense_thr) { h.type = D_ENC_BITMAP; h.ncodes = 0; }
-    else { h.type = D_ENC_COMPLEMENT; h.ncodes = c.n - h.size; }
-    if (h.type == D_ENC_BITMAP) {
-        h.begin = c.offsets[id];
-        h.body = h.begin + delta_code_bits_fast(h.size);
-    } else {  // gap-coded on the host, packed blocks here: ncodes = number of blocks
-        h.begin = h.body = c.blk_wbase[id];
-        h.soff = c.blk_first[id];
-        h.ncodes = (uint32_t)(c.blk_first[id + 1] - h.soff);
-    }
-    return h;
-}
-
-// One resolved colour list of one read (32 bytes). Written by k_desc, a flat kernel with one thread per
-// (read, list) pair, so that the dependent chain id -> offsets -> header bits is walked with full
-// memory-level parallelism once instead of serially inside the per-read kernels.
+// One resolved colour list (32 bytes). DevColors::set_desc holds one per colour set (score = 0, id = its
+// index), so that a kernel reaches everything it needs about a list with ONE gather. k_desc, a flat kernel with
+// one thread per (read, list) pair, copies them into per-read order together with the list's score for the
+// threshold union and the generic codecs; the full intersection gathers them itself, one read ahead.
 struct __attribute__((aligned(16))) ListDesc {
     uint64_t begin;   // bitmap list: bit offset of the list; gap-coded list: first data word in blk_words
     uint64_t soff;    // gap-coded list: first block header
@@ -719,16 +694,9 @@ __global__ __launch_bounds__(256) void k_desc(DevColors c, const uint32_t* __res
     const uint64_t so = src_off[r], dso = dst_off[r];
     for (uint32_t j = (uint32_t)t & 15u; j < cnt; j += 16) {
         const uint32_t id = ids_src[so + j];
-        ListHeader h;
-        h.begin = h.body = h.soff = 0; h.ncodes = h.size = 0; h.type = D_ENC_NONE;
-        if (resolve_hybrid) h = read_header(c, id);
-        ListDesc d;
-        d.begin = h.begin;
-        d.soff = h.soff;
-        d.ncodes = h.ncodes;
-        d.meta = (uint32_t)h.type | ((uint32_t)(h.body - h.begin) << 8);
+        ListDesc d{0, 0, 0, (uint32_t)D_ENC_NONE & 0xFFu, 0, id};
+        if (resolve_hybrid) d = c.set_desc[id];
         d.score = cnt_src ? (int32_t)cnt_src[so + j] : 0;
-        d.id = id;
         out[dso + j] = d;
     }
 }
@@ -860,10 +828,10 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t src) {  //
 }
 __device__ __forceinline__ uint4 or_not(uint4 e, uint4 x) { return make_uint4(e.x | ~x.x, e.y | ~x.y, e.z | ~x.z, e.w | ~x.w); }
 
-__global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint64_t* __restrict__ id_csr,
-                                                     const ListDesc* __restrict__ desc, uint64_t n_reads,
-                                                     uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count,
-                                                     unsigned int* tickets) {
+__global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint32_t* __restrict__ nids,
+                                                     const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
+                                                     uint64_t n_reads, uint32_t* __restrict__ out_bitmap,
+                                                     uint32_t* __restrict__ out_count, unsigned int* tickets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = c.w32, W4 = W >> 2;  // W is a multiple of 4: the bitmaps move as 128-bit groups
@@ -884,17 +852,30 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint6
     wave_lds_sync();
 
     while (wq.pull(t_first, t_count)) {
-        // id_csr[t_first ...] in the lanes; the descriptors of a read are requested one read ahead
-        const uint64_t csr_l = id_csr[min(t_first + (uint64_t)lane, n_reads)];
-        uint64_t off = readlane_u64(csr_l, 0), nxt = readlane_u64(csr_l, 1);
-        ListDesc dcur = none;
-        if ((uint64_t)lane < nxt - off) dcur = desc[off + lane];
+        // Two-stage software pipeline over the reads of the ticket: the colour-set ids of read i + 2 and the
+        // descriptors (one 32-byte gather per list) of read i + 1 are requested while read i is processed.
+        const uint64_t rl = min(t_first + (uint64_t)lane, n_reads - 1);
+        const uint32_t cnt_l = (uint32_t)lane < t_count ? nids[rl] : 0u;  // lanes past the ticket: empty reads
+        const uint64_t off_l = idoff[rl];
+        auto fetch_ids = [&](uint32_t i) -> uint32_t {  // ids of the ticket's read i (first 64)
+            const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, i);
+            return (uint32_t)lane < cn ? ids_pool[readlane_u64(off_l, i) + lane] : 0u;
+        };
+        auto fetch_desc = [&](uint32_t i, uint32_t id) -> ListDesc {
+            const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, i);
+            ListDesc dd = none;
+            if ((uint32_t)lane < cn) dd = c.set_desc[id];
+            return dd;
+        };
+        uint32_t id1 = fetch_ids(0);
+        ListDesc dcur = fetch_desc(0, id1);
+        id1 = fetch_ids(1);  // (t_count <= BATCH < 62: lanes i + 1, i + 2 exist and read as empty past the ticket)
         for (uint32_t ri = 0; ri < t_count; ++ri) {
             const uint64_t r = t_first + ri;
-            const uint32_t cnt = (uint32_t)(nxt - off);
-            const uint64_t nxt2 = readlane_u64(csr_l, ri + 2);  // (== nxt past the last read)
-            ListDesc dnext = none;
-            if ((uint64_t)lane < nxt2 - nxt) dnext = desc[nxt + lane];
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, ri);
+            const uint64_t off = readlane_u64(off_l, ri);
+            const uint32_t id2 = fetch_ids(ri + 2);
+            const ListDesc dnext = fetch_desc(ri + 1, id1);
             uint4* bm4 = (uint4*)(out_bitmap + r * W);
             if (cnt == 0) {
                 for (uint32_t g4 = lane; g4 < W4; g4 += 64) bm4[g4] = make_uint4(0u, 0u, 0u, 0u);
@@ -909,9 +890,9 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint6
                 }
                 for (uint32_t g = 0; g < cnt; g += 64) {
                     ListDesc d = dcur;
-                    if (g) {
+                    if (g) {  // more than 64 lists: rare, fetched in place
                         d = none;
-                        if (g + lane < cnt) d = desc[off + g + lane];
+                        if (g + lane < cnt) d = c.set_desc[ids_pool[off + g + lane]];
                     }
                     const int type = (int)(int8_t)(d.meta & 0xFFu);
                     const uint32_t nblk = d.ncodes;  // 0 for bitmap lists
@@ -984,9 +965,8 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint6
                 if (lane == 0) out_count[r] = pc;
                 wave_lds_sync();
             }
-            off = nxt;
-            nxt = nxt2;
             dcur = dnext;
+            id1 = id2;
         }
     }
 }
@@ -1544,16 +1524,16 @@ __global__ void k_add_totals(unsigned long long* hits, uint32_t n, uint64_t num_
 // algorithmic bytes of the colour-intersection stage:
 //   sum over reads of  sum_c ceil(list bits / 8) + 16|C| + 4|C| + 4|R| + 8
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_account(DevColors c, const uint64_t* __restrict__ id_csr,
-                                                 const ListDesc* __restrict__ desc, const uint32_t* __restrict__ counts,
+__global__ __launch_bounds__(256) void k_account(DevColors c, const uint32_t* __restrict__ nids, const uint64_t* __restrict__ idoff,
+                                                 const uint32_t* __restrict__ ids_pool, const uint32_t* __restrict__ counts,
                                                  uint64_t n_reads, unsigned long long* __restrict__ out,
                                                  const uint32_t* __restrict__ set_bytes) {
     uint64_t in_bytes = 0, out_bytes = 0;  // out[0]: list side (lists + offsets + ids), out[1]: result side
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t off = id_csr[r];
-        const uint32_t cnt = (uint32_t)(id_csr[r + 1] - off);
+        const uint64_t off = idoff[r];
+        const uint32_t cnt = nids[r];
         for (uint32_t i = 0; i < cnt; ++i) {
-            const uint32_t id = desc[off + i].id;
+            const uint32_t id = ids_pool[off + i];
             // hybrid: the list + two 8-byte offsets; other codecs: every list the set touches (+16 each)
             in_bytes += set_bytes ? (uint64_t)set_bytes[id] : (c.offsets[id + 1] - c.offsets[id] + 7) / 8 + 16;
         }
