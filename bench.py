@@ -183,6 +183,17 @@ def main():
         achieved = kbytes[dom] / launches_per_step / (avg_ms * 1e-3) / 1e9
         kernels = {k_: {"avg_ms": round(v[0] / v[1], 4), "launches": v[1]} for k_, v in timing.items() if v[1]}
         stage_ms = sum(timing[k_][0] for k_ in (stage_kernel, "scan", "k2b_expand")) / args.steps
+        # HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+        # build (profiles/traffic.json, made by profiles/traffic_from_pmc.py); only quoted for the configuration the
+        # counters were collected on (same workload, codec and reads per launch), otherwise null.
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if (args.workload == "s4546syn" and itype == 0 and tj["reads_per_launch"] == args.chunk and n_reads >= args.chunk
+                    and dom in tj["kernels"]):
+                traffic, traffic_src = tj["kernels"][dom]["total"], tj["source"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "pseudoaligned reads/sec (150 bp, k=31)",
             "value": round(world * n_reads * args.steps / elapsed, 1),
@@ -202,7 +213,7 @@ def main():
                        "mapped_fraction": round(mapped_job / max(1, total_reads_job), 4),
                        "avg_colours_per_read": round(total_colors / n_reads, 2)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(kbytes[dom] / launches_per_step),
                          "avg_launch_ms": round(avg_ms, 4),
                          "stage": {"kernels": [stage_kernel, "scan", "k2b_expand"],
