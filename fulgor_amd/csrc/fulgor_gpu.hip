@@ -149,6 +149,7 @@ struct fgpu_result {
     uint64_t n = 0, total = 0, mapped = 0, total_kmers = 0, total_bases = 0;
     uint32_t id_stride = 0;
     uint32_t hit_rows = 0;  // rows of d_partial filled by the last expand launch (0: no colours, nothing to add)
+    bool hits_folded = true;  // false: too many colours for the expand kernel's LDS histogram; k_hits counts from the bitmaps
     uint32_t max_kmers_in_batch = 0xFFFFFFFFu;  // bound on #positive k-mers of any read (unknown for id-only calls)
     bool have_ids = false;
 };
@@ -448,16 +449,22 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     res->mapped = res->h_totals[1];
     res->d_colors.ensure(res->total * 4 + 16);
     if (res->total) {
-        const size_t lds = 4 * (2048 + 64) * 2 + (size_t)W * 64;
-        if (lds > 64 * 1024) throw std::runtime_error("colour count too large for the expand kernel's LDS histogram");
+        // the per-colour hit histogram rides along in LDS while it fits (16-bit counters, W * 64 bytes); for
+        // larger collections the expand kernel runs without it and k_hits counts from the bitmaps on demand
+        const size_t stage_lds = 4 * (2048 + 64) * 2;
+        res->hits_folded = stage_lds + (size_t)W * 64 <= 64 * 1024;
+        const size_t lds = res->hits_folded ? stage_lds + (size_t)W * 64 : stage_lds;
         // a block must see fewer than 65536 reads (16-bit hit counters): true for any resident grid >= n / 65535
         const uint32_t grid = std::max<uint32_t>(resident_grid(k2b_expand, n, 4, ix->num_cus, 256, lds), (uint32_t)(n / 60000 + 1));
-        res->d_partial.ensure((size_t)grid * W * 32 * 4);
-        res->hit_rows = grid;
+        if (res->hits_folded) {
+            res->d_partial.ensure((size_t)grid * W * 32 * 4);
+            res->hit_rows = grid;
+        }
         Timed t(ix, res, FGPU_K_EXPAND);
         hipLaunchKernelGGL(k2b_expand, dim3(grid), dim3(256), lds, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
                            res->d_offsets.as<uint64_t>(), n, W, res->d_colors.as<uint32_t>(),
-                           res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE, res->d_partial.as<uint32_t>());
+                           res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE,
+                           res->hits_folded ? res->d_partial.as<uint32_t>() : (uint32_t*)nullptr);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(s));
@@ -703,7 +710,15 @@ int fgpu_result_accumulate_hits(fgpu_index* ix, const fgpu_result* r, void* devi
         if (r->n) {
             const uint32_t W = ix->dc.w32;
             Timed t(ix, const_cast<fgpu_result*>(r), FGPU_K_HITS);
-            // the expand kernel left one row of per-colour counts per block; sum the rows into the totals
+            fgpu_result* rw = const_cast<fgpu_result*>(r);
+            if (r->total && !r->hits_folded) {  // large collections: count from the result bitmaps now
+                const uint32_t rows = (uint32_t)std::min<uint64_t>(256, (r->n + 63) / 64);
+                rw->d_partial.ensure((size_t)rows * W * 32 * 4);
+                hipLaunchKernelGGL(k_hits, dim3(rows), dim3(256), 0, r->stream, r->d_bitmap.as<uint32_t>(), r->n, W,
+                                   rw->d_partial.as<uint32_t>());
+                rw->hit_rows = rows;
+            }
+            // one row of per-colour counts per block (of the expand kernel or of k_hits): sum the rows into the totals
             if (r->hit_rows)
                 hipLaunchKernelGGL(k_hits_reduce, dim3((ix->dc.n + 255) / 256, HITS_ROW_GROUPS), dim3(256), 0, r->stream,
                                    r->d_partial.as<uint32_t>(), r->hit_rows, W, ix->dc.n, (unsigned long long*)device_u64_hits);

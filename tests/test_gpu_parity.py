@@ -398,3 +398,71 @@ def test_fuzz_dirty_ragged_reads(which, s10_gpu, s10_oracle, s4546, built):
         tau = float(rng.choice([0.25, 0.8, 1.0]))
         got, want = ix.pseudoalign_threshold_union_batch(b, o, tau), orc.threshold_union(b, o, tau, threads=32)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+def _write_wide_dump(base, rng, n=70001, k=31):
+    """a small dump (the reference's text interchange format) with more than 65535 colours whose colour sets
+    exercise every device form: wide offset blocks (spans > 2^16), bitmap chunks, bitmap lists, complement
+    lists with few / many / zero missing colours, first and last colour alone"""
+    allc = np.arange(n, dtype=np.int64)
+    def pick(m):
+        return np.sort(rng.choice(n, size=m, replace=False))
+    sets = [pick(50), pick(5000), pick(300), pick(30000), np.setdiff1d(allc, pick(40)), allc, np.array([n - 1]),
+            np.array([0]), np.setdiff1d(allc, pick(10000)), pick(17499), pick(17500), np.setdiff1d(allc, pick(17500)),
+            np.concatenate([np.arange(100, 400), pick(64)]), np.arange(65000, 70001)]
+    sets = [np.unique(s) for s in sets]
+    unitigs = []
+    for sid in range(len(sets)):
+        for _ in range(3):
+            unitigs.append((sid, "".join("ACGT"[c] for c in rng.integers(0, 4, size=200))))
+    with open(base + ".metadata.txt", "w") as f:
+        f.write("k=%d\nnum_kmers=%d\nnum_colors=%d\nnum_unitigs=%d\nnum_color_sets=%d\n" %
+                (k, len(unitigs) * (200 - k + 1), n, len(unitigs), len(sets)))
+    with open(base + ".filenames.txt", "w") as f:
+        f.write("".join("g%d.fa\n" % i for i in range(n)))
+    with open(base + ".unitigs.fa", "w") as f:
+        for sid, seq in sorted(unitigs, key=lambda u: u[0]):
+            f.write("> color_set_id=%d\n%s\n" % (sid, seq))
+    with open(base + ".color_sets.txt", "w") as f:
+        for s in sets:
+            f.write("size=%d %s\n" % (len(s), " ".join(map(str, s))))
+    return [u[1] for u in unitigs], len(sets)
+
+
+def test_gpu_more_than_65535_colours(built, tmp_path):
+    """maximum-size edge: 70001 colours (block fields wider than 16 bits, result rows of 2188 words)"""
+    from oracle.pyoracle import OracleIndex
+    rng = np.random.default_rng(5)
+    base = str(tmp_path / "wide")
+    unitigs, nsets = _write_wide_dump(base, rng)
+    ix = fulgor_amd.Index(base, device=0)
+    orc = OracleIndex.from_dump(base)
+    assert ix.num_colors() == 70001 and ix.num_color_sets() == nsets
+    reads = []
+    for _ in range(400):  # chimeras of 2-3 pieces: every read meets up to 3 colour sets
+        reads.append("".join(u[s:s + 60] for u, s in ((unitigs[rng.integers(len(unitigs))], rng.integers(0, 140))
+                                                    for _ in range(rng.integers(1, 4)))))
+    reads += [u[:150] for u in unitigs]
+    b, o = pack_reads(reads)
+    go, gc = ix.pseudoalign_full_intersection_batch(b, o)
+    oo, oc = orc.full_intersection(b, o, threads=8, self_check=True)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+    for tau in (0.3, 1.0):
+        go, gc = ix.pseudoalign_threshold_union_batch(b, o, tau)
+        oo, oc = orc.threshold_union(b, o, tau, threads=8)
+        assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+    lists = [np.unique(rng.integers(0, nsets, size=l)).astype(np.uint32) for l in rng.integers(1, 6, size=300)]
+    ido = np.zeros(len(lists) + 1, dtype=np.uint64)
+    ido[1:] = np.cumsum([len(l) for l in lists])
+    go, gc = ix.intersect_ids_batch(np.concatenate(lists), ido)
+    oo, oc = orc.intersect_ids(np.concatenate(lists), ido, threads=8)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+    # per-colour hit counts: this many colours do not fit the expand kernel's LDS histogram (bitmap path)
+    import torch
+    rd, res = ix.upload_reads(b, o), ix.new_result()
+    ix.run(rd, res, fulgor_amd.FULL_INTERSECTION)
+    hits = torch.zeros(70001 + 2, dtype=torch.int64, device="cuda:0")
+    res.accumulate_hits(hits.data_ptr())
+    go, gc = res.download()
+    got = hits.cpu().numpy()
+    assert np.array_equal(got[:70001], np.bincount(gc, minlength=70001)) and got[70001] == len(reads)
