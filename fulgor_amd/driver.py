@@ -157,3 +157,98 @@ def pseudoalign_reads(index, bases, offs, algo=FULL_INTERSECTION, threshold=0.0,
     res.close()
     reads.close()
     return n, mapped
+
+
+# ---- the reference's --deduplicate temp files (tools/pseudoalign.cpp:91-226, src/ps_utils.cpp:307-415) -------
+# Stage 1 writes, per read, `u32 read_id, u32 num_ids, u32 x num_ids`; the deduplication pass rewrites the file as
+# `u32 list_len, u32 read_id, u32 x (list_len - 1)` sorted by id list, where list_len == 1 marks a read whose
+# id list equals the previous record's (preprocessed_query_reader, ps_utils.cpp:327-369). Reads without ids never
+# reach the second file: the reference writes their empty result straight to the output (pseudoalign.cpp:186-189).
+def write_fetched_ids(path, id_offs, ids, first_read_id=0):
+    """stage-1 temp file for reads first_read_id .. first_read_id + n - 1"""
+    id_offs = np.asarray(id_offs, dtype=np.int64)
+    ids = np.asarray(ids, dtype=np.uint32)
+    n = len(id_offs) - 1
+    lens = np.diff(id_offs).astype(np.uint32)
+    out = np.empty(2 * n + len(ids), dtype=np.uint32)
+    pos = 2 * np.arange(n, dtype=np.int64) + id_offs[:-1]
+    out[pos] = np.arange(first_read_id, first_read_id + n, dtype=np.uint32)
+    out[pos + 1] = lens
+    mask = np.ones(len(out), dtype=bool)
+    mask[pos] = False
+    mask[pos + 1] = False
+    out[mask] = ids
+    with open(path, "ab") as f:
+        f.write(out.tobytes())
+
+
+def read_fetched_ids(path):
+    """-> (read_ids, id_offs, ids) of a stage-1 temp file"""
+    raw = np.fromfile(path, dtype=np.uint32)
+    rid, offs, chunks, p = [], [0], [], 0
+    while p < len(raw):
+        rid.append(int(raw[p]))
+        m = int(raw[p + 1])
+        chunks.append(raw[p + 2:p + 2 + m])
+        offs.append(offs[-1] + m)
+        p += 2 + m
+    ids = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint32)
+    return np.asarray(rid, dtype=np.uint32), np.asarray(offs, dtype=np.uint64), ids.astype(np.uint32)
+
+
+def deduplicate_fetched(read_ids, id_offs, ids):
+    """the reference's sort + collapse (pseudoalign.cpp:193-216): -> (unmapped read ids, records) where a record is
+    (read_id, id list or None when it repeats the previous record's list), in lexicographic order of the lists"""
+    id_offs = np.asarray(id_offs, dtype=np.int64)
+    lists = [(tuple(int(x) for x in ids[id_offs[i]:id_offs[i + 1]]), int(read_ids[i])) for i in range(len(read_ids))]
+    unmapped = [r for l, r in lists if not l]
+    mapped = sorted(((l, r) for l, r in lists if l), key=lambda t: t[0])  # stable, like std::sort on equal keys modulo order
+    records, prev = [], None
+    for l, r in mapped:
+        records.append((r, None if l == prev else l))
+        prev = l
+    return unmapped, records
+
+
+def write_preprocessed(path, records):
+    with open(path, "wb") as f:
+        for r, l in records:
+            body = [r] + (list(l) if l is not None else [])
+            f.write(np.asarray([len(body)] + body, dtype=np.uint32).tobytes())
+
+
+def read_preprocessed(path, batch=10000):
+    """preprocessed_query_reader: yields batches of (read_id, id list); a list_len == 1 record repeats the previous list"""
+    raw = np.fromfile(path, dtype=np.uint32)
+    out, prev, p = [], None, 0
+    while p < len(raw):
+        s = int(raw[p])
+        rid = int(raw[p + 1])
+        if s > 1:
+            prev = raw[p + 2:p + 1 + s].astype(np.uint32)
+        elif prev is None:
+            raise ValueError("preprocessed query file starts with a duplicate marker")
+        out.append((rid, prev))
+        p += 1 + s
+        if len(out) == batch:
+            yield out
+            out = []
+    if out:
+        yield out
+
+
+def intersect_preprocessed(index, path, batch=10000):
+    """stage 2 of --deduplicate over a preprocessed query file: every distinct id list is intersected once
+    (fgpu_intersect_ids), duplicates reuse the previous result. Yields (read_id, colours) in file order."""
+    for recs in read_preprocessed(path, batch):
+        heads = [i for i, (_, l) in enumerate(recs) if i == 0 or l is not recs[i - 1][1]]
+        lists = [recs[i][1] for i in heads]
+        ido = np.zeros(len(lists) + 1, dtype=np.uint64)
+        ido[1:] = np.cumsum([len(l) for l in lists])
+        ro, rc = index.intersect_ids_batch(np.concatenate(lists).astype(np.uint32), ido)
+        ro = ro.astype(np.int64)
+        h = -1
+        for i, (rid, _) in enumerate(recs):
+            if h + 1 < len(heads) and heads[h + 1] == i:
+                h += 1
+            yield rid, rc[ro[h]:ro[h + 1]]

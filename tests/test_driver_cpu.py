@@ -115,3 +115,28 @@ def test_cli_argument_errors():
     with pytest.raises(ValueError):
         driver.Formatter("weird", 10)
     assert cli.main(["build"]) == 1
+
+
+def test_dedup_temp_file_formats_roundtrip(tmp_path):
+    """the reference's two --deduplicate temp-file layouts (tools/pseudoalign.cpp:91-226, ps_utils.cpp:327-369)"""
+    import struct
+    from fulgor_amd import driver
+    ido = np.array([0, 2, 2, 5, 7, 10], dtype=np.uint64)  # reads 0..4; read 1 has no ids; reads 0 and 3 share a list
+    ids = np.array([4, 9, 1, 2, 3, 4, 9, 1, 2, 8], dtype=np.uint32)
+    p1 = str(tmp_path / "fetch.tmp")
+    driver.write_fetched_ids(p1, ido[:3], ids[:2], first_read_id=0)     # two appends, like two worker flushes
+    driver.write_fetched_ids(p1, ido[2:] - ido[2], ids[2:], first_read_id=2)
+    want = struct.pack("<2I2I", 0, 2, 4, 9) + struct.pack("<2I", 1, 0) + struct.pack("<2I3I", 2, 3, 1, 2, 3) + \
+        struct.pack("<2I2I", 3, 2, 4, 9) + struct.pack("<2I3I", 4, 3, 1, 2, 8)
+    assert open(p1, "rb").read() == want
+    rid, o2, i2 = driver.read_fetched_ids(p1)
+    assert rid.tolist() == [0, 1, 2, 3, 4] and np.array_equal(o2, ido) and np.array_equal(i2, ids)
+    unmapped, recs = driver.deduplicate_fetched(rid, o2, i2)
+    assert unmapped == [1]
+    assert recs == [(2, (1, 2, 3)), (4, (1, 2, 8)), (0, (4, 9)), (3, None)]
+    p2 = str(tmp_path / "dedup.tmp")
+    driver.write_preprocessed(p2, recs)
+    assert open(p2, "rb").read() == struct.pack("<5I", 4, 2, 1, 2, 3) + struct.pack("<5I", 4, 4, 1, 2, 8) + \
+        struct.pack("<4I", 3, 0, 4, 9) + struct.pack("<2I", 1, 3)
+    got = [(r, l.tolist()) for b in driver.read_preprocessed(p2, batch=3) for r, l in b]
+    assert got == [(2, [1, 2, 3]), (4, [1, 2, 8]), (0, [4, 9]), (3, [4, 9])]

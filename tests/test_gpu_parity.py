@@ -466,3 +466,21 @@ def test_gpu_more_than_65535_colours(built, tmp_path):
     go, gc = res.download()
     got = hits.cpu().numpy()
     assert np.array_equal(got[:70001], np.bincount(gc, minlength=70001)) and got[70001] == len(reads)
+
+
+def test_preprocessed_query_file_path_equals_direct_path(s4546, tmp_path):
+    """--deduplicate through the reference's temp-file layouts: stage 1 ids -> sort/collapse -> stage 2 intersections"""
+    from fulgor_amd import driver
+    ix, orc, gen = s4546
+    b, o = gen.generate(7000, 3000, 150, 42)
+    ido, ids = ix.fetch_color_set_ids_batch(b, o)
+    p1, p2 = str(tmp_path / "fetch.tmp"), str(tmp_path / "dedup.tmp")
+    driver.write_fetched_ids(p1, ido, ids, first_read_id=100)
+    unmapped, recs = driver.deduplicate_fetched(*driver.read_fetched_ids(p1))
+    assert any(l is None for _, l in recs)  # real duplicates occur
+    driver.write_preprocessed(p2, recs)
+    got = {rid: cols.tolist() for rid, cols in driver.intersect_preprocessed(ix, p2, batch=700)}
+    got.update({rid: [] for rid in unmapped})
+    do, dc = ix.pseudoalign_full_intersection_batch(b, o)
+    want = {100 + i: l for i, l in enumerate(csr_to_lists(do, dc))}
+    assert got == want
