@@ -400,14 +400,21 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         const uint32_t grid = uni ? resident_grid(k_generic<true>, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave)
                                   : resident_grid(k_generic<false>, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
         Timed t(ix, res, uni ? FGPU_K_UNION : FGPU_K_INTERSECT);
+        uint32_t* scores_out = nullptr;
+        if (uni && res->max_kmers_in_batch > 32767)  // k_generic<true> keeps 16-bit biased score counters
+            throw std::runtime_error("threshold-union on the meta / differential codecs supports reads of at most 32767 k-mers");
+        if (uni && res->want_scores) {
+            res->d_scores.ensure(n * (uint64_t)ix->dc.n * 4 + 16);
+            scores_out = res->d_scores.as<uint32_t>();
+        }
         if (uni)
             hipLaunchKernelGGL(k_generic<true>, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dg, res->d_npos.as<uint32_t>(),
                                res->d_idcsr.as<uint64_t>(), res->d_desc.as<ListDesc>(), tau, n, res->d_bitmap.as<uint32_t>(),
-                               res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
+                               res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, scores_out);
         else
             hipLaunchKernelGGL(k_generic<false>, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dg, res->d_npos.as<uint32_t>(),
                                res->d_idcsr.as<uint64_t>(), res->d_desc.as<ListDesc>(), tau, n, res->d_bitmap.as<uint32_t>(),
-                               res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
+                               res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, (uint32_t*)nullptr);
         HIP_TRY(hipGetLastError());
     } else if (algo == FGPU_FULL_INTERSECTION) {
         const size_t per_wave = (size_t)2 * W * 4 + wave_scratch_bytes();
@@ -940,7 +947,6 @@ int fgpu_kmer_matches(fgpu_index* ix, const char* bases, const uint64_t* offs, u
     if (!ix || !out_counts) return fail(-EINVAL, "null argument");
     NEED_DEVICE(ix);
     *out_counts = nullptr;
-    if (ix->host.type != IDX_HYBRID) return fail(-ENOTSUP, "kmer_matches is implemented for the hybrid codec only");
     fgpu_reads* rd = nullptr;
     fgpu_result* res = nullptr;
     int rc = fgpu_reads_upload(ix, bases, offs, n, &rd);

@@ -1176,7 +1176,9 @@ __device__ __forceinline__ void decode_op_segment(const DevGeneric& g, uint64_t 
 template <bool UNION>
 __global__ __launch_bounds__(256, UNION ? 4 : 8) void k_generic(DevGeneric g, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
                           const ListDesc* __restrict__ desc, double tau, uint64_t n_reads,
-                          uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count, unsigned int* tickets) {
+                          uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count, unsigned int* tickets,
+                          uint32_t* __restrict__ scores_out) {
+    // scores_out (UNION only): also store score[c] for every colour, n u32 per read (index::kmer_matches)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = g.w32, n = g.n;
@@ -1200,6 +1202,8 @@ __global__ __launch_bounds__(256, UNION ? 4 : 8) void k_generic(DevGeneric g, co
         if (cnt == 0) {
             for (uint32_t w = lane; w < W; w += 64) bm[w] = 0;
             if (lane == 0) out_count[r] = 0;
+            if (UNION && scores_out)
+                for (uint32_t cc = lane; cc < n; cc += 64) scores_out[r * (uint64_t)n + cc] = 0;
             continue;
         }
         if (UNION) {
@@ -1290,6 +1294,12 @@ __global__ __launch_bounds__(256, UNION ? 4 : 8) void k_generic(DevGeneric g, co
             wave_lds_sync();
         }
         uint32_t pc = 0;
+        if (UNION && scores_out) {  // colour c: word c / 32, plane (c % 32) / 2, half c % 2; counters are biased by 0x8000
+            for (uint32_t cc = lane; cc < n; cc += 64) {
+                const uint32_t x = ACC[((cc & 31u) >> 1) * W + (cc >> 5)];
+                scores_out[r * (uint64_t)n + cc] = ((x >> (16 * (cc & 1u))) & 0xFFFFu) - 0x8000u;
+            }
+        }
         if (UNION) {
             const long long min_score = (long long)(unsigned long long)((double)npos[r] * tau);
             const long long thr_ll = min_score + 0x8000;

@@ -351,6 +351,18 @@ def test_gpu_kmer_conservation_and_matches(s10_gpu, s10_oracle):
     assert s10_gpu.kmer_conservation(src) == s10_oracle.kmer_conservation(src)
 
 
+@pytest.mark.parametrize("index_type,psize,csize", [(fulgor_amd.DIFF, 10, 4), (fulgor_amd.META, 4, 1), (fulgor_amd.META_DIFF, 4, 4)])
+def test_gpu_kmer_matches_on_other_codecs(s10_gpu, s10_fgidx, index_type, psize, csize):
+    """index::kmer_matches is codec independent: the counts of the re-encoded index equal the hybrid index's"""
+    reads = load_golden_reads()
+    b, o = pack_reads(reads[:80] + reads[1000:1010])
+    mo, pos, counts = s10_gpu.kmer_matches_batch(b, o)
+    ix = fulgor_amd.Index(s10_fgidx, device=0)
+    ix.convert(index_type, psize, csize)
+    mo2, pos2, counts2 = ix.kmer_matches_batch(b, o)
+    assert np.array_equal(mo, mo2) and np.array_equal(pos, pos2) and np.array_equal(counts, counts2)
+
+
 def _fuzz_reads(gen, rng, n):
     """ragged, dirty reads: lengths 0..420, N runs, lower case, homopolymers, low-complexity repeats"""
     b, o = gen.generate(int(rng.integers(0, 1 << 30)), n, 150, int(rng.integers(1, 1000)))
