@@ -155,12 +155,7 @@ FG_HD void string_lmer(uint64_t w0, uint64_t w1, uint32_t sh, uint32_t L, uint32
 #endif
 }
 
-// ---- colour-list skip samples (meta / differential codecs) -----------------------------------------
-// One sample every SAMPLE_STRIDE codes of a gap-coded op: {prev value:32 | bit offset from the
-// start of the op:32}. Sample j is the decoder state after (j+1)*SAMPLE_STRIDE codes.
-constexpr uint32_t SAMPLE_STRIDE = 16;
-
-// ---- packed blocks of the hybrid gap-coded lists --------------------------------------------------
+// ---- packed blocks of the gap-coded lists (all codecs) --------------------------------------------------
 // A block holds up to 64 consecutive values v_0 < v_1 < ... of one list as `width`-bit offsets from
 // `start` (= previous value + 1, or 0 for the first block): v_i = start + field_i. Header word:
 //   start:27 | width:5 | count-1:6 | first data word, relative to the list's first data word:26

@@ -72,7 +72,7 @@ struct fgpu_index {
     hipStream_t stream = nullptr;
     int num_cus = 256;
     DevBuf d_strings, d_pilots, d_slots, d_overflow, d_bits, d_offsets, d_set_desc, d_blk_hdr, d_blk_words;
-    DevBuf d_gbits, d_gops, d_gset_ops_off, d_gset_ops, d_gsamples, d_gset_bytes;
+    DevBuf d_gops, d_gset_ops_off, d_gset_ops, d_garena, d_gblk_hdr, d_gblk_words, d_gset_bytes;
     DevDict dd{};
     DevColors dc{};
     DevGeneric dg{};
@@ -202,20 +202,23 @@ void upload_index(fgpu_index* ix) {
                        ix->d_blk_hdr.as<uint64_t>(), ix->d_blk_words.as<uint32_t>(), h.num_colors, h.sparse_thr, h.dense_thr, w32};
 }
 
-static_assert(sizeof(SetOp) == sizeof(DevOp), "host and device op layouts must match");
+static_assert(sizeof(GenOpDev) == sizeof(ListDesc), "host and device op layouts must match");
 
 void upload_generic(fgpu_index* ix) {
     const GenericSets& g = ix->host.generic;
     hipStream_t s = ix->stream;
-    upload(ix->d_gbits, g.bits, s);
-    upload(ix->d_gops, g.ops, s);
+    // the device holds the ops in their device form (spans / packed blocks); the encoded arena stays on the host
+    upload(ix->d_gops, g.dev_ops, s);
     upload(ix->d_gset_ops_off, g.set_ops_off, s);
     upload(ix->d_gset_ops, g.set_ops, s);
-    upload(ix->d_gsamples, g.samples, s);
+    upload(ix->d_garena, g.dev_arena, s);
+    upload(ix->d_gblk_hdr, g.dev_blk_hdr, s);
+    upload(ix->d_gblk_words, g.dev_blk_words, s);
     upload(ix->d_gset_bytes, g.set_bytes, s);
     HIP_TRY(hipStreamSynchronize(s));
-    ix->dg = DevGeneric{ix->d_gbits.as<uint64_t>(), ix->d_gops.as<DevOp>(), ix->d_gset_ops_off.as<uint64_t>(),
-                        ix->d_gset_ops.as<uint32_t>(), ix->d_gsamples.as<uint64_t>(), g.num_colors, ix->dc.w32};
+    ix->dg = DevGeneric{ix->d_gops.as<ListDesc>(), ix->d_gset_ops_off.as<uint64_t>(), ix->d_gset_ops.as<uint32_t>(),
+                        ix->d_garena.as<uint32_t>(), ix->d_gblk_hdr.as<uint64_t>(), ix->d_gblk_words.as<uint32_t>(),
+                        g.num_colors, ix->dc.w32};
 }
 
 // waves per block such that the dynamic LDS request fits; throws if one wave does not fit a CU
@@ -394,7 +397,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     if (ix->host.type != IDX_HYBRID) {
         const bool uni = algo == FGPU_THRESHOLD_UNION;
         if (!uni && algo != FGPU_FULL_INTERSECTION) throw std::runtime_error("unknown algorithm");
-        const size_t per_wave = wave_scratch_bytes() + 64 * 8 + (size_t)W * 4 + (uni ? (size_t)W * 64 : (size_t)W * 4);
+        const size_t per_wave = wave_scratch_bytes() + (size_t)W * 4 + (uni ? (size_t)W * 64 : (size_t)W * 4);
         const void* kfn = uni ? (const void*)k_generic<true> : (const void*)k_generic<false>;
         const uint32_t wpb = pick_waves(per_wave, kfn);
         const uint32_t grid = uni ? resident_grid(k_generic<true>, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave)
@@ -530,8 +533,8 @@ void fgpu_close(fgpu_index* ix) {
     if (ix->device == FGPU_HOST_ONLY) { delete ix; return; }
     (void)hipSetDevice(ix->device);
     for (DevBuf* b : {&ix->d_strings, &ix->d_pilots, &ix->d_slots, &ix->d_overflow, &ix->d_bits, &ix->d_offsets,
-                      &ix->d_set_desc, &ix->d_blk_hdr, &ix->d_blk_words, &ix->d_gbits, &ix->d_gops, &ix->d_gset_ops_off, &ix->d_gset_ops,
-                      &ix->d_gsamples, &ix->d_gset_bytes})
+                      &ix->d_set_desc, &ix->d_blk_hdr, &ix->d_blk_words, &ix->d_gops, &ix->d_gset_ops_off, &ix->d_gset_ops,
+                      &ix->d_garena, &ix->d_gblk_hdr, &ix->d_gblk_words, &ix->d_gset_bytes})
         b->release();
     for (auto e : ix->event_pool) (void)hipEventDestroy(e);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -564,12 +567,14 @@ int fgpu_convert(fgpu_index* ix, int index_type, uint32_t partition_size, uint32
             ix->host.generic = GenericSets();
         } else {
             convert_sets(ix->host.hybrid, index_type, partition_size, cluster_size, ix->host.generic);
-            // every set must decode to the same colours through its ops (cheap sample: every 97th set)
-            std::vector<uint32_t> a, b;
+            // every set must decode to the same colours through its ops, in the encoded and in the device form
+            // (cheap sample: every 97th set)
+            std::vector<uint32_t> a, b, c;
             for (uint64_t id = 0; id < ix->host.hybrid.num_sets(); id += 97) {
                 hybrid_decode(ix->host.hybrid, id, a);
                 generic_decode(ix->host.generic, id, b);
-                if (a != b) throw std::runtime_error("codec conversion self-check failed");
+                generic_decode_device(ix->host.generic, id, c);
+                if (a != b || a != c) throw std::runtime_error("codec conversion self-check failed");
             }
         }
         ix->host.type = index_type;

@@ -616,51 +616,6 @@ __device__ __forceinline__ uint64_t bits_window(const uint64_t* __restrict__ bit
     if (sh) v |= w[1] << (64 - sh);
     return v;
 }
-// delta(x): gamma(len) then `len` low bits. A code of a 32-bit value is at most 11 + 32 bits long, so
-// one 64-bit window always holds it.
-__device__ __forceinline__ uint32_t read_delta(const uint64_t* __restrict__ bits, uint64_t& pos) {
-    const uint64_t v = bits_window(bits, pos);
-    const uint32_t z = (uint32_t)__builtin_ctzll(v | (1ULL << 63));
-    const uint32_t len = (((uint32_t)(v >> (z + 1)) & ((1u << z) - 1u)) | (1u << z)) - 1u;
-    const uint32_t used = 2 * z + 1;
-    const uint64_t body = len ? ((v >> used) & ((1ULL << len) - 1ULL)) : 0ULL;
-    pos += used + len;
-    return (uint32_t)((body | (1ULL << len)) - 1ULL);
-}
-
-// Narrow form for indexes with fewer than 65536 colours: every value fits 16 bits, so a delta code is at
-// most 9 + 16 = 25 bits. The decoder keeps a 64-bit bit buffer in registers and refills it 32 bits at a
-// time from a word that was requested one refill earlier, so the load latency overlaps with decoding.
-struct NarrowReader {
-    const uint32_t* p;  // next word to request
-    uint64_t buf;
-    uint32_t have;      // valid bits in buf
-    uint32_t nxt;       // prefetched word (the one before p)
-    __device__ __forceinline__ void init(const uint32_t* __restrict__ bits32, uint64_t pos) {
-        const uint32_t* w = bits32 + (pos >> 5);
-        const uint32_t sh = (uint32_t)pos & 31u;
-        buf = (((uint64_t)w[1] << 32) | w[0]) >> sh;
-        have = 64 - sh;
-        nxt = w[2];
-        p = w + 3;
-    }
-    __device__ __forceinline__ uint32_t delta() {
-        if (have < 32) {
-            buf |= (uint64_t)nxt << have;
-            have += 32;
-            nxt = *p++;
-        }
-        const uint32_t v = (uint32_t)buf;
-        const uint32_t z = (uint32_t)__builtin_ctz(v | 0x80000000u);
-        const uint32_t len = (__builtin_amdgcn_ubfe(v, z + 1, z) | (1u << z)) - 1u;
-        const uint32_t used = 2 * z + 1;
-        const uint32_t body = __builtin_amdgcn_ubfe(v, used, len);
-        buf >>= used + len;
-        have -= used + len;
-        return (body | (1u << len)) - 1u;
-    }
-};
-
 struct ListHeader {
     uint64_t begin, body, soff;  // bitmap list: bit offsets of the list / of its bitmap. Gap-coded list: begin = first
                                  // data word in blk_words, soff = first block header
@@ -1130,48 +1085,25 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
 
 // ---------------------------------------------------------------------------------------------
 // Generic colour-set kernel for the meta, differential and meta-differential codecs.
-// Every colour set is a short list of ops over ONE bit arena (host/codecs_build.hpp). Per read, per
-// colour set: T = 0; fills and bitmaps are applied wave-cooperatively; all 16-code segments of all gap
-// ops decode concurrently (OR / clear / XOR into T with LDS atomics); then
-//   full intersection (meta_intersect / diff_intersect, ps_full_intersection.cpp:129-332): R &= T
+// Every colour set is a short list of ops (host/codecs_build.hpp); every op contributes a set of colours that
+// is XORed into the set under construction T (members of disjoint partitions, a representative, a symmetric
+// difference). Device form of an op (GenOpDev): a span of at most 8 plain words of the colour space, one lane
+// per op, or — for large universes — the same packed blocks / bitmap chunks as the hybrid gap lists. Then
+//   full intersection (meta_intersect / diff_intersect, ps_full_intersection.cpp:129-332): EXCL |= ~T
 //   threshold union   (merge_meta / merge_diff / merge_metadiff, ps_threshold_union.cpp:42-318):
 //                     score[c] += s for every c in T, keep c iff score[c] >= min_score
 // The reference reaches the same sets through partition/cluster shortcuts; the results are the sets.
 // ---------------------------------------------------------------------------------------------
-struct DevOp {
-    uint64_t body, soff;
-    uint32_t ncodes, kind, base, np;
-};
 struct DevGeneric {
-    const uint64_t* bits;
-    const DevOp* ops;
+    const ListDesc* ops;  // GenOpDev layout: begin, soff, ncodes = #blocks, meta = kind, score = w0, id = nw
     const uint64_t* set_ops_off;
     const uint32_t* set_ops;
-    const uint64_t* samples;
+    const uint32_t* arena;
+    const uint64_t* blk_hdr;
+    const uint32_t* blk_words;
     uint32_t n, w32;
 };
-enum { G_OR_GAPS = 0, G_OR_BITMAP = 1, G_OR_COMP = 2, G_XOR_GAPS = 3 };
-
-// decode segment `seg` of a gap op (values are relative to the op's colour base)
-template <typename F>
-__device__ __forceinline__ void decode_op_segment(const DevGeneric& g, uint64_t body, uint64_t soff, uint32_t ncodes,
-                                                  uint32_t seg, F f) {
-    uint64_t pos = body;
-    uint32_t prev = 0xFFFFFFFFu;
-    if (seg) {
-        const uint64_t s = g.samples[soff + seg - 1];
-        pos = body + (uint32_t)s;
-        prev = (uint32_t)(s >> 32);
-    }
-    const uint32_t nc = min(SAMPLE_STRIDE, ncodes - seg * SAMPLE_STRIDE);
-    if (g.n < 65536u) {
-        NarrowReader rd;
-        rd.init((const uint32_t*)g.bits, pos);
-        for (uint32_t i = 0; i < nc; ++i) { prev = prev + 1u + rd.delta(); f(prev); }
-    } else {
-        for (uint32_t i = 0; i < nc; ++i) { prev = prev + 1u + read_delta(g.bits, pos); f(prev); }
-    }
-}
+enum { G_SPAN = 0, G_BLOCKS = 1 };
 
 template <bool UNION>
 __global__ __launch_bounds__(256, UNION ? 4 : 8) void k_generic(DevGeneric g, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
@@ -1179,17 +1111,21 @@ __global__ __launch_bounds__(256, UNION ? 4 : 8) void k_generic(DevGeneric g, co
                           uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count, unsigned int* tickets,
                           uint32_t* __restrict__ scores_out) {
     // scores_out (UNION only): also store score[c] for every colour, n u32 per read (index::kmer_matches)
+    constexpr int BITS = 16;  // score counters: biased 16-bit fields, colour c -> plane c % 16, word c / 32, field (c % 32) / 16
+    constexpr uint32_t PLANES = 16, HALF = 0x8000u, ONES = 0x00010001u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    const uint32_t W = g.w32, n = g.n;
-    const uint32_t acc_bytes = UNION ? W * 64 : W * 4;
-    const uint32_t per_wave = wave_scratch_bytes() + 64 * 8 + W * 4 + acc_bytes;
+    const uint32_t W = g.w32, W4 = W >> 2, n = g.n;
+    const uint32_t acc_bytes = UNION ? W * 4 * PLANES : W * 4;
+    const uint32_t per_wave = wave_scratch_bytes() + W * 4 + acc_bytes;
     unsigned char* mine = smem + (size_t)wv * per_wave;
-    WaveScratch sc = carve_scratch(mine);                              // h_begin = body, h_soff, h_ncodes, h_score = kind
-    uint32_t* o_base = (uint32_t*)(mine + wave_scratch_bytes());       // 64 words: colour base of each op
-    uint32_t* o_np = o_base + 64;                                      // 64 words
-    uint32_t* T = o_np + 64;
-    uint32_t* ACC = T + W;                                             // R (W words) or SC (16 planes of W words)
+    WaveScratch sc = carve_scratch(mine);
+    uint32_t* T = (uint32_t*)(mine + wave_scratch_bytes());
+    uint4* T4 = (uint4*)T;
+    uint32_t* ACC = T + W;  // EXCL (W words) or the score planes
+    uint4* EX4 = (uint4*)ACC;
+    const uint32_t tail_word = n >> 5, tail_mask = ~((1u << (n & 31u)) - 1u);
+    const ListDesc none{0, 0, 0, 0xFFu, 0, 0};
     const WorkQueue wq{tickets, n_reads, 8};
     uint64_t t_first;
     uint32_t t_count;
@@ -1206,122 +1142,103 @@ __global__ __launch_bounds__(256, UNION ? 4 : 8) void k_generic(DevGeneric g, co
                 for (uint32_t cc = lane; cc < n; cc += 64) scores_out[r * (uint64_t)n + cc] = 0;
             continue;
         }
+        const uint32_t min_score = UNION ? (uint32_t)(unsigned long long)((double)npos[r] * tau) : 0u;
         if (UNION) {
-            for (uint32_t i = lane; i < W * 16; i += 64) ACC[i] = 0x80008000u;
+            const uint32_t start = (HALF - min_score) * ONES;  // score >= min_score  <=>  top bit of the field
+            for (uint32_t i = lane; i < W * PLANES; i += 64) ACC[i] = start;
         } else {
-            for (uint32_t w = lane; w < W; w += 64) {
-                const uint32_t lo = w * 32;
-                ACC[w] = lo >= n ? 0u : (n - lo >= 32 ? 0xFFFFFFFFu : ((1u << (n - lo)) - 1u));
+            for (uint32_t g4 = lane; g4 < W4; g4 += 64) {  // colours >= n start excluded
+                const uint32_t w = 4 * g4;
+                EX4[g4] = make_uint4(w < tail_word ? 0u : (w == tail_word ? tail_mask : 0xFFFFFFFFu),
+                                     w + 1 < tail_word ? 0u : (w + 1 == tail_word ? tail_mask : 0xFFFFFFFFu),
+                                     w + 2 < tail_word ? 0u : (w + 2 == tail_word ? tail_mask : 0xFFFFFFFFu),
+                                     w + 3 < tail_word ? 0u : (w + 3 == tail_word ? tail_mask : 0xFFFFFFFFu));
             }
         }
         for (uint32_t li = 0; li < cnt; ++li) {
             const ListDesc d = desc[off + li];
             const uint64_t o0 = g.set_ops_off[d.id], o1 = g.set_ops_off[d.id + 1];
-            for (uint32_t w = lane; w < W; w += 64) T[w] = 0;
+            for (uint32_t g4 = lane; g4 < W4; g4 += 64) T4[g4] = make_uint4(0u, 0u, 0u, 0u);
             wave_lds_sync();
             for (uint64_t og = o0; og < o1; og += 64) {
-                DevOp op;
-                op.body = op.soff = 0; op.ncodes = 0; op.kind = G_OR_BITMAP; op.base = 0; op.np = 0;
-                const bool have = og + lane < o1;
-                if (have) op = g.ops[g.set_ops[og + lane]];
-                const uint32_t nseg = (have && op.kind != G_OR_BITMAP) ? (op.ncodes + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE : 0u;
-                sc.h_begin[lane] = op.body; sc.h_soff[lane] = op.soff; sc.h_ncodes[lane] = op.ncodes;
-                sc.h_score[lane] = (int32_t)op.kind;
-                o_base[lane] = op.base; o_np[lane] = op.np;
-                const uint32_t incl = wave_incl_scan_u32(nseg);
-                sc.pref[lane] = incl;
-                const uint32_t total_seg = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                wave_lds_sync();
-                // complemented hybrid lists: fill the partition's colour range first
-                uint64_t mc = __ballot(have && op.kind == G_OR_COMP);
-                while (mc) {
-                    const int src = __builtin_ctzll(mc);
-                    mc &= mc - 1;
-                    const uint32_t b = o_base[src], e = b + o_np[src];
-                    for (uint32_t w = (b >> 5) + lane; w * 32 < e; w += 64) {
-                        uint32_t m = 0xFFFFFFFFu;
-                        if (w * 32 < b) m &= 0xFFFFFFFFu << (b & 31);
-                        if (e - w * 32 < 32) m &= (1u << (e - w * 32)) - 1u;
-                        atomicOr(&T[w], m);
+                ListDesc op = none;
+                if (og + lane < o1) op = g.ops[g.set_ops[og + lane]];
+                // span ops: one lane per op walks its (at most 8) words
+                const uint32_t nw = op.meta == G_SPAN ? op.id : 0u;
+                for (uint32_t j = 0; __any(j < nw); ++j) {
+                    if (j < nw) {
+                        const uint32_t x = g.arena[op.begin + j];
+                        if (x) atomicXor(&T[(uint32_t)op.score + j], x);
                     }
                 }
-                // hybrid bitmaps: OR the np bits at `body` into T at colour `base`
-                uint64_t mb = __ballot(have && op.kind == G_OR_BITMAP && op.np != 0);
-                while (mb) {
-                    const int src = __builtin_ctzll(mb);
-                    mb &= mb - 1;
-                    const uint64_t body = sc.h_begin[src];
-                    const uint32_t b = o_base[src], np = o_np[src];
-                    for (uint32_t kk = lane; kk * 32 < np; kk += 64) {
-                        uint32_t v = (uint32_t)bits_window(g.bits, body + 32ull * kk);
-                        if (np - kk * 32 < 32) v &= (1u << (np - kk * 32)) - 1u;
-                        const uint32_t dpos = b + kk * 32, sh = dpos & 31u;
-                        atomicOr(&T[dpos >> 5], v << sh);
-                        if (sh && (v >> (32 - sh))) atomicOr(&T[(dpos >> 5) + 1], v >> (32 - sh));
+                // block ops: the blocks of all of them through one loop, as in k2a
+                const uint32_t nblk = op.meta == G_BLOCKS ? op.ncodes : 0u;
+                const uint32_t incl = wave_incl_scan_u32(nblk);
+                const uint32_t total_blk = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (total_blk) {
+                    sc.h_begin[lane] = op.begin; sc.h_soff[lane] = op.soff; sc.h_ncodes[lane] = nblk;
+                    sc.pref[lane] = incl;
+                    wave_lds_sync();
+                    for (uint32_t s0 = 0; s0 < total_blk; s0 += 64) {
+                        BlockLane bl{0u, 0u, 0u, 0u, 0u};
+                        const uint32_t s = s0 + lane;
+                        if (s < total_blk) {
+                            const uint32_t i = upper_slot(sc.pref, s);
+                            const uint32_t jb = s - (sc.pref[i] - sc.h_ncodes[i]);
+                            const uint64_t hd = g.blk_hdr[sc.h_soff[i] + jb];
+                            const uint64_t a = (uint64_t)(g.blk_words + sc.h_begin[i] + blk_rel_word(hd));
+                            bl.a_lo = (uint32_t)a;
+                            bl.a_hi = (uint32_t)(a >> 32);
+                            bl.start = blk_start(hd);
+                            bl.meta = blk_width(hd) | ((blk_count(hd) - 1u) << 5);
+                        }
+                        run_blocks(bl, min(64u, total_blk - s0), lane,
+                                   [&](uint32_t v, uint32_t) { atomicXor(&T[v >> 5], 1u << (v & 31)); },
+                                   [&](uint32_t wi, uint32_t x, uint32_t) { atomicXor(&T[wi], x); },
+                                   [](uint32_t) {});
                     }
+                    wave_lds_sync();
                 }
-                wave_lds_sync();
-                for (uint32_t t0 = 0; t0 < total_seg; t0 += 64) {
-                    const uint32_t t = t0 + lane;
-                    if (t < total_seg) {
-                        const uint32_t i = upper_slot(sc.pref, t);
-                        const uint32_t nc = sc.h_ncodes[i];
-                        const uint32_t ns = (nc + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
-                        const uint32_t seg = t - (sc.pref[i] - ns);
-                        // every gap op is a toggle: sparse members flip 0 -> 1 (partitions are disjoint and a
-                        // list holds distinct colours), missing colours of a complemented list flip the filled
-                        // range 1 -> 0, representative and differential lists XOR by definition
-                        const uint32_t b = o_base[i];
-                        decode_op_segment(g, sc.h_begin[i], sc.h_soff[i], nc, seg,
-                                          [&](uint32_t v) { atomicXor(&T[(b + v) >> 5], 1u << ((b + v) & 31)); });
-                    }
-                }
-                wave_lds_sync();
             }
+            wave_lds_sync();
             if (UNION) {
                 const uint32_t s = (uint32_t)d.score;
                 for (uint32_t w = lane; w < W; w += 64) {
                     const uint32_t x = T[w];
+                    if (x) {
 #pragma unroll
-                    for (uint32_t q = 0; q < 16; ++q) {
-                        const uint32_t add = ((x >> (2 * q)) & 1u) * s + (((x >> (2 * q + 1)) & 1u) * s << 16);
-                        if (add) ACC[q * W + w] += add;
+                        for (uint32_t q = 0; q < PLANES; ++q) atomicAdd(&ACC[q * W + w], counter_spread<BITS>(x, q, s, 0u));
                     }
                 }
             } else {
-                for (uint32_t w = lane; w < W; w += 64) ACC[w] &= T[w];
+                for (uint32_t g4 = lane; g4 < W4; g4 += 64) EX4[g4] = or_not(EX4[g4], T4[g4]);
             }
             wave_lds_sync();
         }
         uint32_t pc = 0;
-        if (UNION && scores_out) {  // colour c: word c / 32, plane (c % 32) / 2, half c % 2; counters are biased by 0x8000
-            for (uint32_t cc = lane; cc < n; cc += 64) {
-                const uint32_t x = ACC[((cc & 31u) >> 1) * W + (cc >> 5)];
-                scores_out[r * (uint64_t)n + cc] = ((x >> (16 * (cc & 1u))) & 0xFFFFu) - 0x8000u;
-            }
-        }
         if (UNION) {
-            const long long min_score = (long long)(unsigned long long)((double)npos[r] * tau);
-            const long long thr_ll = min_score + 0x8000;
-            const uint32_t thr = thr_ll > 0x10000 ? 0x10000u : (uint32_t)thr_ll;
+            if (scores_out) {  // counter = HALF - min_score + score
+                for (uint32_t cc = lane; cc < n; cc += 64) {
+                    const uint32_t x = ACC[(cc % PLANES) * W + (cc >> 5)];
+                    scores_out[r * (uint64_t)n + cc] = ((x >> (BITS * ((cc & 31u) / PLANES))) & 0xFFFFu) - HALF + min_score;
+                }
+            }
             for (uint32_t w = lane; w < W; w += 64) {
                 uint32_t m = 0;
 #pragma unroll
-                for (uint32_t q = 0; q < 16; ++q) {
-                    const uint32_t x = ACC[q * W + w];
-                    m |= (uint32_t)((x & 0xFFFFu) >= thr) << (2 * q);
-                    m |= (uint32_t)((x >> 16) >= thr) << (2 * q + 1);
-                }
+                for (uint32_t q = 0; q < PLANES; ++q) m |= ((ACC[q * W + w] >> (BITS - 1)) & ONES) << q;
                 const uint32_t lo = w * 32;
                 m &= lo >= n ? 0u : (n - lo >= 32 ? 0xFFFFFFFFu : ((1u << (n - lo)) - 1u));
                 bm[w] = m;
                 pc += __popc(m);
             }
         } else {
-            for (uint32_t w = lane; w < W; w += 64) {
-                const uint32_t x = ACC[w];
-                bm[w] = x;
-                pc += __popc(x);
+            uint4* bm4 = (uint4*)bm;
+            for (uint32_t g4 = lane; g4 < W4; g4 += 64) {
+                const uint4 e = EX4[g4];
+                const uint4 x = make_uint4(~e.x, ~e.y, ~e.z, ~e.w);
+                bm4[g4] = x;
+                pc += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
             }
         }
         pc = wave_sum_u32(pc);

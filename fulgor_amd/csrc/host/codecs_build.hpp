@@ -7,8 +7,8 @@
 //   meta-differential partitions whose partial sets are differential                 (meta_differential.hpp:35-73)
 // All lists live in ONE bit arena (the reference keeps one bit_vector per partition; the concatenation
 // is a layout choice for HBM). On top of the streams the engine keeps, per colour set, a short list of
-// *ops* — (kind, colour base, universe, stream position, code count, restart samples) — so that a
-// wavefront can rebuild the set as an n-bit bitmap with all list segments decoding concurrently:
+// *ops* — (kind, colour base, universe, stream position, code count) — so that a wavefront can rebuild
+// the set as an n-bit bitmap from its ops (device form of an op: build_generic_device below):
 //   OR_GAPS    sparse hybrid list            -> set bits
 //   OR_BITMAP  hybrid bitmap                 -> OR shifted words
 //   OR_COMP    complemented hybrid list      -> fill [base, base+np), then clear the listed colours
@@ -122,34 +122,100 @@ struct VecHash {
 
 }  // namespace detail
 
-inline void build_generic_samples(GenericSets& g, unsigned nthreads = 0) {
-    if (nthreads == 0) nthreads = std::max(1u, std::thread::hardware_concurrency());
-    uint64_t total = 0;
-    for (auto& op : g.ops) {
-        op.soff = total;
-        if (op.kind != OP_OR_BITMAP && op.ncodes > SAMPLE_STRIDE) total += (op.ncodes - 1) / SAMPLE_STRIDE;
+// colours an op contributes (absolute, ascending)
+inline void op_members(const GenericSets& g, const SetOp& op, std::vector<uint32_t>& out) {
+    out.clear();
+    if (op.kind == OP_OR_BITMAP) {
+        for (uint32_t c = 0; c < op.np; ++c) {
+            const uint64_t p = op.body + c;
+            if ((g.bits[p >> 6] >> (p & 63)) & 1) out.push_back(op.base + c);
+        }
+        return;
     }
-    g.samples.assign(total, 0);
-    auto work = [&](size_t a, size_t b) {
+    BitReader r(g.bits.data(), op.body);
+    uint32_t prev = 0xFFFFFFFFu;
+    if (op.kind == OP_OR_COMP) {  // the universe minus the listed colours
+        uint32_t c = 0;
+        for (uint32_t i = 0; i < op.ncodes; ++i) {
+            prev = prev + 1 + (uint32_t)r.delta();
+            for (; c < prev; ++c) out.push_back(op.base + c);
+            c = prev + 1;
+        }
+        for (; c < op.np; ++c) out.push_back(op.base + c);
+        return;
+    }
+    for (uint32_t i = 0; i < op.ncodes; ++i) {
+        prev = prev + 1 + (uint32_t)r.delta();
+        out.push_back(op.base + prev);
+    }
+}
+
+// device form of every op (two passes over the ops, multi-threaded)
+inline void build_generic_device(GenericSets& g, unsigned nthreads = 0) {
+    if (g.num_colors > BLK_MAX_COLORS) throw std::runtime_error("more than 2^27 colours are not supported");
+    if (nthreads == 0) nthreads = std::max(1u, std::thread::hardware_concurrency());
+    const size_t n = g.ops.size();
+    g.dev_ops.assign(n, GenOpDev{});
+    std::vector<uint64_t> arena_off(n + 1, 0), blk_off(n + 1, 0), word_off(n + 1, 0);
+    auto run = [&](auto fn) {
+        std::vector<std::thread> th;
+        const size_t per = (n + nthreads - 1) / nthreads;
+        for (unsigned t = 0; t < nthreads; ++t) {
+            size_t a = std::min(n, t * per), b = std::min(n, a + per);
+            if (a < b) th.emplace_back(fn, a, b);
+        }
+        for (auto& x : th) x.join();
+    };
+    auto span_words = [](const SetOp& op) -> uint32_t {
+        return op.np ? ((op.base + op.np - 1) >> 5) - (op.base >> 5) + 1 : 0u;
+    };
+    run([&](size_t a, size_t b) {
+        std::vector<uint32_t> vals;
         for (size_t i = a; i < b; ++i) {
             const SetOp& op = g.ops[i];
-            if (op.kind == OP_OR_BITMAP || op.ncodes <= SAMPLE_STRIDE) continue;
-            BitReader r(g.bits.data(), op.body);
-            uint32_t prev = 0xFFFFFFFFu;
-            uint64_t* dst = g.samples.data() + op.soff;
-            for (uint32_t c = 0; c < op.ncodes; ++c) {
-                prev = prev + 1 + (uint32_t)r.delta();
-                if ((c + 1) % SAMPLE_STRIDE == 0 && c + 1 < op.ncodes) *dst++ = ((uint64_t)prev << 32) | (uint32_t)(r.pos - op.body);
-            }
+            const uint32_t sw = span_words(op);
+            if (sw <= GOP_SPAN_WORDS) { arena_off[i + 1] = sw; continue; }
+            op_members(g, op, vals);
+            cut_blocks(vals.data(), (uint32_t)vals.size(), [&](uint32_t, uint32_t, uint32_t, uint32_t nw, const uint32_t*, uint32_t) {
+                ++blk_off[i + 1];
+                word_off[i + 1] += nw;
+            });
         }
-    };
-    std::vector<std::thread> th;
-    const size_t n = g.ops.size(), per = (n + nthreads - 1) / nthreads;
-    for (unsigned t = 0; t < nthreads; ++t) {
-        size_t a = std::min(n, t * per), b = std::min(n, a + per);
-        if (a < b) th.emplace_back(work, a, b);
-    }
-    for (auto& x : th) x.join();
+    });
+    for (size_t i = 0; i < n; ++i) { arena_off[i + 1] += arena_off[i]; blk_off[i + 1] += blk_off[i]; word_off[i + 1] += word_off[i]; }
+    g.dev_arena.assign(arena_off[n] + 2, 0);
+    g.dev_blk_hdr.assign(blk_off[n], 0);
+    g.dev_blk_words.assign(word_off[n] + 64, 0);
+    run([&](size_t a, size_t b) {
+        std::vector<uint32_t> vals;
+        for (size_t i = a; i < b; ++i) {
+            const SetOp& op = g.ops[i];
+            GenOpDev& d = g.dev_ops[i];
+            op_members(g, op, vals);
+            const uint32_t sw = span_words(op);
+            if (sw <= GOP_SPAN_WORDS) {
+                d.kind = GOP_SPAN;
+                d.begin = arena_off[i];
+                d.w0 = op.base >> 5;
+                d.nw = sw;
+                uint32_t* w = g.dev_arena.data() + arena_off[i];
+                for (uint32_t c : vals) w[(c >> 5) - d.w0] |= 1u << (c & 31);
+                continue;
+            }
+            d.kind = GOP_BLOCKS;
+            d.begin = word_off[i];
+            d.soff = blk_off[i];
+            d.ncodes = (uint32_t)(blk_off[i + 1] - blk_off[i]);
+            uint64_t* hdr = g.dev_blk_hdr.data() + blk_off[i];
+            uint32_t* base = g.dev_blk_words.data() + word_off[i];
+            uint64_t rel = 0;
+            cut_blocks(vals.data(), (uint32_t)vals.size(), [&](uint32_t start, uint32_t width, uint32_t cnt, uint32_t nw, const uint32_t* v, uint32_t nv) {
+                *hdr++ = blk_pack(start, width, cnt, (uint32_t)rel);
+                write_block_words(base + rel, start, width, v, nv);
+                rel += nw;
+            });
+        }
+    });
 }
 
 // re-encode the colour sets of a hybrid index with another codec
@@ -249,7 +315,7 @@ inline void convert_sets(const HybridSets& h, int type, uint32_t psize, uint32_t
     g.set_bytes.assign(ns, 0);
     for (uint64_t id = 0; id < ns; ++id)
         for (uint64_t o = g.set_ops_off[id]; o < g.set_ops_off[id + 1]; ++o) g.set_bytes[id] += op_bytes[g.set_ops[o]] + 16;
-    build_generic_samples(g);
+    build_generic_device(g);
 }
 
 // host decode of one colour set through its ops (self check / export)
@@ -279,6 +345,37 @@ inline void generic_decode(const GenericSets& g, uint64_t id, std::vector<uint32
     out.clear();
     for (uint32_t w = 0; w < T.size(); ++w)
         for (uint64_t x = T[w]; x; x &= x - 1) out.push_back(w * 64 + (uint32_t)__builtin_ctzll(x));
+}
+
+// host decode of one colour set through the DEVICE form of its ops (self check of build_generic_device):
+// what k_generic computes, word for word
+inline void generic_decode_device(const GenericSets& g, uint64_t id, std::vector<uint32_t>& out) {
+    std::vector<uint32_t> T((g.num_colors + 31) / 32 + 64, 0);
+    for (uint64_t o = g.set_ops_off[id]; o < g.set_ops_off[id + 1]; ++o) {
+        const GenOpDev& d = g.dev_ops[g.set_ops[o]];
+        if (d.kind == GOP_SPAN) {
+            for (uint32_t j = 0; j < d.nw; ++j) T[d.w0 + j] ^= g.dev_arena[d.begin + j];
+            continue;
+        }
+        for (uint32_t b = 0; b < d.ncodes; ++b) {
+            const uint64_t h = g.dev_blk_hdr[d.soff + b];
+            const uint32_t* w = g.dev_blk_words.data() + d.begin + blk_rel_word(h);
+            const uint32_t width = blk_width(h), cnt = blk_count(h), start = blk_start(h);
+            if (width == BLK_CHUNK_WIDTH) {
+                for (uint32_t j = 0; j < cnt; ++j) T[(start >> 5) + j] ^= w[j];
+            } else {
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    const uint64_t bit = (uint64_t)i * width;
+                    const uint64_t two = (uint64_t)w[bit >> 5] | ((uint64_t)w[(bit >> 5) + 1] << 32);
+                    const uint32_t v = start + (uint32_t)((two >> (bit & 31)) & ((1ULL << width) - 1ULL));
+                    T[v >> 5] ^= 1u << (v & 31);
+                }
+            }
+        }
+    }
+    out.clear();
+    for (uint32_t w = 0; w < T.size(); ++w)
+        for (uint32_t x = T[w]; x; x &= x - 1) out.push_back(w * 32 + (uint32_t)__builtin_ctz(x));
 }
 
 }  // namespace fg

@@ -103,6 +103,40 @@ inline void hybrid_decode(const HybridSets& h, uint64_t id, std::vector<uint32_t
     }
 }
 
+// cut a sorted list of distinct values into device blocks (common/kmer_common.h):
+// emit(start, width, count field, data words, first value of the block, values in the block)
+template <typename Emit>
+inline void cut_blocks(const uint32_t* vals, uint32_t n, Emit emit) {
+    for (uint32_t i = 0; i < n;) {
+        const uint32_t cnt = std::min(BLK_VALUES, n - i);
+        const uint32_t origin = vals[i] & ~31u;
+        if (vals[i + cnt - 1] - origin < BLK_CHUNK_SPAN) {  // dense here: bitmap chunk
+            uint32_t j = i + cnt;
+            while (j < n && vals[j] - origin < BLK_CHUNK_SPAN) ++j;
+            const uint32_t nw = ((vals[j - 1] - origin) >> 5) + 1;
+            emit(origin, BLK_CHUNK_WIDTH, nw, nw, vals + i, j - i);
+            i = j;
+        } else {
+            const uint32_t start = i ? vals[i - 1] + 1 : 0u, span = vals[i + cnt - 1] - start;
+            uint32_t width = 0;
+            while ((span >> width) != 0) ++width;
+            emit(start, width, cnt, (uint32_t)(((uint64_t)cnt * width + 31) / 32), vals + i, cnt);
+            i += cnt;
+        }
+    }
+}
+inline void write_block_words(uint32_t* w, uint32_t start, uint32_t width, const uint32_t* v, uint32_t nv) {
+    if (width == BLK_CHUNK_WIDTH) {
+        for (uint32_t i = 0; i < nv; ++i) w[(v[i] - start) >> 5] |= 1u << ((v[i] - start) & 31);
+    } else {
+        for (uint32_t i = 0; i < nv && width; ++i) {
+            const uint64_t f = (uint64_t)(v[i] - start) << ((i * width) & 31);
+            w[(i * width) >> 5] |= (uint32_t)f;
+            if (f >> 32) w[((i * width) >> 5) + 1] |= (uint32_t)(f >> 32);
+        }
+    }
+}
+
 // packed 64-value blocks for every gap-coded list (multi-threaded over lists); see common/kmer_common.h
 inline void hybrid_build_blocks(HybridSets& h, unsigned nthreads = 0) {
     const uint64_t ns = h.num_sets();
@@ -131,23 +165,7 @@ inline void hybrid_build_blocks(HybridSets& h, unsigned nthreads = 0) {
         vals.resize(ncodes);
         uint32_t prev = 0xFFFFFFFFu;
         for (uint32_t i = 0; i < ncodes; ++i) { prev = prev + 1 + (uint32_t)r.delta(); vals[i] = prev; }
-        for (uint32_t i = 0; i < ncodes;) {
-            const uint32_t cnt = std::min(BLK_VALUES, ncodes - i);
-            const uint32_t origin = vals[i] & ~31u;
-            if (vals[i + cnt - 1] - origin < BLK_CHUNK_SPAN) {  // dense here: bitmap chunk
-                uint32_t j = i + cnt;
-                while (j < ncodes && vals[j] - origin < BLK_CHUNK_SPAN) ++j;
-                const uint32_t nw = ((vals[j - 1] - origin) >> 5) + 1;
-                emit(origin, BLK_CHUNK_WIDTH, nw, nw, vals.data() + i, j - i);
-                i = j;
-            } else {
-                const uint32_t start = i ? vals[i - 1] + 1 : 0u, span = vals[i + cnt - 1] - start;
-                uint32_t width = 0;
-                while ((span >> width) != 0) ++width;
-                emit(start, width, cnt, (uint32_t)(((uint64_t)cnt * width + 31) / 32), vals.data() + i, cnt);
-                i += cnt;
-            }
-        }
+        cut_blocks(vals.data(), ncodes, emit);
     };
     run([&](uint64_t a, uint64_t b) {
         std::vector<uint32_t> vals;
@@ -169,16 +187,7 @@ inline void hybrid_build_blocks(HybridSets& h, unsigned nthreads = 0) {
             uint64_t rel = 0;
             walk(id, vals, [&](uint32_t start, uint32_t width, uint32_t cnt, uint32_t nw, const uint32_t* v, uint32_t nv) {
                 *hdr++ = blk_pack(start, width, cnt, (uint32_t)rel);
-                uint32_t* w = base + rel;
-                if (width == BLK_CHUNK_WIDTH) {
-                    for (uint32_t i = 0; i < nv; ++i) w[(v[i] - start) >> 5] |= 1u << ((v[i] - start) & 31);
-                } else {
-                    for (uint32_t i = 0; i < nv && width; ++i) {
-                        const uint64_t f = (uint64_t)(v[i] - start) << ((i * width) & 31);
-                        w[(i * width) >> 5] |= (uint32_t)f;
-                        if (f >> 32) w[((i * width) >> 5) + 1] |= (uint32_t)(f >> 32);
-                    }
-                }
+                write_block_words(base + rel, start, width, v, nv);
                 rel += nw;
             });
         }

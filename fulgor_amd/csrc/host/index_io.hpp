@@ -195,7 +195,7 @@ inline void load_binary(const std::string& path, HostIndex& idx) {
         rd(i, g.num_colors); rd(i, g.partition_size); rd(i, g.cluster_size); rd(i, g.num_partitions);
         rd(i, g.num_partial_sets); rd(i, g.num_clusters); rd(i, g.nbits);
         rdv(i, g.bits); rdv(i, g.ops); rdv(i, g.set_ops_off); rdv(i, g.set_ops); rdv(i, g.set_bytes);
-        build_generic_samples(g);
+        build_generic_device(g);
     }
     uint64_t nf;
     rd(i, nf);

@@ -58,11 +58,28 @@ enum OpKind : uint32_t { OP_OR_GAPS = 0, OP_OR_BITMAP = 1, OP_OR_COMP = 2, OP_XO
 
 struct SetOp {         // 32 bytes, read as two 16-byte loads on the device
     uint64_t body;     // bit position of the first gap code / of the bitmap
-    uint64_t soff;     // first restart sample (samples hold bit offsets relative to `body`)
+    uint64_t soff;     // unused (kept for the 32-byte layout)
     uint32_t ncodes;   // gap codes (0 for bitmaps)
     uint32_t kind;     // OpKind
     uint32_t base;     // first colour of the partition (0 for differential)
     uint32_t np;       // colours in the partition
+};
+
+// Device form of one op, built at load / convert (codecs_build.hpp: build_generic_device). Every op of
+// every codec contributes a set of colours that is XORed into the set under construction (members of disjoint
+// partitions, a representative, a symmetric difference), so the device needs no universal-code decoder:
+//   GOP_SPAN   the op's universe covers at most GOP_SPAN_WORDS 32-bit words of the colour space: its members
+//              are stored as that many plain words (arena), XORed at word w0 — one lane per op
+//   GOP_BLOCKS larger universes: the same packed blocks / bitmap chunks as the hybrid gap lists
+enum GenOpKind : uint32_t { GOP_SPAN = 0, GOP_BLOCKS = 1 };
+constexpr uint32_t GOP_SPAN_WORDS = 8;
+struct GenOpDev {      // 32 bytes, same layout as the device's ListDesc
+    uint64_t begin;    // SPAN: first word in dev_arena; BLOCKS: first data word in dev_blk_words
+    uint64_t soff;     // BLOCKS: first block header
+    uint32_t ncodes;   // BLOCKS: number of blocks
+    uint32_t kind;     // GenOpKind
+    uint32_t w0;       // SPAN: first 32-bit word of the colour space the op touches
+    uint32_t nw;       // SPAN: words
 };
 
 struct GenericSets {
@@ -75,7 +92,11 @@ struct GenericSets {
     std::vector<SetOp> ops;
     std::vector<uint64_t> set_ops_off;  // num_sets + 1
     std::vector<uint32_t> set_ops;      // op indices
-    std::vector<uint64_t> samples;      // restart samples of all gap ops (acceleration, rebuilt at load)
+    // device form (acceleration structure, rebuilt at load): see GenOpDev
+    std::vector<GenOpDev> dev_ops;
+    std::vector<uint32_t> dev_arena;     // 2 padding words
+    std::vector<uint64_t> dev_blk_hdr;
+    std::vector<uint32_t> dev_blk_words; // 64 padding words
     std::vector<uint32_t> set_bytes;    // algorithmic bytes per colour set (accounting only)
     uint64_t num_sets() const { return set_ops_off.empty() ? 0 : set_ops_off.size() - 1; }
 };
