@@ -210,14 +210,14 @@ void upload_generic(fgpu_index* ix) {
     // the device holds the ops in their device form (spans / packed blocks); the encoded arena stays on the host
     upload(ix->d_gops, g.dev_ops, s);
     upload(ix->d_gset_ops_off, g.set_ops_off, s);
-    upload(ix->d_gset_ops, g.set_ops, s);
-    upload(ix->d_garena, g.dev_arena, s);
+    upload(ix->d_gset_ops, g.dev_set_ops, s);
+    upload(ix->d_garena, g.dev_span, s);
     upload(ix->d_gblk_hdr, g.dev_blk_hdr, s);
     upload(ix->d_gblk_words, g.dev_blk_words, s);
     upload(ix->d_gset_bytes, g.set_bytes, s);
     HIP_TRY(hipStreamSynchronize(s));
-    ix->dg = DevGeneric{ix->d_gops.as<ListDesc>(), ix->d_gset_ops_off.as<uint64_t>(), ix->d_gset_ops.as<uint32_t>(),
-                        ix->d_garena.as<uint32_t>(), ix->d_gblk_hdr.as<uint64_t>(), ix->d_gblk_words.as<uint32_t>(),
+    ix->dg = DevGeneric{ix->d_gset_ops_off.as<uint64_t>(), ix->d_gset_ops.as<uint32_t>(), ix->d_garena.as<uint4>(),
+                        ix->d_gops.as<ListDesc>(), ix->d_gblk_hdr.as<uint64_t>(), ix->d_gblk_words.as<uint32_t>(),
                         g.num_colors, ix->dc.w32};
 }
 
@@ -397,7 +397,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     if (ix->host.type != IDX_HYBRID) {
         const bool uni = algo == FGPU_THRESHOLD_UNION;
         if (!uni && algo != FGPU_FULL_INTERSECTION) throw std::runtime_error("unknown algorithm");
-        const size_t per_wave = wave_scratch_bytes() + (size_t)W * 4 + (uni ? (size_t)W * 64 : (size_t)W * 4);
+        const size_t per_wave = wave_scratch_bytes() + (size_t)G_SETS * W * 4 + (uni ? (size_t)W * 64 : (size_t)W * 4);
         const void* kfn = uni ? (const void*)k_generic<true> : (const void*)k_generic<false>;
         const uint32_t wpb = pick_waves(per_wave, kfn);
         const uint32_t grid = uni ? resident_grid(k_generic<true>, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave)

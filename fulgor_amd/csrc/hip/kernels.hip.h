@@ -1087,26 +1087,29 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
 // Generic colour-set kernel for the meta, differential and meta-differential codecs.
 // Every colour set is a short list of ops (host/codecs_build.hpp); every op contributes a set of colours that
 // is XORed into the set under construction T (members of disjoint partitions, a representative, a symmetric
-// difference). Device form of an op (GenOpDev): a span of at most 8 plain words of the colour space, one lane
-// per op, or — for large universes — the same packed blocks / bitmap chunks as the hybrid gap lists. Then
+// difference). Device form of an op: a 32-byte record holding a span of at most 7 plain words of the colour
+// space, one lane per op, or — for large universes — the same packed blocks / bitmap chunks as the hybrid gap
+// lists. Then
 //   full intersection (meta_intersect / diff_intersect, ps_full_intersection.cpp:129-332): EXCL |= ~T
 //   threshold union   (merge_meta / merge_diff / merge_metadiff, ps_threshold_union.cpp:42-318):
 //                     score[c] += s for every c in T, keep c iff score[c] >= min_score
 // The reference reaches the same sets through partition/cluster shortcuts; the results are the sets.
 // ---------------------------------------------------------------------------------------------
 struct DevGeneric {
-    const ListDesc* ops;  // GenOpDev layout: begin, soff, ncodes = #blocks, meta = kind, score = w0, id = nw
     const uint64_t* set_ops_off;
-    const uint32_t* set_ops;
-    const uint32_t* arena;
+    const uint32_t* set_ops;  // per colour set: span record index, or G_BLOCK_REF | block-op index
+    const uint4* span;        // two uint4 per span op: {first word | count << 24, 7 words}
+    const ListDesc* ops;      // block ops (GenOpDev layout: begin, soff, ncodes = #blocks)
     const uint64_t* blk_hdr;
     const uint32_t* blk_words;
     uint32_t n, w32;
 };
-enum { G_SPAN = 0, G_BLOCKS = 1 };
+constexpr uint32_t G_BLOCK_REF = 0x80000000u;
+
+constexpr uint32_t G_SETS = 4;  // colour sets of a read rebuilt concurrently (one LDS plane each)
 
 template <bool UNION>
-__global__ __launch_bounds__(256, UNION ? 4 : 8) void k_generic(DevGeneric g, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
+__global__ __launch_bounds__(256, UNION ? 4 : 6) void k_generic(DevGeneric g, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
                           const ListDesc* __restrict__ desc, double tau, uint64_t n_reads,
                           uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count, unsigned int* tickets,
                           uint32_t* __restrict__ scores_out) {
@@ -1117,12 +1120,12 @@ __global__ __launch_bounds__(256, UNION ? 4 : 8) void k_generic(DevGeneric g, co
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = g.w32, W4 = W >> 2, n = g.n;
     const uint32_t acc_bytes = UNION ? W * 4 * PLANES : W * 4;
-    const uint32_t per_wave = wave_scratch_bytes() + W * 4 + acc_bytes;
+    const uint32_t per_wave = wave_scratch_bytes() + G_SETS * W * 4 + acc_bytes;
     unsigned char* mine = smem + (size_t)wv * per_wave;
     WaveScratch sc = carve_scratch(mine);
-    uint32_t* T = (uint32_t*)(mine + wave_scratch_bytes());
+    uint32_t* T = (uint32_t*)(mine + wave_scratch_bytes());  // G_SETS planes of W words
     uint4* T4 = (uint4*)T;
-    uint32_t* ACC = T + W;  // EXCL (W words) or the score planes
+    uint32_t* ACC = T + G_SETS * W;  // EXCL (W words) or the score planes
     uint4* EX4 = (uint4*)ACC;
     const uint32_t tail_word = n >> 5, tail_mask = ~((1u << (n & 31u)) - 1u);
     const ListDesc none{0, 0, 0, 0xFFu, 0, 0};
@@ -1155,28 +1158,58 @@ __global__ __launch_bounds__(256, UNION ? 4 : 8) void k_generic(DevGeneric g, co
                                      w + 3 < tail_word ? 0u : (w + 3 == tail_word ? tail_mask : 0xFFFFFFFFu));
             }
         }
-        for (uint32_t li = 0; li < cnt; ++li) {
-            const ListDesc d = desc[off + li];
-            const uint64_t o0 = g.set_ops_off[d.id], o1 = g.set_ops_off[d.id + 1];
-            for (uint32_t g4 = lane; g4 < W4; g4 += 64) T4[g4] = make_uint4(0u, 0u, 0u, 0u);
+        // rounds of up to G_SETS colour sets: the (set, op) pairs of the round are spread over the lanes, so the
+        // dependent fetches set -> op list -> op -> data are walked once per round, not once per set
+        for (uint32_t g0 = 0; g0 < cnt; g0 += G_SETS) {
+            const uint32_t nl = min(G_SETS, cnt - g0);
+            uint64_t o0 = 0;
+            uint32_t nops = 0, score = 0;
+            if ((uint32_t)lane < nl) {
+                const ListDesc d = desc[off + g0 + lane];
+                o0 = g.set_ops_off[d.id];
+                nops = (uint32_t)(g.set_ops_off[d.id + 1] - o0);
+                score = (uint32_t)d.score;
+            }
+            for (uint32_t g4 = lane; g4 < nl * W4; g4 += 64) T4[g4] = make_uint4(0u, 0u, 0u, 0u);
+            const uint32_t incl_ops = wave_incl_scan_u32(nops);
+            const uint32_t excl_ops = incl_ops - nops;
+            const uint32_t total_ops = (uint32_t)__builtin_amdgcn_readlane((int)incl_ops, 63);
+            sc.h_body[lane] = o0;
             wave_lds_sync();
-            for (uint64_t og = o0; og < o1; og += 64) {
+            for (uint32_t p0 = 0; p0 < total_ops; p0 += 64) {
+                const uint32_t p = p0 + lane;
                 ListDesc op = none;
-                if (og + lane < o1) op = g.ops[g.set_ops[og + lane]];
-                // span ops: one lane per op walks its (at most 8) words
-                const uint32_t nw = op.meta == G_SPAN ? op.id : 0u;
-                for (uint32_t j = 0; __any(j < nw); ++j) {
-                    if (j < nw) {
-                        const uint32_t x = g.arena[op.begin + j];
-                        if (x) atomicXor(&T[(uint32_t)op.score + j], x);
+                uint32_t plane = 0, ref = G_BLOCK_REF;  // (lanes past the end: a block reference that is never followed)
+                if (p < total_ops) {
+                    uint32_t e = 0;  // (v_readlane, unlike a shuffle, also reads lanes that are masked off here)
+                    for (uint32_t i = 1; i < nl; ++i) {
+                        const uint32_t ei = (uint32_t)__builtin_amdgcn_readlane((int)excl_ops, i);
+                        if (p >= ei) { plane = i; e = ei; }
                     }
+                    ref = g.set_ops[sc.h_body[plane] + (p - e)];
+                }
+                const uint32_t tbase = plane * W;
+                // span ops: one 32-byte record per lane, its (at most 7) words XORed in place
+                if (!(ref & G_BLOCK_REF)) {
+                    const uint4 a = g.span[2 * (uint64_t)ref], b = g.span[2 * (uint64_t)ref + 1];
+                    uint32_t* dst = T + tbase + (a.x & 0xFFFFFFu);
+                    if (a.y) atomicXor(dst + 0, a.y);
+                    if (a.z) atomicXor(dst + 1, a.z);
+                    if (a.w) atomicXor(dst + 2, a.w);
+                    if (b.x) atomicXor(dst + 3, b.x);
+                    if (b.y) atomicXor(dst + 4, b.y);
+                    if (b.z) atomicXor(dst + 5, b.z);
+                    if (b.w) atomicXor(dst + 6, b.w);
+                } else if (p < total_ops) {
+                    op = g.ops[ref & ~G_BLOCK_REF];
                 }
                 // block ops: the blocks of all of them through one loop, as in k2a
-                const uint32_t nblk = op.meta == G_BLOCKS ? op.ncodes : 0u;
+                const uint32_t nblk = (p < total_ops && (ref & G_BLOCK_REF)) ? op.ncodes : 0u;
                 const uint32_t incl = wave_incl_scan_u32(nblk);
                 const uint32_t total_blk = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 if (total_blk) {
                     sc.h_begin[lane] = op.begin; sc.h_soff[lane] = op.soff; sc.h_ncodes[lane] = nblk;
+                    sc.h_score[lane] = (int32_t)(tbase * 32u);
                     sc.pref[lane] = incl;
                     wave_lds_sync();
                     for (uint32_t s0 = 0; s0 < total_blk; s0 += 64) {
@@ -1189,7 +1222,7 @@ __global__ __launch_bounds__(256, UNION ? 4 : 8) void k_generic(DevGeneric g, co
                             const uint64_t a = (uint64_t)(g.blk_words + sc.h_begin[i] + blk_rel_word(hd));
                             bl.a_lo = (uint32_t)a;
                             bl.a_hi = (uint32_t)(a >> 32);
-                            bl.start = blk_start(hd);
+                            bl.start = blk_start(hd) + (uint32_t)sc.h_score[i];  // bit index relative to T
                             bl.meta = blk_width(hd) | ((blk_count(hd) - 1u) << 5);
                         }
                         run_blocks(bl, min(64u, total_blk - s0), lane,
@@ -1201,17 +1234,19 @@ __global__ __launch_bounds__(256, UNION ? 4 : 8) void k_generic(DevGeneric g, co
                 }
             }
             wave_lds_sync();
-            if (UNION) {
-                const uint32_t s = (uint32_t)d.score;
-                for (uint32_t w = lane; w < W; w += 64) {
-                    const uint32_t x = T[w];
-                    if (x) {
+            for (uint32_t l = 0; l < nl; ++l) {
+                if (UNION) {
+                    const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)score, l);
+                    for (uint32_t w = lane; w < W; w += 64) {
+                        const uint32_t x = T[l * W + w];
+                        if (x) {
 #pragma unroll
-                        for (uint32_t q = 0; q < PLANES; ++q) atomicAdd(&ACC[q * W + w], counter_spread<BITS>(x, q, s, 0u));
+                            for (uint32_t q = 0; q < PLANES; ++q) atomicAdd(&ACC[q * W + w], counter_spread<BITS>(x, q, s, 0u));
+                        }
                     }
+                } else {
+                    for (uint32_t g4 = lane; g4 < W4; g4 += 64) EX4[g4] = or_not(EX4[g4], T4[l * W4 + g4]);
                 }
-            } else {
-                for (uint32_t g4 = lane; g4 < W4; g4 += 64) EX4[g4] = or_not(EX4[g4], T4[g4]);
             }
             wave_lds_sync();
         }

@@ -155,8 +155,7 @@ inline void build_generic_device(GenericSets& g, unsigned nthreads = 0) {
     if (g.num_colors > BLK_MAX_COLORS) throw std::runtime_error("more than 2^27 colours are not supported");
     if (nthreads == 0) nthreads = std::max(1u, std::thread::hardware_concurrency());
     const size_t n = g.ops.size();
-    g.dev_ops.assign(n, GenOpDev{});
-    std::vector<uint64_t> arena_off(n + 1, 0), blk_off(n + 1, 0), word_off(n + 1, 0);
+    std::vector<uint64_t> span_off(n + 1, 0), bop_off(n + 1, 0), blk_off(n + 1, 0), word_off(n + 1, 0);
     auto run = [&](auto fn) {
         std::vector<std::thread> th;
         const size_t per = (n + nthreads - 1) / nthreads;
@@ -173,8 +172,8 @@ inline void build_generic_device(GenericSets& g, unsigned nthreads = 0) {
         std::vector<uint32_t> vals;
         for (size_t i = a; i < b; ++i) {
             const SetOp& op = g.ops[i];
-            const uint32_t sw = span_words(op);
-            if (sw <= GOP_SPAN_WORDS) { arena_off[i + 1] = sw; continue; }
+            if (span_words(op) <= GOP_SPAN_WORDS) { span_off[i + 1] = 1; continue; }
+            bop_off[i + 1] = 1;
             op_members(g, op, vals);
             cut_blocks(vals.data(), (uint32_t)vals.size(), [&](uint32_t, uint32_t, uint32_t, uint32_t nw, const uint32_t*, uint32_t) {
                 ++blk_off[i + 1];
@@ -182,30 +181,35 @@ inline void build_generic_device(GenericSets& g, unsigned nthreads = 0) {
             });
         }
     });
-    for (size_t i = 0; i < n; ++i) { arena_off[i + 1] += arena_off[i]; blk_off[i + 1] += blk_off[i]; word_off[i + 1] += word_off[i]; }
-    g.dev_arena.assign(arena_off[n] + 2, 0);
+    for (size_t i = 0; i < n; ++i) {
+        span_off[i + 1] += span_off[i]; bop_off[i + 1] += bop_off[i];
+        blk_off[i + 1] += blk_off[i]; word_off[i + 1] += word_off[i];
+    }
+    if (span_off[n] >= GOP_BLOCK_REF || bop_off[n] >= GOP_BLOCK_REF) throw std::runtime_error("too many ops for 31-bit references");
+    g.dev_span.assign(span_off[n] * 8 + 8, 0);
+    g.dev_ops.assign(bop_off[n], GenOpDev{});
     g.dev_blk_hdr.assign(blk_off[n], 0);
     g.dev_blk_words.assign(word_off[n] + 64, 0);
+    std::vector<uint32_t> ref(n, 0);
     run([&](size_t a, size_t b) {
         std::vector<uint32_t> vals;
         for (size_t i = a; i < b; ++i) {
             const SetOp& op = g.ops[i];
-            GenOpDev& d = g.dev_ops[i];
             op_members(g, op, vals);
             const uint32_t sw = span_words(op);
             if (sw <= GOP_SPAN_WORDS) {
-                d.kind = GOP_SPAN;
-                d.begin = arena_off[i];
-                d.w0 = op.base >> 5;
-                d.nw = sw;
-                uint32_t* w = g.dev_arena.data() + arena_off[i];
-                for (uint32_t c : vals) w[(c >> 5) - d.w0] |= 1u << (c & 31);
+                uint32_t* rec = g.dev_span.data() + span_off[i] * 8;
+                const uint32_t w0 = op.base >> 5;
+                rec[0] = w0 | (sw << 24);
+                for (uint32_t c : vals) rec[1 + (c >> 5) - w0] |= 1u << (c & 31);
+                ref[i] = (uint32_t)span_off[i];
                 continue;
             }
-            d.kind = GOP_BLOCKS;
+            GenOpDev& d = g.dev_ops[bop_off[i]];
             d.begin = word_off[i];
             d.soff = blk_off[i];
             d.ncodes = (uint32_t)(blk_off[i + 1] - blk_off[i]);
+            ref[i] = GOP_BLOCK_REF | (uint32_t)bop_off[i];
             uint64_t* hdr = g.dev_blk_hdr.data() + blk_off[i];
             uint32_t* base = g.dev_blk_words.data() + word_off[i];
             uint64_t rel = 0;
@@ -216,6 +220,8 @@ inline void build_generic_device(GenericSets& g, unsigned nthreads = 0) {
             });
         }
     });
+    g.dev_set_ops.resize(g.set_ops.size());
+    for (size_t i = 0; i < g.set_ops.size(); ++i) g.dev_set_ops[i] = ref[g.set_ops[i]];
 }
 
 // re-encode the colour sets of a hybrid index with another codec
@@ -352,11 +358,13 @@ inline void generic_decode(const GenericSets& g, uint64_t id, std::vector<uint32
 inline void generic_decode_device(const GenericSets& g, uint64_t id, std::vector<uint32_t>& out) {
     std::vector<uint32_t> T((g.num_colors + 31) / 32 + 64, 0);
     for (uint64_t o = g.set_ops_off[id]; o < g.set_ops_off[id + 1]; ++o) {
-        const GenOpDev& d = g.dev_ops[g.set_ops[o]];
-        if (d.kind == GOP_SPAN) {
-            for (uint32_t j = 0; j < d.nw; ++j) T[d.w0 + j] ^= g.dev_arena[d.begin + j];
+        const uint32_t ref = g.dev_set_ops[o];
+        if (!(ref & GOP_BLOCK_REF)) {
+            const uint32_t* rec = g.dev_span.data() + (uint64_t)ref * 8;
+            for (uint32_t j = 0; j < GOP_SPAN_WORDS; ++j) T[(rec[0] & 0xFFFFFFu) + j] ^= rec[1 + j];
             continue;
         }
+        const GenOpDev& d = g.dev_ops[ref & ~GOP_BLOCK_REF];
         for (uint32_t b = 0; b < d.ncodes; ++b) {
             const uint64_t h = g.dev_blk_hdr[d.soff + b];
             const uint32_t* w = g.dev_blk_words.data() + d.begin + blk_rel_word(h);

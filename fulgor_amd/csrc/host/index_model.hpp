@@ -65,21 +65,20 @@ struct SetOp {         // 32 bytes, read as two 16-byte loads on the device
     uint32_t np;       // colours in the partition
 };
 
-// Device form of one op, built at load / convert (codecs_build.hpp: build_generic_device). Every op of
-// every codec contributes a set of colours that is XORed into the set under construction (members of disjoint
+// Device form of the ops, built at load / convert (codecs_build.hpp: build_generic_device). Every op of every
+// codec contributes a set of colours that is XORed into the set under construction (members of disjoint
 // partitions, a representative, a symmetric difference), so the device needs no universal-code decoder:
-//   GOP_SPAN   the op's universe covers at most GOP_SPAN_WORDS 32-bit words of the colour space: its members
-//              are stored as that many plain words (arena), XORed at word w0 — one lane per op
-//   GOP_BLOCKS larger universes: the same packed blocks / bitmap chunks as the hybrid gap lists
-enum GenOpKind : uint32_t { GOP_SPAN = 0, GOP_BLOCKS = 1 };
-constexpr uint32_t GOP_SPAN_WORDS = 8;
+//   span op   the op's universe covers at most GOP_SPAN_WORDS 32-bit words of the colour space: one 32-byte
+//             record {first word | count << 24, the words}, fetched with one request and XORed by one lane
+//   block op  larger universes: the same packed blocks / bitmap chunks as the hybrid gap lists (GenOpDev)
+// dev_set_ops lists, per colour set, references to them: span record index, or GOP_BLOCK_REF | block-op index.
+constexpr uint32_t GOP_SPAN_WORDS = 7;
+constexpr uint32_t GOP_BLOCK_REF = 0x80000000u;
 struct GenOpDev {      // 32 bytes, same layout as the device's ListDesc
-    uint64_t begin;    // SPAN: first word in dev_arena; BLOCKS: first data word in dev_blk_words
-    uint64_t soff;     // BLOCKS: first block header
-    uint32_t ncodes;   // BLOCKS: number of blocks
-    uint32_t kind;     // GenOpKind
-    uint32_t w0;       // SPAN: first 32-bit word of the colour space the op touches
-    uint32_t nw;       // SPAN: words
+    uint64_t begin;    // first data word in dev_blk_words
+    uint64_t soff;     // first block header
+    uint32_t ncodes;   // number of blocks
+    uint32_t pad0, pad1, pad2;
 };
 
 struct GenericSets {
@@ -93,8 +92,9 @@ struct GenericSets {
     std::vector<uint64_t> set_ops_off;  // num_sets + 1
     std::vector<uint32_t> set_ops;      // op indices
     // device form (acceleration structure, rebuilt at load): see GenOpDev
-    std::vector<GenOpDev> dev_ops;
-    std::vector<uint32_t> dev_arena;     // 2 padding words
+    std::vector<uint32_t> dev_set_ops;   // parallel to set_ops
+    std::vector<uint32_t> dev_span;      // 8 words per span op
+    std::vector<GenOpDev> dev_ops;       // block ops
     std::vector<uint64_t> dev_blk_hdr;
     std::vector<uint32_t> dev_blk_words; // 64 padding words
     std::vector<uint32_t> set_bytes;    // algorithmic bytes per colour set (accounting only)
