@@ -397,28 +397,27 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     if (ix->host.type != IDX_HYBRID) {
         const bool uni = algo == FGPU_THRESHOLD_UNION;
         if (!uni && algo != FGPU_FULL_INTERSECTION) throw std::runtime_error("unknown algorithm");
-        const size_t per_wave = wave_scratch_bytes() + (size_t)G_SETS * W * 4 + (uni ? (size_t)W * 64 : (size_t)W * 4);
-        const void* kfn = uni ? (const void*)k_generic<true> : (const void*)k_generic<false>;
-        const uint32_t wpb = pick_waves(per_wave, kfn);
-        const uint32_t grid = uni ? resident_grid(k_generic<true>, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave)
-                                  : resident_grid(k_generic<false>, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
-        Timed t(ix, res, uni ? FGPU_K_UNION : FGPU_K_INTERSECT);
-        uint32_t* scores_out = nullptr;
-        if (uni && res->max_kmers_in_batch > 32767)  // k_generic<true> keeps 16-bit biased score counters
+        if (uni && res->max_kmers_in_batch > 32767)  // biased 16-bit score counters at most
             throw std::runtime_error("threshold-union on the meta / differential codecs supports reads of at most 32767 k-mers");
+        const int bits = res->max_kmers_in_batch <= 127 ? 8 : 16;
+        const size_t per_wave = wave_scratch_bytes() + (size_t)G_SETS * W * 4 + (uni ? (size_t)W * 4 * bits : (size_t)W * 4);
+        uint32_t* scores_out = nullptr;
         if (uni && res->want_scores) {
             res->d_scores.ensure(n * (uint64_t)ix->dc.n * 4 + 16);
             scores_out = res->d_scores.as<uint32_t>();
         }
-        if (uni)
-            hipLaunchKernelGGL(k_generic<true>, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dg, res->d_npos.as<uint32_t>(),
+        auto launch = [&](auto kernel) {
+            const uint32_t wpb = pick_waves(per_wave, (const void*)kernel);
+            const uint32_t grid = resident_grid(kernel, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
+            Timed t(ix, res, uni ? FGPU_K_UNION : FGPU_K_INTERSECT);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dg, res->d_npos.as<uint32_t>(),
                                res->d_idcsr.as<uint64_t>(), res->d_desc.as<ListDesc>(), tau, n, res->d_bitmap.as<uint32_t>(),
                                res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, scores_out);
-        else
-            hipLaunchKernelGGL(k_generic<false>, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dg, res->d_npos.as<uint32_t>(),
-                               res->d_idcsr.as<uint64_t>(), res->d_desc.as<ListDesc>(), tau, n, res->d_bitmap.as<uint32_t>(),
-                               res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, (uint32_t*)nullptr);
-        HIP_TRY(hipGetLastError());
+            HIP_TRY(hipGetLastError());
+        };
+        if (!uni) launch(k_generic<false, 16>);
+        else if (bits == 8) launch(k_generic<true, 8>);
+        else launch(k_generic<true, 16>);
     } else if (algo == FGPU_FULL_INTERSECTION) {
         const size_t per_wave = (size_t)2 * W * 4 + wave_scratch_bytes();
         const uint32_t wpb = pick_waves(per_wave, (const void*)k2a_intersect);

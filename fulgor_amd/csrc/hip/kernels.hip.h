@@ -1108,14 +1108,16 @@ constexpr uint32_t G_BLOCK_REF = 0x80000000u;
 
 constexpr uint32_t G_SETS = 4;  // colour sets of a read rebuilt concurrently (one LDS plane each)
 
-template <bool UNION>
-__global__ __launch_bounds__(256, UNION ? 4 : 6) void k_generic(DevGeneric g, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
+template <bool UNION, int BITS>
+__global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 6 : 4) : 6) void k_generic(DevGeneric g, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
                           const ListDesc* __restrict__ desc, double tau, uint64_t n_reads,
                           uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count, unsigned int* tickets,
                           uint32_t* __restrict__ scores_out) {
     // scores_out (UNION only): also store score[c] for every colour, n u32 per read (index::kmer_matches)
-    constexpr int BITS = 16;  // score counters: biased 16-bit fields, colour c -> plane c % 16, word c / 32, field (c % 32) / 16
-    constexpr uint32_t PLANES = 16, HALF = 0x8000u, ONES = 0x00010001u;
+    // score counters as in k3a: biased BITS-bit fields (8 for reads of at most 127 k-mers, else 16),
+    // colour c -> plane c % PLANES, word c / 32, field (c % 32) / PLANES
+    constexpr uint32_t PLANES = BITS, HALF = 1u << (BITS - 1), ONES = BITS == 8 ? 0x01010101u : 0x00010001u;
+    constexpr uint32_t FIELD = (1u << BITS) - 1u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = g.w32, W4 = W >> 2, n = g.n;
@@ -1255,7 +1257,7 @@ __global__ __launch_bounds__(256, UNION ? 4 : 6) void k_generic(DevGeneric g, co
             if (scores_out) {  // counter = HALF - min_score + score
                 for (uint32_t cc = lane; cc < n; cc += 64) {
                     const uint32_t x = ACC[(cc % PLANES) * W + (cc >> 5)];
-                    scores_out[r * (uint64_t)n + cc] = ((x >> (BITS * ((cc & 31u) / PLANES))) & 0xFFFFu) - HALF + min_score;
+                    scores_out[r * (uint64_t)n + cc] = ((x >> (BITS * ((cc & 31u) / PLANES))) & FIELD) - HALF + min_score;
                 }
             }
             for (uint32_t w = lane; w < W; w += 64) {
