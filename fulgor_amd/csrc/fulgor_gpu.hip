@@ -355,10 +355,12 @@ void run_scan(fgpu_index* ix, fgpu_result* res, const uint32_t* sizes, uint64_t 
 }
 
 // per-read id lists (nids + source offsets into ids/cnt arrays) -> compact CSR of resolved descriptors
-// Per-read descriptor lists for the threshold union and the generic codecs. The hybrid full intersection
-// gathers DevColors::set_desc itself (no scan, no descriptor array, no host round trip), so it skips this.
+// Per-read descriptor lists (colour-set id + score) for the generic codecs. The hybrid kernels gather
+// DevColors::set_desc themselves from the lookup kernel's id slab (no scan, no descriptor array, no host
+// round trip), so they skip this.
 void stage_descriptors(fgpu_index* ix, fgpu_result* res, uint64_t max_total_ids, int algo) {
-    if (ix->host.type == IDX_HYBRID && algo == FGPU_FULL_INTERSECTION) return;
+    (void)algo;
+    if (ix->host.type == IDX_HYBRID) return;
     hipStream_t s = res->stream;
     const uint64_t n = res->n;
     res->d_idcsr.ensure((n + 1) * 8 + 16);
@@ -441,7 +443,8 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
                 scores_out = res->d_scores.as<uint32_t>();
             }
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_npos.as<uint32_t>(),
-                               res->d_idcsr.as<uint64_t>(), res->d_desc.as<ListDesc>(), tau, n, res->d_bitmap.as<uint32_t>(),
+                               res->d_nids.as<uint32_t>(), res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(),
+                               res->d_cnt_pool.as<uint32_t>(), tau, n, res->d_bitmap.as<uint32_t>(),
                                res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, scores_out);
             HIP_TRY(hipGetLastError());
         };

@@ -625,8 +625,8 @@ struct ListHeader {
 
 // One resolved colour list (32 bytes). DevColors::set_desc holds one per colour set (score = 0, id = its
 // index), so that a kernel reaches everything it needs about a list with ONE gather. k_desc, a flat kernel with
-// one thread per (read, list) pair, copies them into per-read order together with the list's score for the
-// threshold union and the generic codecs; the full intersection gathers them itself, one read ahead.
+// one thread per (read, list) pair, writes (id, score) descriptors in per-read order for the generic codecs;
+// the hybrid kernels gather set_desc themselves (the full intersection one read ahead).
 struct __attribute__((aligned(16))) ListDesc {
     uint64_t begin;   // bitmap list: bit offset of the list; gap-coded list: first data word in blk_words
     uint64_t soff;    // gap-coded list: first block header
@@ -952,8 +952,9 @@ __device__ __forceinline__ uint32_t counter_spread(uint32_t x, uint32_t q, uint3
 
 template <int BITS>
 __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a_union(DevColors c, const uint32_t* __restrict__ npos,
-                                                                  const uint64_t* __restrict__ id_csr,
-                                                                  const ListDesc* __restrict__ desc, double tau, uint64_t n_reads,
+                                                                  const uint32_t* __restrict__ nids, const uint64_t* __restrict__ idoff,
+                                                                  const uint32_t* __restrict__ ids_pool,
+                                                                  const uint32_t* __restrict__ cnt_pool, double tau, uint64_t n_reads,
                                                                   uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count,
                                                                   unsigned int* tickets, uint32_t* __restrict__ scores_out) {
     // scores_out != nullptr: also store score[c] (= #positive k-mers of the read whose colour set contains c,
@@ -974,10 +975,12 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
     uint64_t t_first;
     uint32_t t_count;
 
+    const ListDesc none{0, 0, 0, 0xFFu, 0, 0};
     while (wq.pull(t_first, t_count))
     for (uint64_t r = t_first; r < t_first + t_count; ++r) {
-        const uint64_t off = id_csr[r];
-        const uint32_t cnt = (uint32_t)(id_csr[r + 1] - off);
+        // ids and multiplicities straight from the lookup kernel's slab; one 32-byte descriptor gather per list
+        const uint64_t off = idoff[r];
+        const uint32_t cnt = nids[r];
         uint32_t* bm = out_bitmap + r * W;
         if (cnt == 0) {
             for (uint32_t w = lane; w < W; w += 64) bm[w] = 0;
@@ -986,28 +989,30 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
                 for (uint32_t cc = lane; cc < n; cc += 64) scores_out[r * (uint64_t)n + cc] = 0;
             continue;
         }
+        auto load_desc = [&](uint32_t g) -> ListDesc {
+            ListDesc d = none;
+            if (g + lane < cnt) {
+                d = c.set_desc[ids_pool[off + g + lane]];
+                d.score = (int32_t)cnt_pool[off + g + lane];
+            }
+            return d;
+        };
         const uint32_t min_score = (uint32_t)(unsigned long long)((double)npos[r] * tau);
+        const ListDesc d_first = load_desc(0);
         uint32_t comp_total = 0;
         for (uint32_t g = 0; g < cnt; g += 64) {
-            uint32_t cs = 0;
-            if (g + lane < cnt) {
-                const ListDesc d = desc[off + g + lane];
-                cs = desc_type(d) == D_ENC_COMPLEMENT ? (uint32_t)d.score : 0u;
-            }
-            comp_total += wave_sum_u32(cs);
+            const ListDesc d = g ? load_desc(g) : d_first;
+            comp_total += wave_sum_u32(desc_type(d) == D_ENC_COMPLEMENT ? (uint32_t)d.score : 0u);
         }
         const uint32_t start = (HALF - min_score + comp_total) * ONES;
         for (uint32_t i = lane; i < W * PLANES; i += 64) SC[i] = start;
         wave_lds_sync();
         for (uint32_t g = 0; g < cnt; g += 64) {
+            const ListDesc d = g ? load_desc(g) : d_first;
             ListHeader h;
-            h.type = D_ENC_NONE; h.ncodes = 0; h.begin = h.body = h.soff = 0; h.size = 0;
-            int32_t score = 0;
-            if (g + lane < cnt) {
-                const ListDesc d = desc[off + g + lane];
-                h.type = desc_type(d); h.ncodes = d.ncodes; h.begin = d.begin; h.body = desc_body(d); h.soff = d.soff;
-                score = d.score;
-            }
+            h.size = 0;
+            h.type = (int)(int8_t)(d.meta & 0xFFu); h.ncodes = d.ncodes; h.begin = d.begin; h.body = desc_body(d); h.soff = d.soff;
+            const int32_t score = d.score;
             const uint32_t nblk = h.ncodes;  // gap-coded lists of both kinds
             sc.h_begin[lane] = h.begin; sc.h_body[lane] = h.body; sc.h_soff[lane] = h.soff; sc.h_ncodes[lane] = nblk;
             sc.h_score[lane] = h.type == D_ENC_COMPLEMENT ? -score : score;
