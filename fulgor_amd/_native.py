@@ -66,6 +66,7 @@ def lib():
     L.fgpu_result_sizes.argtypes = [vp, u64p, u64p, u64p]
     L.fgpu_result_download.argtypes = [vp, vp, vp]
     L.fgpu_result_accumulate_hits.argtypes = [vp, vp, vp]
+    L.fgpu_result_format.argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(vp), u64p]
     L.fgpu_result_algorithmic_bytes.argtypes = [vp, u64p, u64p, u64p]
     L.fgpu_timing_enable.argtypes = [vp, C.c_int]
     L.fgpu_timing_reset.argtypes = [vp]
@@ -82,3 +83,13 @@ def lib():
 def check(rc):
     if rc != 0:
         raise RuntimeError("libfulgor_gpu: %s (code %d)" % (lib().fgpu_last_error().decode(), rc))
+
+
+def take_bytes(ptr, size):
+    """copy `size` bytes of a malloc'd library buffer into a bytes object and release the buffer
+    (ctypes.string_at takes a C int: outputs of one pass routinely exceed 2 GB)"""
+    n = int(size)
+    try:
+        return bytes((C.c_ubyte * n).from_address(ptr.value)) if n else b""
+    finally:
+        lib().fgpu_free(ptr)

@@ -62,7 +62,7 @@ void upload(DevBuf& b, const std::vector<T>& v, hipStream_t s) {
 
 constexpr size_t TICKET_BYTES = 3 * 8 * TICKET_STRIDE * sizeof(unsigned int);
 
-const char* KERNEL_NAMES[FGPU_K_COUNT] = {"k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits", "k_desc"};
+const char* KERNEL_NAMES[FGPU_K_COUNT] = {"k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits", "k_desc", "k_format"};
 
 }  // namespace
 
@@ -149,6 +149,7 @@ struct fgpu_result {
     uint64_t n = 0, total = 0, mapped = 0, total_kmers = 0, total_bases = 0;
     uint32_t id_stride = 0;
     uint32_t hit_rows = 0;  // rows of d_partial filled by the last expand launch (0: no colours, nothing to add)
+    DevBuf d_fmt_sizes, d_fmt_off, d_fmt_out;  // device-side formatter
     bool hits_folded = true;  // false: too many colours for the expand kernel's LDS histogram; k_hits counts from the bitmaps
     uint32_t max_kmers_in_batch = 0xFFFFFFFFu;  // bound on #positive k-mers of any read (unknown for id-only calls)
     bool have_ids = false;
@@ -339,7 +340,7 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
 }
 
 // exclusive scan of n u32 sizes into n+1 u64 offsets; totals -> d_totals {sum, #nonzero}
-void run_scan(fgpu_index* ix, fgpu_result* res, const uint32_t* sizes, uint64_t n, uint64_t* offsets) {
+void run_scan(fgpu_index* ix, fgpu_result* res, const uint32_t* sizes, uint64_t n, uint64_t* offsets, uint64_t* totals = nullptr) {
     hipStream_t s = res->stream;
     const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     res->d_block_sums.ensure(std::max<uint64_t>(1, nb) * 8);
@@ -349,7 +350,7 @@ void run_scan(fgpu_index* ix, fgpu_result* res, const uint32_t* sizes, uint64_t 
     hipLaunchKernelGGL(scan_block_sums, dim3((uint32_t)nb), dim3(256), 0, s, sizes, n, res->d_block_sums.as<uint64_t>(),
                        res->d_block_mapped.as<uint64_t>());
     hipLaunchKernelGGL(scan_top, dim3(1), dim3(256), 0, s, res->d_block_sums.as<uint64_t>(), res->d_block_mapped.as<uint64_t>(), nb,
-                       res->d_totals.as<uint64_t>());
+                       totals ? totals : res->d_totals.as<uint64_t>());
     hipLaunchKernelGGL(scan_apply, dim3((uint32_t)nb), dim3(256), 0, s, sizes, n, res->d_block_sums.as<uint64_t>(), offsets);
     HIP_TRY(hipGetLastError());
 }
@@ -679,7 +680,7 @@ void fgpu_result_free(fgpu_result* r) {
     if (!r) return;
     (void)hipSetDevice(r->ix->device);
     for (DevBuf* b : {&r->d_nids, &r->d_npos, &r->d_idoff, &r->d_ids_pool, &r->d_cnt_pool, &r->d_cursor, &r->d_bitmap,
-                      &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct, &r->d_partial, &r->d_tickets, &r->d_idcsr, &r->d_desc, &r->d_kmer_ids, &r->d_scores})
+                      &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct, &r->d_partial, &r->d_tickets, &r->d_idcsr, &r->d_desc, &r->d_kmer_ids, &r->d_scores, &r->d_fmt_sizes, &r->d_fmt_off, &r->d_fmt_out})
         b->release();
     if (r->h_totals) (void)hipHostFree(r->h_totals);
     if (r->stream) (void)hipStreamDestroy(r->stream);
@@ -714,6 +715,59 @@ int fgpu_result_download(const fgpu_result* r, uint64_t* offsets, uint32_t* colo
         HIP_TRY(hipSetDevice(r->ix->device));
         HIP_TRY(hipMemcpy(offsets, r->d_offsets.p, (r->n + 1) * 8, hipMemcpyDeviceToHost));
         if (r->total && colors) HIP_TRY(hipMemcpy(colors, r->d_colors.p, r->total * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+int fgpu_result_format(const fgpu_result* r, int format, uint32_t first_read_id, char** out, uint64_t* out_len) {
+    if (!r || !out || !out_len) return fail(-EINVAL, "null argument");
+    if (format != FGPU_FMT_ASCII && format != FGPU_FMT_BINARY)
+        return fail(-ENOTSUP, "device-side formatting covers ascii and binary; use fgpu_formatter_* for the compressed format");
+    fgpu_result* res = const_cast<fgpu_result*>(r);
+    fgpu_index* ix = r->ix;
+    return guarded([&] {
+        HIP_TRY(hipSetDevice(ix->device));
+        hipStream_t s = res->stream;
+        const uint64_t n = res->n;
+        uint64_t bytes = 0;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 3) / 4, (uint64_t)ix->num_cus * 16);
+        if (n && format == FGPU_FMT_BINARY) {
+            bytes = 8 * n + 4 * res->total;
+            res->d_fmt_out.ensure(bytes);
+            Timed t(ix, res, FGPU_K_FORMAT);
+            hipLaunchKernelGGL(k_fmt_binary_write, dim3(grid), dim3(256), 0, s, res->d_offsets.as<uint64_t>(), res->d_colors.as<uint32_t>(),
+                               n, first_read_id, res->d_fmt_out.as<uint32_t>());
+            HIP_TRY(hipGetLastError());
+        } else if (n) {
+            res->d_fmt_sizes.ensure(n * 4 + 16);
+            res->d_fmt_off.ensure((n + 1) * 8 + 48);
+            {
+            Timed t(ix, res, FGPU_K_FORMAT);
+            hipLaunchKernelGGL(k_fmt_ascii_sizes, dim3(grid), dim3(256), 0, s, res->d_offsets.as<uint64_t>(), res->d_colors.as<uint32_t>(),
+                               n, first_read_id, res->d_fmt_sizes.as<uint32_t>());
+            }
+            uint64_t* totals = res->d_fmt_off.as<uint64_t>() + (n + 2);  // scratch behind the offsets (keeps d_totals intact)
+            run_scan(ix, res, res->d_fmt_sizes.as<uint32_t>(), n, res->d_fmt_off.as<uint64_t>(), totals);
+            uint64_t h[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(h, totals, 16, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            bytes = h[0];
+            res->d_fmt_out.ensure(bytes + 16);
+            Timed t(ix, res, FGPU_K_FORMAT);
+            hipLaunchKernelGGL(k_fmt_ascii_write, dim3(grid), dim3(256), 0, s, res->d_offsets.as<uint64_t>(), res->d_colors.as<uint32_t>(),
+                               n, first_read_id, res->d_fmt_off.as<uint64_t>(), res->d_fmt_out.as<unsigned char>());
+            HIP_TRY(hipGetLastError());
+        }
+        char* buf = (char*)malloc(std::max<uint64_t>(1, bytes));
+        if (!buf) throw std::bad_alloc();
+        if (bytes) {
+            const hipError_t e = hipMemcpyAsync(buf, res->d_fmt_out.p, bytes, hipMemcpyDeviceToHost, s);
+            if (e != hipSuccess) { free(buf); HIP_TRY(e); }
+        }
+        const hipError_t e2 = hipStreamSynchronize(s);
+        if (e2 != hipSuccess) { free(buf); HIP_TRY(e2); }
+        if (ix->timing) ix->collect_timing(res->pending);
+        *out = buf;
+        *out_len = bytes;
     });
 }
 

@@ -1490,6 +1490,83 @@ __global__ void k_add_totals(unsigned long long* hits, uint32_t n, uint64_t num_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Device-side output formatters (src/ps_utils.cpp:48-135): the CSR result of a pass as the bytes the reference
+// writes — ascii "<id>\t<count>[\t<colour>...]\n" (psa_ascii_formatter, digits as util::vec_to_tsv) or binary
+// u32 id, u32 count, u32 x count (psa_binary_formatter). One wave per read; record sizes first, an exclusive scan
+// gives the byte offsets, then every lane writes the text of its colour at its prefix position.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dec_digits(uint32_t x) {
+    return 1u + (x >= 10u) + (x >= 100u) + (x >= 1000u) + (x >= 10000u) + (x >= 100000u) + (x >= 1000000u) +
+           (x >= 10000000u) + (x >= 100000000u) + (x >= 1000000000u);
+}
+// writes x in decimal, most significant digit first, at p; returns the digit count
+__device__ __forceinline__ uint32_t put_dec(unsigned char* p, uint32_t x) {
+    const uint32_t nd = dec_digits(x);
+    for (uint32_t i = nd; i-- > 0;) {
+        p[i] = (unsigned char)('0' + x % 10u);
+        x /= 10u;
+    }
+    return nd;
+}
+
+__global__ __launch_bounds__(256) void k_fmt_ascii_sizes(const uint64_t* __restrict__ off, const uint32_t* __restrict__ colors,
+                                                         uint64_t n_reads, uint32_t first_id, uint32_t* __restrict__ sizes) {
+    const int lane = lane_id();
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave; r < n_reads; r += nwaves) {
+        const uint64_t o0 = off[r], o1 = off[r + 1];
+        uint32_t b = 0;
+        for (uint64_t i = o0 + lane; i < o1; i += 64) b += 1u + dec_digits(colors[i]);
+        b = wave_sum_u32(b);
+        if (lane == 0) sizes[r] = b + dec_digits(first_id + (uint32_t)r) + 1u + dec_digits((uint32_t)(o1 - o0)) + 1u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fmt_ascii_write(const uint64_t* __restrict__ off, const uint32_t* __restrict__ colors,
+                                                         uint64_t n_reads, uint32_t first_id, const uint64_t* __restrict__ byte_off,
+                                                         unsigned char* __restrict__ out) {
+    const int lane = lane_id();
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave; r < n_reads; r += nwaves) {
+        const uint64_t o0 = off[r], o1 = off[r + 1];
+        unsigned char* p = out + byte_off[r];
+        const uint32_t id = first_id + (uint32_t)r, cnt = (uint32_t)(o1 - o0);
+        const uint32_t hdr = dec_digits(id) + 1u + dec_digits(cnt);
+        if (lane == 0) {
+            const uint32_t a = put_dec(p, id);
+            p[a] = '\t';
+            put_dec(p + a + 1, cnt);
+        }
+        uint64_t at = hdr;  // bytes of the record already placed
+        for (uint64_t i0 = o0; i0 < o1; i0 += 64) {
+            const bool have = i0 + lane < o1;
+            const uint32_t c = have ? colors[i0 + lane] : 0u;
+            const uint32_t len = have ? 1u + dec_digits(c) : 0u;
+            const uint32_t incl = wave_incl_scan_u32(len);
+            if (have) {
+                unsigned char* q = p + at + (incl - len);
+                q[0] = '\t';
+                put_dec(q + 1, c);
+            }
+            at += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        if (lane == 0) p[at] = '\n';
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fmt_binary_write(const uint64_t* __restrict__ off, const uint32_t* __restrict__ colors,
+                                                          uint64_t n_reads, uint32_t first_id, uint32_t* __restrict__ out) {
+    const int lane = lane_id();
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave; r < n_reads; r += nwaves) {
+        const uint64_t o0 = off[r], o1 = off[r + 1];
+        uint32_t* p = out + 2 * r + o0;  // every earlier record: 2 header words + its colours
+        if (lane == 0) { p[0] = first_id + (uint32_t)r; p[1] = (uint32_t)(o1 - o0); }
+        for (uint64_t i = o0 + lane; i < o1; i += 64) p[2 + (i - o0)] = colors[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // algorithmic bytes of the colour-intersection stage:
 //   sum over reads of  sum_c ceil(list bits / 8) + 16|C| + 4|C| + 4|R| + 8
 // ---------------------------------------------------------------------------------------------

@@ -54,9 +54,7 @@ class Formatter:
         self.header = self._take(p, n)
 
     def _take(self, p, n):
-        b = self._C.string_at(p, n.value)
-        self._L.fgpu_free(p)
-        return b
+        return self._N.take_bytes(p, n.value)
 
     def add(self, first_id, offsets, colors):
         C = self._C
@@ -150,8 +148,11 @@ def pseudoalign_reads(index, bases, offs, algo=FULL_INTERSECTION, threshold=0.0,
         _, _, m = res.sizes()
         mapped += m
         if f is not None:
-            o, c = res.download()
-            sink.write(f.add(first_id + a, o, c))
+            if fmt in ("ascii", "binary"):  # formatted by HIP kernels from the resident CSR (fgpu_result_format)
+                sink.write(res.format(FORMATS[fmt], first_id + a))
+            else:
+                o, c = res.download()
+                sink.write(f.add(first_id + a, o, c))
     if f is not None:
         sink.write(f.finish())
     res.close()

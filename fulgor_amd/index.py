@@ -15,7 +15,7 @@ from . import _native
 FULL_INTERSECTION = 0
 THRESHOLD_UNION = 1
 HYBRID, DIFF, META, META_DIFF = 0, 1, 2, 3  # index_t, include/util.hpp:18
-KERNELS = ("k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits", "k_desc")
+KERNELS = ("k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits", "k_desc", "k_format")
 
 
 def pack_reads(reads):
@@ -94,6 +94,12 @@ class Result:
         cols = np.zeros(max(total, 1), dtype=np.uint32)
         _native.check(self._L.fgpu_result_download(self._h, _ptr(offs), _ptr(cols)))
         return offs, cols[:total]
+
+    def format(self, fmt, first_read_id=0):
+        """the records of this pass as the reference writes them (0 = ascii, 1 = binary), formatted on the device"""
+        p, n = C.c_void_p(), C.c_uint64()
+        _native.check(self._L.fgpu_result_format(self._h, int(fmt), int(first_read_id), C.byref(p), C.byref(n)))
+        return _native.take_bytes(p, n.value)
 
     def accumulate_hits(self, device_ptr):
         _native.check(self._L.fgpu_result_accumulate_hits(self.index._h, self._h, C.c_void_p(device_ptr)))

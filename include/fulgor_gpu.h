@@ -112,7 +112,7 @@ int fgpu_result_algorithmic_bytes(const fgpu_result* res, uint64_t* list_bytes, 
 
 /* per-kernel HIP-event timing on the engine's stream */
 enum { FGPU_K_LOOKUP = 0, FGPU_K_INTERSECT = 1, FGPU_K_UNION = 2, FGPU_K_SCAN = 3, FGPU_K_EXPAND = 4,
-       FGPU_K_HITS = 5, FGPU_K_DESC = 6, FGPU_K_COUNT = 7 };
+       FGPU_K_HITS = 5, FGPU_K_DESC = 6, FGPU_K_FORMAT = 7, FGPU_K_COUNT = 8 };
 int fgpu_timing_enable(fgpu_index* idx, int on);
 int fgpu_timing_reset(fgpu_index* idx);
 int fgpu_timing_get(fgpu_index* idx, int kernel, double* total_ms, uint64_t* launches);
@@ -128,6 +128,12 @@ int fgpu_formatter_create(int format, uint64_t num_colors, fgpu_formatter** out,
 int fgpu_formatter_add(fgpu_formatter* f, uint32_t first_id, const uint64_t* offsets, const uint32_t* colors, uint64_t n,
                        char** out, uint64_t* out_len);
 int fgpu_formatter_finish(fgpu_formatter* f, char** out, uint64_t* out_len);
+
+/* Device-side formatting of the last pass of `res` (src/ps_utils.cpp:48-135): the records of reads
+ * first_read_id .. first_read_id + n - 1 in file order, ascii ("<id>\t<count>[\t<colour>...]\n") or binary (u32 id, u32
+ * count, u32 x count), built by HIP kernels from the resident CSR and copied to a malloc'd host buffer (fgpu_free).
+ * Byte-identical to fgpu_formatter_add on the downloaded CSR. FGPU_FMT_COMPRESSED: -ENOTSUP (host formatter). */
+int fgpu_result_format(const fgpu_result* res, int format, uint32_t first_read_id, char** out, uint64_t* out_len);
 
 /* ---- index export (lets tests hand the same encoded index to the oracle) -------------------------- */
 int fgpu_export_sizes(const fgpu_index* idx, uint64_t* unitig_bases, uint64_t* num_unitigs, uint64_t* color_words,

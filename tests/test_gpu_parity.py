@@ -496,3 +496,26 @@ def test_preprocessed_query_file_path_equals_direct_path(s4546, tmp_path):
     do, dc = ix.pseudoalign_full_intersection_batch(b, o)
     want = {100 + i: l for i, l in enumerate(csr_to_lists(do, dc))}
     assert got == want
+
+
+@pytest.mark.parametrize("which", ["s10", "s4546"])
+def test_device_formatters_are_byte_identical_to_host_formatters(which, s10_gpu, seeded_reads, s4546):
+    """fgpu_result_format (HIP kernels over the resident CSR) against fgpu_formatter_add (host code, itself
+    byte-identical to the restated psa_*_formatter): ascii and binary, both algorithms, first id != 0"""
+    from fulgor_amd.driver import Formatter
+    if which == "s10":
+        ix, (b, o) = s10_gpu, seeded_reads
+        b, o = b[:150 * 20000], o[:20001]
+    else:
+        ix, _, gen = s4546
+        b, o = gen.generate(555, 6000, 150, 42)
+    rd, res = ix.upload_reads(b, o), ix.new_result()
+    for algo, tau in ((fulgor_amd.FULL_INTERSECTION, 0.0), (fulgor_amd.THRESHOLD_UNION, 0.6)):
+        ix.run(rd, res, algo, tau)
+        offs, cols = res.download()
+        for fmt, code in (("ascii", 0), ("binary", 1)):
+            want = Formatter(fmt, ix.num_colors()).add(4000000000 if which == "s10" else 17, offs, cols)
+            got = res.format(code, 4000000000 if which == "s10" else 17)
+            assert got == want
+    ix.run(rd, res, fulgor_amd.FULL_INTERSECTION, 0.0, 0, 0)  # an empty pass formats to nothing
+    assert res.format(0, 5) == b"" and res.format(1, 5) == b""
