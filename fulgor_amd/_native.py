@@ -67,6 +67,10 @@ def lib():
     L.fgpu_result_download.argtypes = [vp, vp, vp]
     L.fgpu_result_accumulate_hits.argtypes = [vp, vp, vp]
     L.fgpu_result_format.argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(vp), u64p]
+    L.fgpu_fastx_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.fgpu_fastx_next.argtypes = [vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp), u64p]
+    L.fgpu_fastx_close.argtypes = [vp]
+    L.fgpu_fastx_close.restype = None
     L.fgpu_result_algorithmic_bytes.argtypes = [vp, u64p, u64p, u64p]
     L.fgpu_timing_enable.argtypes = [vp, C.c_int]
     L.fgpu_timing_reset.argtypes = [vp]
@@ -90,6 +94,21 @@ def take_bytes(ptr, size):
     (ctypes.string_at takes a C int: outputs of one pass routinely exceed 2 GB)"""
     n = int(size)
     try:
-        return bytes((C.c_ubyte * n).from_address(ptr.value)) if n else b""
+        if n == 0:
+            return b""
+        out = bytearray(n)
+        C.memmove((C.c_char * n).from_buffer(out), ptr.value, n)
+        return bytes(out) if n < (1 << 20) else out  # large outputs stay a bytearray: file.write takes either
     finally:
         lib().fgpu_free(ptr)
+
+
+def copy_array(ptr, count, dtype):
+    """numpy copy of `count` items of `dtype` at a library pointer (one memmove; np.ctypeslib.as_array and buffer
+    views of ctypes arrays walk large buffers far too slowly)"""
+    import numpy as np
+    out = np.empty(int(count), dtype=dtype)
+    if out.nbytes:
+        addr = ptr.value if hasattr(ptr, "value") else C.cast(ptr, C.c_void_p).value
+        C.memmove(out.ctypes.data, addr, out.nbytes)
+    return out

@@ -5,8 +5,8 @@ import sys
 import time
 
 from . import driver
-from .index import FULL_INTERSECTION, THRESHOLD_UNION, Index, pack_reads
-from .reads import parse_fastx
+from .index import FULL_INTERSECTION, THRESHOLD_UNION, Index
+from .reads import FastxReader
 
 
 def pseudoalign(argv):
@@ -45,12 +45,16 @@ def pseudoalign(argv):
     except RuntimeError as e:
         print(str(e), file=sys.stderr)
         return 1
-    seqs = parse_fastx(a.query_filename)  # read id = 0-based file order (src/ps_utils.cpp:276,286)
-    bases, offs = pack_reads(seqs)
+    try:  # read id = 0-based file order (src/ps_utils.cpp:276,286); parsing overlaps with the GPU passes
+        batches = FastxReader(a.query_filename, batch=1 << 20, copy=False)
+    except RuntimeError as e:
+        print(str(e), file=sys.stderr)
+        return 1
     t1 = time.time()
     with open(a.output_filename, "wb") as out:
-        n, mapped = driver.pseudoalign_reads(index, bases, offs, algo, a.threshold or 0.0, sink=out, fmt=a.format,
-                                             deduplicate=a.deduplicate)
+        n, mapped = driver.pseudoalign_stream(index, batches, algo, a.threshold or 0.0, sink=out, fmt=a.format,
+                                              deduplicate=a.deduplicate)
+    batches.close()
     el = (time.time() - t1) * 1000.0
     if a.verbose:  # tools/pseudoalign.cpp:79-88
         print("processed %d reads" % n)

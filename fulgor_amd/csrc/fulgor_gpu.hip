@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/fulgor_gpu.h"
+#include "host/fastx_reader.hpp"
 #include "hip/kernels.hip.h"
 #include "host/formatters.hpp"
 #include "host/index_io.hpp"
@@ -1078,6 +1079,36 @@ int fgpu_formatter_finish(fgpu_formatter* f, char** out, uint64_t* out_len) {
     delete f;
     return rc;
 }
+
+// ---- query reader -------------------------------------------------------------------------------------------
+struct fgpu_fastx {
+    FastxReader reader;
+    std::vector<char> bases;     // the current batch (owned by the reader, recycled)
+    std::vector<uint64_t> offs;
+    explicit fgpu_fastx(const char* path) : reader(path) {}
+};
+
+int fgpu_fastx_open(const char* path, fgpu_fastx** out) {
+    if (!path || !out) return fail(-EINVAL, "null argument");
+    *out = nullptr;
+    return guarded([&] { *out = new fgpu_fastx(path); });
+}
+
+int fgpu_fastx_next(fgpu_fastx* f, uint64_t max_reads, const char** bases, const uint64_t** offs, uint64_t* n) {
+    if (!f || !bases || !offs || !n) return fail(-EINVAL, "null argument");
+    if (max_reads == 0) return fail(-EINVAL, "max_reads must be positive");
+    return guarded([&] {
+        f->reader.next(max_reads, f->bases, f->offs);
+        *n = f->offs.size() - 1;
+        const size_t len = f->bases.size();
+        f->bases.resize(len + 256, 0);  // slack: the lookup kernel over-reads padded reads
+        f->bases.resize(len);
+        *bases = f->bases.data();
+        *offs = f->offs.data();
+    });
+}
+
+void fgpu_fastx_close(fgpu_fastx* f) { delete f; }
 
 // ---- export ---------------------------------------------------------------------------------------------
 int fgpu_export_sizes(const fgpu_index* ix, uint64_t* unitig_bases, uint64_t* num_unitigs, uint64_t* color_words,

@@ -160,6 +160,42 @@ def pseudoalign_reads(index, bases, offs, algo=FULL_INTERSECTION, threshold=0.0,
     return n, mapped
 
 
+def pseudoalign_stream(index, batches, algo=FULL_INTERSECTION, threshold=0.0, sink=None, fmt="ascii", deduplicate=False,
+                       first_id=0):
+    """the worker loop over a stream of read batches (reads.FastxReader): while a batch is on the GPU the reader's
+    thread inflates and parses the next ones. Read ids follow file order. returns (num_reads, num_mapped_reads)"""
+    if deduplicate and algo != FULL_INTERSECTION:
+        raise ValueError("Deduplication not available for threshold < 1.0. Remove --deduplicate flag.")
+    f = Formatter(fmt, index.num_colors()) if sink is not None else None
+    if f is not None:
+        sink.write(f.header)
+    res = index.new_result()
+    n = mapped = 0
+    for bases, offs in batches:
+        cnt = len(offs) - 1
+        if deduplicate:
+            o, c = deduplicated_full_intersection(index, bases, offs)
+            mapped += int((np.diff(o.astype(np.int64)) > 0).sum())
+            if f is not None:
+                sink.write(f.add(first_id + n, o, c))
+        else:
+            reads = index.upload_reads(bases, offs)
+            index.run(reads, res, algo, threshold)
+            mapped += res.sizes()[2]
+            if f is not None:
+                if fmt in ("ascii", "binary"):
+                    sink.write(res.format(FORMATS[fmt], first_id + n))
+                else:
+                    o, c = res.download()
+                    sink.write(f.add(first_id + n, o, c))
+            reads.close()
+        n += cnt
+    if f is not None:
+        sink.write(f.finish())
+    res.close()
+    return n, mapped
+
+
 # ---- the reference's --deduplicate temp files (tools/pseudoalign.cpp:91-226, src/ps_utils.cpp:307-415) -------
 # Stage 1 writes, per read, `u32 read_id, u32 num_ids, u32 x num_ids`; the deduplication pass rewrites the file as
 # `u32 list_len, u32 read_id, u32 x (list_len - 1)` sorted by id list, where list_len == 1 marks a read whose

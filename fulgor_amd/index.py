@@ -43,9 +43,9 @@ def _ptr(a):
 
 
 def _take_csr(L, n, p_off, p_val):
-    offs = np.ctypeslib.as_array(C.cast(p_off, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+    offs = _native.copy_array(p_off, n + 1, np.uint64)
     total = int(offs[n])
-    vals = (np.ctypeslib.as_array(C.cast(p_val, C.POINTER(C.c_uint32)), shape=(max(total, 1),))[:total].copy())
+    vals = _native.copy_array(p_val, total, np.uint32)
     L.fgpu_free(p_off)
     L.fgpu_free(p_val)
     return offs, vals
@@ -198,7 +198,7 @@ class Index:
         p = C.c_void_p()
         _native.check(self._L.fgpu_kmer_matches(self._h, _ptr(bases), _ptr(offs), n, C.byref(p)))
         nc = self._num_colors
-        counts = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(max(1, n * nc),))[:n * nc].copy().reshape(n, nc)
+        counts = _native.copy_array(p, n * nc, np.uint32).reshape(n, nc)
         self._L.fgpu_free(p)
         ko, ki = self.kmer_color_set_ids_batch(bases, offs)
         return ko, (ki != 0xFFFFFFFF).astype(np.uint8), counts

@@ -82,3 +82,48 @@ def parse_fastx(path):
             if cur is not None:
                 seqs.append(b"".join(cur))
     return seqs
+
+
+class FastxReader:
+    """native FASTA/FASTQ(.gz) reader (fgpu_fastx_*): a background thread inflates and parses while the caller works.
+    Iterating yields (bases uint8 array, offsets uint64 array) batches of at most `batch` reads in file order.
+    copy=False hands out views of the reader's own recycled buffers, valid until the next batch is requested (what
+    the worker loop wants: the batch goes straight to the GPU)."""
+
+    def __init__(self, path, batch=1 << 20, copy=True):
+        import ctypes as C
+        from . import _native
+        self._C, self._N, self._L = C, _native, _native.lib()
+        self.batch = int(batch)
+        self.copy = bool(copy)
+        h = C.c_void_p()
+        _native.check(self._L.fgpu_fastx_open(str(path).encode(), C.byref(h)))
+        self._h = h
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        C = self._C
+        pb, po, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._N.check(self._L.fgpu_fastx_next(self._h, self.batch, C.byref(pb), C.byref(po), C.byref(n)))
+        if n.value == 0:
+            raise StopIteration
+        if self.copy:
+            offs = self._N.copy_array(po, n.value + 1, np.uint64)
+            return self._N.copy_array(pb, int(offs[-1]), np.uint8), offs
+        offs = np.frombuffer((C.c_uint64 * (n.value + 1)).from_address(po.value), dtype=np.uint64)
+        total = int(offs[-1])
+        bases = np.frombuffer((C.c_ubyte * max(total, 1)).from_address(pb.value), dtype=np.uint8)[:total]
+        return bases, offs
+
+    def close(self):
+        if self._h:
+            self._L.fgpu_fastx_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

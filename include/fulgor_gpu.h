@@ -129,6 +129,16 @@ int fgpu_formatter_add(fgpu_formatter* f, uint32_t first_id, const uint64_t* off
                        char** out, uint64_t* out_len);
 int fgpu_formatter_finish(fgpu_formatter* f, char** out, uint64_t* out_len);
 
+/* Query reader (src/ps_utils.cpp:245-305): FASTA / FASTQ, plain or gzip, parsed natively by a background
+ * thread (inflate + parse overlap with the GPU passes). fgpu_fastx_next returns the next at most max_reads reads in
+ * file order (read id = position in the file, as FQFeeder numbers them) as concatenated bases + (n + 1) offsets.
+ * The two buffers belong to the reader and stay valid until the next call on it (they are recycled: no allocation
+ * per batch); *n = 0 at end of file. */
+typedef struct fgpu_fastx fgpu_fastx;
+int fgpu_fastx_open(const char* path, fgpu_fastx** out);
+int fgpu_fastx_next(fgpu_fastx* f, uint64_t max_reads, const char** bases, const uint64_t** offs, uint64_t* n);
+void fgpu_fastx_close(fgpu_fastx* f);
+
 /* Device-side formatting of the last pass of `res` (src/ps_utils.cpp:48-135): the records of reads
  * first_read_id .. first_read_id + n - 1 in file order, ascii ("<id>\t<count>[\t<colour>...]\n") or binary (u32 id, u32
  * count, u32 x count), built by HIP kernels from the resident CSR and copied to a malloc'd host buffer (fgpu_free).

@@ -140,3 +140,39 @@ def test_dedup_temp_file_formats_roundtrip(tmp_path):
         struct.pack("<4I", 3, 0, 4, 9) + struct.pack("<2I", 1, 3)
     got = [(r, l.tolist()) for b in driver.read_preprocessed(p2, batch=3) for r, l in b]
     assert got == [(2, [1, 2, 3]), (4, [1, 2, 8]), (0, [4, 9]), (3, [4, 9])]
+
+
+def test_native_fastx_reader_matches_python_parser(built, tmp_path):
+    """fgpu_fastx_* (kseq semantics: multi-line FASTA and FASTQ, CRLF, quality lines starting with '@', missing final
+    newline, gzip or plain) against the simple Python parser and hand-made expectations; batches keep file order"""
+    import gzip
+    from fulgor_amd.reads import FastxReader, parse_fastx
+    rng = np.random.default_rng(3)
+    seqs = ["".join("ACGTN"[c] for c in rng.integers(0, 5, size=int(l))) for l in rng.integers(0, 400, size=3000)]
+    fq = "".join("@r%d some text\n%s\n+\n%s\n" % (i, s, "@" * len(s)) for i, s in enumerate(seqs))  # '@' qualities
+    fa = "".join(">s%d\r\n%s" % (i, "".join(s[j:j + 60] + "\r\n" for j in range(0, len(s), 60))) for i, s in enumerate(seqs))
+    files = {"a.fq": fq.encode(), "b.fa": fa.encode(), "c.fq": fq.encode()[:-1]}  # c: no final newline
+    for name, data in files.items():
+        for gz in (False, True):
+            p = str(tmp_path / (name + (".gz" if gz else "")))
+            with (gzip.open if gz else open)(p, "wb") as f:
+                f.write(data)
+            got = []
+            for bases, offs in FastxReader(p, batch=70000):  # reader chunks are 65536 reads: batches of one chunk
+                b = bytes(bases)
+                got += [b[int(offs[i]):int(offs[i + 1])].decode() for i in range(len(offs) - 1)]
+            assert got == seqs, name
+    # multi-line FASTQ (kseq accepts it): sequence and quality wrapped at 50
+    ml = "".join("@m%d\n%s+\n%s" % (i, "".join(s[j:j + 50] + "\n" for j in range(0, len(s), 50)) or "\n",
+                                     "".join("I" * len(s[j:j + 50]) + "\n" for j in range(0, len(s), 50)) or "\n")
+                 for i, s in enumerate(seqs[:200]))
+    p = str(tmp_path / "ml.fq")
+    open(p, "w").write(ml)
+    got = []
+    for bases, offs in FastxReader(p):
+        b = bytes(bases)
+        got += [b[int(offs[i]):int(offs[i + 1])].decode() for i in range(len(offs) - 1)]
+    assert got == seqs[:200]
+    assert [s.decode() for s in parse_fastx(str(tmp_path / "a.fq.gz"))] == seqs  # the Python parser agrees on plain 4-line FASTQ
+    with pytest.raises(RuntimeError):
+        FastxReader(str(tmp_path / "missing.fq"))
