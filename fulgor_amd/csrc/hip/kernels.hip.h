@@ -1393,13 +1393,33 @@ __global__ __launch_bounds__(256) void k2b_expand(const uint32_t* __restrict__ b
     const WorkQueue wq{tickets, n_reads, 32};
     uint64_t t_first;
     uint32_t t_count;
-    while (wq.pull(t_first, t_count))
-    for (uint64_t r = t_first; r < t_first + t_count; ++r) {
-        if (counts[r] == 0) continue;
-        uint32_t* out = colors + out_off[r];
+    // the first three 64-word rounds of a read's bitmap (all of it up to 6144 colours) are requested one read
+    // ahead, its size and output offset once per ticket: the per-read fetch chain is off the critical path
+    auto fetch3 = [&](uint64_t r, uint32_t (&x)[3]) {
+        const uint32_t* bm = bitmap + r * W;
+#pragma unroll
+        for (uint32_t q = 0; q < 3; ++q) x[q] = q * 64 + lane < W ? bm[q * 64 + lane] : 0u;
+    };
+    while (wq.pull(t_first, t_count)) {
+    const uint64_t rl = t_first + min((uint32_t)lane, t_count - 1);
+    const uint32_t cnt_l = (uint32_t)lane < t_count ? counts[rl] : 0u;
+    const uint64_t off_l = out_off[rl];
+    uint32_t cur[3], nxt[3] = {0u, 0u, 0u};
+    fetch3(t_first, nxt);
+    for (uint32_t j = 0; j < t_count; ++j) {
+        const uint64_t r = t_first + j;
+#pragma unroll
+        for (uint32_t q = 0; q < 3; ++q) cur[q] = nxt[q];
+        if (j + 1 < t_count && __builtin_amdgcn_readlane((int)cnt_l, j + 1) != 0) fetch3(r + 1, nxt);
+        if (__builtin_amdgcn_readlane((int)cnt_l, j) == 0) continue;
+        uint32_t* out = colors + readlane_u64(off_l, j);
         const uint32_t* bm = bitmap + r * W;
         for (uint32_t w0 = 0; w0 < W; w0 += 64) {
-            uint32_t x = w0 + lane < W ? bm[w0 + lane] : 0u;
+            uint32_t x;
+            if (w0 == 0) x = cur[0];
+            else if (w0 == 64) x = cur[1];
+            else if (w0 == 128) x = cur[2];
+            else x = w0 + lane < W ? bm[w0 + lane] : 0u;
             const uint32_t pc = __popc(x);
             const uint32_t incl = wave_incl_scan_u32(pc);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -1421,6 +1441,7 @@ __global__ __launch_bounds__(256) void k2b_expand(const uint32_t* __restrict__ b
             out += total;
             wave_lds_sync();
         }
+    }
     }
     if (hit_partial) {
         __syncthreads();
