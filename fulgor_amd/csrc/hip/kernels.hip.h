@@ -976,11 +976,44 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
     uint32_t t_count;
 
     const ListDesc none{0, 0, 0, 0xFFu, 0, 0};
-    while (wq.pull(t_first, t_count))
-    for (uint64_t r = t_first; r < t_first + t_count; ++r) {
-        // ids and multiplicities straight from the lookup kernel's slab; one 32-byte descriptor gather per list
-        const uint64_t off = idoff[r];
-        const uint32_t cnt = nids[r];
+    while (wq.pull(t_first, t_count)) {
+    // ids and multiplicities straight from the lookup kernel's slab, one 32-byte descriptor gather per list; as in
+    // k2a the ids of read i + 2 and the descriptors of read i + 1 are requested while read i is processed
+    const uint64_t rl = min(t_first + (uint64_t)lane, n_reads - 1);
+    const uint32_t cnt_l = (uint32_t)lane < t_count ? nids[rl] : 0u;
+    const uint64_t off_l = idoff[rl];
+    auto fetch_ids = [&](uint32_t i, uint32_t& id, uint32_t& mult) {
+        const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, i);
+        id = mult = 0;
+        if ((uint32_t)lane < cn) {
+            const uint64_t p = readlane_u64(off_l, i) + lane;
+            id = ids_pool[p];
+            mult = cnt_pool[p];
+        }
+    };
+    auto fetch_desc = [&](uint32_t i, uint32_t id, uint32_t mult) -> ListDesc {
+        const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, i);
+        ListDesc dd = none;
+        if ((uint32_t)lane < cn) {
+            dd = c.set_desc[id];
+            dd.score = (int32_t)mult;
+        }
+        return dd;
+    };
+    uint32_t id1, mu1, id2, mu2;
+    fetch_ids(0, id1, mu1);
+    ListDesc dcur = fetch_desc(0, id1, mu1);
+    fetch_ids(1, id1, mu1);
+    for (uint32_t ri = 0; ri < t_count; ++ri) {
+        const uint64_t r = t_first + ri;
+        const uint64_t off = readlane_u64(off_l, ri);
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, ri);
+        fetch_ids(ri + 2, id2, mu2);
+        const ListDesc dnext = fetch_desc(ri + 1, id1, mu1);
+        const ListDesc d_first = dcur;
+        dcur = dnext;
+        id1 = id2;
+        mu1 = mu2;
         uint32_t* bm = out_bitmap + r * W;
         if (cnt == 0) {
             for (uint32_t w = lane; w < W; w += 64) bm[w] = 0;
@@ -989,7 +1022,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
                 for (uint32_t cc = lane; cc < n; cc += 64) scores_out[r * (uint64_t)n + cc] = 0;
             continue;
         }
-        auto load_desc = [&](uint32_t g) -> ListDesc {
+        auto load_desc = [&](uint32_t g) -> ListDesc {  // more than 64 lists: rare, fetched in place
             ListDesc d = none;
             if (g + lane < cnt) {
                 d = c.set_desc[ids_pool[off + g + lane]];
@@ -998,7 +1031,6 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
             return d;
         };
         const uint32_t min_score = (uint32_t)(unsigned long long)((double)npos[r] * tau);
-        const ListDesc d_first = load_desc(0);
         uint32_t comp_total = 0;
         for (uint32_t g = 0; g < cnt; g += 64) {
             const ListDesc d = g ? load_desc(g) : d_first;
@@ -1085,6 +1117,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
         pc = wave_sum_u32(pc);
         if (lane == 0) out_count[r] = pc;
         wave_lds_sync();
+    }
     }
 }
 
