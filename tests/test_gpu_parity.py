@@ -519,3 +519,44 @@ def test_device_formatters_are_byte_identical_to_host_formatters(which, s10_gpu,
             assert got == want
     ix.run(rd, res, fulgor_amd.FULL_INTERSECTION, 0.0, 0, 0)  # an empty pass formats to nothing
     assert res.format(0, 5) == b"" and res.format(1, 5) == b""
+
+
+def test_concurrent_workers_share_one_index(s4546):
+    """the reference's workers share one `const index&` (tools/pseudoalign.cpp:66-74): several host threads, each
+    with its own result (own HIP stream), run different algorithms and read ranges on one index at the same time;
+    every pass must equal the single-threaded answer, and chunked passes must concatenate to the one-pass result"""
+    import threading
+    ix, orc, gen = s4546
+    b, o = gen.generate(31337, 24000, 150, 42)
+    reads = ix.upload_reads(b, o)
+    ref = ix.new_result()
+    ix.run(reads, ref, fulgor_amd.FULL_INTERSECTION)
+    fo, fc = ref.download()
+    ix.run(reads, ref, fulgor_amd.THRESHOLD_UNION, 0.7)
+    to, tc = ref.download()
+    fo, to = fo.astype(np.int64), to.astype(np.int64)
+    errors = []
+
+    def worker(w):
+        try:
+            res = ix.new_result()
+            for rep in range(3):
+                for first in range((w * 1000) % 6000, 24000, 6000):
+                    cnt = min(6000, 24000 - first)
+                    algo = fulgor_amd.FULL_INTERSECTION if (w + rep) % 2 == 0 else fulgor_amd.THRESHOLD_UNION
+                    ix.run(reads, res, algo, 0.7 if algo else 0.0, first, cnt)
+                    go, gc = res.download()
+                    wo, wc = (fo, fc) if algo == fulgor_amd.FULL_INTERSECTION else (to, tc)
+                    if not (np.array_equal(go.astype(np.int64), wo[first:first + cnt + 1] - wo[first]) and
+                            np.array_equal(gc, wc[wo[first]:wo[first + cnt]])):
+                        errors.append((w, rep, first, int(algo)))
+            res.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((w, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(w,)) for w in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert errors == []
