@@ -1410,7 +1410,11 @@ __global__ __launch_bounds__(256) void scan_apply(const uint32_t* __restrict__ c
 __global__ __launch_bounds__(256) void k2b_expand(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
                                                   const uint64_t* __restrict__ out_off, uint64_t n_reads, uint32_t W,
                                                   uint32_t* __restrict__ colors, unsigned int* tickets,
-                                                  uint32_t* __restrict__ hit_partial) {
+                                                  uint32_t* __restrict__ hit_partial, const uint64_t* __restrict__ totals,
+                                                  uint64_t capacity) {
+    // launched behind the scan without a host round trip: if the colours of the pass do not fit `colors`
+    // (capacity in u32), do nothing — the host enlarges the buffer and launches again
+    if (totals[0] > capacity) return;
     // hit_partial != nullptr: also count, per colour, the reads of this launch that contain it. Each block
     // keeps 16-bit counters in LDS (a block sees far fewer than 65536 reads) and stores them as one row of
     // hit_partial[gridDim.x][W*32] at the end; k_hits_reduce sums the rows.
