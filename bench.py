@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the BASELINE config size)")
     ap.add_argument("--algo", default="full-intersection", choices=["full-intersection", "threshold-union"])
     ap.add_argument("--tau", type=float, default=0.8)
-    ap.add_argument("--chunk", type=int, default=1 << 22, help="reads per kernel pass")
+    ap.add_argument("--chunk", type=int, default=2_500_000, help="reads per kernel pass (10M reads = 4 equal passes)")
     ap.add_argument("--index-type", default="hybrid", choices=["hybrid", "diff", "meta", "meta-diff"],
                     help="colour-set codec (fur / dfur / mfur / mdfur of the reference)")
     ap.add_argument("--partition-size", type=int, default=160)
