@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
             comp_total += wave_sum_u32(desc_type(d) == D_ENC_COMPLEMENT ? (uint32_t)d.score : 0u);
         }
         const uint32_t start = (HALF - min_score + comp_total) * ONES;
-        for (uint32_t i = lane; i < W * PLANES; i += 64) SC[i] = start;
+        for (uint32_t i = lane; i < (W >> 2) * PLANES; i += 64) ((uint4*)SC)[i] = make_uint4(start, start, start, start);
         wave_lds_sync();
         for (uint32_t g = 0; g < cnt; g += 64) {
             const ListDesc d = g ? load_desc(g) : d_first;
@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 6 : 4) : 6) void k_generi
         const uint32_t min_score = UNION ? (uint32_t)(unsigned long long)((double)npos[r] * tau) : 0u;
         if (UNION) {
             const uint32_t start = (HALF - min_score) * ONES;  // score >= min_score  <=>  top bit of the field
-            for (uint32_t i = lane; i < W * PLANES; i += 64) ACC[i] = start;
+            for (uint32_t i = lane; i < W4 * PLANES; i += 64) EX4[i] = make_uint4(start, start, start, start);
         } else {
             for (uint32_t g4 = lane; g4 < W4; g4 += 64) {  // colours >= n start excluded
                 const uint32_t w = 4 * g4;
