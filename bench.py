@@ -222,11 +222,33 @@ def main():
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
+            out["end_to_end"] = end_to_end(ix, bases, offs, algo, args.tau, min(n_reads, 1 << 20))
             out["cpu_baseline"] = cpu_baseline(ix, bases, offs, algo, args.tau, itype, args.partition_size, args.cluster_size)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def end_to_end(ix, bases, offs, algo, tau, n):
+    """PCIe-inclusive rate of one bounded pass (SURVEY §8d timing protocol): host-resident reads -> H2D -> kernels ->
+    ascii records formatted on the device -> D2H of the text into host memory. Reported beside `value`, never as it."""
+    import fulgor_amd
+    b, o = bases[:int(offs[n])], offs[:n + 1]
+    res = ix.new_result()
+    best = None
+    for _ in range(2):  # the second pass runs with warm buffers
+        t0 = time.perf_counter()
+        rd = ix.upload_reads(b, o)
+        ix.run(rd, res, algo, tau)
+        text = res.format_view(0, 0)
+        dt = time.perf_counter() - t0
+        rd.close()
+        best = dt if best is None else min(best, dt)
+    out_bytes = len(text)
+    res.close()
+    return {"value": round(n / best, 1), "unit": "reads/s", "reads": int(n), "output_bytes": int(out_bytes),
+            "includes": "H2D of the reads, all kernels, device-side ascii formatting, D2H of the text into a pinned, recycled host buffer"}
 
 
 def cpu_baseline(ix, bases, offs, algo, tau, itype=0, psize=160, csize=16):

@@ -151,6 +151,8 @@ struct fgpu_result {
     uint32_t id_stride = 0;
     uint32_t hit_rows = 0;  // rows of d_partial filled by the last expand launch (0: no colours, nothing to add)
     DevBuf d_fmt_sizes, d_fmt_off, d_fmt_out;  // device-side formatter
+    char* h_fmt = nullptr;                     // pinned host copy of the formatted records (recycled)
+    size_t h_fmt_cap = 0;
     bool hits_folded = true;  // false: too many colours for the expand kernel's LDS histogram; k_hits counts from the bitmaps
     uint32_t max_kmers_in_batch = 0xFFFFFFFFu;  // bound on #positive k-mers of any read (unknown for id-only calls)
     bool have_ids = false;
@@ -692,6 +694,7 @@ void fgpu_result_free(fgpu_result* r) {
                       &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct, &r->d_partial, &r->d_tickets, &r->d_idcsr, &r->d_desc, &r->d_kmer_ids, &r->d_scores, &r->d_fmt_sizes, &r->d_fmt_off, &r->d_fmt_out})
         b->release();
     if (r->h_totals) (void)hipHostFree(r->h_totals);
+    if (r->h_fmt) (void)hipHostFree(r->h_fmt);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     for (auto& p : r->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     delete r;
@@ -727,7 +730,7 @@ int fgpu_result_download(const fgpu_result* r, uint64_t* offsets, uint32_t* colo
     });
 }
 
-int fgpu_result_format(const fgpu_result* r, int format, uint32_t first_read_id, char** out, uint64_t* out_len) {
+int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_read_id, const char** out, uint64_t* out_len) {
     if (!r || !out || !out_len) return fail(-EINVAL, "null argument");
     if (format != FGPU_FMT_ASCII && format != FGPU_FMT_BINARY)
         return fail(-ENOTSUP, "device-side formatting covers ascii and binary; use fgpu_formatter_* for the compressed format");
@@ -750,9 +753,9 @@ int fgpu_result_format(const fgpu_result* r, int format, uint32_t first_read_id,
             res->d_fmt_sizes.ensure(n * 4 + 16);
             res->d_fmt_off.ensure((n + 1) * 8 + 48);
             {
-            Timed t(ix, res, FGPU_K_FORMAT);
-            hipLaunchKernelGGL(k_fmt_ascii_sizes, dim3(grid), dim3(256), 0, s, res->d_offsets.as<uint64_t>(), res->d_colors.as<uint32_t>(),
-                               n, first_read_id, res->d_fmt_sizes.as<uint32_t>());
+                Timed t(ix, res, FGPU_K_FORMAT);
+                hipLaunchKernelGGL(k_fmt_ascii_sizes, dim3(grid), dim3(256), 0, s, res->d_offsets.as<uint64_t>(),
+                                   res->d_colors.as<uint32_t>(), n, first_read_id, res->d_fmt_sizes.as<uint32_t>());
             }
             uint64_t* totals = res->d_fmt_off.as<uint64_t>() + (n + 2);  // scratch behind the offsets (keeps d_totals intact)
             run_scan(ix, res, res->d_fmt_sizes.as<uint32_t>(), n, res->d_fmt_off.as<uint64_t>(), totals);
@@ -766,18 +769,31 @@ int fgpu_result_format(const fgpu_result* r, int format, uint32_t first_read_id,
                                n, first_read_id, res->d_fmt_off.as<uint64_t>(), res->d_fmt_out.as<unsigned char>());
             HIP_TRY(hipGetLastError());
         }
-        char* buf = (char*)malloc(std::max<uint64_t>(1, bytes));
-        if (!buf) throw std::bad_alloc();
-        if (bytes) {
-            const hipError_t e = hipMemcpyAsync(buf, res->d_fmt_out.p, bytes, hipMemcpyDeviceToHost, s);
-            if (e != hipSuccess) { free(buf); HIP_TRY(e); }
+        if (bytes > res->h_fmt_cap) {  // pinned: the copy runs at PCIe speed and the buffer is reused by later passes
+            if (res->h_fmt) (void)hipHostFree(res->h_fmt);
+            res->h_fmt = nullptr;
+            res->h_fmt_cap = 0;
+            const size_t want = bytes + bytes / 4 + 4096;
+            HIP_TRY(hipHostMalloc((void**)&res->h_fmt, want, hipHostMallocDefault));
+            res->h_fmt_cap = want;
         }
-        const hipError_t e2 = hipStreamSynchronize(s);
-        if (e2 != hipSuccess) { free(buf); HIP_TRY(e2); }
+        if (bytes) HIP_TRY(hipMemcpyAsync(res->h_fmt, res->d_fmt_out.p, bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
         if (ix->timing) ix->collect_timing(res->pending);
-        *out = buf;
+        *out = res->h_fmt ? res->h_fmt : "";
         *out_len = bytes;
     });
+}
+
+int fgpu_result_format(const fgpu_result* r, int format, uint32_t first_read_id, char** out, uint64_t* out_len) {
+    if (!out) return fail(-EINVAL, "null argument");
+    const char* view = nullptr;
+    const int rc = fgpu_result_format_view(r, format, first_read_id, &view, out_len);
+    if (rc) return rc;
+    *out = (char*)malloc(std::max<uint64_t>(1, *out_len));
+    if (!*out) return fail(-ENOMEM, "out of host memory");
+    memcpy(*out, view, *out_len);
+    return 0;
 }
 
 int fgpu_result_accumulate_hits(fgpu_index* ix, const fgpu_result* r, void* device_u64_hits) {

@@ -149,7 +149,7 @@ def pseudoalign_reads(index, bases, offs, algo=FULL_INTERSECTION, threshold=0.0,
         mapped += m
         if f is not None:
             if fmt in ("ascii", "binary"):  # formatted by HIP kernels from the resident CSR (fgpu_result_format)
-                sink.write(res.format(FORMATS[fmt], first_id + a))
+                sink.write(res.format_view(FORMATS[fmt], first_id + a))
             else:
                 o, c = res.download()
                 sink.write(f.add(first_id + a, o, c))
@@ -184,7 +184,7 @@ def pseudoalign_stream(index, batches, algo=FULL_INTERSECTION, threshold=0.0, si
             mapped += res.sizes()[2]
             if f is not None:
                 if fmt in ("ascii", "binary"):
-                    sink.write(res.format(FORMATS[fmt], first_id + n))
+                    sink.write(res.format_view(FORMATS[fmt], first_id + n))
                 else:
                     o, c = res.download()
                     sink.write(f.add(first_id + n, o, c))

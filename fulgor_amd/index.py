@@ -101,6 +101,15 @@ class Result:
         _native.check(self._L.fgpu_result_format(self._h, int(fmt), int(first_read_id), C.byref(p), C.byref(n)))
         return _native.take_bytes(p, n.value)
 
+    def format_view(self, fmt, first_read_id=0):
+        """like format(), without copies: a memoryview of the result's pinned host buffer, valid until the next
+        format call on this result (write it to the output file, then move on)"""
+        p, n = C.c_void_p(), C.c_uint64()
+        _native.check(self._L.fgpu_result_format_view(self._h, int(fmt), int(first_read_id), C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return memoryview(b"")
+        return memoryview((C.c_char * n.value).from_address(p.value)).cast("B")
+
     def accumulate_hits(self, device_ptr):
         _native.check(self._L.fgpu_result_accumulate_hits(self.index._h, self._h, C.c_void_p(device_ptr)))
 

@@ -144,6 +144,9 @@ void fgpu_fastx_close(fgpu_fastx* f);
  * count, u32 x count), built by HIP kernels from the resident CSR and copied to a malloc'd host buffer (fgpu_free).
  * Byte-identical to fgpu_formatter_add on the downloaded CSR. FGPU_FMT_COMPRESSED: -ENOTSUP (host formatter). */
 int fgpu_result_format(const fgpu_result* res, int format, uint32_t first_read_id, char** out, uint64_t* out_len);
+/* Same records without the extra copy: *out points into a pinned host buffer owned by `res` (the D2H copy runs at PCIe
+ * speed and the buffer is recycled); valid until the next format call on `res` or fgpu_result_free. */
+int fgpu_result_format_view(const fgpu_result* res, int format, uint32_t first_read_id, const char** out, uint64_t* out_len);
 
 /* ---- index export (lets tests hand the same encoded index to the oracle) -------------------------- */
 int fgpu_export_sizes(const fgpu_index* idx, uint64_t* unitig_bases, uint64_t* num_unitigs, uint64_t* color_words,

@@ -517,6 +517,7 @@ def test_device_formatters_are_byte_identical_to_host_formatters(which, s10_gpu,
             want = Formatter(fmt, ix.num_colors()).add(4000000000 if which == "s10" else 17, offs, cols)
             got = res.format(code, 4000000000 if which == "s10" else 17)
             assert got == want
+            assert bytes(res.format_view(code, 4000000000 if which == "s10" else 17)) == want  # pinned, zero-copy view
     ix.run(rd, res, fulgor_amd.FULL_INTERSECTION, 0.0, 0, 0)  # an empty pass formats to nothing
     assert res.format(0, 5) == b"" and res.format(1, 5) == b""
 
