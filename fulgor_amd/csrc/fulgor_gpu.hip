@@ -732,8 +732,7 @@ int fgpu_result_download(const fgpu_result* r, uint64_t* offsets, uint32_t* colo
 
 int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_read_id, const char** out, uint64_t* out_len) {
     if (!r || !out || !out_len) return fail(-EINVAL, "null argument");
-    if (format != FGPU_FMT_ASCII && format != FGPU_FMT_BINARY)
-        return fail(-ENOTSUP, "device-side formatting covers ascii and binary; use fgpu_formatter_* for the compressed format");
+    if (format != FGPU_FMT_ASCII && format != FGPU_FMT_BINARY && format != FGPU_FMT_COMPRESSED) return fail(-EINVAL, "unknown format");
     fgpu_result* res = const_cast<fgpu_result*>(r);
     fgpu_index* ix = r->ix;
     return guarded([&] {
@@ -742,7 +741,39 @@ int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_rea
         const uint64_t n = res->n;
         uint64_t bytes = 0;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 3) / 4, (uint64_t)ix->num_cus * 16);
-        if (n && format == FGPU_FMT_BINARY) {
+        if (n && format == FGPU_FMT_COMPRESSED) {
+            // from the result bitmaps: bits per record -> offsets inside blocks of CFMT_BLOCK_READS records -> block offsets
+            const uint32_t W = ix->dc.w32, nc = ix->dc.n;
+            const uint32_t sthr = ix->host.hybrid.sparse_thr, dthr = ix->host.hybrid.dense_thr;
+            const uint64_t nb = (n + CFMT_BLOCK_READS - 1) / CFMT_BLOCK_READS;
+            res->d_fmt_sizes.ensure((n + 3 * nb) * 4 + 64);
+            res->d_fmt_off.ensure((nb + 1) * 8 + 48 + n * 4);
+            uint32_t* bits = res->d_fmt_sizes.as<uint32_t>();
+            uint32_t* block_bits = bits + n;
+            uint32_t* block_bytes = block_bits + nb;
+            uint64_t* block_off = res->d_fmt_off.as<uint64_t>();
+            uint64_t* totals = block_off + (nb + 2);
+            uint32_t* rec_off = (uint32_t*)(block_off + (nb + 6));
+            {
+                Timed t(ix, res, FGPU_K_FORMAT);
+                hipLaunchKernelGGL(k_cfmt_sizes, dim3(grid), dim3(256), 0, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
+                                   n, W, nc, sthr, dthr, first_read_id, bits);
+                hipLaunchKernelGGL(k_cfmt_blocks, dim3((uint32_t)nb), dim3(CFMT_BLOCK_READS), 0, s, bits, n, rec_off, block_bits,
+                                   block_bytes);
+            }
+            run_scan(ix, res, block_bytes, nb, block_off, totals);
+            uint64_t h[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(h, totals, 16, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            bytes = h[0];
+            res->d_fmt_out.ensure(bytes + 64);
+            HIP_TRY(hipMemsetAsync(res->d_fmt_out.p, 0, bytes + 64, s));
+            Timed t(ix, res, FGPU_K_FORMAT);
+            hipLaunchKernelGGL(k_cfmt_write, dim3(grid), dim3(256), 0, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
+                               n, W, nc, sthr, dthr, first_read_id, rec_off, block_bits, block_off,
+                               res->d_fmt_out.as<unsigned long long>());
+            HIP_TRY(hipGetLastError());
+        } else if (n && format == FGPU_FMT_BINARY) {
             bytes = 8 * n + 4 * res->total;
             res->d_fmt_out.ensure(bytes);
             Timed t(ix, res, FGPU_K_FORMAT);

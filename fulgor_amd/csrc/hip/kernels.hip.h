@@ -1634,6 +1634,175 @@ __global__ __launch_bounds__(256) void k_fmt_binary_write(const uint64_t* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// Device-side compressed formatter (psa_compressed_formatter, src/ps_utils.cpp:158-239): blocks of
+// `u64 num_bits` + words; a record is delta(id) delta(count) followed by delta-gaps (count < 0.25 n), the raw
+// n-bit bitmap (count < 0.75 n) or the delta-gaps of the missing colours. It works from the RESULT BITMAPS of the
+// pass (the colour lists are not needed): sizes per read -> bit offsets inside blocks of CFMT_BLOCK_READS
+// records -> byte offsets of the blocks -> every code ORed into the zeroed output at its bit position. Where the
+// reference cuts blocks depends on its worker threads' buffers; any cut is the same format.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t CFMT_BLOCK_READS = 256;
+
+__device__ __forceinline__ uint64_t delta_code(uint64_t x, uint32_t& len) {  // x < 2^32; LSB-first code of at most 43 bits
+    const uint64_t y = x + 1;
+    const uint32_t b = 63u - (uint32_t)__builtin_clzll(y);
+    const uint32_t yb = b + 1, c = 31u - (uint32_t)__builtin_clz(yb);
+    len = 2 * c + 1 + b;
+    return (1ull << c) | ((uint64_t)(yb & ((1u << c) - 1u)) << (c + 1)) | ((y & ((1ull << b) - 1ull)) << (2 * c + 1));
+}
+__device__ __forceinline__ void put_bits(unsigned long long* out, uint64_t bitpos, uint64_t code, uint32_t len) {
+    const uint32_t sh = (uint32_t)bitpos & 63u;
+    atomicOr(&out[bitpos >> 6], (unsigned long long)(code << sh));
+    if (sh + len > 64) atomicOr(&out[(bitpos >> 6) + 1], (unsigned long long)(code >> (64 - sh)));
+}
+// inclusive running maximum over the lanes
+__device__ __forceinline__ int wave_incl_max_i32(int v) {
+    const int lane = lane_id();
+    int x = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o);
+        if (lane >= o) x = max(x, y);
+    }
+    return x;
+}
+
+// payload of the gap-coded kinds: walks the set bits of `word(w)` (the result row, complemented for the dense kind)
+// in colour order; emit(gap, bit offset of its code inside the payload) when WRITE, and returns the payload bits
+template <bool WRITE, typename WordFn, typename Emit>
+__device__ __forceinline__ uint32_t cfmt_gap_payload(uint32_t W, int lane, WordFn word, Emit emit) {
+    uint32_t total = 0;
+    int carry_last = -1;  // position of the last set bit of earlier rounds
+    for (uint32_t w0 = 0; w0 < W; w0 += 64) {
+        const uint32_t w = w0 + lane;
+        const uint32_t x = w < W ? word(w) : 0u;
+        const int last = x ? (int)(w * 32 + 31 - __builtin_clz(x)) : -1;
+        const int run = wave_incl_max_i32(last);  // last set bit up to and including this lane's word
+        const int before = __shfl_up(run, 1);
+        const int prev0 = max(carry_last, lane == 0 ? -1 : before);
+        uint32_t mine = 0;
+        {
+            int prev = prev0;
+            for (uint32_t y = x; y; y &= y - 1) {
+                const int p = (int)(w * 32 + __builtin_ctz(y));
+                uint32_t len;
+                (void)delta_code((uint64_t)(p - prev - 1), len);
+                mine += len;
+                prev = p;
+            }
+        }
+        const uint32_t incl = wave_incl_scan_u32(mine);
+        if (WRITE) {
+            uint32_t at = total + incl - mine;
+            int prev = prev0;
+            for (uint32_t y = x; y; y &= y - 1) {
+                const int p = (int)(w * 32 + __builtin_ctz(y));
+                uint32_t len;
+                (void)delta_code((uint64_t)(p - prev - 1), len);
+                emit((uint32_t)(p - prev - 1), at);
+                at += len;
+                prev = p;
+            }
+        }
+        total += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        carry_last = max(carry_last, __builtin_amdgcn_readlane(run, 63));
+    }
+    return total;
+}
+
+__device__ __forceinline__ uint32_t cfmt_word(const uint32_t* row, uint32_t w, uint32_t n, bool complemented) {
+    uint32_t x = row[w];
+    if (complemented) {
+        x = ~x;
+        const uint32_t lo = w * 32;
+        x &= lo >= n ? 0u : (n - lo >= 32 ? 0xFFFFFFFFu : ((1u << (n - lo)) - 1u));
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_cfmt_sizes(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
+                                                    uint64_t n_reads, uint32_t W, uint32_t n, uint32_t sparse_thr, uint32_t dense_thr,
+                                                    uint32_t first_id, uint32_t* __restrict__ bits) {
+    const int lane = lane_id();
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave; r < n_reads; r += nwaves) {
+        const uint32_t size = counts[r];
+        uint32_t l1, l2;
+        (void)delta_code((uint64_t)first_id + r, l1);
+        (void)delta_code(size, l2);
+        uint32_t payload = 0;
+        if (size == 0) payload = 0;
+        else if (size >= sparse_thr && size < dense_thr) payload = n;
+        else {
+            const uint32_t* row = bitmap + r * W;
+            const bool comp = size >= dense_thr;
+            payload = cfmt_gap_payload<false>(W, lane, [&](uint32_t w) { return cfmt_word(row, w, n, comp); }, [](uint32_t, uint32_t) {});
+        }
+        if (lane == 0) bits[r] = l1 + l2 + payload;
+    }
+}
+
+// one thread block per format block: bit offset of every record inside its block, bytes of the block (header + words)
+__global__ __launch_bounds__(CFMT_BLOCK_READS) void k_cfmt_blocks(const uint32_t* __restrict__ bits, uint64_t n_reads,
+                                                                   uint32_t* __restrict__ rec_off, uint32_t* __restrict__ block_bits,
+                                                                   uint32_t* __restrict__ block_bytes) {
+    __shared__ uint32_t wsum[CFMT_BLOCK_READS / 64];
+    const uint64_t r = (uint64_t)blockIdx.x * CFMT_BLOCK_READS + threadIdx.x;
+    const uint32_t b = r < n_reads ? bits[r] : 0u;
+    const uint32_t incl = wave_incl_scan_u32(b);
+    if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t i = 0; i < (threadIdx.x >> 6); ++i) base += wsum[i];
+    if (r < n_reads) rec_off[r] = base + incl - b;
+    if (threadIdx.x == CFMT_BLOCK_READS - 1) {
+        const uint32_t tot = base + incl;
+        block_bits[blockIdx.x] = tot;
+        block_bytes[blockIdx.x] = 8u + 8u * ((tot + 63u) >> 6);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cfmt_write(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
+                                                    uint64_t n_reads, uint32_t W, uint32_t n, uint32_t sparse_thr, uint32_t dense_thr,
+                                                    uint32_t first_id, const uint32_t* __restrict__ rec_off,
+                                                    const uint32_t* __restrict__ block_bits, const uint64_t* __restrict__ block_off,
+                                                    unsigned long long* __restrict__ out) {
+    const int lane = lane_id();
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave; r < n_reads; r += nwaves) {
+        const uint64_t blk = r / CFMT_BLOCK_READS;
+        const uint64_t hdr_word = block_off[blk] >> 3;  // blocks start on 8-byte boundaries
+        if (r % CFMT_BLOCK_READS == 0 && lane == 0) out[hdr_word] = block_bits[blk];
+        const uint64_t pos0 = (hdr_word + 1) * 64 + rec_off[r];
+        const uint32_t size = counts[r];
+        uint32_t l1, l2;
+        const uint64_t c1 = delta_code((uint64_t)first_id + r, l1), c2 = delta_code(size, l2);
+        if (lane == 0) {
+            put_bits(out, pos0, c1, l1);
+            put_bits(out, pos0 + l1, c2, l2);
+        }
+        const uint64_t pay = pos0 + l1 + l2;
+        const uint32_t* row = bitmap + r * W;
+        if (size == 0) continue;
+        if (size >= sparse_thr && size < dense_thr) {  // the n bits of the row, shifted into place
+            for (uint32_t w = lane; w * 32 < n; w += 64) {
+                uint32_t x = row[w];
+                const uint32_t lo = w * 32, nb = n - lo >= 32 ? 32u : n - lo;
+                if (nb < 32) x &= (1u << nb) - 1u;
+                if (x) put_bits(out, pay + lo, x, nb);
+            }
+        } else {
+            const bool comp = size >= dense_thr;
+            cfmt_gap_payload<true>(W, lane, [&](uint32_t w) { return cfmt_word(row, w, n, comp); },
+                                   [&](uint32_t gap, uint32_t at) {
+                                       uint32_t len;
+                                       const uint64_t code = delta_code(gap, len);
+                                       put_bits(out, pay + at, code, len);
+                                   });
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // algorithmic bytes of the colour-intersection stage:
 //   sum over reads of  sum_c ceil(list bits / 8) + 16|C| + 4|C| + 4|R| + 8
 // ---------------------------------------------------------------------------------------------

@@ -147,14 +147,10 @@ def pseudoalign_reads(index, bases, offs, algo=FULL_INTERSECTION, threshold=0.0,
         index.run(reads, res, algo, threshold, a, cnt)
         _, _, m = res.sizes()
         mapped += m
-        if f is not None:
-            if fmt in ("ascii", "binary"):  # formatted by HIP kernels from the resident CSR (fgpu_result_format)
-                sink.write(res.format_view(FORMATS[fmt], first_id + a))
-            else:
-                o, c = res.download()
-                sink.write(f.add(first_id + a, o, c))
+        if f is not None:  # formatted by HIP kernels from the resident results (fgpu_result_format_view)
+            sink.write(res.format_view(FORMATS[fmt], first_id + a))
     if f is not None:
-        sink.write(f.finish())
+        f.finish()  # (the host formatter only supplied the file header)
     res.close()
     reads.close()
     return n, mapped
@@ -183,15 +179,13 @@ def pseudoalign_stream(index, batches, algo=FULL_INTERSECTION, threshold=0.0, si
             index.run(reads, res, algo, threshold)
             mapped += res.sizes()[2]
             if f is not None:
-                if fmt in ("ascii", "binary"):
-                    sink.write(res.format_view(FORMATS[fmt], first_id + n))
-                else:
-                    o, c = res.download()
-                    sink.write(f.add(first_id + n, o, c))
+                sink.write(res.format_view(FORMATS[fmt], first_id + n))
             reads.close()
         n += cnt
     if f is not None:
-        sink.write(f.finish())
+        tail = f.finish()
+        if deduplicate:  # the deduplicated path formats on the host: flush its last compressed block
+            sink.write(tail)
     res.close()
     return n, mapped
 

@@ -142,7 +142,9 @@ void fgpu_fastx_close(fgpu_fastx* f);
 /* Device-side formatting of the last pass of `res` (src/ps_utils.cpp:48-135): the records of reads
  * first_read_id .. first_read_id + n - 1 in file order, ascii ("<id>\t<count>[\t<colour>...]\n") or binary (u32 id, u32
  * count, u32 x count), built by HIP kernels from the resident CSR and copied to a malloc'd host buffer (fgpu_free).
- * Byte-identical to fgpu_formatter_add on the downloaded CSR. FGPU_FMT_COMPRESSED: -ENOTSUP (host formatter). */
+ * Byte-identical to fgpu_formatter_add on the downloaded CSR. FGPU_FMT_COMPRESSED (src/ps_utils.cpp:158-239) is built from the
+ * result bitmaps: the same records in blocks of 256 (the reference's block cuts depend on its workers' buffers; any cut
+ * is the same format); the caller writes the 8-byte file header (fgpu_formatter_create) once in front. */
 int fgpu_result_format(const fgpu_result* res, int format, uint32_t first_read_id, char** out, uint64_t* out_len);
 /* Same records without the extra copy: *out points into a pinned host buffer owned by `res` (the D2H copy runs at PCIe
  * speed and the buffer is recycled); valid until the next format call on `res` or fgpu_result_free. */

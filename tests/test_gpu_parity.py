@@ -561,3 +561,30 @@ def test_concurrent_workers_share_one_index(s4546):
     for t in ts:
         t.join()
     assert errors == []
+
+
+@pytest.mark.parametrize("which", ["s10", "s4546"])
+def test_device_compressed_formatter_parses_back_to_the_results(which, s10_gpu, seeded_reads, s4546):
+    """psa_compressed_formatter on the device, built from the result bitmaps: the oracle's reader of the format must
+    recover exactly the ids and colour lists of the pass (all three record kinds occur on s4546)"""
+    from oracle.pyoracle import parse_compressed
+    from fulgor_amd.driver import Formatter
+    if which == "s10":
+        ix, (b, o) = s10_gpu, seeded_reads
+        b, o = b[:150 * 7000], o[:7001]
+    else:
+        ix, _, gen = s4546
+        b, o = gen.generate(999, 7000, 150, 42)
+    rd, res = ix.upload_reads(b, o), ix.new_result()
+    for algo, tau, first in ((fulgor_amd.FULL_INTERSECTION, 0.0, 0), (fulgor_amd.THRESHOLD_UNION, 0.5, 4000000000)):
+        ix.run(rd, res, algo, tau)
+        offs, cols = res.download()
+        data = Formatter("compressed", ix.num_colors()).header + bytes(res.format_view(2, first))
+        ids, po, pc = parse_compressed(data)
+        assert np.array_equal(ids, (np.arange(7000, dtype=np.uint64) + first).astype(np.uint32))
+        assert np.array_equal(po, offs) and np.array_equal(pc, cols)
+        if which == "s4546" and algo == fulgor_amd.FULL_INTERSECTION:
+            sz, n = np.diff(offs.astype(np.int64)), ix.num_colors()
+            assert (sz == 0).any() and ((sz > 0) & (sz < n // 4)).any() and ((sz >= n // 4) & (sz < 3 * n // 4)).any() and (sz >= 3 * n // 4 + 1).any()
+        host = Formatter("compressed", ix.num_colors())
+        assert len(data) < 1.2 * len(host.header + host.add(first, offs, cols) + host.finish()) + 64 * 7000 // 256
