@@ -1341,10 +1341,11 @@ __global__ __launch_bounds__(256) void scan_block_sums(const uint32_t* __restric
                                                        uint64_t* __restrict__ block_sums, uint64_t* __restrict__ block_mapped) {
     __shared__ uint64_t s_sum[4], s_map[4];
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t s = 0, mp = 0;
+    uint64_t s = 0;  // 64-bit throughout: the sizes may be record bytes of a formatter, not only colour counts
+    uint32_t mp = 0;
     for (int i = 0; i < SCAN_ITEMS; ++i)
         if (base + i < n) { uint32_t v = counts[base + i]; s += v; mp += v != 0; }
-    s = wave_sum_u32(s);  // tile total fits 32 bits only if counts are small; widen below
+    for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
     mp = wave_sum_u32(mp);
     if (lane_id() == 0) { s_sum[threadIdx.x >> 6] = s; s_map[threadIdx.x >> 6] = mp; }
     __syncthreads();

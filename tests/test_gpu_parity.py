@@ -478,6 +478,13 @@ def test_gpu_more_than_65535_colours(built, tmp_path):
     go, gc = res.download()
     got = hits.cpu().numpy()
     assert np.array_equal(got[:70001], np.bincount(gc, minlength=70001)) and got[70001] == len(reads)
+    # the three device formatters on wide rows (records of up to 70001 bitmap bits / tens of thousands of codes)
+    from fulgor_amd.driver import Formatter
+    from oracle.pyoracle import parse_compressed
+    for fmt, code in (("ascii", 0), ("binary", 1)):
+        assert bytes(res.format_view(code, 7)) == Formatter(fmt, 70001).add(7, go, gc)
+    ids, po, pc = parse_compressed(Formatter("compressed", 70001).header + bytes(res.format_view(2, 7)))
+    assert np.array_equal(ids, np.arange(7, 7 + len(reads), dtype=np.uint32)) and np.array_equal(po, go) and np.array_equal(pc, gc)
 
 
 def test_preprocessed_query_file_path_equals_direct_path(s4546, tmp_path):
