@@ -11,13 +11,21 @@ import json, re, sys
 path, reads = sys.argv[1], int(sys.argv[2])
 sec = None
 vals = {}
+early_exit = set()  # kernels with one launch that returned at once (k2b_expand's device-side capacity check on the first pass)
 for line in open(path):
     if line.startswith("== "):
-        sec = line.split()[1].rstrip(":")
+        sec = line.split()[1].rstrip(":") if not line.startswith("== kernel trace") else "trace"
+        continue
+    if sec == "trace":
+        f = line.split()
+        if len(f) == 5 and f[1].isdigit() and float(f[3]) < 0.02 * float(f[4]):
+            early_exit.add(f[0])
         continue
     m = re.match(r"^(\S+)\s+\[(\d+)\]\s+(FETCH_SIZE|WRITE_SIZE)=([0-9.e+]+)", line)
     if m and sec in ("pmc_fetch", "pmc_write"):
         name, n, ctr, v = m.group(1), int(m.group(2)), m.group(3), float(m.group(4))
+        if name in early_exit:
+            n -= 1  # that launch moved no data
         vals.setdefault(name, {})[ctr] = v * 1024.0 / n
 out = {"source": path, "reads_per_launch": reads, "unit": "bytes per launch",
        "method": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes), separate rocprofv3 --pmc passes, averaged over the dispatches",
