@@ -783,7 +783,7 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t src) {  //
 }
 __device__ __forceinline__ uint4 or_not(uint4 e, uint4 x) { return make_uint4(e.x | ~x.x, e.y | ~x.y, e.z | ~x.z, e.w | ~x.w); }
 
-__global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint32_t* __restrict__ nids,
+__global__ __launch_bounds__(256, 7) void k2a_intersect(DevColors c, const uint32_t* __restrict__ nids,
                                                      const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
                                                      uint64_t n_reads, uint32_t* __restrict__ out_bitmap,
                                                      uint32_t* __restrict__ out_count, unsigned int* tickets) {
@@ -1156,7 +1156,7 @@ constexpr uint32_t G_BLOCK_REF = 0x80000000u;
 constexpr uint32_t G_SETS = 4;  // colour sets of a read rebuilt concurrently (one LDS plane each)
 
 template <bool UNION, int BITS>
-__global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 6 : 4) : 6) void k_generic(DevGeneric g, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
+__global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 6 : 4) : 7) void k_generic(DevGeneric g, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
                           const ListDesc* __restrict__ desc, double tau, uint64_t n_reads,
                           uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count, unsigned int* tickets,
                           uint32_t* __restrict__ scores_out) {
