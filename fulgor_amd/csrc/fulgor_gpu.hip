@@ -425,7 +425,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         else if (bits == 8) launch(k_generic<true, 8>);
         else launch(k_generic<true, 16>);
     } else if (algo == FGPU_FULL_INTERSECTION) {
-        const size_t per_wave = (size_t)2 * W * 4 + wave_scratch_bytes();
+        const size_t per_wave = (size_t)2 * W * 4 + wave_scratch_bytes_compact();
         const uint32_t wpb = pick_waves(per_wave, (const void*)k2a_intersect);
         const uint32_t grid = resident_grid(k2a_intersect, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
         Timed t(ix, res, FGPU_K_INTERSECT);
@@ -436,7 +436,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     } else if (algo == FGPU_THRESHOLD_UNION) {
         // score counter width from the longest read of the batch: 8 bits up to 127 k-mers, 16 up to 32767, else 32
         const int bits = res->max_kmers_in_batch <= 127 ? 8 : (res->max_kmers_in_batch <= 32767 ? 16 : 32);
-        const size_t per_wave = (size_t)W * 4 * bits + wave_scratch_bytes();
+        const size_t per_wave = (size_t)W * 4 * bits + wave_scratch_bytes_compact();
         auto launch = [&](auto kernel) {
             const uint32_t wpb = pick_waves(per_wave, (const void*)kernel);
             const uint32_t grid = resident_grid(kernel, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);

@@ -756,14 +756,17 @@ struct WaveScratch {
     int32_t* h_score;
 };
 __host__ __device__ inline uint32_t wave_scratch_bytes() { return 64 * (8 * 3 + 4 * 3); }
+// the hybrid kernels do without h_body (a bitmap list keeps its body offset in h_soff, which only gap-coded lists
+// use otherwise): 512 bytes less per wave, one more wave per SIMD for the threshold union's counter planes
+__host__ __device__ inline uint32_t wave_scratch_bytes_compact() { return wave_scratch_bytes() - 64 * 8; }
 __device__ __forceinline__ WaveScratch carve_scratch(unsigned char* p) {
     WaveScratch s;
     s.h_begin = (uint64_t*)p;
-    s.h_body = s.h_begin + 64;
-    s.h_soff = s.h_body + 64;
+    s.h_soff = s.h_begin + 64;
     s.h_ncodes = (uint32_t*)(s.h_soff + 64);
     s.pref = s.h_ncodes + 64;
     s.h_score = (int32_t*)(s.pref + 64);
+    s.h_body = (uint64_t*)(s.h_score + 64);  // last: absent from the compact layout
     return s;
 }
 
@@ -790,10 +793,10 @@ __global__ __launch_bounds__(256, 7) void k2a_intersect(DevColors c, const uint3
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = c.w32, W4 = W >> 2;  // W is a multiple of 4: the bitmaps move as 128-bit groups
-    const uint32_t per_wave = 2 * W * 4 + wave_scratch_bytes();
+    const uint32_t per_wave = 2 * W * 4 + wave_scratch_bytes_compact();
     unsigned char* mine = smem + (size_t)wv * per_wave;
     WaveScratch sc = carve_scratch(mine);
-    uint32_t* EXCL = (uint32_t*)(mine + wave_scratch_bytes());
+    uint32_t* EXCL = (uint32_t*)(mine + wave_scratch_bytes_compact());
     uint4* EX4 = (uint4*)EXCL;
     uint4* T4 = EX4 + W4;  // the plane T, all zero between sparse lists
     constexpr uint32_t BATCH = 8;
@@ -854,7 +857,7 @@ __global__ __launch_bounds__(256, 7) void k2a_intersect(DevColors c, const uint3
                     const uint32_t incl = wave_incl_scan_u32(nblk);
                     const uint32_t excl = incl - nblk;
                     const uint32_t total_blk = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    sc.h_begin[lane] = d.begin; sc.h_body[lane] = desc_body(d); sc.h_soff[lane] = d.soff;
+                    sc.h_begin[lane] = d.begin; sc.h_soff[lane] = type == D_ENC_BITMAP ? desc_body(d) : d.soff;
                     sc.h_ncodes[lane] = nblk | (type == D_ENC_DELTA_GAPS ? 0x80000000u : 0u);
                     sc.pref[lane] = incl;
                     wave_lds_sync();
@@ -864,7 +867,7 @@ __global__ __launch_bounds__(256, 7) void k2a_intersect(DevColors c, const uint3
                     while (mb) {
                         const int src = __builtin_ctzll(mb);
                         mb &= mb - 1;
-                        const uint64_t body = sc.h_body[src];
+                        const uint64_t body = sc.h_soff[src];
                         const uint32_t* words = (const uint32_t*)c.bits + (body >> 5);
                         const uint32_t sh = (uint32_t)body & 31u;
                         for (uint32_t g4 = lane; g4 * 128 < n; g4 += 64) {
@@ -976,10 +979,10 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = c.w32;
     const uint32_t n = c.n;
-    const uint32_t per_wave = W * PLANES * 4 + wave_scratch_bytes();
+    const uint32_t per_wave = W * PLANES * 4 + wave_scratch_bytes_compact();
     unsigned char* mine = smem + (size_t)wv * per_wave;
     WaveScratch sc = carve_scratch(mine);
-    uint32_t* SC = (uint32_t*)(mine + wave_scratch_bytes());
+    uint32_t* SC = (uint32_t*)(mine + wave_scratch_bytes_compact());
     const WorkQueue wq{tickets, n_reads, 8};
     uint64_t t_first;
     uint32_t t_count;
@@ -1055,7 +1058,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
             h.type = (int)(int8_t)(d.meta & 0xFFu); h.ncodes = d.ncodes; h.begin = d.begin; h.body = desc_body(d); h.soff = d.soff;
             const int32_t score = d.score;
             const uint32_t nblk = h.ncodes;  // gap-coded lists of both kinds
-            sc.h_begin[lane] = h.begin; sc.h_body[lane] = h.body; sc.h_soff[lane] = h.soff; sc.h_ncodes[lane] = nblk;
+            sc.h_begin[lane] = h.begin; sc.h_soff[lane] = h.type == D_ENC_BITMAP ? h.body : h.soff; sc.h_ncodes[lane] = nblk;
             sc.h_score[lane] = h.type == D_ENC_COMPLEMENT ? -score : score;
             const uint32_t incl = wave_incl_scan_u32(nblk);
             const uint32_t excl = incl - nblk;
@@ -1067,7 +1070,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
             while (mb) {
                 const int src = __builtin_ctzll(mb);
                 mb &= mb - 1;
-                const uint64_t body = sc.h_body[src];
+                const uint64_t body = sc.h_soff[src];
                 const uint32_t s = (uint32_t)sc.h_score[src];
                 for (uint32_t w = lane; w * 32 < n; w += 64) {
                     uint32_t x = (uint32_t)bits_window(c.bits, body + 32ull * w);
