@@ -465,16 +465,16 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     // results) the buffer is enlarged and the launch repeated. One host round trip per pass instead of two.
     // the per-colour hit histogram rides along in LDS while it fits (16-bit counters, W * 64 bytes); for
     // larger collections the expand kernel runs without it and k_hits counts from the bitmaps on demand
-    const size_t stage_lds = 4 * (2048 + 64) * 2;
-    res->hits_folded = stage_lds + (size_t)W * 64 <= 64 * 1024;
+    const size_t stage_lds = (K2B_THREADS / 64) * (2048 + 64) * 2;
+    res->hits_folded = stage_lds + (size_t)W * 64 <= 80 * 1024;  // two blocks per CU
     const size_t lds = res->hits_folded ? stage_lds + (size_t)W * 64 : stage_lds;
     // a block must see fewer than 65536 reads (16-bit hit counters): true for any resident grid >= n / 65535
-    const uint32_t grid = std::max<uint32_t>(resident_grid(k2b_expand, n, 4, ix->num_cus, 256, lds), (uint32_t)(n / 60000 + 1));
+    const uint32_t grid = std::max<uint32_t>(resident_grid(k2b_expand, n, K2B_THREADS / 64, ix->num_cus, K2B_THREADS, lds), (uint32_t)(n / 60000 + 1));
     if (res->hits_folded) res->d_partial.ensure((size_t)grid * W * 32 * 4);
     res->d_colors.ensure(16);
     auto expand = [&] {
         Timed t(ix, res, FGPU_K_EXPAND);
-        hipLaunchKernelGGL(k2b_expand, dim3(grid), dim3(256), lds, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
+        hipLaunchKernelGGL(k2b_expand, dim3(grid), dim3(K2B_THREADS), lds, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
                            res->d_offsets.as<uint64_t>(), n, W, res->d_colors.as<uint32_t>(),
                            res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE,
                            res->hits_folded ? res->d_partial.as<uint32_t>() : (uint32_t*)nullptr, res->d_totals.as<uint64_t>(),

@@ -1420,7 +1420,8 @@ __global__ __launch_bounds__(256) void scan_apply(const uint32_t* __restrict__ c
 // (16-bit entries relative to the round's first colour), then the wave copies the staged run out with
 // full-width coalesced stores. 64 words (2048 colours) per round.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k2b_expand(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
+constexpr uint32_t K2B_THREADS = 1024;  // 16 waves share one LDS hit histogram: 2 blocks per CU = 8 waves/SIMD
+__global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
                                                   const uint64_t* __restrict__ out_off, uint64_t n_reads, uint32_t W,
                                                   uint32_t* __restrict__ colors, unsigned int* tickets,
                                                   uint32_t* __restrict__ hit_partial, const uint64_t* __restrict__ totals,
@@ -1432,8 +1433,8 @@ __global__ __launch_bounds__(256) void k2b_expand(const uint32_t* __restrict__ b
     // keeps 16-bit counters in LDS (a block sees far fewer than 65536 reads) and stores them as one row of
     // hit_partial[gridDim.x][W*32] at the end; k_hits_reduce sums the rows.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_x[];
-    uint16_t* stage_all = (uint16_t*)smem_x;                        // 4 x (2048 + 64) entries
-    uint32_t* hist = (uint32_t*)(smem_x + 4 * (2048 + 64) * 2);     // W*16 words (two counters per word)
+    uint16_t* stage_all = (uint16_t*)smem_x;                                           // one (2048 + 64)-entry stage per wave
+    uint32_t* hist = (uint32_t*)(smem_x + (K2B_THREADS / 64) * (2048 + 64) * 2);       // W*16 words (two counters per word)
     const int lane = lane_id();
     uint16_t* stage = stage_all + (threadIdx.x >> 6) * (2048 + 64);
     if (hit_partial) {
