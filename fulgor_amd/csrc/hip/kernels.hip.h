@@ -641,7 +641,7 @@ __device__ __forceinline__ uint64_t desc_body(const ListDesc& d) { return d.begi
 __global__ __launch_bounds__(256) void k_desc(DevColors c, const uint32_t* __restrict__ nids,
                                               const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ ids_src,
                                               const uint32_t* __restrict__ cnt_src, const uint64_t* __restrict__ dst_off,
-                                              uint64_t n_reads, ListDesc* __restrict__ out, int resolve_hybrid) {
+                                              uint64_t n_reads, ListDesc* __restrict__ out) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t r = t >> 4;
     if (r >= n_reads) return;
@@ -650,7 +650,6 @@ __global__ __launch_bounds__(256) void k_desc(DevColors c, const uint32_t* __res
     for (uint32_t j = (uint32_t)t & 15u; j < cnt; j += 16) {
         const uint32_t id = ids_src[so + j];
         ListDesc d{0, 0, 0, (uint32_t)D_ENC_NONE & 0xFFu, 0, id};
-        if (resolve_hybrid) d = c.set_desc[id];
         d.score = cnt_src ? (int32_t)cnt_src[so + j] : 0;
         out[dso + j] = d;
     }
