@@ -190,6 +190,7 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if (args.workload == "s4546syn" and itype == 0 and tj["reads_per_launch"] == args.chunk and n_reads >= args.chunk
+                    and tj.get("algo", "full-intersection") == args.algo
                     and dom in tj["kernels"]):
                 traffic, traffic_src = tj["kernels"][dom]["total"], tj["source"]
         except (OSError, ValueError, KeyError):

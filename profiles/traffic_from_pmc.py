@@ -27,7 +27,8 @@ for line in open(path):
         if name in early_exit:
             n -= 1  # that launch moved no data
         vals.setdefault(name, {})[ctr] = v * 1024.0 / n
-out = {"source": path, "reads_per_launch": reads, "unit": "bytes per launch",
+out = {"source": path, "reads_per_launch": reads, "algo": sys.argv[3] if len(sys.argv) > 3 else "full-intersection",
+       "unit": "bytes per launch",
        "method": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes), separate rocprofv3 --pmc passes, averaged over the dispatches",
        "kernels": {}}
 for k, v in vals.items():
