@@ -188,8 +188,8 @@ void upload_index(fgpu_index* ix) {
                 d.meta = (uint32_t)D_ENC_BITMAP | (delta_code_bits(size) << 8);
             } else {  // gap-coded on the host, packed blocks here
                 d.begin = h.blk_wbase[id];
-                d.soff = h.blk_first[id];
                 d.ncodes = (uint32_t)(h.blk_first[id + 1] - h.blk_first[id]);
+                d.soff = d.ncodes == 1 ? h.blk_hdr[h.blk_first[id]] : h.blk_first[id];  // single block: the header itself
                 d.meta = (uint32_t)(size < h.sparse_thr ? D_ENC_DELTA_GAPS : D_ENC_COMPLEMENT);
             }
         }

@@ -629,7 +629,7 @@ struct ListHeader {
 // the hybrid kernels gather set_desc themselves (the full intersection one read ahead).
 struct __attribute__((aligned(16))) ListDesc {
     uint64_t begin;   // bitmap list: bit offset of the list; gap-coded list: first data word in blk_words
-    uint64_t soff;    // gap-coded list: first block header
+    uint64_t soff;    // gap-coded list: index of its first block header — or, for a single-block list, the header itself
     uint32_t ncodes;  // blocks of a gap-coded list (0 for bitmap lists)
     uint32_t meta;    // encoding | (body - begin) << 8
     int32_t score;    // positive k-mers that produced this id (threshold-union)
@@ -886,7 +886,8 @@ __global__ __launch_bounds__(256, 7) void k2a_intersect(DevColors c, const uint3
                             const uint32_t i = owner_list(excl, min(64u, cnt - g), s);
                             const uint32_t nb = sc.h_ncodes[i];
                             const uint32_t j = s - (sc.pref[i] - (nb & 0x7FFFFFFFu));
-                            const uint64_t hd = c.blk_hdr[sc.h_soff[i] + j];
+                            // a single-block list carries its block header in the descriptor itself (one fetch less)
+                            const uint64_t hd = (nb & 0x7FFFFFFFu) == 1 ? sc.h_soff[i] : c.blk_hdr[sc.h_soff[i] + j];
                             const uint64_t a = (uint64_t)(c.blk_words + sc.h_begin[i] + blk_rel_word(hd));
                             const bool sparse = (nb >> 31) != 0;
                             bl.a_lo = (uint32_t)a;
@@ -1087,7 +1088,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
                 if (s < total_blk) {
                     const uint32_t i = owner_list(excl, min(64u, cnt - g), s);
                     const uint32_t j = s - (sc.pref[i] - sc.h_ncodes[i]);
-                    const uint64_t hd = c.blk_hdr[sc.h_soff[i] + j];
+                    const uint64_t hd = sc.h_ncodes[i] == 1 ? sc.h_soff[i] : c.blk_hdr[sc.h_soff[i] + j];  // (as in k2a)
                     const uint64_t a = (uint64_t)(c.blk_words + sc.h_begin[i] + blk_rel_word(hd));
                     bl.a_lo = (uint32_t)a;
                     bl.a_hi = (uint32_t)(a >> 32);
