@@ -1,8 +1,12 @@
 """`fulgor pseudoalign`-compatible command line (tools/pseudoalign.cpp:228-369): same flags, same exit
 codes, same summary lines; the index argument is a dump basename or an .fgidx container."""
 import argparse
+
+import os
 import sys
 import time
+
+import numpy as np
 
 from . import driver
 from .index import FULL_INTERSECTION, THRESHOLD_UNION, Index
@@ -63,9 +67,85 @@ def pseudoalign(argv):
     return 0
 
 
+def _query_tool(argv, prog, emit):
+    """common driver of the two per-k-mer tools (tools/kmer_conservation.cpp:58-127, tools/kmer_matches.cpp:57-126):
+    -i index -q reads -o output [-t threads] [--verbose]; one output line per record, in file order"""
+    ap = argparse.ArgumentParser(prog="fulgor " + prog, add_help=True)
+    ap.add_argument("-i", dest="index_filename", required=True)
+    ap.add_argument("-q", dest="query_filename", required=True)
+    ap.add_argument("-o", dest="output_filename", required=True)
+    ap.add_argument("-t", dest="num_threads", type=int, default=1)
+    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--device", type=int, default=0)
+    try:
+        a = ap.parse_args(argv)
+    except SystemExit:
+        return 1
+    if not os.path.exists(a.query_filename):
+        print("error in opening the file '%s'" % a.query_filename, file=sys.stderr)
+        return 1
+    try:
+        index = Index(a.index_filename, device=a.device)
+        batches = FastxReader(a.query_filename, batch=4096, copy=False)
+    except RuntimeError as e:
+        print(str(e), file=sys.stderr)
+        return 1
+    t0 = time.time()
+    n = 0
+    try:
+        out = open(a.output_filename, "w")
+    except OSError:
+        print("could not open output file " + a.output_filename, file=sys.stderr)
+        return 1
+    with out:
+        state = {}
+        for bases, offs in batches:
+            names = batches.names()
+            out.write(emit(index, bases, offs, names, state))
+            n += len(names)
+    batches.close()
+    el = (time.time() - t0) * 1000.0
+    if a.verbose:
+        print("processed %d reads" % n)
+        print("elapsed = %d millisec / %d sec / %d min / %g musec/read" % (el, el / 1000, el / 60000, el * 1000 / max(1, n)))
+    return 0
+
+
+def _emit_conservation(index, bases, offs, names, state):
+    """`name <tab> #triples [<tab>(start num_kmers color_set_id)]...` (tools/kmer_conservation.cpp:26-36)"""
+    from .index import conservation_triples
+    ko, ki = index.kmer_color_set_ids_batch(bases, offs)
+    lines = []
+    for j, name in enumerate(names):
+        tr = conservation_triples(ki[int(ko[j]):int(ko[j + 1])])
+        lines.append(name + "\t%d" % len(tr) + "".join("\t(%d %d %d)" % t for t in tr) + "\n")
+    return "".join(lines)
+
+
+def _emit_matches(index, bases, offs, names, state):
+    """`name <tab> #k-mers [<tab>0|1 per k-mer] [<tab>count per colour]` (tools/kmer_matches.cpp:28-35). A record
+    shorter than k leaves the worker's buffers untouched in the reference (src/kmer_matches.cpp:11), so the line
+    repeats the previous record's flags and counts: reproduced here as one worker sees them, in file order."""
+    ko, pos, counts = index.kmer_matches_batch(bases, offs)
+    k = index.k()
+    lens = np.diff(np.asarray(offs).astype(np.int64))
+    lines = []
+    for j, name in enumerate(names):
+        if lens[j] >= k:
+            state["pos"], state["counts"] = pos[int(ko[j]):int(ko[j + 1])], counts[j]
+        p = state.get("pos", np.zeros(0, dtype=np.uint8))
+        c = state.get("counts", np.zeros(index.num_colors(), dtype=np.uint32))
+        lines.append(name + "\t%d" % len(p) + "".join("\t%d" % x for x in p) + "".join("\t%d" % x for x in c) + "\n")
+    return "".join(lines)
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    if not argv or argv[0] != "pseudoalign":
-        print("usage: python -m fulgor_amd pseudoalign -i <index> -q <reads> -o <out> [-r tau] [--format ascii|binary] [--verbose]")
+    tools = {"pseudoalign": pseudoalign,
+             "kmer-conservation": lambda av: _query_tool(av, "kmer-conservation", _emit_conservation),
+             "kmer-matches": lambda av: _query_tool(av, "kmer-matches", _emit_matches)}
+    if not argv or argv[0] not in tools:
+        print("usage: python -m fulgor_amd <pseudoalign|kmer-conservation|kmer-matches> -i <index> -q <reads> -o <out> "
+              "[-r tau] [--format ascii|binary|compressed] [--deduplicate] [--verbose]")
         return 1
-    return pseudoalign(argv[1:])
+    return tools[argv[0]](argv[1:])

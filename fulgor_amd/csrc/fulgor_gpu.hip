@@ -1140,6 +1140,8 @@ struct fgpu_fastx {
     FastxReader reader;
     std::vector<char> bases;     // the current batch (owned by the reader, recycled)
     std::vector<uint64_t> offs;
+    std::vector<char> names;
+    std::vector<uint64_t> name_offs{0};
     explicit fgpu_fastx(const char* path) : reader(path) {}
 };
 
@@ -1153,7 +1155,7 @@ int fgpu_fastx_next(fgpu_fastx* f, uint64_t max_reads, const char** bases, const
     if (!f || !bases || !offs || !n) return fail(-EINVAL, "null argument");
     if (max_reads == 0) return fail(-EINVAL, "max_reads must be positive");
     return guarded([&] {
-        f->reader.next(max_reads, f->bases, f->offs);
+        f->reader.next(max_reads, f->bases, f->offs, &f->names, &f->name_offs);
         *n = f->offs.size() - 1;
         const size_t len = f->bases.size();
         f->bases.resize(len + 256, 0);  // slack: the lookup kernel over-reads padded reads
@@ -1161,6 +1163,14 @@ int fgpu_fastx_next(fgpu_fastx* f, uint64_t max_reads, const char** bases, const
         *bases = f->bases.data();
         *offs = f->offs.data();
     });
+}
+
+int fgpu_fastx_names(fgpu_fastx* f, const char** names, const uint64_t** name_offs) {
+    if (!f || !names || !name_offs) return fail(-EINVAL, "null argument");
+    f->names.reserve(f->names.size() + 1);
+    *names = f->names.data();
+    *name_offs = f->name_offs.data();
+    return 0;
 }
 
 void fgpu_fastx_close(fgpu_fastx* f) { delete f; }

@@ -21,6 +21,8 @@ public:
     struct Chunk {
         std::vector<char> bases;
         std::vector<uint64_t> offs{0};
+        std::vector<char> names;  // record names (header up to the first blank, as kseq's name), concatenated
+        std::vector<uint64_t> name_offs{0};
         uint64_t reads() const { return offs.size() - 1; }
     };
 
@@ -44,9 +46,11 @@ public:
     // next batch of at most max_reads reads (at least one chunk unless the file is exhausted); false at end of file.
     // Buffers are recycled (the batch vectors by the caller, the chunk vectors through a pool): after the first
     // batches no fresh pages are touched.
-    bool next(uint64_t max_reads, std::vector<char>& bases, std::vector<uint64_t>& offs) {
+    bool next(uint64_t max_reads, std::vector<char>& bases, std::vector<uint64_t>& offs, std::vector<char>* names = nullptr,
+              std::vector<uint64_t>* name_offs = nullptr) {
         bases.clear();
         offs.assign(1, 0);
+        if (names) { names->clear(); name_offs->assign(1, 0); }
         for (;;) {
             Chunk c;
             {
@@ -62,8 +66,15 @@ public:
             const uint64_t base = bases.size();
             bases.insert(bases.end(), c.bases.begin(), c.bases.end());
             for (size_t i = 1; i < c.offs.size(); ++i) offs.push_back(base + c.offs[i]);
+            if (names) {
+                const uint64_t nb = names->size();
+                names->insert(names->end(), c.names.begin(), c.names.end());
+                for (size_t i = 1; i < c.name_offs.size(); ++i) name_offs->push_back(nb + c.name_offs[i]);
+            }
             c.bases.clear();
             c.offs.assign(1, 0);
+            c.names.clear();
+            c.name_offs.assign(1, 0);
             std::lock_guard<std::mutex> g(m_);
             if (pool_.size() < 16) pool_.push_back(std::move(c));
         }
@@ -110,6 +121,12 @@ private:
             bool have = line(s, n);
             while (have) {
                 if (n == 0 || (s[0] != '>' && s[0] != '@')) { have = line(s, n); continue; }  // stray text before a header
+                {
+                    size_t e = 1;
+                    while (e < n && s[e] != ' ' && s[e] != '\t') ++e;
+                    c.names.insert(c.names.end(), s + 1, s + e);
+                    c.name_offs.push_back(c.names.size());
+                }
                 // sequence lines up to the next header or the '+' separator
                 uint64_t len = 0;
                 while ((have = line(s, n)) && !(n && (s[0] == '>' || s[0] == '@' || s[0] == '+'))) {

@@ -107,6 +107,7 @@ class FastxReader:
         C = self._C
         pb, po, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
         self._N.check(self._L.fgpu_fastx_next(self._h, self.batch, C.byref(pb), C.byref(po), C.byref(n)))
+        self._last_n = n.value
         if n.value == 0:
             raise StopIteration
         if self.copy:
@@ -116,6 +117,16 @@ class FastxReader:
         total = int(offs[-1])
         bases = np.frombuffer((C.c_ubyte * max(total, 1)).from_address(pb.value), dtype=np.uint8)[:total]
         return bases, offs
+
+    def names(self):
+        """names of the records of the batch returned last (header up to the first blank), as a list of str"""
+        C = self._C
+        pn, po = C.c_void_p(), C.c_void_p()
+        self._N.check(self._L.fgpu_fastx_names(self._h, C.byref(pn), C.byref(po)))
+        n = self._last_n
+        offs = self._N.copy_array(po, n + 1, np.uint64)
+        raw = bytes(self._N.copy_array(pn, int(offs[-1]), np.uint8))
+        return [raw[int(offs[i]):int(offs[i + 1])].decode("latin-1") for i in range(n)]
 
     def close(self):
         if self._h:

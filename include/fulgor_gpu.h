@@ -137,6 +137,9 @@ int fgpu_formatter_finish(fgpu_formatter* f, char** out, uint64_t* out_len);
 typedef struct fgpu_fastx fgpu_fastx;
 int fgpu_fastx_open(const char* path, fgpu_fastx** out);
 int fgpu_fastx_next(fgpu_fastx* f, uint64_t max_reads, const char** bases, const uint64_t** offs, uint64_t* n);
+/* names of the records of the last batch (kseq's name: the header up to the first blank), concatenated + (n + 1) offsets;
+ * same lifetime as the batch */
+int fgpu_fastx_names(fgpu_fastx* f, const char** names, const uint64_t** name_offs);
 void fgpu_fastx_close(fgpu_fastx* f);
 
 /* Device-side formatting of the last pass of `res` (src/ps_utils.cpp:48-135): the records of reads

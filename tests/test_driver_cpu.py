@@ -174,5 +174,10 @@ def test_native_fastx_reader_matches_python_parser(built, tmp_path):
         got += [b[int(offs[i]):int(offs[i + 1])].decode() for i in range(len(offs) - 1)]
     assert got == seqs[:200]
     assert [s.decode() for s in parse_fastx(str(tmp_path / "a.fq.gz"))] == seqs  # the Python parser agrees on plain 4-line FASTQ
+    rd = FastxReader(str(tmp_path / "a.fq.gz"), batch=70000)  # record names: the header up to the first blank
+    names = []
+    for _ in rd:
+        names += rd.names()
+    assert names == ["r%d" % i for i in range(len(seqs))]
     with pytest.raises(RuntimeError):
         FastxReader(str(tmp_path / "missing.fq"))

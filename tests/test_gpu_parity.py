@@ -595,3 +595,33 @@ def test_device_compressed_formatter_parses_back_to_the_results(which, s10_gpu, 
             assert (sz == 0).any() and ((sz > 0) & (sz < n // 4)).any() and ((sz >= n // 4) & (sz < 3 * n // 4)).any() and (sz >= 3 * n // 4 + 1).any()
         host = Formatter("compressed", ix.num_colors())
         assert len(data) < 1.2 * len(host.header + host.add(first, offs, cols) + host.finish()) + 64 * 7000 // 256
+
+
+def test_kmer_tools_cli(s10_gpu, s10_fgidx, s10_oracle, tmp_path):
+    """`fulgor kmer-conservation` / `kmer-matches` (tools/kmer_conservation.cpp, tools/kmer_matches.cpp): one line per
+    record with its name; expected text assembled from the oracle's restatement of the two index members"""
+    import subprocess, sys
+    from conftest import ROOT
+    reads = load_golden_reads()  # bytes
+    sel = list(range(0, 40)) + list(range(1000, 1010))  # the edge cases (short, N, empty) are in 1000..1009
+    fa = tmp_path / "q.fa"
+    with open(fa, "w") as f:
+        for i in sel:
+            f.write(">q%d extra words\n%s\n" % (i, reads[i].decode()))
+    k = s10_gpu.k()
+    want_c, want_m = [], []
+    prev_pos, prev_cnt = np.zeros(0, dtype=np.uint8), np.zeros(10, dtype=np.uint32)
+    for i in sel:
+        tr = s10_oracle.kmer_conservation(reads[i]) if len(reads[i]) >= k else []
+        want_c.append("q%d\t%d%s\n" % (i, len(tr), "".join("\t(%d %d %d)" % t for t in tr)))
+        if len(reads[i]) >= k:
+            prev_pos, prev_cnt = s10_oracle.kmer_matches(reads[i])
+        want_m.append("q%d\t%d%s%s\n" % (i, len(prev_pos), "".join("\t%d" % x for x in prev_pos), "".join("\t%d" % x for x in prev_cnt)))
+    for tool, want in (("kmer-conservation", want_c), ("kmer-matches", want_m)):
+        out = tmp_path / (tool + ".txt")
+        rc = subprocess.run([sys.executable, "-m", "fulgor_amd", tool, "-i", s10_fgidx, "-q", str(fa), "-o", str(out), "-t", "2"],
+                            cwd=ROOT).returncode
+        assert rc == 0
+        assert open(out).read() == "".join(want)
+    assert subprocess.run([sys.executable, "-m", "fulgor_amd", "kmer-matches", "-i", s10_fgidx, "-q", str(tmp_path / "nope.fa"),
+                           "-o", str(tmp_path / "x")], cwd=ROOT).returncode == 1
