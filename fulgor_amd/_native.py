@@ -80,6 +80,7 @@ def lib():
     L.fgpu_formatter_create.argtypes = [C.c_int, C.c_uint64, C.POINTER(vp), C.POINTER(vp), u64p]
     L.fgpu_formatter_add.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint64, C.POINTER(vp), u64p]
     L.fgpu_formatter_finish.argtypes = [vp, C.POINTER(vp), u64p]
+    L.fgpu_dump.argtypes = [vp, C.c_char_p]
     L.fgpu_export_sizes.argtypes = [vp, u64p, u64p, u64p, u64p, u64p]
     L.fgpu_export.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     _lib = L

@@ -139,13 +139,29 @@ def _emit_matches(index, bases, offs, names, state):
     return "".join(lines)
 
 
+def dump(argv):
+    """`fulgor dump -i index -o basename` (tools/util.cpp): the index as the reference's text interchange files"""
+    ap = argparse.ArgumentParser(prog="fulgor dump", add_help=True)
+    ap.add_argument("-i", dest="index_filename", required=True)
+    ap.add_argument("-o", dest="basename", required=True)
+    try:
+        a = ap.parse_args(argv)
+        Index(a.index_filename, device=-1).dump(a.basename)
+    except SystemExit:
+        return 1
+    except RuntimeError as e:
+        print(str(e), file=sys.stderr)
+        return 1
+    return 0
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    tools = {"pseudoalign": pseudoalign,
+    tools = {"pseudoalign": pseudoalign, "dump": dump,
              "kmer-conservation": lambda av: _query_tool(av, "kmer-conservation", _emit_conservation),
              "kmer-matches": lambda av: _query_tool(av, "kmer-matches", _emit_matches)}
     if not argv or argv[0] not in tools:
-        print("usage: python -m fulgor_amd <pseudoalign|kmer-conservation|kmer-matches> -i <index> -q <reads> -o <out> "
+        print("usage: python -m fulgor_amd <pseudoalign|kmer-conservation|kmer-matches|dump> -i <index> -q <reads> -o <out> "
               "[-r tau] [--format ascii|binary|compressed] [--deduplicate] [--verbose]")
         return 1
     return tools[argv[0]](argv[1:])

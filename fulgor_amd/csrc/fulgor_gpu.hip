@@ -1206,4 +1206,53 @@ int fgpu_export(const fgpu_index* ix, char* unitig_bases, uint64_t* unitig_off, 
     return 0;
 }
 
+int fgpu_dump(const fgpu_index* ix, const char* basename) {
+    if (!ix || !basename) return fail(-EINVAL, "null argument");
+    return guarded([&] {
+        const Dict& d = ix->host.dict;
+        const HybridSets& h = ix->host.hybrid;
+        const std::string base(basename);
+        auto open = [&](const char* suffix) {
+            FILE* f = fopen((base + suffix).c_str(), "w");
+            if (!f) throw std::runtime_error("cannot open output file");
+            return f;
+        };
+        FILE* f = open(".metadata.txt");
+        fprintf(f, "k=%u\nnum_kmers=%llu\nnum_colors=%u\nnum_unitigs=%llu\nnum_color_sets=%llu\n", d.k,
+                (unsigned long long)d.num_kmers, h.num_colors, (unsigned long long)d.num_unitigs(), (unsigned long long)h.num_sets());
+        fclose(f);
+        f = open(".filenames.txt");
+        for (uint32_t i = 0; i < h.num_colors; ++i)
+            fprintf(f, "%s\n", i < ix->host.filenames.size() ? ix->host.filenames[i].c_str() : "");
+        fclose(f);
+        f = open(".unitigs.fa");
+        std::string seq;
+        for (uint64_t u = 0; u < d.num_unitigs(); ++u) {
+            fprintf(f, "> color_set_id=%u\n", d.unitig_csid[u]);
+            seq.clear();
+            for (uint64_t i = d.unitig_off[u]; i < d.unitig_off[u + 1]; ++i) {
+                const uint64_t w = d.strings[i >> 5];
+                seq.push_back("ACGT"[(uint32_t)((w >> (i & 31)) & 1) | (uint32_t)(((w >> (32 + (i & 31))) & 1) << 1)]);
+            }
+            seq.push_back('\n');
+            fwrite(seq.data(), 1, seq.size(), f);
+        }
+        fclose(f);
+        f = open(".color_sets.txt");
+        std::vector<uint32_t> set;
+        std::string line;
+        for (uint64_t id = 0; id < h.num_sets(); ++id) {
+            hybrid_decode(h, id, set);
+            line = "size=" + std::to_string(set.size()) + " ";
+            for (size_t j = 0; j < set.size(); ++j) {
+                line += std::to_string(set[j]);
+                if (j + 1 != set.size()) line.push_back(' ');
+            }
+            line.push_back('\n');
+            fwrite(line.data(), 1, line.size(), f);
+        }
+        fclose(f);
+    });
+}
+
 }  // extern "C"

@@ -265,6 +265,10 @@ class Index:
             out[name] = (ms.value, n.value)
         return out
 
+    def dump(self, basename):
+        """`fulgor dump`: the index as the reference's four text files (src/index.cpp:59-120)"""
+        _native.check(self._L.fgpu_dump(self._h, str(basename).encode()))
+
     def export(self):
         """Encoded index content (unitigs + hybrid colour stream) as numpy arrays."""
         v = [C.c_uint64() for _ in range(5)]

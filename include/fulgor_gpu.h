@@ -153,6 +153,10 @@ int fgpu_result_format(const fgpu_result* res, int format, uint32_t first_read_i
  * speed and the buffer is recycled); valid until the next format call on `res` or fgpu_result_free. */
 int fgpu_result_format_view(const fgpu_result* res, int format, uint32_t first_read_id, const char** out, uint64_t* out_len);
 
+/* `fulgor dump` (src/index.cpp:59-120): writes <basename>.metadata.txt / .filenames.txt / .unitigs.fa / .color_sets.txt,
+ * the reference's text interchange format (the same files fgpu_open reads): indexes travel in both directions. */
+int fgpu_dump(const fgpu_index* idx, const char* basename);
+
 /* ---- index export (lets tests hand the same encoded index to the oracle) -------------------------- */
 int fgpu_export_sizes(const fgpu_index* idx, uint64_t* unitig_bases, uint64_t* num_unitigs, uint64_t* color_words,
                       uint64_t* color_bits, uint64_t* num_sets);

