@@ -916,7 +916,9 @@ __global__ __launch_bounds__(256, 7) void k2a_intersect(DevColors c, const uint3
                 for (uint32_t g4 = lane; g4 < W4; g4 += 64) {
                     const uint4 e = EX4[g4];
                     const uint4 x = make_uint4(~e.x, ~e.y, ~e.z, ~e.w);
-                    bm4[g4] = x;
+                    // streamed past the L2 (nontemporal): the rows are read back by another kernel, the L2 is for the lists
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store((u32x4){x.x, x.y, x.z, x.w}, (u32x4*)&bm4[g4]);
                     pc += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
                 }
                 pc = wave_sum_u32(pc);
