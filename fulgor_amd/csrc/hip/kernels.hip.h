@@ -1451,7 +1451,7 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
     auto fetch3 = [&](uint64_t r, uint32_t (&x)[3]) {
         const uint32_t* bm = bitmap + r * W;
 #pragma unroll
-        for (uint32_t q = 0; q < 3; ++q) x[q] = q * 64 + lane < W ? bm[q * 64 + lane] : 0u;
+        for (uint32_t q = 0; q < 3; ++q) x[q] = q * 64 + lane < W ? __builtin_nontemporal_load(&bm[q * 64 + lane]) : 0u;  // read once
     };
     while (wq.pull(t_first, t_count)) {
     const uint64_t rl = t_first + min((uint32_t)lane, t_count - 1);
