@@ -625,3 +625,57 @@ def test_kmer_tools_cli(s10_gpu, s10_fgidx, s10_oracle, tmp_path):
         assert open(out).read() == "".join(want)
     assert subprocess.run([sys.executable, "-m", "fulgor_amd", "kmer-matches", "-i", s10_fgidx, "-q", str(tmp_path / "nope.fa"),
                            "-o", str(tmp_path / "x")], cwd=ROOT).returncode == 1
+
+
+def test_s4546_config_size_10M_reads_properties(s4546):
+    """BASELINE configs[2] / [3] at full size (10M reads, 4546 colours), through size-independent properties: the
+    per-colour hit vector (a checksum over all 10M results) must not depend on how the reads are cut into passes;
+    mapped counts agree; the union maps at least what the intersection maps; slices far apart inside the batch are bit-exact
+    against the oracle; the compressed records of a pass parse back to its colour lists."""
+    import torch
+    from oracle.pyoracle import parse_compressed
+    from fulgor_amd.driver import Formatter
+    ix, orc, gen = s4546
+    N = 10_000_000
+    b, o = gen.generate(0, N, 150, 42)
+    reads = ix.upload_reads(b, o)
+    res = ix.new_result()
+    nc = ix.num_colors()
+
+    def hit_vector(algo, tau, chunk):
+        hits = torch.zeros(nc + 2, dtype=torch.int64, device="cuda:0")
+        total = mapped = 0
+        for first in range(0, N, chunk):
+            ix.run(reads, res, algo, tau, first, min(chunk, N - first))
+            res.accumulate_hits(hits.data_ptr())
+            _, t, m = res.sizes()
+            total += t
+            mapped += m
+        h = hits.cpu().numpy()
+        assert h[nc] == N and h[nc + 1] == mapped and h[:nc].sum() == total
+        return h
+
+    fi_a = hit_vector(fulgor_amd.FULL_INTERSECTION, 0.0, 2_500_000)
+    fi_b = hit_vector(fulgor_amd.FULL_INTERSECTION, 0.0, 1_300_000)   # ragged last pass
+    assert np.array_equal(fi_a, fi_b)
+    tu_a = hit_vector(fulgor_amd.THRESHOLD_UNION, 0.8, 2_500_000)
+    tu_b = hit_vector(fulgor_amd.THRESHOLD_UNION, 0.8, 3_333_333)
+    assert np.array_equal(tu_a, tu_b)
+    # a read mapped by the full intersection has >= 1 positive k-mer, so the union at 0.8 maps it too; per colour the
+    # union can only add reads
+    assert tu_a[nc + 1] >= fi_a[nc + 1] and (tu_a[:nc] >= fi_a[:nc]).all()
+    # slices far apart inside the big batch, bit-exact against the oracle
+    for first in (0, 4_999_000, N - 20_000):
+        cnt = 20_000
+        lo, hi = int(o[first]), int(o[first + cnt])
+        sb, so = b[lo:hi], o[first:first + cnt + 1] - o[first]
+        ix.run(reads, res, fulgor_amd.FULL_INTERSECTION, 0.0, first, cnt)
+        go, gc = res.download()
+        oo, oc = orc.full_intersection(sb, so, threads=32)
+        assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+        ids, po, pc = parse_compressed(Formatter("compressed", nc).header + bytes(res.format_view(2, first)))
+        assert ids[0] == first and np.array_equal(po, go) and np.array_equal(pc, gc)
+        ix.run(reads, res, fulgor_amd.THRESHOLD_UNION, 0.8, first, cnt)
+        go, gc = res.download()
+        oo, oc = orc.threshold_union(sb, so, 0.8, threads=32)
+        assert np.array_equal(go, oo) and np.array_equal(gc, oc)
