@@ -679,3 +679,28 @@ def test_s4546_config_size_10M_reads_properties(s4546):
         go, gc = res.download()
         oo, oc = orc.threshold_union(sb, so, 0.8, threads=32)
         assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+
+
+@pytest.mark.parametrize("k", [21, 27])
+def test_gpu_other_kmer_lengths(built, tmp_path, k):
+    """k != 31 (the dictionary derives m = k - 12): a 3-genome index built at that k, lookups and both algorithms
+    against the oracle. (k = 15, i.e. 3-base minimizers with very long overflow lists, also passes but takes minutes.)"""
+    import subprocess
+    from fulgor_amd.reads import ReadGenerator
+    from oracle.pyoracle import OracleIndex
+    base = str(tmp_path / ("s3_k%d" % k))
+    subprocess.run([built.BIN_CCDBG, str(k), base] + S10_GENOMES[:3], check=True)
+    ix = fulgor_amd.Index(base, device=0)
+    assert ix.k() == k
+    ix.selfcheck(unitig_stride=64)
+    orc = OracleIndex.from_dump(base)
+    b, o = ReadGenerator(S10_GENOMES[:3]).generate(0, 6000, 150, 3)
+    i1, d1 = ix.fetch_color_set_ids_batch(b, o)
+    i2, d2 = orc.fetch_color_set_ids(b, o, threads=16)
+    assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+    go, gc = ix.pseudoalign_full_intersection_batch(b, o)
+    oo, oc = orc.full_intersection(b, o, threads=16)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+    go, gc = ix.pseudoalign_threshold_union_batch(b, o, 0.6)
+    oo, oc = orc.threshold_union(b, o, 0.6, threads=16)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
