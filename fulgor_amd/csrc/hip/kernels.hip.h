@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __res
 // because on this kernel the scalar unit (exec-mask bookkeeping of divergent branches), not memory, was
 // the limiter.
 template <bool W13>
-__global__ __launch_bounds__(256, 6) void k1_lookup_short(DevDict d, const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(256, 7) void k1_lookup_short(DevDict d, const uint8_t* __restrict__ bases,
                                                        const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
                                                        uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
                                                        uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
@@ -459,55 +459,67 @@ __global__ __launch_bounds__(256, 6) void k1_lookup_short(DevDict d, const uint8
                 p0[a] = p[0];
                 p1[a] = p[1];
             }
-            // one candidate per record: the strand bit of the record against the canonical flag of the
-            // query's minimizer tells whether the k-mer (offset jL) or its reverse complement (offset jB)
-            // can sit on that super-k-mer
-            uint64_t w0[2][2], w1[2][2];
-            uint32_t cs[2][2], csh[2][2];
-            bool con[2][2], rcq[2][2];
-            bool slow[2] = {false, false};
+            // First candidate: the slot's record, or the first record of its overflow list. A second record, when the
+            // slot has one and the first did not match, is tried in a second short step: keeping both candidates alive
+            // through the fetches costs 16 VGPRs, i.e. a wave per SIMD. The strand bit of the record against the
+            // canonical flag of the query's minimizer tells whether the k-mer (offset jL) or its reverse complement
+            // (offset jB) can sit on that super-k-mer.
+            bool slow[2], qfwd[2], simple[2], try2[2];
+            auto candidate = [&](int a, uint64_t rec, bool wanted, bool& con, bool& rcq, uint32_t& cs, uint32_t& csh,
+                                 uint64_t& w0, uint64_t& w1) {
+                rcq = rec_fwd(rec) != qfwd[a];  // opposite strand: compare the reverse complement
+                const uint32_t jd = rcq ? km - jR[a] : jL[a];
+                con = wanted && jd >= rec_jmin(rec) && jd <= rec_jmax(rec);
+                const uint32_t sp = con ? rec_pos(rec) - jd : 0u;
+                csh = sp & 31u;
+                cs = rec_csid(rec);
+                const uint64_t* w = d.strings + (sp >> 5);
+                w0 = w[0];
+                w1 = w[1];
+            };
+            auto matches = [&](int a, bool con, bool rcq, uint32_t csh, uint64_t w0, uint64_t w1) -> bool {
+                uint32_t lo, hi;
+                string_lmer(w0, w1, csh, k, lo, hi);
+                return con && lo == (rcq ? rlo[a] : klo[a]) && hi == (rcq ? rhi[a] : khi[a]);
+            };
+            {
+                uint64_t w0[2], w1[2];
+                uint32_t cs[2], csh[2];
+                bool con[2], rcq[2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const bool tag = (e[a] & REC_TAG) != 0;
-                const uint64_t r0 = tag ? p0[a] : e[a], r1 = tag ? p1[a] : REC_EMPTY;
-                const bool same = hL[a] == hR[a];
-                const uint32_t jB = km - jR[a];
-                const uint32_t mlo = (klo[a] >> jL[a]) & low_mask32(m), mhi = (khi[a] >> jL[a]) & low_mask32(m);
-                const uint64_t kf = lmer_key(mlo, mhi), kr = lmer_key(rc_plane(mlo, m), rc_plane(mhi, m));
-                const bool qfwd = kf <= kr;
-                // leave to the slow path: a palindromic minimizer (even m only), distinct tied minimizers, or the
-                // same canonical m-mer occurring twice in the k-mer (then jL != jR and the two occurrences may
-                // have opposite orientations, so one flag cannot decide the strand)
-                const bool simple = same && kf != kr && jL[a] == jR[a];
-                slow[a] = valid[a] && !simple;
+                for (int a = 0; a < 2; ++a) {
+                    const bool tag = (e[a] & REC_TAG) != 0;
+                    const bool same = hL[a] == hR[a];
+                    const uint32_t mlo = (klo[a] >> jL[a]) & low_mask32(m), mhi = (khi[a] >> jL[a]) & low_mask32(m);
+                    const uint64_t kf = lmer_key(mlo, mhi), kr = lmer_key(rc_plane(mlo, m), rc_plane(mhi, m));
+                    qfwd[a] = kf <= kr;
+                    // leave to the slow path: a palindromic minimizer (even m only), distinct tied minimizers, or the
+                    // same canonical m-mer occurring twice in the k-mer (then jL != jR and the two occurrences may
+                    // have opposite orientations, so one flag cannot decide the strand)
+                    simple[a] = same && kf != kr && jL[a] == jR[a];
+                    slow[a] = valid[a] && !simple[a];
+                    candidate(a, tag ? p0[a] : e[a], valid[a] && simple[a], con[a], rcq[a], cs[a], csh[a], w0[a], w1[a]);
+                }
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const uint64_t rec = q ? r1 : r0;
-                    rcq[a][q] = rec_fwd(rec) != qfwd;  // opposite strand: compare the reverse complement
-                    const uint32_t jd = rcq[a][q] ? jB : jL[a];
-                    con[a][q] = valid[a] && simple && jd >= rec_jmin(rec) && jd <= rec_jmax(rec);
-                    const uint32_t sp = con[a][q] ? rec_pos(rec) - jd : 0u;
-                    csh[a][q] = sp & 31u;
-                    cs[a][q] = rec_csid(rec);
-                    const uint64_t* w = d.strings + (sp >> 5);
-                    w0[a][q] = w[0];
-                    w1[a][q] = w[1];
+                for (int a = 0; a < 2; ++a) {
+                    const bool hit = matches(a, con[a], rcq[a], csh[a], w0[a], w1[a]);
+                    csid[a] = hit ? cs[a] : NEG;
+                    try2[a] = valid[a] && simple[a] && !hit && (e[a] & REC_TAG) && ovf_cnt(e[a]) >= 2;
                 }
             }
+            if (__any(try2[0] || try2[1])) {
+                uint64_t w0[2], w1[2];
+                uint32_t cs[2], csh[2];
+                bool con[2], rcq[2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                uint32_t found = NEG;
+                for (int a = 0; a < 2; ++a) candidate(a, p1[a], try2[a], con[a], rcq[a], cs[a], csh[a], w0[a], w1[a]);
 #pragma unroll
-                for (int q = 1; q >= 0; --q) {
-                    uint32_t lo, hi;
-                    string_lmer(w0[a][q], w1[a][q], csh[a][q], k, lo, hi);
-                    const bool hit = con[a][q] && lo == (rcq[a][q] ? rlo[a] : klo[a]) && hi == (rcq[a][q] ? rhi[a] : khi[a]);
-                    found = hit ? cs[a][q] : found;
-                }
-                csid[a] = found;
-                const bool more = (e[a] & REC_TAG) && ovf_cnt(e[a]) > 2;
-                slow[a] = slow[a] || (valid[a] && found == NEG && more);
+                for (int a = 0; a < 2; ++a)
+                    if (matches(a, con[a], rcq[a], csh[a], w0[a], w1[a])) csid[a] = cs[a];
             }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                slow[a] = slow[a] || (valid[a] && csid[a] == NEG && (e[a] & REC_TAG) && ovf_cnt(e[a]) > 2);
             // rare continuations: more than two records under the key, or a different rightmost key
             if (__any(slow[0] || slow[1])) {
 #pragma unroll
