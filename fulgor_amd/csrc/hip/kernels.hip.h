@@ -41,6 +41,10 @@ constexpr uint32_t NEG = 0xFFFFFFFFu;
 enum { D_ENC_NONE = -1, D_ENC_DELTA_GAPS = 0, D_ENC_BITMAP = 1, D_ENC_COMPLEMENT = 2 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t src) {  // src wave-uniform
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+}
 
 // order LDS traffic of one wave: LDS ops of a wave complete in issue order; the wait + compiler
 // barrier makes earlier writes visible to later reads by other lanes of the same wave
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __res
 // because on this kernel the scalar unit (exec-mask bookkeeping of divergent branches), not memory, was
 // the limiter.
 template <bool W13>
-__global__ __launch_bounds__(256, 7) void k1_lookup_short(DevDict d, const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(256, 8) void k1_lookup_short(DevDict d, const uint8_t* __restrict__ bases,
                                                        const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
                                                        uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
                                                        uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(256, 7) void k1_lookup_short(DevDict d, const uint8
 
     while (wq.pull(t_first, t_count)) {
         const uint64_t myoff = (uint32_t)lane <= t_count ? offs[first + t_first + lane] : 0;
-        uint64_t rb = __shfl(myoff, 0), re = __shfl(myoff, 1);
+        uint64_t rb = readlane_u64(myoff, 0), re = readlane_u64(myoff, 1);  // wave-uniform: scalar registers
         uint32_t len = (uint32_t)(re - rb);
         const uint8_t* seq = bases + rb;
         // reads are padded by the host buffer: positions past the read end are masked below, not branched on
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(256, 7) void k1_lookup_short(DevDict d, const uint8
             const uint32_t c2 = (uint32_t)lane + 128 < cur_len ? base_code_fast(b2) : 0xFFu;
             if (j + 1 < t_count) {  // request the next read's bases now; they are consumed next iteration
                 rb = re;
-                re = __shfl(myoff, (int)j + 2);
+                re = readlane_u64(myoff, j + 2);
                 len = (uint32_t)(re - rb);
                 seq = bases + rb;
                 b0 = seq[lane];
@@ -791,10 +795,6 @@ __device__ __forceinline__ WaveScratch carve_scratch(unsigned char* p) {
 //   sparse lists      : the list sets its bits in the plane T; after its last block EXCL |= ~T and T = 0
 // so every value of every gap-coded list ORs one bit into LDS, and all blocks of all lists of the read run
 // through one loop (run_blocks), one block of up to 64 values per step.
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t src) {  // src wave-uniform
-    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32) |
-           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
-}
 __device__ __forceinline__ uint4 or_not(uint4 e, uint4 x) { return make_uint4(e.x | ~x.x, e.y | ~x.y, e.z | ~x.z, e.w | ~x.w); }
 
 __global__ __launch_bounds__(256, 7) void k2a_intersect(DevColors c, const uint32_t* __restrict__ nids,
