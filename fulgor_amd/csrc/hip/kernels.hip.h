@@ -797,7 +797,7 @@ __device__ __forceinline__ WaveScratch carve_scratch(unsigned char* p) {
 // through one loop (run_blocks), one block of up to 64 values per step.
 __device__ __forceinline__ uint4 or_not(uint4 e, uint4 x) { return make_uint4(e.x | ~x.x, e.y | ~x.y, e.z | ~x.z, e.w | ~x.w); }
 
-__global__ __launch_bounds__(256, 7) void k2a_intersect(DevColors c, const uint32_t* __restrict__ nids,
+__global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint32_t* __restrict__ nids,
                                                      const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
                                                      uint64_t n_reads, uint32_t* __restrict__ out_bitmap,
                                                      uint32_t* __restrict__ out_count, unsigned int* tickets) {
@@ -821,8 +821,9 @@ __global__ __launch_bounds__(256, 7) void k2a_intersect(DevColors c, const uint3
     wave_lds_sync();
 
     while (wq.pull(t_first, t_count)) {
-        // Two-stage software pipeline over the reads of the ticket: the colour-set ids of read i + 2 and the
-        // descriptors (one 32-byte gather per list) of read i + 1 are requested while read i is processed.
+        // The colour-set ids of read i + 1 are requested while read i is processed; its descriptors (one 32-byte gather
+        // per list) are fetched at the top of the read. (Requesting the descriptors a read ahead as well costs 7 VGPRs,
+        // i.e. a wave per SIMD, and was slower.)
         const uint64_t rl = min(t_first + (uint64_t)lane, n_reads - 1);
         const uint32_t cnt_l = (uint32_t)lane < t_count ? nids[rl] : 0u;  // lanes past the ticket: empty reads
         const uint64_t off_l = idoff[rl];
@@ -837,14 +838,12 @@ __global__ __launch_bounds__(256, 7) void k2a_intersect(DevColors c, const uint3
             return dd;
         };
         uint32_t id1 = fetch_ids(0);
-        ListDesc dcur = fetch_desc(0, id1);
-        id1 = fetch_ids(1);  // (t_count <= BATCH < 62: lanes i + 1, i + 2 exist and read as empty past the ticket)
         for (uint32_t ri = 0; ri < t_count; ++ri) {
             const uint64_t r = t_first + ri;
             const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, ri);
             const uint64_t off = readlane_u64(off_l, ri);
-            const uint32_t id2 = fetch_ids(ri + 2);
-            const ListDesc dnext = fetch_desc(ri + 1, id1);
+            const ListDesc dcur = fetch_desc(ri, id1);
+            const uint32_t id2 = fetch_ids(ri + 1);  // (t_count <= BATCH < 62: lane i + 1 exists and reads as empty past the ticket)
             uint4* bm4 = (uint4*)(out_bitmap + r * W);
             if (cnt == 0) {
                 for (uint32_t g4 = lane; g4 < W4; g4 += 64) bm4[g4] = make_uint4(0u, 0u, 0u, 0u);
@@ -937,7 +936,6 @@ __global__ __launch_bounds__(256, 7) void k2a_intersect(DevColors c, const uint3
                 if (lane == 0) out_count[r] = pc;
                 wave_lds_sync();
             }
-            dcur = dnext;
             id1 = id2;
         }
     }
