@@ -436,7 +436,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     } else if (algo == FGPU_THRESHOLD_UNION) {
         // score counter width from the longest read of the batch: 8 bits up to 127 k-mers, 16 up to 32767, else 32
         const int bits = res->max_kmers_in_batch <= 127 ? 8 : (res->max_kmers_in_batch <= 32767 ? 16 : 32);
-        const size_t per_wave = (size_t)W * 4 * bits + wave_scratch_bytes_compact();
+        const size_t per_wave = (size_t)W * 4 * bits + k3a_scratch_bytes();
         auto launch = [&](auto kernel) {
             const uint32_t wpb = pick_waves(per_wave, (const void*)kernel);
             const uint32_t grid = resident_grid(kernel, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);

@@ -974,8 +974,11 @@ __device__ __forceinline__ uint32_t counter_spread(uint32_t x, uint32_t q, uint3
     return (v ^ neg) - neg;
 }
 
+constexpr uint32_t K3A_GROUP = 32;
+__host__ __device__ inline uint32_t k3a_scratch_bytes() { return K3A_GROUP * (8 + 8 + 4 + 4 + 4); }
+
 template <int BITS>
-__global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a_union(DevColors c, const uint32_t* __restrict__ npos,
+__global__ __launch_bounds__(256, BITS == 8 ? 7 : (BITS == 16 ? 4 : 2)) void k3a_union(DevColors c, const uint32_t* __restrict__ npos,
                                                                   const uint32_t* __restrict__ nids, const uint64_t* __restrict__ idoff,
                                                                   const uint32_t* __restrict__ ids_pool,
                                                                   const uint32_t* __restrict__ cnt_pool, double tau, uint64_t n_reads,
@@ -991,10 +994,18 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = c.w32;
     const uint32_t n = c.n;
-    const uint32_t per_wave = W * PLANES * 4 + wave_scratch_bytes_compact();
+    // lists are taken in groups of K3A_GROUP (a read has 5 on average): a 896-byte scratch, so that with the
+    // 8 counter planes of the 8-bit variant 7 waves fit a SIMD's share of the LDS
+    const uint32_t per_wave = W * PLANES * 4 + k3a_scratch_bytes();
     unsigned char* mine = smem + (size_t)wv * per_wave;
-    WaveScratch sc = carve_scratch(mine);
-    uint32_t* SC = (uint32_t*)(mine + wave_scratch_bytes_compact());
+    WaveScratch sc;
+    sc.h_begin = (uint64_t*)mine;
+    sc.h_soff = sc.h_begin + K3A_GROUP;
+    sc.h_ncodes = (uint32_t*)(sc.h_soff + K3A_GROUP);
+    sc.pref = sc.h_ncodes + K3A_GROUP;
+    sc.h_score = (int32_t*)(sc.pref + K3A_GROUP);
+    sc.h_body = nullptr;
+    uint32_t* SC = (uint32_t*)(mine + k3a_scratch_bytes());
     const WorkQueue wq{tickets, n_reads, 8};
     uint64_t t_first;
     uint32_t t_count;
@@ -1009,7 +1020,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
     auto fetch_ids = [&](uint32_t i, uint32_t& id, uint32_t& mult) {
         const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, i);
         id = mult = 0;
-        if ((uint32_t)lane < cn) {
+        if ((uint32_t)lane < min(cn, K3A_GROUP)) {
             const uint64_t p = readlane_u64(off_l, i) + lane;
             id = ids_pool[p];
             mult = cnt_pool[p];
@@ -1018,7 +1029,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
     auto fetch_desc = [&](uint32_t i, uint32_t id, uint32_t mult) -> ListDesc {
         const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, i);
         ListDesc dd = none;
-        if ((uint32_t)lane < cn) {
+        if ((uint32_t)lane < min(cn, K3A_GROUP)) {
             dd = c.set_desc[id];
             dd.score = (int32_t)mult;
         }
@@ -1046,9 +1057,9 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
                 for (uint32_t cc = lane; cc < n; cc += 64) scores_out[r * (uint64_t)n + cc] = 0;
             continue;
         }
-        auto load_desc = [&](uint32_t g) -> ListDesc {  // more than 64 lists: rare, fetched in place
+        auto load_desc = [&](uint32_t g) -> ListDesc {  // more than K3A_GROUP lists: rare, fetched in place
             ListDesc d = none;
-            if (g + lane < cnt) {
+            if (g + lane < cnt && (uint32_t)lane < K3A_GROUP) {
                 d = c.set_desc[ids_pool[off + g + lane]];
                 d.score = (int32_t)cnt_pool[off + g + lane];
             }
@@ -1056,25 +1067,27 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
         };
         const uint32_t min_score = (uint32_t)(unsigned long long)((double)npos[r] * tau);
         uint32_t comp_total = 0;
-        for (uint32_t g = 0; g < cnt; g += 64) {
+        for (uint32_t g = 0; g < cnt; g += K3A_GROUP) {
             const ListDesc d = g ? load_desc(g) : d_first;
             comp_total += wave_sum_u32(desc_type(d) == D_ENC_COMPLEMENT ? (uint32_t)d.score : 0u);
         }
         const uint32_t start = (HALF - min_score + comp_total) * ONES;
         for (uint32_t i = lane; i < (W >> 2) * PLANES; i += 64) ((uint4*)SC)[i] = make_uint4(start, start, start, start);
         wave_lds_sync();
-        for (uint32_t g = 0; g < cnt; g += 64) {
+        for (uint32_t g = 0; g < cnt; g += K3A_GROUP) {
             const ListDesc d = g ? load_desc(g) : d_first;
             ListHeader h;
             h.size = 0;
             h.type = (int)(int8_t)(d.meta & 0xFFu); h.ncodes = d.ncodes; h.begin = d.begin; h.body = desc_body(d); h.soff = d.soff;
             const int32_t score = d.score;
             const uint32_t nblk = h.ncodes;  // gap-coded lists of both kinds
-            sc.h_begin[lane] = h.begin; sc.h_soff[lane] = h.type == D_ENC_BITMAP ? h.body : h.soff; sc.h_ncodes[lane] = nblk;
-            sc.h_score[lane] = h.type == D_ENC_COMPLEMENT ? -score : score;
             const uint32_t incl = wave_incl_scan_u32(nblk);
             const uint32_t excl = incl - nblk;
-            sc.pref[lane] = incl;
+            if ((uint32_t)lane < K3A_GROUP) {  // (lanes past the group hold empty descriptors)
+                sc.h_begin[lane] = h.begin; sc.h_soff[lane] = h.type == D_ENC_BITMAP ? h.body : h.soff; sc.h_ncodes[lane] = nblk;
+                sc.h_score[lane] = h.type == D_ENC_COMPLEMENT ? -score : score;
+                sc.pref[lane] = incl;
+            }
             const uint32_t total_blk = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             wave_lds_sync();
 
@@ -1098,7 +1111,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 6 : (BITS == 16 ? 4 : 2)) void k3a
                 BlockLane bl{0u, 0u, 0u, 0u, 0u};
                 const uint32_t s = s0 + lane;
                 if (s < total_blk) {
-                    const uint32_t i = owner_list(excl, min(64u, cnt - g), s);
+                    const uint32_t i = owner_list(excl, min(K3A_GROUP, cnt - g), s);
                     const uint32_t j = s - (sc.pref[i] - sc.h_ncodes[i]);
                     const uint64_t hd = sc.h_ncodes[i] == 1 ? sc.h_soff[i] : c.blk_hdr[sc.h_soff[i] + j];  // (as in k2a)
                     const uint64_t a = (uint64_t)(c.blk_words + sc.h_begin[i] + blk_rel_word(hd));

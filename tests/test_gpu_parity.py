@@ -704,3 +704,22 @@ def test_gpu_other_kmer_lengths(built, tmp_path, k):
     go, gc = ix.pseudoalign_threshold_union_batch(b, o, 0.6)
     oo, oc = orc.threshold_union(b, o, 0.6, threads=16)
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+
+
+def test_s4546_reads_with_many_colour_sets(s4546):
+    """chimeric long reads (40 fragments of 150 bp joined by N): a hundred and more distinct colour sets per read, i.e.
+    several descriptor groups per read in both kernels (k3a takes lists in groups of 32, k2a of 64), 16-bit score counters"""
+    ix, orc, gen = s4546
+    b, o = gen.generate(424242, 40 * 60, 150, 42)
+    frags = [bytes(b[int(o[i]):int(o[i + 1])]) for i in range(len(o) - 1)]
+    reads = [b"N".join(frags[40 * j:40 * j + 40]) for j in range(60)] + [b"N".join(frags[:7]), frags[3]]
+    bb, oo_ = pack_reads(reads)
+    i1, d1 = ix.fetch_color_set_ids_batch(bb, oo_)
+    assert np.diff(i1.astype(np.int64)).max() > 64
+    for tau in (0.05, 0.4):
+        go, gc = ix.pseudoalign_threshold_union_batch(bb, oo_, tau)
+        wo, wc = orc.threshold_union(bb, oo_, tau, threads=16)
+        assert np.array_equal(go, wo) and np.array_equal(gc, wc)
+    go, gc = ix.pseudoalign_full_intersection_batch(bb, oo_)
+    wo, wc = orc.full_intersection(bb, oo_, threads=16)
+    assert np.array_equal(go, wo) and np.array_equal(gc, wc)
