@@ -1197,10 +1197,10 @@ __global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 6 : 4) : 7) void k_generi
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = g.w32, W4 = W >> 2, n = g.n;
     const uint32_t acc_bytes = UNION ? W * 4 * PLANES : W * 4;
-    const uint32_t per_wave = wave_scratch_bytes() + G_SETS * W * 4 + acc_bytes;
+    const uint32_t per_wave = wave_scratch_bytes_compact() + G_SETS * W * 4 + acc_bytes;
     unsigned char* mine = smem + (size_t)wv * per_wave;
     WaveScratch sc = carve_scratch(mine);
-    uint32_t* T = (uint32_t*)(mine + wave_scratch_bytes());  // G_SETS planes of W words
+    uint32_t* T = (uint32_t*)(mine + wave_scratch_bytes_compact());  // G_SETS planes of W words
     uint4* T4 = (uint4*)T;
     uint32_t* ACC = T + G_SETS * W;  // EXCL (W words) or the score planes
     uint4* EX4 = (uint4*)ACC;
@@ -1251,7 +1251,6 @@ __global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 6 : 4) : 7) void k_generi
             const uint32_t incl_ops = wave_incl_scan_u32(nops);
             const uint32_t excl_ops = incl_ops - nops;
             const uint32_t total_ops = (uint32_t)__builtin_amdgcn_readlane((int)incl_ops, 63);
-            sc.h_body[lane] = o0;
             wave_lds_sync();
             for (uint32_t p0 = 0; p0 < total_ops; p0 += 64) {
                 const uint32_t p = p0 + lane;
@@ -1259,11 +1258,13 @@ __global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 6 : 4) : 7) void k_generi
                 uint32_t plane = 0, ref = G_BLOCK_REF;  // (lanes past the end: a block reference that is never followed)
                 if (p < total_ops) {
                     uint32_t e = 0;  // (v_readlane, unlike a shuffle, also reads lanes that are masked off here)
+                    uint64_t first = readlane_u64(o0, 0);  // first op of the set this pair belongs to
                     for (uint32_t i = 1; i < nl; ++i) {
                         const uint32_t ei = (uint32_t)__builtin_amdgcn_readlane((int)excl_ops, i);
-                        if (p >= ei) { plane = i; e = ei; }
+                        const uint64_t oi = readlane_u64(o0, i);
+                        if (p >= ei) { plane = i; e = ei; first = oi; }
                     }
-                    ref = g.set_ops[sc.h_body[plane] + (p - e)];
+                    ref = g.set_ops[first + (p - e)];
                 }
                 const uint32_t tbase = plane * W;
                 // span ops: one 32-byte record per lane, its (at most 7) words XORed in place
