@@ -974,11 +974,11 @@ __device__ __forceinline__ uint32_t counter_spread(uint32_t x, uint32_t q, uint3
     return (v ^ neg) - neg;
 }
 
-constexpr uint32_t K3A_GROUP = 32;
+constexpr uint32_t K3A_GROUP = 16;
 __host__ __device__ inline uint32_t k3a_scratch_bytes() { return K3A_GROUP * (8 + 8 + 4 + 4 + 4); }
 
 template <int BITS>
-__global__ __launch_bounds__(256, BITS == 8 ? 7 : (BITS == 16 ? 4 : 2)) void k3a_union(DevColors c, const uint32_t* __restrict__ npos,
+__global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 4 : 2)) void k3a_union(DevColors c, const uint32_t* __restrict__ npos,
                                                                   const uint32_t* __restrict__ nids, const uint64_t* __restrict__ idoff,
                                                                   const uint32_t* __restrict__ ids_pool,
                                                                   const uint32_t* __restrict__ cnt_pool, double tau, uint64_t n_reads,
@@ -994,8 +994,8 @@ __global__ __launch_bounds__(256, BITS == 8 ? 7 : (BITS == 16 ? 4 : 2)) void k3a
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = c.w32;
     const uint32_t n = c.n;
-    // lists are taken in groups of K3A_GROUP (a read has 5 on average): a 896-byte scratch, so that with the
-    // 8 counter planes of the 8-bit variant 7 waves fit a SIMD's share of the LDS
+    // lists are taken in groups of K3A_GROUP (a read has 5 on average, 12 at the 99th percentile): a 448-byte scratch,
+    // so that with the 8 counter planes of the 8-bit variant 8 waves fit a SIMD's share of the LDS
     const uint32_t per_wave = W * PLANES * 4 + k3a_scratch_bytes();
     unsigned char* mine = smem + (size_t)wv * per_wave;
     WaveScratch sc;

@@ -708,7 +708,7 @@ def test_gpu_other_kmer_lengths(built, tmp_path, k):
 
 def test_s4546_reads_with_many_colour_sets(s4546):
     """chimeric long reads (40 fragments of 150 bp joined by N): a hundred and more distinct colour sets per read, i.e.
-    several descriptor groups per read in both kernels (k3a takes lists in groups of 32, k2a of 64), 16-bit score counters"""
+    several descriptor groups per read in both kernels (k3a takes lists in groups of 16, k2a of 64), 16-bit score counters"""
     ix, orc, gen = s4546
     b, o = gen.generate(424242, 40 * 60, 150, 42)
     frags = [bytes(b[int(o[i]):int(o[i + 1])]) for i in range(len(o) - 1)]
