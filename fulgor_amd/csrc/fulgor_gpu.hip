@@ -406,7 +406,8 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         if (uni && res->max_kmers_in_batch > 32767)  // biased 16-bit score counters at most
             throw std::runtime_error("threshold-union on the meta / differential codecs supports reads of at most 32767 k-mers");
         const int bits = res->max_kmers_in_batch <= 127 ? 8 : 16;
-        const size_t per_wave = wave_scratch_bytes_compact() + (size_t)G_SETS * W * 4 + (uni ? (size_t)W * 4 * bits : (size_t)W * 4);
+        const size_t per_wave = wave_scratch_bytes_compact() + (size_t)(uni ? G_SETS_UNION : G_SETS) * W * 4 +
+                                (uni ? (size_t)W * 4 * bits : (size_t)W * 4);
         uint32_t* scores_out = nullptr;
         if (uni && res->want_scores) {
             res->d_scores.ensure(n * (uint64_t)ix->dc.n * 4 + 16);

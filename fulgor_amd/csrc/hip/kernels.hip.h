@@ -1182,9 +1182,10 @@ struct DevGeneric {
 constexpr uint32_t G_BLOCK_REF = 0x80000000u;
 
 constexpr uint32_t G_SETS = 4;  // colour sets of a read rebuilt concurrently (one LDS plane each)
+constexpr uint32_t G_SETS_UNION = 2;  // fewer for the union: its score planes take most of the LDS
 
 template <bool UNION, int BITS>
-__global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 6 : 4) : 7) void k_generic(DevGeneric g, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
+__global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 5 : 4) : 7) void k_generic(DevGeneric g, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
                           const ListDesc* __restrict__ desc, double tau, uint64_t n_reads,
                           uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count, unsigned int* tickets,
                           uint32_t* __restrict__ scores_out) {
@@ -1197,12 +1198,13 @@ __global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 6 : 4) : 7) void k_generi
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = g.w32, W4 = W >> 2, n = g.n;
     const uint32_t acc_bytes = UNION ? W * 4 * PLANES : W * 4;
-    const uint32_t per_wave = wave_scratch_bytes_compact() + G_SETS * W * 4 + acc_bytes;
+    constexpr uint32_t GS = UNION ? G_SETS_UNION : G_SETS;
+    const uint32_t per_wave = wave_scratch_bytes_compact() + GS * W * 4 + acc_bytes;
     unsigned char* mine = smem + (size_t)wv * per_wave;
     WaveScratch sc = carve_scratch(mine);
-    uint32_t* T = (uint32_t*)(mine + wave_scratch_bytes_compact());  // G_SETS planes of W words
+    uint32_t* T = (uint32_t*)(mine + wave_scratch_bytes_compact());  // GS planes of W words
     uint4* T4 = (uint4*)T;
-    uint32_t* ACC = T + G_SETS * W;  // EXCL (W words) or the score planes
+    uint32_t* ACC = T + GS * W;  // EXCL (W words) or the score planes
     uint4* EX4 = (uint4*)ACC;
     const uint32_t tail_word = n >> 5, tail_mask = ~((1u << (n & 31u)) - 1u);
     const ListDesc none{0, 0, 0, 0xFFu, 0, 0};
@@ -1237,8 +1239,8 @@ __global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 6 : 4) : 7) void k_generi
         }
         // rounds of up to G_SETS colour sets: the (set, op) pairs of the round are spread over the lanes, so the
         // dependent fetches set -> op list -> op -> data are walked once per round, not once per set
-        for (uint32_t g0 = 0; g0 < cnt; g0 += G_SETS) {
-            const uint32_t nl = min(G_SETS, cnt - g0);
+        for (uint32_t g0 = 0; g0 < cnt; g0 += GS) {
+            const uint32_t nl = min(GS, cnt - g0);
             uint64_t o0 = 0;
             uint32_t nops = 0, score = 0;
             if ((uint32_t)lane < nl) {
