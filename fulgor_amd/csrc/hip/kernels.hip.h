@@ -1097,8 +1097,10 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 4 : 2)) void k3a
                 mb &= mb - 1;
                 const uint64_t body = sc.h_soff[src];
                 const uint32_t s = (uint32_t)sc.h_score[src];
-                for (uint32_t w = lane; w * 32 < n; w += 64) {
-                    uint32_t x = (uint32_t)bits_window(c.bits, body + 32ull * w);
+                const uint32_t* words = (const uint32_t*)c.bits + (body >> 5);
+                const uint32_t sh = (uint32_t)body & 31u;
+                for (uint32_t w = lane; w * 32 < n; w += 64) {  // one funnel shift per word (c.bits carries padding)
+                    uint32_t x = __builtin_amdgcn_alignbit(words[w + 1], words[w], sh);
                     if (n - w * 32 < 32) x &= (1u << (n - w * 32)) - 1u;
 #pragma unroll
                     for (uint32_t q = 0; q < PLANES; ++q)  // only this lane touches these words
