@@ -134,7 +134,7 @@ struct fgpu_reads {
     // lookup kernel treats as units; seg_first[r] = first segment of read r (n + 1 entries)
     bool has_long = false;
     std::vector<uint64_t> seg_first, seg_start, seg_end;
-    DevBuf d_seg_start, d_seg_end;
+    DevBuf d_seg_start, d_seg_end, d_seg_first;
 };
 constexpr uint32_t SEG_KMERS = 1024;
 
@@ -144,11 +144,13 @@ struct fgpu_result {
     std::vector<fgpu_index::Pending> pending;     // timing events recorded on that stream
     DevBuf d_nids, d_npos, d_idoff, d_ids_pool, d_cnt_pool, d_cursor, d_bitmap, d_counts, d_offsets, d_block_sums,
         d_block_mapped, d_totals, d_colors, d_acct, d_partial, d_tickets, d_idcsr, d_desc, d_kmer_ids, d_scores;
+    DevBuf d_nids2, d_npos2, d_idoff2, d_ids_pool2, d_cnt_pool2;  // long reads: merged per-read lists (stage_lookup)
     bool want_kmer_ids = false, want_scores = false;
     uint64_t total_ids = 0;
     uint64_t* h_totals = nullptr;  // pinned {total colours, mapped reads, ids used}
     uint64_t n = 0, total = 0, mapped = 0, total_kmers = 0, total_bases = 0;
     uint32_t id_stride = 0;
+    uint64_t pool_units = 0;  // slabs of id_stride entries in d_ids_pool / d_cnt_pool (reads, or segments of long reads)
     uint32_t hit_rows = 0;  // rows of d_partial filled by the last expand launch (0: no colours, nothing to add)
     DevBuf d_fmt_sizes, d_fmt_off, d_fmt_out;  // device-side formatter
     char* h_fmt = nullptr;                     // pinned host copy of the formatted records (recycled)
@@ -265,6 +267,7 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     HIP_TRY(hipMemsetAsync(res->d_tickets.p, 0, TICKET_BYTES, s));
     const uint32_t stride = std::max<uint32_t>(1, rd->max_kmers);  // at most one id per k-mer
     res->id_stride = stride;
+    res->pool_units = units;
     res->d_ids_pool.ensure(units * (uint64_t)stride * 4 + 16);
     res->d_cnt_pool.ensure(units * (uint64_t)stride * 4 + 16);
     res->have_ids = true;
@@ -302,44 +305,27 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
         HIP_TRY(hipGetLastError());
     }
     if (!seg) return;
-    // long-read path (rare): merge the per-segment id lists of every read on the host. Sorted unique ids,
-    // summed multiplicities, summed positive counts — what one pass over the whole read would have produced
-    // (fetch_color_set_ids sorts + deduplicates over the whole read: ps_full_intersection.cpp:361-373).
-    HIP_TRY(hipStreamSynchronize(s));
-    std::vector<uint32_t> s_nids(units), s_npos(units), s_ids(units * stride), s_cnt(units * stride);
-    HIP_TRY(hipMemcpy(s_nids.data(), res->d_nids.p, units * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(s_npos.data(), res->d_npos.p, units * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(s_ids.data(), res->d_ids_pool.p, units * (uint64_t)stride * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(s_cnt.data(), res->d_cnt_pool.p, units * (uint64_t)stride * 4, hipMemcpyDeviceToHost));
-    std::vector<uint32_t> r_nids(count), r_npos(count), r_ids, r_cnt;
-    std::vector<uint64_t> r_off(count);
-    std::vector<std::pair<uint32_t, uint32_t>> tmp;
-    for (uint64_t r = 0; r < count; ++r) {
-        tmp.clear();
-        uint32_t pos = 0;
-        for (uint64_t u = rd->seg_first[first + r] - u_first; u < rd->seg_first[first + r + 1] - u_first; ++u) {
-            pos += s_npos[u];
-            for (uint32_t j = 0; j < s_nids[u]; ++j) tmp.push_back({s_ids[u * stride + j], s_cnt[u * stride + j]});
-        }
-        std::sort(tmp.begin(), tmp.end());
-        r_off[r] = r_ids.size();
-        for (size_t i = 0; i < tmp.size(); ++i) {
-            if (i && tmp[i].first == tmp[i - 1].first) r_cnt.back() += tmp[i].second;
-            else { r_ids.push_back(tmp[i].first); r_cnt.push_back(tmp[i].second); }
-        }
-        r_nids[r] = (uint32_t)(r_ids.size() - r_off[r]);
-        r_npos[r] = pos;
+    // long reads: merge the per-segment id lists of every read on the device (k_merge_segments) into a second set
+    // of slabs, which then take the place of the per-segment ones
+    res->d_nids2.ensure(count * 4 + 16);
+    res->d_npos2.ensure(count * 4 + 16);
+    res->d_idoff2.ensure(count * 8 + 16);
+    res->d_ids_pool2.ensure(units * (uint64_t)stride * 4 + 16);
+    res->d_cnt_pool2.ensure(units * (uint64_t)stride * 4 + 16);
+    {
+        Timed t(ix, res, FGPU_K_LOOKUP);
+        const uint32_t mgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((count + 3) / 4, (uint64_t)ix->num_cus * 8));
+        hipLaunchKernelGGL(k_merge_segments, dim3(mgrid), dim3(256), 0, s, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
+                           res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(), stride, rd->d_seg_first.as<uint64_t>(),
+                           first, count, res->d_nids2.as<uint32_t>(), res->d_npos2.as<uint32_t>(), res->d_idoff2.as<uint64_t>(),
+                           res->d_ids_pool2.as<uint32_t>(), res->d_cnt_pool2.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
     }
-    res->d_ids_pool.ensure(r_ids.size() * 4 + 16);
-    res->d_cnt_pool.ensure(r_cnt.size() * 4 + 16);
-    HIP_TRY(hipMemcpy(res->d_nids.p, r_nids.data(), count * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(res->d_npos.p, r_npos.data(), count * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(res->d_idoff.p, r_off.data(), count * 8, hipMemcpyHostToDevice));
-    if (!r_ids.empty()) {
-        HIP_TRY(hipMemcpy(res->d_ids_pool.p, r_ids.data(), r_ids.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(res->d_cnt_pool.p, r_cnt.data(), r_cnt.size() * 4, hipMemcpyHostToDevice));
-    }
-    res->id_stride = 0;  // ids are a compact CSR now (d_idoff holds the offsets)
+    std::swap(res->d_nids, res->d_nids2);
+    std::swap(res->d_npos, res->d_npos2);
+    std::swap(res->d_idoff, res->d_idoff2);
+    std::swap(res->d_ids_pool, res->d_ids_pool2);
+    std::swap(res->d_cnt_pool, res->d_cnt_pool2);
 }
 
 // exclusive scan of n u32 sizes into n+1 u64 offsets; totals -> d_totals {sum, #nonzero}
@@ -649,6 +635,7 @@ int fgpu_reads_upload(fgpu_index* ix, const char* bases, const uint64_t* offs, u
             }
             upload(rd->d_seg_start, rd->seg_start, ix->stream);
             upload(rd->d_seg_end, rd->seg_end, ix->stream);
+            upload(rd->d_seg_first, rd->seg_first, ix->stream);
         }
         const uint64_t nb = offs[n];
         rd->d_bases.ensure(nb + 256);
@@ -657,7 +644,7 @@ int fgpu_reads_upload(fgpu_index* ix, const char* bases, const uint64_t* offs, u
         HIP_TRY(hipMemcpyAsync(rd->d_offs.p, offs, (n + 1) * 8, hipMemcpyHostToDevice, ix->stream));
         HIP_TRY(hipStreamSynchronize(ix->stream));
     });
-    if (rc) { if (rd) { rd->d_bases.release(); rd->d_offs.release(); delete rd; } return rc; }
+    if (rc) { fgpu_reads_free(rd); return rc; }
     *out = rd;
     return 0;
 }
@@ -669,6 +656,7 @@ void fgpu_reads_free(fgpu_reads* rd) {
     rd->d_offs.release();
     rd->d_seg_start.release();
     rd->d_seg_end.release();
+    rd->d_seg_first.release();
     delete rd;
 }
 
@@ -692,7 +680,8 @@ void fgpu_result_free(fgpu_result* r) {
     if (!r) return;
     (void)hipSetDevice(r->ix->device);
     for (DevBuf* b : {&r->d_nids, &r->d_npos, &r->d_idoff, &r->d_ids_pool, &r->d_cnt_pool, &r->d_cursor, &r->d_bitmap,
-                      &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct, &r->d_partial, &r->d_tickets, &r->d_idcsr, &r->d_desc, &r->d_kmer_ids, &r->d_scores, &r->d_fmt_sizes, &r->d_fmt_off, &r->d_fmt_out})
+                      &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct, &r->d_partial, &r->d_tickets, &r->d_idcsr, &r->d_desc, &r->d_kmer_ids, &r->d_scores, &r->d_fmt_sizes, &r->d_fmt_off, &r->d_fmt_out,
+                      &r->d_nids2, &r->d_npos2, &r->d_idoff2, &r->d_ids_pool2, &r->d_cnt_pool2})
         b->release();
     if (r->h_totals) (void)hipHostFree(r->h_totals);
     if (r->h_fmt) (void)hipHostFree(r->h_fmt);
@@ -950,17 +939,17 @@ int fgpu_fetch_color_set_ids(fgpu_index* ix, const char* bases, const uint64_t* 
         if (n) HIP_TRY(hipMemcpy(nids.data(), res->d_nids.p, n * 4, hipMemcpyDeviceToHost));
         uint64_t used = 0;
         for (uint64_t r = 0; r < n; ++r) used += nids[r];
-        const uint64_t stride = res->id_stride ? res->id_stride : 0;
-        std::vector<uint32_t> pool(stride ? n * stride : used);
+        // every read's list sits at d_idoff[r] in the slab pool (its own slab, or its first segment's)
+        std::vector<uint32_t> pool(res->pool_units * res->id_stride);
         if (!pool.empty()) HIP_TRY(hipMemcpy(pool.data(), res->d_ids_pool.p, pool.size() * 4, hipMemcpyDeviceToHost));
         std::vector<uint64_t> src(n);
-        if (!stride && n) HIP_TRY(hipMemcpy(src.data(), res->d_idoff.p, n * 8, hipMemcpyDeviceToHost));
+        if (n) HIP_TRY(hipMemcpy(src.data(), res->d_idoff.p, n * 8, hipMemcpyDeviceToHost));
         uint64_t* o = (uint64_t*)malloc((n + 1) * 8);
         uint32_t* v = (uint32_t*)malloc(std::max<uint64_t>(1, used) * 4);
         if (!o || !v) { free(o); free(v); throw std::bad_alloc(); }
         o[0] = 0;
         for (uint64_t r = 0; r < n; ++r) {
-            memcpy(v + o[r], pool.data() + (stride ? r * stride : src[r]), (size_t)nids[r] * 4);
+            memcpy(v + o[r], pool.data() + src[r], (size_t)nids[r] * 4);
             o[r + 1] = o[r] + nids[r];
         }
         *out_offsets = o;

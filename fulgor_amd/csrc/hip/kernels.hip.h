@@ -623,6 +623,87 @@ __global__ __launch_bounds__(256, 8) void k1_lookup_short(DevDict d, const uint8
 }
 
 // ---------------------------------------------------------------------------------------------
+// Long reads: the lookup kernel ran on segments of at most 1024 k-mers; this kernel merges the sorted id
+// lists of the segments of every read into what one pass over the whole read would have produced: sorted
+// distinct ids, summed multiplicities, summed positive counts (fetch_color_set_ids sorts and deduplicates
+// over the whole read: ps_full_intersection.cpp:361-373). One wave per read. Up to 64 segments (65536
+// k-mers): lane = one segment with a cursor into its sorted list, every step emits the smallest id under
+// the cursors. More segments: repeated minimum extraction over all the lists (quadratic, very long reads only).
+// The merged list of read r is written to out_ids/out_cnt at the slab offset of its first segment.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_merge_segments(const uint32_t* __restrict__ seg_nids, const uint32_t* __restrict__ seg_npos,
+                                                        const uint32_t* __restrict__ seg_ids, const uint32_t* __restrict__ seg_cnt,
+                                                        uint32_t stride, const uint64_t* __restrict__ seg_first, uint64_t first,
+                                                        uint64_t n_reads, uint32_t* __restrict__ out_nids,
+                                                        uint32_t* __restrict__ out_npos, uint64_t* __restrict__ out_idoff,
+                                                        uint32_t* __restrict__ out_ids, uint32_t* __restrict__ out_cnt) {
+    const int lane = lane_id();
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t u_first = seg_first[first];
+    for (uint64_t r = wave; r < n_reads; r += n_waves) {
+        const uint64_t u0 = seg_first[first + r] - u_first, u1 = seg_first[first + r + 1] - u_first;
+        const uint64_t base = u0 * stride;
+        uint32_t pos = 0;
+        for (uint64_t u = u0 + lane; u < u1; u += 64) pos += seg_npos[u];
+        pos = wave_sum_u32(pos);
+        uint32_t out = 0;
+        if (u1 - u0 <= 64) {
+            const bool mine = u0 + lane < u1;
+            const uint32_t my_n = mine ? seg_nids[u0 + lane] : 0u;
+            const uint64_t my_base = (u0 + (mine ? lane : 0)) * stride;
+            uint32_t cur = 0;
+            for (;;) {
+                const uint32_t v = cur < my_n ? seg_ids[my_base + cur] : NEG;
+                const uint32_t wm = wave_min_u32(v);
+                if (wm == NEG) break;
+                const bool hit = v == wm;
+                const uint32_t total = wave_sum_u32(hit ? seg_cnt[my_base + cur] : 0u);
+                if (hit) ++cur;  // ids are distinct within a segment
+                if (lane == 0) {
+                    out_ids[base + out] = wm;
+                    out_cnt[base + out] = total;
+                }
+                ++out;
+            }
+        } else {
+            uint32_t last = 0;
+            bool have_last = false;
+            for (;;) {
+                uint32_t lm = NEG;
+                for (uint64_t u = u0; u < u1; ++u) {
+                    const uint32_t nu = seg_nids[u];
+                    for (uint32_t j = lane; j < nu; j += 64) {
+                        const uint32_t v = seg_ids[u * stride + j];
+                        if (!have_last || v > last) lm = min(lm, v);
+                    }
+                }
+                const uint32_t wm = wave_min_u32(lm);
+                if (wm == NEG) break;
+                uint32_t c = 0;
+                for (uint64_t u = u0; u < u1; ++u) {
+                    const uint32_t nu = seg_nids[u];
+                    for (uint32_t j = lane; j < nu; j += 64) c += seg_ids[u * stride + j] == wm ? seg_cnt[u * stride + j] : 0u;
+                }
+                c = wave_sum_u32(c);
+                if (lane == 0) {
+                    out_ids[base + out] = wm;
+                    out_cnt[base + out] = c;
+                }
+                last = wm;
+                have_last = true;
+                ++out;
+            }
+        }
+        if (lane == 0) {
+            out_nids[r] = out;
+            out_npos[r] = pos;
+            out_idoff[r] = base;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Elias-delta decoding straight from the colour bit vector
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t bits_window(const uint64_t* __restrict__ bits, uint64_t pos) {
