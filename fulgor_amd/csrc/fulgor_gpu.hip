@@ -452,7 +452,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     // results) the buffer is enlarged and the launch repeated. One host round trip per pass instead of two.
     // the per-colour hit histogram rides along in LDS while it fits (16-bit counters, W * 64 bytes); for
     // larger collections the expand kernel runs without it and k_hits counts from the bitmaps on demand
-    const size_t stage_lds = (K2B_THREADS / 64) * (2048 + 64) * 2;
+    const size_t stage_lds = (K2B_THREADS / 64) * K2B_STAGE_ENTRIES * 2;
     res->hits_folded = stage_lds + (size_t)W * 64 <= 80 * 1024;  // two blocks per CU
     const size_t lds = res->hits_folded ? stage_lds + (size_t)W * 64 : stage_lds;
     // a block must see fewer than 65536 reads (16-bit hit counters): true for any resident grid >= n / 65535

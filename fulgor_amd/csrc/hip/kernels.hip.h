@@ -53,6 +53,9 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));  // 16-byte global access at any 4-byte boundary
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
     for (int o = 32; o; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
@@ -1009,7 +1012,6 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
                     const uint4 e = EX4[g4];
                     const uint4 x = make_uint4(~e.x, ~e.y, ~e.z, ~e.w);
                     // streamed past the L2 (nontemporal): the rows are read back by another kernel, the L2 is for the lists
-                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                     __builtin_nontemporal_store((u32x4){x.x, x.y, x.z, x.w}, (u32x4*)&bm4[g4]);
                     pc += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
                 }
@@ -1532,6 +1534,9 @@ __global__ __launch_bounds__(256) void scan_apply(const uint32_t* __restrict__ c
 // full-width coalesced stores. 64 words (2048 colours) per round.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t K2B_THREADS = 1024;  // 16 waves share one LDS hit histogram: 2 blocks per CU = 8 waves/SIMD
+// per-wave stage of 16-bit entries: slot i lives at entry i + 2 * (i / 32) — dense words (prefix = 32 * lane) would
+// otherwise share 2 banks, and a skew of two entries keeps every aligned group of 4 slots contiguous and 4-byte aligned
+constexpr uint32_t K2B_STAGE_ENTRIES = 2048 + 2 * 64;
 __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
                                                   const uint64_t* __restrict__ out_off, uint64_t n_reads, uint32_t W,
                                                   uint32_t* __restrict__ colors, unsigned int* tickets,
@@ -1544,10 +1549,10 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
     // keeps 16-bit counters in LDS (a block sees far fewer than 65536 reads) and stores them as one row of
     // hit_partial[gridDim.x][W*32] at the end; k_hits_reduce sums the rows.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_x[];
-    uint16_t* stage_all = (uint16_t*)smem_x;                                           // one (2048 + 64)-entry stage per wave
-    uint32_t* hist = (uint32_t*)(smem_x + (K2B_THREADS / 64) * (2048 + 64) * 2);       // W*16 words (two counters per word)
+    uint16_t* stage_all = (uint16_t*)smem_x;                                           // one stage per wave
+    uint32_t* hist = (uint32_t*)(smem_x + (K2B_THREADS / 64) * K2B_STAGE_ENTRIES * 2);  // W*16 words (two counters per word)
     const int lane = lane_id();
-    uint16_t* stage = stage_all + (threadIdx.x >> 6) * (2048 + 64);
+    unsigned char* stage = (unsigned char*)(stage_all + (threadIdx.x >> 6) * K2B_STAGE_ENTRIES);
     if (hit_partial) {
         for (uint32_t i = threadIdx.x; i < W * 16; i += blockDim.x) hist[i] = 0;
         __syncthreads();
@@ -1588,17 +1593,37 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
             if (total == 0) continue;
             uint32_t at = incl - pc;
             const uint32_t rel = (uint32_t)lane * 32;
-            while (x) {  // slot i lives at i + i/32: dense words (prefix = 32 * lane) would otherwise share 2 banks
-                stage[at + (at >> 5)] = (uint16_t)(rel + __builtin_ctz(x));
+            while (x) {
+                *(uint16_t*)(stage + (at << 1) + ((at >> 5) << 2)) = (uint16_t)(rel + __builtin_ctz(x));
                 ++at;
                 x &= x - 1;
             }
             wave_lds_sync();
             const uint32_t cbase = w0 * 32;
-            for (uint32_t i = lane; i < total; i += 64) {
-                const uint32_t col = cbase + stage[i + (i >> 5)];
-                out[i] = col;
-                if (hit_partial) atomicAdd(&hist[col >> 1], 1u << (16 * (col & 1)));
+            // copy-out: every lane takes 4 consecutive slots (two LDS words) and stores 4 colours at once
+            for (uint32_t i = (uint32_t)lane * 4; i < total; i += 256) {
+                const uint32_t* sp = (const uint32_t*)(stage + (i << 1) + ((i >> 5) << 2));
+                const uint32_t e01 = sp[0], e23 = sp[1];
+                const uint32_t c0 = cbase + (e01 & 0xFFFFu), c1 = cbase + (e01 >> 16), c2 = cbase + (e23 & 0xFFFFu),
+                               c3 = cbase + (e23 >> 16);
+                if (i + 4 <= total) {
+                    *(u32x4_a4*)(out + i) = u32x4{c0, c1, c2, c3};
+                    if (hit_partial) {
+                        atomicAdd(&hist[c0 >> 1], (c0 & 1u) ? 0x10000u : 1u);
+                        atomicAdd(&hist[c1 >> 1], (c1 & 1u) ? 0x10000u : 1u);
+                        atomicAdd(&hist[c2 >> 1], (c2 & 1u) ? 0x10000u : 1u);
+                        atomicAdd(&hist[c3 >> 1], (c3 & 1u) ? 0x10000u : 1u);
+                    }
+                } else {  // last group of the round: slots past `total` hold stale entries
+                    const uint32_t cs[3] = {c0, c1, c2};
+#pragma unroll
+                    for (uint32_t q = 0; q < 3; ++q) {
+                        if (i + q < total) {
+                            out[i + q] = cs[q];
+                            if (hit_partial) atomicAdd(&hist[cs[q] >> 1], (cs[q] & 1u) ? 0x10000u : 1u);
+                        }
+                    }
+                }
             }
             out += total;
             wave_lds_sync();
