@@ -1600,30 +1600,27 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
             }
             wave_lds_sync();
             const uint32_t cbase = w0 * 32;
-            // copy-out: every lane takes 4 consecutive slots (two LDS words) and stores 4 colours at once
-            for (uint32_t i = (uint32_t)lane * 4; i < total; i += 256) {
+            // copy-out: every lane takes 4 consecutive slots (two LDS words) and stores 4 colours at once; the last
+            // total % 4 slots (all of them in a round of at most 64) go out one per lane
+            const uint32_t full = total <= 64 ? 0u : total & ~3u;  // short rounds: one slot per lane, one pass
+            for (uint32_t i = (uint32_t)lane * 4; i < full; i += 256) {
                 const uint32_t* sp = (const uint32_t*)(stage + (i << 1) + ((i >> 5) << 2));
                 const uint32_t e01 = sp[0], e23 = sp[1];
                 const uint32_t c0 = cbase + (e01 & 0xFFFFu), c1 = cbase + (e01 >> 16), c2 = cbase + (e23 & 0xFFFFu),
                                c3 = cbase + (e23 >> 16);
-                if (i + 4 <= total) {
-                    *(u32x4_a4*)(out + i) = u32x4{c0, c1, c2, c3};
-                    if (hit_partial) {
-                        atomicAdd(&hist[c0 >> 1], (c0 & 1u) ? 0x10000u : 1u);
-                        atomicAdd(&hist[c1 >> 1], (c1 & 1u) ? 0x10000u : 1u);
-                        atomicAdd(&hist[c2 >> 1], (c2 & 1u) ? 0x10000u : 1u);
-                        atomicAdd(&hist[c3 >> 1], (c3 & 1u) ? 0x10000u : 1u);
-                    }
-                } else {  // last group of the round: slots past `total` hold stale entries
-                    const uint32_t cs[3] = {c0, c1, c2};
-#pragma unroll
-                    for (uint32_t q = 0; q < 3; ++q) {
-                        if (i + q < total) {
-                            out[i + q] = cs[q];
-                            if (hit_partial) atomicAdd(&hist[cs[q] >> 1], (cs[q] & 1u) ? 0x10000u : 1u);
-                        }
-                    }
+                *(u32x4_a4*)(out + i) = u32x4{c0, c1, c2, c3};
+                if (hit_partial) {
+                    atomicAdd(&hist[c0 >> 1], (c0 & 1u) ? 0x10000u : 1u);
+                    atomicAdd(&hist[c1 >> 1], (c1 & 1u) ? 0x10000u : 1u);
+                    atomicAdd(&hist[c2 >> 1], (c2 & 1u) ? 0x10000u : 1u);
+                    atomicAdd(&hist[c3 >> 1], (c3 & 1u) ? 0x10000u : 1u);
                 }
+            }
+            if ((uint32_t)lane < total - full) {
+                const uint32_t i = full + lane;
+                const uint32_t col = cbase + *(const uint16_t*)(stage + (i << 1) + ((i >> 5) << 2));
+                out[i] = col;
+                if (hit_partial) atomicAdd(&hist[col >> 1], (col & 1u) ? 0x10000u : 1u);
             }
             out += total;
             wave_lds_sync();
