@@ -1038,23 +1038,13 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
 //     score[c] >= min_score   <=>   counter[c] >= HALF   <=>   top bit of the field set,
 // and they never leave [0, 2*HALF) because 0 <= min_score <= #positive k-mers < HALF. A signed score is
 // added as a 32-bit two's complement shifted to the field: fields cannot borrow from each other.
-// score `mag` (negated when neg = ~0) for the colours of bitmap word x that live in counter plane q
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// signed score sv for the colours of bitmap word x that live in counter plane q: flags times the score with one
+// 32-bit multiply (full rate on gfx950, profiles/r1/valu_rates_r1q.txt). flag * |sv| < 2^BITS stays inside its field,
+// and a negative sv gives the two's complement of the whole word, which is what the counters are added with
 template <int BITS>
-__device__ __forceinline__ uint32_t counter_spread(uint32_t x, uint32_t q, uint32_t mag, uint32_t neg) {
+__device__ __forceinline__ uint32_t counter_spread(uint32_t x, uint32_t q, uint32_t sv) {
     constexpr uint32_t ONES = BITS == 8 ? 0x01010101u : (BITS == 16 ? 0x00010001u : 1u);
-    const uint32_t t = (x >> q) & ONES;  // one flag per field
-    uint32_t v;
-    if (BITS == 32) {
-        v = (0u - t) & mag;
-    } else {
-        // flags times the score, field-wise, with one packed 16-bit multiply (v_pk_mul_lo_u16): a 16-bit half
-        // holds two byte flags (0x0101 * mag = mag in both bytes, mag < 128) or one 16-bit flag
-        const uint32_t m2 = mag | (mag << 16);
-        const u16x2 p = __builtin_bit_cast(u16x2, t) * __builtin_bit_cast(u16x2, m2);
-        v = __builtin_bit_cast(uint32_t, p);
-    }
-    return (v ^ neg) - neg;
+    return ((x >> q) & ONES) * sv;
 }
 
 constexpr uint32_t K3A_GROUP = 16;
@@ -1187,7 +1177,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 4 : 2)) void k3a
                     if (n - w * 32 < 32) x &= (1u << (n - w * 32)) - 1u;
 #pragma unroll
                     for (uint32_t q = 0; q < PLANES; ++q)  // only this lane touches these words
-                        atomicAdd(&SC[q * W + w], counter_spread<BITS>(x, q, s, 0u));
+                        atomicAdd(&SC[q * W + w], counter_spread<BITS>(x, q, s));
                 }
                 wave_lds_sync();
             }
@@ -1211,9 +1201,8 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 4 : 2)) void k3a
                                atomicAdd(&SC[(v % PLANES) * W + (v >> 5)], sv << ((BITS & 31) * ((v & 31u) / PLANES)));
                            },
                            [&](uint32_t wi, uint32_t x, uint32_t sv) {  // only this lane touches these words
-                               const uint32_t neg = (uint32_t)((int32_t)sv >> 31), mag = (sv ^ neg) - neg;
 #pragma unroll
-                               for (uint32_t q = 0; q < PLANES; ++q) atomicAdd(&SC[q * W + wi], counter_spread<BITS>(x, q, mag, neg));
+                               for (uint32_t q = 0; q < PLANES; ++q) atomicAdd(&SC[q * W + wi], counter_spread<BITS>(x, q, sv));
                            },
                            [](uint32_t) {});
             }
@@ -1406,7 +1395,7 @@ __global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 5 : 4) : 7) void k_generi
                         const uint32_t x = T[l * W + w];
                         if (x) {
 #pragma unroll
-                            for (uint32_t q = 0; q < PLANES; ++q) atomicAdd(&ACC[q * W + w], counter_spread<BITS>(x, q, s, 0u));
+                            for (uint32_t q = 0; q < PLANES; ++q) atomicAdd(&ACC[q * W + w], counter_spread<BITS>(x, q, s));
                         }
                     }
                 } else {
