@@ -4,11 +4,16 @@
 //                  (+ multiplicities). Replaces index::fetch_color_set_ids and the k-mer streaming half
 //                  of pseudoalign_threshold_union (ps_full_intersection.cpp:334-374,
 //                  ps_threshold_union.cpp:327-387) including u2c (index.hpp:37).
+//   k_merge_segments  reads longer than 1024 k-mers: id lists of their segments -> one list per read
 //   k2a_intersect  hybrid `intersect` (ps_full_intersection.cpp:32-127) -> result bitmap + size
 //   k3a_union      hybrid `merge`     (ps_threshold_union.cpp:16-40)   -> result bitmap + size
+//   k_generic      meta / differential / meta-differential: intersect and merge (ps_full_intersection.cpp:129-332,
+//                  ps_threshold_union.cpp:42-318) over the device form of those codecs (host/codecs_build.hpp)
 //   scan_*         sizes -> CSR offsets
 //   k2b_expand     bitmap -> sorted u32 colour list (the vector<uint32_t> the reference returns)
-//   k_hits         per-colour hit counts over a batch
+//   k_hits*        per-colour hit counts over a batch
+//   k_fmt_* / k_cfmt_*  the three output formats of psa_formatter (ascii, binary, compressed) on the device
+//   k_account      algorithmic bytes of a pass, outside the timed region
 //
 // One wavefront owns one read. Cross-lane steps use ballot / mbcnt / shuffles; per-wave scratch lives
 // in LDS; there is no inter-workgroup communication inside a launch.
@@ -707,15 +712,8 @@ __global__ __launch_bounds__(256) void k_merge_segments(const uint32_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// Elias-delta decoding straight from the colour bit vector
+// Per-list descriptors of the colour kernels
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t bits_window(const uint64_t* __restrict__ bits, uint64_t pos) {
-    const uint64_t* w = bits + (pos >> 6);
-    const uint32_t sh = (uint32_t)pos & 63u;
-    uint64_t v = w[0] >> sh;
-    if (sh) v |= w[1] << (64 - sh);
-    return v;
-}
 struct ListHeader {
     uint64_t begin, body, soff;  // bitmap list: bit offsets of the list / of its bitmap. Gap-coded list: begin = first
                                  // data word in blk_words, soff = first block header
