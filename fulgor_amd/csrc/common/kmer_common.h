@@ -158,7 +158,7 @@ FG_HD void string_lmer(uint64_t w0, uint64_t w1, uint32_t sh, uint32_t L, uint32
 // ---- packed blocks of the gap-coded lists (all codecs) --------------------------------------------------
 // A block holds up to 64 consecutive values v_0 < v_1 < ... of one list as `width`-bit offsets from
 // `start` (= previous value + 1, or 0 for the first block): v_i = start + field_i. Header word:
-//   start:27 | width:5 | count-1:6 | first data word, relative to the list's first data word:26
+//   start:27 | width:5 | count-1:6 | first data word, relative to the start of the list's region (its headers, then its data):26
 // (so num_colors <= 2^27; a list owns fewer than n/4 codes, hence fewer than 2^26 data words).
 // Where a list is dense — its next 64 values fall within BLK_CHUNK_SPAN colours — the block is instead a
 // plain bitmap chunk: width = BLK_CHUNK_WIDTH, start = first colour rounded down to a multiple of 32,

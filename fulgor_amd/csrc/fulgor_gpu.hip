@@ -72,7 +72,7 @@ struct fgpu_index {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 256;
-    DevBuf d_strings, d_pilots, d_slots, d_overflow, d_bits, d_offsets, d_set_desc, d_blk_hdr, d_blk_words;
+    DevBuf d_strings, d_pilots, d_slots, d_overflow, d_bits, d_offsets, d_set_desc, d_blk_words;
     DevBuf d_gops, d_gset_ops_off, d_gset_ops, d_garena, d_gblk_hdr, d_gblk_words, d_gset_bytes;
     DevDict dd{};
     DevColors dc{};
@@ -198,14 +198,13 @@ void upload_index(fgpu_index* ix) {
         upload(ix->d_set_desc, sd, s);
         HIP_TRY(hipStreamSynchronize(s));  // sd is released at the end of this block
     }
-    upload(ix->d_blk_hdr, h.blk_hdr, s);
     upload(ix->d_blk_words, h.blk_words, s);
     HIP_TRY(hipStreamSynchronize(s));
     ix->dd = DevDict{ix->d_strings.as<uint64_t>(), ix->d_pilots.as<uint16_t>(), ix->d_slots.as<uint64_t>(),
                      ix->d_overflow.as<uint64_t>(), d.num_buckets, d.num_slots, d.k, d.m, d.seed};
     const uint32_t w32 = ((h.num_colors + 31) / 32 + 3) & ~3u;  // result bitmaps move as 128-bit groups
     ix->dc = DevColors{ix->d_bits.as<uint64_t>(), ix->d_offsets.as<uint64_t>(), ix->d_set_desc.as<ListDesc>(),
-                       ix->d_blk_hdr.as<uint64_t>(), ix->d_blk_words.as<uint32_t>(), h.num_colors, h.sparse_thr, h.dense_thr, w32};
+                       ix->d_blk_words.as<uint32_t>(), h.num_colors, h.sparse_thr, h.dense_thr, w32};
 }
 
 static_assert(sizeof(GenOpDev) == sizeof(ListDesc), "host and device op layouts must match");
@@ -534,7 +533,7 @@ void fgpu_close(fgpu_index* ix) {
     if (ix->device == FGPU_HOST_ONLY) { delete ix; return; }
     (void)hipSetDevice(ix->device);
     for (DevBuf* b : {&ix->d_strings, &ix->d_pilots, &ix->d_slots, &ix->d_overflow, &ix->d_bits, &ix->d_offsets,
-                      &ix->d_set_desc, &ix->d_blk_hdr, &ix->d_blk_words, &ix->d_gops, &ix->d_gset_ops_off, &ix->d_gset_ops,
+                      &ix->d_set_desc, &ix->d_blk_words, &ix->d_gops, &ix->d_gset_ops_off, &ix->d_gset_ops,
                       &ix->d_garena, &ix->d_gblk_hdr, &ix->d_gblk_words, &ix->d_gset_bytes})
         b->release();
     for (auto e : ix->event_pool) (void)hipEventDestroy(e);

@@ -36,8 +36,7 @@ struct DevColors {
     const uint64_t* bits;       // the hybrid bit stream (bitmap lists are read from it)
     const uint64_t* offsets;
     const struct ListDesc* set_desc;  // one resolved descriptor per colour set (built at upload)
-    const uint64_t* blk_hdr;          // packed blocks of the gap-coded lists (host/hybrid_codec.hpp)
-    const uint32_t* blk_words;
+    const uint32_t* blk_words;        // packed blocks of the gap-coded lists, headers in front of the data (host/hybrid_codec.hpp)
     uint32_t n, sparse_thr, dense_thr;
     uint32_t w32;  // 32-bit words per result bitmap, rounded up to a multiple of 4
 };
@@ -980,7 +979,7 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
                             const uint32_t nb = sc.h_ncodes[i];
                             const uint32_t j = s - (sc.pref[i] - (nb & 0x7FFFFFFFu));
                             // a single-block list carries its block header in the descriptor itself (one fetch less)
-                            const uint64_t hd = (nb & 0x7FFFFFFFu) == 1 ? sc.h_soff[i] : c.blk_hdr[sc.h_soff[i] + j];
+                            const uint64_t hd = (nb & 0x7FFFFFFFu) == 1 ? sc.h_soff[i] : ((const uint64_t*)(c.blk_words + sc.h_begin[i]))[j];
                             const uint64_t a = (uint64_t)(c.blk_words + sc.h_begin[i] + blk_rel_word(hd));
                             const bool sparse = (nb >> 31) != 0;
                             bl.a_lo = (uint32_t)a;
@@ -1186,7 +1185,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 4 : 2)) void k3a
                 if (s < total_blk) {
                     const uint32_t i = owner_list(excl, min(K3A_GROUP, cnt - g), s);
                     const uint32_t j = s - (sc.pref[i] - sc.h_ncodes[i]);
-                    const uint64_t hd = sc.h_ncodes[i] == 1 ? sc.h_soff[i] : c.blk_hdr[sc.h_soff[i] + j];  // (as in k2a)
+                    const uint64_t hd = sc.h_ncodes[i] == 1 ? sc.h_soff[i] : ((const uint64_t*)(c.blk_words + sc.h_begin[i]))[j];  // (as in k2a)
                     const uint64_t a = (uint64_t)(c.blk_words + sc.h_begin[i] + blk_rel_word(hd));
                     bl.a_lo = (uint32_t)a;
                     bl.a_hi = (uint32_t)(a >> 32);

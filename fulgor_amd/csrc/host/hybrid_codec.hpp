@@ -175,18 +175,37 @@ inline void hybrid_build_blocks(HybridSets& h, unsigned nthreads = 0) {
                 nwords[id + 1] += nw;
             });
     });
-    for (uint64_t i = 0; i < ns; ++i) { h.blk_first[i + 1] += h.blk_first[i]; nwords[i + 1] += nwords[i]; }
+    // A list of two or more blocks keeps its headers (two words each) in front of its block data, so that the header
+    // fetch and the data fetch of a short list touch the same 128-byte line; a single block's header travels in the
+    // per-set descriptor instead. Every list starts on an even word (headers are read as u64), rel_word counts from
+    // the start of the list's region, headers included (a gap-coded list owns fewer than n/4 <= 2^25 codes of at most 27
+    // bits and one header per 64 codes at most: always below 2^26 words).
+    for (uint64_t i = 0; i < ns; ++i) {
+        const uint64_t nb = h.blk_first[i + 1];
+        uint64_t tot = nwords[i + 1] + (nb >= 2 ? 2 * nb : 0);
+        tot += tot & 1;
+        h.blk_first[i + 1] += h.blk_first[i];
+        nwords[i + 1] = nwords[i] + tot;
+    }
     for (uint64_t i = 0; i < ns; ++i) h.blk_wbase[i] = nwords[i];
     h.blk_hdr.assign(h.blk_first[ns], 0);
     h.blk_words.assign(nwords[ns] + 64, 0);  // a wave reads up to 64 * 27 bits + 1 word past a block's start
     run([&](uint64_t a, uint64_t b) {
         std::vector<uint32_t> vals;
         for (uint64_t id = a; id < b; ++id) {
+            const uint64_t nb = h.blk_first[id + 1] - h.blk_first[id];
             uint64_t* hdr = h.blk_hdr.data() + h.blk_first[id];
             uint32_t* base = h.blk_words.data() + h.blk_wbase[id];
-            uint64_t rel = 0;
+            uint64_t rel = nb >= 2 ? 2 * nb : 0;
+            uint64_t j = 0;
             walk(id, vals, [&](uint32_t start, uint32_t width, uint32_t cnt, uint32_t nw, const uint32_t* v, uint32_t nv) {
-                *hdr++ = blk_pack(start, width, cnt, (uint32_t)rel);
+                const uint64_t hd = blk_pack(start, width, cnt, (uint32_t)rel);
+                hdr[j] = hd;
+                if (nb >= 2) {
+                    base[2 * j] = (uint32_t)hd;
+                    base[2 * j + 1] = (uint32_t)(hd >> 32);
+                }
+                ++j;
                 write_block_words(base + rel, start, width, v, nv);
                 rel += nw;
             });
