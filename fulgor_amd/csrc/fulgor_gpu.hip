@@ -758,9 +758,12 @@ int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_rea
             res->d_fmt_out.ensure(bytes + 64);
             HIP_TRY(hipMemsetAsync(res->d_fmt_out.p, 0, bytes + 64, s));
             Timed t(ix, res, FGPU_K_FORMAT);
-            hipLaunchKernelGGL(k_cfmt_write, dim3(grid), dim3(256), 0, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
-                               n, W, nc, sthr, dthr, first_read_id, rec_off, block_bits, block_off,
-                               res->d_fmt_out.as<unsigned long long>());
+            // per-wave LDS stage of one record: the n bits of a bitmap record or the codes of at most n/4 gaps, plus its
+            // header codes and the alignment slack (larger records, if any, are written code by code)
+            const uint32_t cap_words = (uint32_t)std::min<uint64_t>(((uint64_t)nc * 3 / 2 + 256 + 63) / 64, 1024);
+            hipLaunchKernelGGL(k_cfmt_write, dim3(grid), dim3(256), (size_t)4 * cap_words * 8, s, res->d_bitmap.as<uint32_t>(),
+                               res->d_counts.as<uint32_t>(), n, W, nc, sthr, dthr, first_read_id, bits, rec_off, block_bits, block_off,
+                               res->d_fmt_out.as<unsigned long long>(), cap_words);
             HIP_TRY(hipGetLastError());
         } else if (n && format == FGPU_FMT_BINARY) {
             bytes = 8 * n + 4 * res->total;

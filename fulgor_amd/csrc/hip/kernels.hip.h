@@ -1885,34 +1885,55 @@ __global__ __launch_bounds__(CFMT_BLOCK_READS) void k_cfmt_blocks(const uint32_t
     }
 }
 
+// The record of a read is assembled in LDS (64-bit ds_or at the record's own bit alignment) and flushed with plain
+// stores; only its first and last word, which it may share with its neighbours, are ORed into the zeroed output.
+// cap_words = LDS words per wave; a record that does not fit (never for valid thresholds: at most ~1.25 n bits) is
+// ORed into the output code by code.
 __global__ __launch_bounds__(256) void k_cfmt_write(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
                                                     uint64_t n_reads, uint32_t W, uint32_t n, uint32_t sparse_thr, uint32_t dense_thr,
-                                                    uint32_t first_id, const uint32_t* __restrict__ rec_off,
+                                                    uint32_t first_id, const uint32_t* __restrict__ rec_bits,
+                                                    const uint32_t* __restrict__ rec_off,
                                                     const uint32_t* __restrict__ block_bits, const uint64_t* __restrict__ block_off,
-                                                    unsigned long long* __restrict__ out) {
+                                                    unsigned long long* __restrict__ out, uint32_t cap_words) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
     const int lane = lane_id();
+    unsigned long long* buf = (unsigned long long*)smem_c + (size_t)(threadIdx.x >> 6) * cap_words;
+    for (uint32_t i = lane; i < cap_words; i += 64) buf[i] = 0;
+    wave_lds_sync();
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t r = wave; r < n_reads; r += nwaves) {
         const uint64_t blk = r / CFMT_BLOCK_READS;
         const uint64_t hdr_word = block_off[blk] >> 3;  // blocks start on 8-byte boundaries
         if (r % CFMT_BLOCK_READS == 0 && lane == 0) out[hdr_word] = block_bits[blk];
         const uint64_t pos0 = (hdr_word + 1) * 64 + rec_off[r];
+        const uint64_t base_bit = pos0 & ~63ull;
+        const uint32_t nwords = (uint32_t)((pos0 - base_bit) + rec_bits[r] + 63) >> 6;
+        const bool staged = nwords <= cap_words;
+        auto put = [&](uint64_t pos, uint64_t code, uint32_t len) {
+            if (staged) {
+                const uint32_t lp = (uint32_t)(pos - base_bit), sh = lp & 63u;
+                atomicOr(&buf[lp >> 6], (unsigned long long)(code << sh));
+                if (sh + len > 64) atomicOr(&buf[(lp >> 6) + 1], (unsigned long long)(code >> (64 - sh)));
+            } else {
+                put_bits(out, pos, code, len);
+            }
+        };
         const uint32_t size = counts[r];
         uint32_t l1, l2;
         const uint64_t c1 = delta_code((uint64_t)first_id + r, l1), c2 = delta_code(size, l2);
         if (lane == 0) {
-            put_bits(out, pos0, c1, l1);
-            put_bits(out, pos0 + l1, c2, l2);
+            put(pos0, c1, l1);
+            put(pos0 + l1, c2, l2);
         }
         const uint64_t pay = pos0 + l1 + l2;
         const uint32_t* row = bitmap + r * W;
-        if (size == 0) continue;
-        if (size >= sparse_thr && size < dense_thr) {  // the n bits of the row, shifted into place
+        if (size == 0) {
+        } else if (size >= sparse_thr && size < dense_thr) {  // the n bits of the row, shifted into place
             for (uint32_t w = lane; w * 32 < n; w += 64) {
                 uint32_t x = row[w];
                 const uint32_t lo = w * 32, nb = n - lo >= 32 ? 32u : n - lo;
                 if (nb < 32) x &= (1u << nb) - 1u;
-                if (x) put_bits(out, pay + lo, x, nb);
+                if (x) put(pay + lo, x, nb);
             }
         } else {
             const bool comp = size >= dense_thr;
@@ -1920,8 +1941,19 @@ __global__ __launch_bounds__(256) void k_cfmt_write(const uint32_t* __restrict__
                                    [&](uint32_t gap, uint32_t at) {
                                        uint32_t len;
                                        const uint64_t code = delta_code(gap, len);
-                                       put_bits(out, pay + at, code, len);
+                                       put(pay + at, code, len);
                                    });
+        }
+        if (staged) {
+            wave_lds_sync();
+            unsigned long long* dst = out + (base_bit >> 6);
+            for (uint32_t w = lane; w < nwords; w += 64) {
+                const unsigned long long v = buf[w];
+                buf[w] = 0;
+                if (w == 0 || w + 1 == nwords) { if (v) atomicOr(&dst[w], v); }
+                else dst[w] = v;
+            }
+            wave_lds_sync();
         }
     }
 }
