@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--cluster-size", type=int, default=16)
     ap.add_argument("--streams", type=int, default=1,
                     help="passes in flight per GPU: chunk i runs on stream i %% streams (own result buffers, own host thread)")
+    ap.add_argument("--read-len", type=int, default=150, help="read length in bases (the metric is quoted on 150)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -102,7 +103,7 @@ def main():
         desc += "; colour sets re-encoded as %s (partitions of %d colours, clusters of %d sets)" % (
             args.index_type, args.partition_size, args.cluster_size)
     algo = fulgor_amd.FULL_INTERSECTION if args.algo == "full-intersection" else fulgor_amd.THRESHOLD_UNION
-    bases, offs = gen.generate(rank * n_reads, n_reads, 150, 42)
+    bases, offs = gen.generate(rank * n_reads, n_reads, args.read_len, 42)
     reads = ix.upload_reads(bases, offs)
     results = [ix.new_result() for _ in range(max(1, args.streams))]
     res = results[0]
@@ -196,7 +197,7 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         out = {
-            "metric": "pseudoaligned reads/sec (150 bp, k=31)",
+            "metric": "pseudoaligned reads/sec (%d bp, k=31)" % args.read_len,
             "value": round(world * n_reads * args.steps / elapsed, 1),
             "unit": "reads/s",
             "n_gpus": world,
@@ -208,8 +209,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "%s, %s, %d synthetic 150 bp reads per GPU (seed 42), k=31, chunk %d reads/pass"
-                                   % (desc, args.algo + (" tau=%g" % args.tau if algo else ""), n_reads, args.chunk),
+            "config": {"workload": "%s, %s, %d synthetic %d bp reads per GPU (seed 42), k=31, chunk %d reads/pass"
+                                   % (desc, args.algo + (" tau=%g" % args.tau if algo else ""), n_reads, args.read_len, args.chunk),
                        "index_replicated": True, "reads_per_gpu": n_reads, "streams": len(results),
                        "mapped_fraction": round(mapped_job / max(1, total_reads_job), 4),
                        "avg_colours_per_read": round(total_colors / n_reads, 2)},
