@@ -277,23 +277,24 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     }
     if (units == 0) return;
     const bool w13 = ix->dd.k - ix->dd.m == 12;
-    const bool short_reads = rd->max_kmers <= 128 && !seg;
-    const uint32_t grid = !short_reads ? resident_grid(k1_lookup<1024>, units, 4, ix->num_cus, 256, 0)
-                          : w13        ? resident_grid(k1_lookup_short<true>, units, 4, ix->num_cus, 256, 0)
-                                       : resident_grid(k1_lookup_short<false>, units, 4, ix->num_cus, 256, 0);
+    // reads of at most 128 k-mers: one window per read; up to 256 k-mers (e.g. 250-base reads): two windows; else the general kernel
+    const int halves = seg ? 0 : rd->max_kmers <= 128 ? 1 : rd->max_kmers <= 256 ? 2 : 0;
     {
-        Timed t(ix, res, FGPU_K_LOOKUP);
-        if (short_reads && w13) {
-            hipLaunchKernelGGL(k1_lookup_short<true>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
-                               rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
-                               res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
-                               stride, res->d_tickets.as<unsigned int>(), kmer_out);
-        } else if (short_reads) {
-            hipLaunchKernelGGL(k1_lookup_short<false>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
-                               rd->d_offs.as<uint64_t>(), first, count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
-                               res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(),
-                               stride, res->d_tickets.as<unsigned int>(), kmer_out);
-        } else {
+        auto launch_short = [&](auto kernel) {
+            const uint32_t grid = resident_grid(kernel, units, 4, ix->num_cus, 256, 0);
+            Timed t(ix, res, FGPU_K_LOOKUP);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(), rd->d_offs.as<uint64_t>(), first,
+                               count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(), res->d_idoff.as<uint64_t>(),
+                               res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(), stride, res->d_tickets.as<unsigned int>(),
+                               kmer_out);
+        };
+        if (halves == 1 && w13) launch_short(k1_lookup_short<true, 1>);
+        else if (halves == 1) launch_short(k1_lookup_short<false, 1>);
+        else if (halves == 2 && w13) launch_short(k1_lookup_short<true, 2>);
+        else if (halves == 2) launch_short(k1_lookup_short<false, 2>);
+        else {
+            const uint32_t grid = resident_grid(k1_lookup<1024>, units, 4, ix->num_cus, 256, 0);
+            Timed t(ix, res, FGPU_K_LOOKUP);
             hipLaunchKernelGGL(k1_lookup<1024>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
                                seg ? rd->d_seg_start.as<uint64_t>() : rd->d_offs.as<uint64_t>(),
                                seg ? rd->d_seg_end.as<uint64_t>() : (const uint64_t*)nullptr, u_first, units,
@@ -637,7 +638,7 @@ int fgpu_reads_upload(fgpu_index* ix, const char* bases, const uint64_t* offs, u
             upload(rd->d_seg_first, rd->seg_first, ix->stream);
         }
         const uint64_t nb = offs[n];
-        rd->d_bases.ensure(nb + 256);
+        rd->d_bases.ensure(nb + 512);  // the lookup kernels read up to 320 bases past a read's start unconditionally
         rd->d_offs.ensure((n + 1) * 8);
         if (nb) HIP_TRY(hipMemcpyAsync(rd->d_bases.p, bases, nb, hipMemcpyHostToDevice, ix->stream));
         HIP_TRY(hipMemcpyAsync(rd->d_offs.p, offs, (n + 1) * 8, hipMemcpyHostToDevice, ix->stream));

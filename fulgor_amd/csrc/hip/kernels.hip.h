@@ -340,14 +340,18 @@ __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __res
 // unconditionally from an in-bounds address (inactive candidates read word 0) and results are selected,
 // because on this kernel the scalar unit (exec-mask bookkeeping of divergent branches), not memory, was
 // the limiter.
-template <bool W13>
-__global__ __launch_bounds__(256, 8) void k1_lookup_short(DevDict d, const uint8_t* __restrict__ bases,
+// HALVES = 2 takes reads of up to 256 k-mers (286 bases at k = 31) as two overlapping windows of 128 k-mers (k-mers
+// [0,128) from bases [0,158), k-mers [128,256) from bases [128,286)): the window minima and the probe run once per
+// window, the distinct-id step once per read.
+template <bool W13, int HALVES>
+__global__ __launch_bounds__(256, HALVES == 1 ? 8 : 6) void k1_lookup_short(DevDict d, const uint8_t* __restrict__ bases,
                                                        const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
                                                        uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
                                                        uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
                                                        uint32_t* __restrict__ cnt_pool, uint32_t stride, unsigned int* tickets,
                                                        uint32_t* __restrict__ kmer_out) {
-    constexpr int KMAX = 128;
+    constexpr int KMAX = 128 * HALVES;
+    constexpr int NB = 2 * HALVES + 1;  // 64-base groups fetched per read
     // sliding-window minima by doubling: entry p = (24-bit order << 8 | tie-break position) of the best m-mer in
     // [p, p + span), span = 1, 2, 4, 8; L breaks ties to the left (position p), R to the right (255 - p)
     __shared__ uint32_t s_minL[4][152];
@@ -374,23 +378,28 @@ __global__ __launch_bounds__(256, 8) void k1_lookup_short(DevDict d, const uint8
         uint32_t len = (uint32_t)(re - rb);
         const uint8_t* seq = bases + rb;
         // reads are padded by the host buffer: positions past the read end are masked below, not branched on
-        uint32_t b0 = seq[lane], b1 = seq[lane + 64], b2 = seq[lane + 128];
+        uint32_t bb[NB];
+#pragma unroll
+        for (int g = 0; g < NB; ++g) bb[g] = seq[lane + 64 * g];
         for (uint32_t j = 0; j < t_count; ++j) {
             const uint64_t r = t_first + j;
             const uint32_t cur_len = len;
-            const uint32_t c0 = (uint32_t)lane < cur_len ? base_code_fast(b0) : 0xFFu;
-            const uint32_t c1 = (uint32_t)lane + 64 < cur_len ? base_code_fast(b1) : 0xFFu;
-            const uint32_t c2 = (uint32_t)lane + 128 < cur_len ? base_code_fast(b2) : 0xFFu;
+            uint32_t cc[NB];
+#pragma unroll
+            for (int g = 0; g < NB; ++g) cc[g] = (uint32_t)lane + 64 * g < cur_len ? base_code_fast(bb[g]) : 0xFFu;
             if (j + 1 < t_count) {  // request the next read's bases now; they are consumed next iteration
                 rb = re;
                 re = readlane_u64(myoff, j + 2);
                 len = (uint32_t)(re - rb);
                 seq = bases + rb;
-                b0 = seq[lane];
-                b1 = seq[lane + 64];
-                b2 = seq[lane + 128];
+#pragma unroll
+                for (int g = 0; g < NB; ++g) bb[g] = seq[lane + 64 * g];
             }
-            const uint32_t nk = cur_len >= k ? min(cur_len - k + 1, (uint32_t)KMAX) : 0;
+            const uint32_t nk_read = cur_len >= k ? min(cur_len - k + 1, (uint32_t)KMAX) : 0;
+#pragma unroll
+            for (int half = 0; half < HALVES; ++half) {
+            const uint32_t c0 = cc[2 * half], c1 = cc[2 * half + 1], c2 = cc[2 * half + 2];
+            const uint32_t nk = nk_read > 128u * half ? min(nk_read - 128u * half, 128u) : 0u;  // k-mers of this window
             const uint64_t loA = __ballot(c0 <= 3 && (c0 & 1)), hiA = __ballot(c0 <= 3 && (c0 & 2)), nvA = __ballot(c0 > 3);
             const uint64_t loB = __ballot(c1 <= 3 && (c1 & 1)), hiB = __ballot(c1 <= 3 && (c1 & 2)), nvB = __ballot(c1 > 3);
             const uint64_t loC = __ballot(c2 <= 3 && (c2 & 1)), hiC = __ballot(c2 <= 3 && (c2 & 2)), nvC = __ballot(c2 > 3);
@@ -544,13 +553,15 @@ __global__ __launch_bounds__(256, 8) void k1_lookup_short(DevDict d, const uint8
                     }
                 }
             }
-            ids[lane] = (uint32_t)lane < nk ? csid[0] : NEG;
-            ids[64 + lane] = (uint32_t)(64 + lane) < nk ? csid[1] : NEG;
+            ids[128 * half + lane] = (uint32_t)lane < nk ? csid[0] : NEG;
+            ids[128 * half + 64 + lane] = (uint32_t)(64 + lane) < nk ? csid[1] : NEG;
             if (kmer_out) {
-                if ((uint32_t)lane < nk) kmer_out[r * (uint64_t)stride + lane] = csid[0];
-                if ((uint32_t)(64 + lane) < nk) kmer_out[r * (uint64_t)stride + 64 + lane] = csid[1];
+                if ((uint32_t)lane < nk) kmer_out[r * (uint64_t)stride + 128 * half + lane] = csid[0];
+                if ((uint32_t)(64 + lane) < nk) kmer_out[r * (uint64_t)stride + 128 * half + 64 + lane] = csid[1];
             }
             wave_lds_sync();
+            }  // window
+            const uint32_t nk = nk_read;
 
             // ---- sorted distinct ids + multiplicities (run heads, see k1_lookup) ----
             uint32_t H = 0, positives = 0;

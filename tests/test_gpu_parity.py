@@ -96,6 +96,40 @@ def test_gpu_edge_batches(s10_gpu):
         s10_gpu.pseudoalign_threshold_union_batch(b, o, 1.5)
 
 
+def test_gpu_reads_up_to_256_kmers(s10_gpu, s10_oracle):
+    """batches whose longest read has 129..256 k-mers (e.g. 250-base reads) run the two-window variant of the short-read
+    lookup kernel: every length around the window boundaries, invalid bases in both windows, substitutions."""
+    from oracle.kmer_oracle import read_fasta
+    rng = np.random.default_rng(250)
+    src = max(read_fasta(S10_GENOMES[3]), key=len)
+    lens = [286, 285, 250, 251, 159, 160, 158, 157, 191, 192, 193, 222, 223, 224, 200, 100, 31, 30, 0, 64, 128, 129, 286]
+    reads = []
+    for i, l in enumerate(lens * 8):
+        st = int(rng.integers(0, len(src) - 400))
+        r = bytearray(src[st:st + l])
+        if i % 3 == 1 and l > 40:  # substitutions anywhere
+            for p_ in rng.integers(0, l, 3):
+                r[p_] = b"ACGT"[int(rng.integers(0, 4))]
+        if i % 5 == 2 and l > 40:  # invalid bases: one in each window
+            r[int(rng.integers(0, min(l, 128)))] = ord("N")
+            r[int(rng.integers(l // 2, l))] = ord("N")
+        if i % 7 == 3:
+            r = bytearray(bytes(r).lower())
+        reads.append(bytes(r))
+    b, o = pack_reads(reads)
+    for got, want in ((s10_gpu.pseudoalign_full_intersection_batch(b, o), s10_oracle.full_intersection(b, o)),
+                      (s10_gpu.pseudoalign_threshold_union_batch(b, o, 0.8), s10_oracle.threshold_union(b, o, 0.8)),
+                      (s10_gpu.fetch_color_set_ids_batch(b, o), s10_oracle.fetch_color_set_ids(b, o))):
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    # per-k-mer ids keep their order across the two windows
+    from fulgor_amd.index import conservation_triples
+    ko, ki = s10_gpu.kmer_color_set_ids_batch(b, o)
+    for j, r in enumerate(reads):
+        ids = ki[int(ko[j]):int(ko[j + 1])]
+        assert len(ids) == max(0, len(r) - 31 + 1)
+        assert conservation_triples(ids) == s10_oracle.kmer_conservation(r)
+
+
 def test_gpu_reads_of_any_length(s10_gpu, s10_oracle):
     """ragged batch: 31 bp .. 100 kbp. Reads above 1024 k-mers are cut into overlapping segments by the host
     and their id lists merged on the device (k_merge_segments); answers must not depend on that."""
