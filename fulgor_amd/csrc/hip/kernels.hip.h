@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __res
 // [0,128) from bases [0,158), k-mers [128,256) from bases [128,286)): the window minima and the probe run once per
 // window, the distinct-id step once per read.
 template <bool W13, int HALVES>
-__global__ __launch_bounds__(256, HALVES == 1 ? 8 : 6) void k1_lookup_short(DevDict d, const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(256, 8) void k1_lookup_short(DevDict d, const uint8_t* __restrict__ bases,
                                                        const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
                                                        uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
                                                        uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
