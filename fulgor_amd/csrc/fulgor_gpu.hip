@@ -277,8 +277,8 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     }
     if (units == 0) return;
     const bool w13 = ix->dd.k - ix->dd.m == 12;
-    // reads of at most 128 k-mers: one window per read; up to 256 k-mers (e.g. 250-base reads): two windows; else the general kernel
-    const int halves = seg ? 0 : rd->max_kmers <= 128 ? 1 : rd->max_kmers <= 256 ? 2 : 0;
+    // reads of at most 128 k-mers: one window per read; up to 512 k-mers (250- to 500-base reads): 2 to 4 windows; else the general kernel
+    const int halves = seg || rd->max_kmers > 512 ? 0 : (int)((std::max<uint32_t>(rd->max_kmers, 1) + 127) / 128);
     {
         auto launch_short = [&](auto kernel) {
             const uint32_t grid = resident_grid(kernel, units, 4, ix->num_cus, 256, 0);
@@ -292,6 +292,10 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
         else if (halves == 1) launch_short(k1_lookup_short<false, 1>);
         else if (halves == 2 && w13) launch_short(k1_lookup_short<true, 2>);
         else if (halves == 2) launch_short(k1_lookup_short<false, 2>);
+        else if (halves == 3 && w13) launch_short(k1_lookup_short<true, 3>);
+        else if (halves == 3) launch_short(k1_lookup_short<false, 3>);
+        else if (halves == 4 && w13) launch_short(k1_lookup_short<true, 4>);
+        else if (halves == 4) launch_short(k1_lookup_short<false, 4>);
         else {
             const uint32_t grid = resident_grid(k1_lookup<1024>, units, 4, ix->num_cus, 256, 0);
             Timed t(ix, res, FGPU_K_LOOKUP);
@@ -638,7 +642,7 @@ int fgpu_reads_upload(fgpu_index* ix, const char* bases, const uint64_t* offs, u
             upload(rd->d_seg_first, rd->seg_first, ix->stream);
         }
         const uint64_t nb = offs[n];
-        rd->d_bases.ensure(nb + 512);  // the lookup kernels read up to 320 bases past a read's start unconditionally
+        rd->d_bases.ensure(nb + 1024);  // the lookup kernels read up to 576 bases past a read's start unconditionally
         rd->d_offs.ensure((n + 1) * 8);
         if (nb) HIP_TRY(hipMemcpyAsync(rd->d_bases.p, bases, nb, hipMemcpyHostToDevice, ix->stream));
         HIP_TRY(hipMemcpyAsync(rd->d_offs.p, offs, (n + 1) * 8, hipMemcpyHostToDevice, ix->stream));

@@ -340,11 +340,12 @@ __global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __res
 // unconditionally from an in-bounds address (inactive candidates read word 0) and results are selected,
 // because on this kernel the scalar unit (exec-mask bookkeeping of divergent branches), not memory, was
 // the limiter.
-// HALVES = 2 takes reads of up to 256 k-mers (286 bases at k = 31) as two overlapping windows of 128 k-mers (k-mers
-// [0,128) from bases [0,158), k-mers [128,256) from bases [128,286)): the window minima and the probe run once per
-// window, the distinct-id step once per read.
+// HALVES = 2, 3, 4 take reads of up to 256 / 384 / 512 k-mers (286 / 414 / 542 bases at k = 31) as overlapping windows of
+// 128 k-mers (k-mers [0,128) from bases [0,158), k-mers [128,256) from bases [128,286), ...): the window minima and the
+// probe run once per window, the distinct-id step once per read. Occupancy: 8 waves/SIMD up to two windows (64 VGPRs, the
+// two-window variant with 24 bytes of scratch), then bounded by the LDS id arrays (6 and 5 waves).
 template <bool W13, int HALVES>
-__global__ __launch_bounds__(256, 8) void k1_lookup_short(DevDict d, const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(256, HALVES <= 2 ? 8 : (HALVES == 3 ? 6 : 5)) void k1_lookup_short(DevDict d, const uint8_t* __restrict__ bases,
                                                        const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
                                                        uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
                                                        uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,

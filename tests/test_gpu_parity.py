@@ -96,23 +96,29 @@ def test_gpu_edge_batches(s10_gpu):
         s10_gpu.pseudoalign_threshold_union_batch(b, o, 1.5)
 
 
-def test_gpu_reads_up_to_256_kmers(s10_gpu, s10_oracle):
-    """batches whose longest read has 129..256 k-mers (e.g. 250-base reads) run the two-window variant of the short-read
-    lookup kernel: every length around the window boundaries, invalid bases in both windows, substitutions."""
+@pytest.mark.parametrize("windows", [2, 3, 4])
+def test_gpu_reads_up_to_512_kmers(s10_gpu, s10_oracle, windows):
+    """batches whose longest read has 129..512 k-mers (250- to 500-base reads) run the 2-, 3- and 4-window variants of the
+    short-read lookup kernel: every length around the window boundaries, invalid bases in several windows, substitutions."""
     from oracle.kmer_oracle import read_fasta
-    rng = np.random.default_rng(250)
+    rng = np.random.default_rng(250 + windows)
     src = max(read_fasta(S10_GENOMES[3]), key=len)
-    lens = [286, 285, 250, 251, 159, 160, 158, 157, 191, 192, 193, 222, 223, 224, 200, 100, 31, 30, 0, 64, 128, 129, 286]
+    top = 128 * windows + 30
+    lens = [top, top - 1, top - 36, 250, 159, 160, 158, 157, 191, 192, 193, 222, 223, 224, 200, 100, 31, 30, 0, 64, 128, 129, top]
+    for j in range(1, windows):
+        lens += [128 * j + 29, 128 * j + 30, 128 * j + 31, 128 * j + 94]
+    lens = [min(l, top) for l in lens]
     reads = []
-    for i, l in enumerate(lens * 8):
-        st = int(rng.integers(0, len(src) - 400))
+    for i, l in enumerate(lens * 6):
+        st = int(rng.integers(0, len(src) - 600))
         r = bytearray(src[st:st + l])
         if i % 3 == 1 and l > 40:  # substitutions anywhere
             for p_ in rng.integers(0, l, 3):
                 r[p_] = b"ACGT"[int(rng.integers(0, 4))]
-        if i % 5 == 2 and l > 40:  # invalid bases: one in each window
+        if i % 5 == 2 and l > 40:  # invalid bases: in the first window and further on
             r[int(rng.integers(0, min(l, 128)))] = ord("N")
             r[int(rng.integers(l // 2, l))] = ord("N")
+            r[int(rng.integers(0, l))] = ord("N")
         if i % 7 == 3:
             r = bytearray(bytes(r).lower())
         reads.append(bytes(r))
