@@ -401,6 +401,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? 8 : (HALVES == 3 ? 6 : 5)) void 
             for (int half = 0; half < HALVES; ++half) {
             const uint32_t c0 = cc[2 * half], c1 = cc[2 * half + 1], c2 = cc[2 * half + 2];
             const uint32_t nk = nk_read > 128u * half ? min(nk_read - 128u * half, 128u) : 0u;  // k-mers of this window
+            if (half > 0 && nk == 0) continue;  // (wave-uniform) a shorter read of the batch: nothing reads this window's ids
             const uint64_t loA = __ballot(c0 <= 3 && (c0 & 1)), hiA = __ballot(c0 <= 3 && (c0 & 2)), nvA = __ballot(c0 > 3);
             const uint64_t loB = __ballot(c1 <= 3 && (c1 & 1)), hiB = __ballot(c1 <= 3 && (c1 & 2)), nvB = __ballot(c1 > 3);
             const uint64_t loC = __ballot(c2 <= 3 && (c2 & 1)), hiC = __ballot(c2 <= 3 && (c2 & 2)), nvC = __ballot(c2 > 3);
