@@ -425,8 +425,10 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
                            res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
         HIP_TRY(hipGetLastError());
     } else if (algo == FGPU_THRESHOLD_UNION) {
-        // score counter width from the longest read of the batch: 8 bits up to 127 k-mers, 16 up to 32767, else 32
-        const int bits = res->max_kmers_in_batch <= 127 ? 8 : (res->max_kmers_in_batch <= 32767 ? 16 : 32);
+        // score counters from the longest read of the batch: biased 8-bit up to 127 k-mers, plain 8-bit up to 255, biased
+        // 16-bit up to 32767, else 32-bit
+        const bool plain8 = res->max_kmers_in_batch > 127 && res->max_kmers_in_batch <= 255;
+        const int bits = res->max_kmers_in_batch <= 255 ? 8 : (res->max_kmers_in_batch <= 32767 ? 16 : 32);
         const size_t per_wave = (size_t)W * 4 * bits + k3a_scratch_bytes();
         auto launch = [&](auto kernel) {
             const uint32_t wpb = pick_waves(per_wave, (const void*)kernel);
@@ -443,7 +445,8 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
                                res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, scores_out);
             HIP_TRY(hipGetLastError());
         };
-        if (bits == 8) launch(k3a_union<8>);
+        if (plain8) launch(k3a_union<8, false>);
+        else if (bits == 8) launch(k3a_union<8>);
         else if (bits == 16) launch(k3a_union<16>);
         else launch(k3a_union<32>);
     } else {

@@ -1060,7 +1060,10 @@ __device__ __forceinline__ uint32_t counter_spread(uint32_t x, uint32_t q, uint3
 constexpr uint32_t K3A_GROUP = 16;
 __host__ __device__ inline uint32_t k3a_scratch_bytes() { return K3A_GROUP * (8 + 8 + 4 + 4 + 4); }
 
-template <int BITS>
+// BIASED = false (8-bit only): reads of 128 to 255 k-mers. The counters hold the plain scores (0 <= score <= #positive
+// k-mers <= 255 at every moment, because they start at the total score of the complemented lists), and the final
+// pass compares every byte with min_score by the carry out of byte + (256 - min_score).
+template <int BITS, bool BIASED = true>
 __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 4 : 2)) void k3a_union(DevColors c, const uint32_t* __restrict__ npos,
                                                                   const uint32_t* __restrict__ nids, const uint64_t* __restrict__ idoff,
                                                                   const uint32_t* __restrict__ ids_pool,
@@ -1154,7 +1157,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 4 : 2)) void k3a
             const ListDesc d = g ? load_desc(g) : d_first;
             comp_total += wave_sum_u32(desc_type(d) == D_ENC_COMPLEMENT ? (uint32_t)d.score : 0u);
         }
-        const uint32_t start = (HALF - min_score + comp_total) * ONES;
+        const uint32_t start = (BIASED ? HALF - min_score + comp_total : comp_total) * ONES;
         for (uint32_t i = lane; i < (W >> 2) * PLANES; i += 64) ((uint4*)SC)[i] = make_uint4(start, start, start, start);
         wave_lds_sync();
         for (uint32_t g = 0; g < cnt; g += K3A_GROUP) {
@@ -1222,14 +1225,26 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 4 : 2)) void k3a
             for (uint32_t cc = lane; cc < n; cc += 64) {
                 const uint32_t x = SC[(cc % PLANES) * W + (cc >> 5)];
                 const uint32_t field = BITS == 32 ? x : ((x >> ((BITS & 31) * ((cc & 31u) / PLANES))) & ((1u << (BITS & 31)) - 1u));
-                scores_out[r * (uint64_t)n + cc] = field - HALF + min_score;
+                scores_out[r * (uint64_t)n + cc] = BIASED ? field - HALF + min_score : field;
             }
         }
         uint32_t pc = 0;
+        const uint32_t thr_c = (256u - min_score) & 0xFFu;  // (unbiased counters only)
+        const uint32_t add7 = (thr_c & 0x7Fu) * 0x01010101u, top7 = (thr_c & 0x80u) ? 0xFFFFFFFFu : 0u;
+        const uint32_t all_pass = min_score == 0 ? 0xFFFFFFFFu : 0u;
         for (uint32_t w = lane; w < W; w += 64) {
             uint32_t m = 0;
 #pragma unroll
-            for (uint32_t q = 0; q < PLANES; ++q) m |= ((SC[q * W + w] >> (BITS - 1)) & ONES) << q;
+            for (uint32_t q = 0; q < PLANES; ++q) {
+                const uint32_t x = SC[q * W + w];
+                if (BIASED) {
+                    m |= ((x >> (BITS - 1)) & ONES) << q;
+                } else {  // byte >= min_score  <=>  carry out of byte + (256 - min_score); min_score = 0 keeps every colour
+                    const uint32_t low = (x & 0x7F7F7F7Fu) + add7;         // carry into bit 7 of every byte
+                    const uint32_t out = (x & low) | ((x ^ low) & top7);   // majority(x7, low7, bit 7 of 256 - min_score)
+                    m |= (((out | all_pass) >> 7) & ONES) << q;
+                }
+            }
             const uint32_t lo = w * 32;
             m &= lo >= n ? 0u : (n - lo >= 32 ? 0xFFFFFFFFu : ((1u << (n - lo)) - 1u));
             bm[w] = m;

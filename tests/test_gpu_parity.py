@@ -136,6 +136,41 @@ def test_gpu_reads_up_to_512_kmers(s10_gpu, s10_oracle, windows):
         assert conservation_triples(ids) == s10_oracle.kmer_conservation(r)
 
 
+def test_gpu_threshold_union_reads_of_128_to_255_kmers(s10_gpu, s10_oracle):
+    """batches whose longest read has 128..255 k-mers (e.g. 250-base reads) keep 8-bit score counters, unbiased, and
+    compare them with the threshold byte-wise: thresholds on both sides of 128, zero, and equal to the score; chimeric reads
+    (many colour sets, complemented lists included); the scores themselves through kmer_matches."""
+    from oracle.kmer_oracle import read_fasta
+    rng = np.random.default_rng(255)
+    srcs = [max(read_fasta(g), key=len) for g in S10_GENOMES[:4]]
+    reads = []
+    for i in range(160):
+        l = int(rng.integers(158, 286)) if i else 285
+        src = srcs[i % 4]
+        st = int(rng.integers(0, len(src) - 400))
+        r = bytearray(src[st:st + l])
+        if i % 4 == 1:  # chimera of two genomes
+            o2 = srcs[(i + 1) % 4]
+            st2 = int(rng.integers(0, len(o2) - 400))
+            r[l // 2:] = o2[st2:st2 + l - l // 2]
+        if i % 3 == 2:
+            for p_ in rng.integers(0, l, 4):
+                r[p_] = b"ACGT"[int(rng.integers(0, 4))]
+        if i % 9 == 4:
+            r[int(rng.integers(0, l))] = ord("N")
+        reads.append(bytes(r))
+    reads += [srcs[0][1000:1100], srcs[1][5000:5031], b""]  # shorter reads in the same batch
+    b, o = pack_reads(reads)
+    for tau in (0.001, 0.3, 0.5, 0.55, 0.8, 1.0):
+        got, want = s10_gpu.pseudoalign_threshold_union_batch(b, o, tau), s10_oracle.threshold_union(b, o, tau)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), tau
+    mo, pos, counts = s10_gpu.kmer_matches_batch(b, o)
+    for j in range(0, len(reads), 7):
+        opos, ocnt = s10_oracle.kmer_matches(reads[j])
+        assert np.array_equal(pos[int(mo[j]):int(mo[j + 1])], opos)
+        assert np.array_equal(counts[j], ocnt)
+
+
 def test_gpu_reads_of_any_length(s10_gpu, s10_oracle):
     """ragged batch: 31 bp .. 100 kbp. Reads above 1024 k-mers are cut into overlapping segments by the host
     and their id lists merged on the device (k_merge_segments); answers must not depend on that."""
