@@ -130,13 +130,14 @@ struct fgpu_reads {
     std::vector<uint64_t> h_offs;
     uint32_t max_kmers = 0;
     uint64_t max_total_kmers = 0;  // longest read, in k-mers (not capped by segmentation)
-    // reads with more than SEG_KMERS k-mers are cut into overlapping segments (k-1 shared bases) that the
+    // reads with more than SEG_KMERS k-mers are cut into overlapping segments (k-1 shared bases), copied one after
+    // the other into the device base buffer (d_bases / d_seg_offs replace the reads' own bases and offsets), that the
     // lookup kernel treats as units; seg_first[r] = first segment of read r (n + 1 entries)
     bool has_long = false;
     std::vector<uint64_t> seg_first, seg_start, seg_end;
-    DevBuf d_seg_start, d_seg_end, d_seg_first;
+    DevBuf d_seg_offs, d_seg_first;
 };
-constexpr uint32_t SEG_KMERS = 1024;
+constexpr uint32_t SEG_KMERS = 512;  // what the 4-window lookup kernel takes as one unit
 
 struct fgpu_result {
     fgpu_index* ix = nullptr;
@@ -277,14 +278,15 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     }
     if (units == 0) return;
     const bool w13 = ix->dd.k - ix->dd.m == 12;
-    // reads of at most 128 k-mers: one window per read; up to 512 k-mers (250- to 500-base reads): 2 to 4 windows; else the general kernel
-    const int halves = seg || rd->max_kmers > 512 ? 0 : (int)((std::max<uint32_t>(rd->max_kmers, 1) + 127) / 128);
+    // units of at most 128 k-mers: one window each; up to 512 k-mers (250- to 500-base reads, segments of longer reads): 2 to 4 windows
+    const int halves = (int)((std::max<uint32_t>(rd->max_kmers, 1) + 127) / 128);
     {
         auto launch_short = [&](auto kernel) {
             const uint32_t grid = resident_grid(kernel, units, 4, ix->num_cus, 256, 0);
             Timed t(ix, res, FGPU_K_LOOKUP);
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(), rd->d_offs.as<uint64_t>(), first,
-                               count, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(), res->d_idoff.as<uint64_t>(),
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
+                               seg ? rd->d_seg_offs.as<uint64_t>() : rd->d_offs.as<uint64_t>(), seg ? u_first : first, units,
+                               res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(), res->d_idoff.as<uint64_t>(),
                                res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(), stride, res->d_tickets.as<unsigned int>(),
                                kmer_out);
         };
@@ -296,16 +298,7 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
         else if (halves == 3) launch_short(k1_lookup_short<false, 3>);
         else if (halves == 4 && w13) launch_short(k1_lookup_short<true, 4>);
         else if (halves == 4) launch_short(k1_lookup_short<false, 4>);
-        else {
-            const uint32_t grid = resident_grid(k1_lookup<1024>, units, 4, ix->num_cus, 256, 0);
-            Timed t(ix, res, FGPU_K_LOOKUP);
-            hipLaunchKernelGGL(k1_lookup<1024>, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
-                               seg ? rd->d_seg_start.as<uint64_t>() : rd->d_offs.as<uint64_t>(),
-                               seg ? rd->d_seg_end.as<uint64_t>() : (const uint64_t*)nullptr, u_first, units,
-                               res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(), res->d_idoff.as<uint64_t>(),
-                               res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(), stride,
-                               res->d_tickets.as<unsigned int>(), kmer_out);
-        }
+        else throw std::runtime_error("internal error: lookup unit longer than 512 k-mers");
         HIP_TRY(hipGetLastError());
     }
     if (!seg) return;
@@ -624,32 +617,39 @@ int fgpu_reads_upload(fgpu_index* ix, const char* bases, const uint64_t* offs, u
             rd->max_kmers = std::max<uint32_t>(rd->max_kmers, (uint32_t)std::min<uint64_t>(nk, SEG_KMERS));
             rd->cum_kmers[i + 1] = rd->cum_kmers[i] + nk;
         }
+        const uint64_t nb = offs[n];
         if (rd->has_long) {
             rd->seg_first.assign(1, 0);
+            std::vector<char> seg_bases;
+            std::vector<uint64_t> seg_offs(1, 0);
+            seg_bases.reserve(nb + nb / 16 + 64);
+            auto add_segment = [&](uint64_t b0, uint64_t b1) {
+                rd->seg_start.push_back(b0);
+                rd->seg_end.push_back(b1);
+                seg_bases.insert(seg_bases.end(), bases + b0, bases + b1);
+                seg_offs.push_back(seg_bases.size());
+            };
             for (uint64_t i = 0; i < n; ++i) {
                 const uint64_t len = offs[i + 1] - offs[i];
                 const uint64_t nk = len >= k ? len - k + 1 : 0;
-                if (nk <= SEG_KMERS) {
-                    rd->seg_start.push_back(offs[i]);
-                    rd->seg_end.push_back(offs[i + 1]);
-                } else {
-                    for (uint64_t s0 = 0; s0 < nk; s0 += SEG_KMERS) {
-                        rd->seg_start.push_back(offs[i] + s0);
-                        rd->seg_end.push_back(offs[i] + std::min(nk, s0 + SEG_KMERS) + k - 1);
-                    }
-                }
+                if (nk <= SEG_KMERS) add_segment(offs[i], offs[i + 1]);
+                else
+                    for (uint64_t s0 = 0; s0 < nk; s0 += SEG_KMERS) add_segment(offs[i] + s0, offs[i] + std::min(nk, s0 + SEG_KMERS) + k - 1);
                 rd->seg_first.push_back(rd->seg_start.size());
             }
-            upload(rd->d_seg_start, rd->seg_start, ix->stream);
-            upload(rd->d_seg_end, rd->seg_end, ix->stream);
+            upload(rd->d_seg_offs, seg_offs, ix->stream);
             upload(rd->d_seg_first, rd->seg_first, ix->stream);
+            rd->d_bases.ensure(seg_bases.size() + 1024);  // the lookup kernel reads up to 576 bases past a unit's start unconditionally
+            if (!seg_bases.empty())
+                HIP_TRY(hipMemcpyAsync(rd->d_bases.p, seg_bases.data(), seg_bases.size(), hipMemcpyHostToDevice, ix->stream));
+            HIP_TRY(hipStreamSynchronize(ix->stream));  // seg_bases / seg_offs are released at the end of this block
+        } else {
+            rd->d_bases.ensure(nb + 1024);
+            rd->d_offs.ensure((n + 1) * 8);
+            if (nb) HIP_TRY(hipMemcpyAsync(rd->d_bases.p, bases, nb, hipMemcpyHostToDevice, ix->stream));
+            HIP_TRY(hipMemcpyAsync(rd->d_offs.p, offs, (n + 1) * 8, hipMemcpyHostToDevice, ix->stream));
+            HIP_TRY(hipStreamSynchronize(ix->stream));
         }
-        const uint64_t nb = offs[n];
-        rd->d_bases.ensure(nb + 1024);  // the lookup kernels read up to 576 bases past a read's start unconditionally
-        rd->d_offs.ensure((n + 1) * 8);
-        if (nb) HIP_TRY(hipMemcpyAsync(rd->d_bases.p, bases, nb, hipMemcpyHostToDevice, ix->stream));
-        HIP_TRY(hipMemcpyAsync(rd->d_offs.p, offs, (n + 1) * 8, hipMemcpyHostToDevice, ix->stream));
-        HIP_TRY(hipStreamSynchronize(ix->stream));
     });
     if (rc) { fgpu_reads_free(rd); return rc; }
     *out = rd;
@@ -661,8 +661,7 @@ void fgpu_reads_free(fgpu_reads* rd) {
     (void)hipSetDevice(rd->ix->device);
     rd->d_bases.release();
     rd->d_offs.release();
-    rd->d_seg_start.release();
-    rd->d_seg_end.release();
+    rd->d_seg_offs.release();
     rd->d_seg_first.release();
     delete rd;
 }

@@ -4,7 +4,7 @@
 //                  (+ multiplicities). Replaces index::fetch_color_set_ids and the k-mer streaming half
 //                  of pseudoalign_threshold_union (ps_full_intersection.cpp:334-374,
 //                  ps_threshold_union.cpp:327-387) including u2c (index.hpp:37).
-//   k_merge_segments  reads longer than 1024 k-mers: id lists of their segments -> one list per read
+//   k_merge_segments  reads longer than 512 k-mers: id lists of their segments -> one list per read
 //   k2a_intersect  hybrid `intersect` (ps_full_intersection.cpp:32-127) -> result bitmap + size
 //   k3a_union      hybrid `merge`     (ps_threshold_union.cpp:16-40)   -> result bitmap + size
 //   k_generic      meta / differential / meta-differential: intersect and merge (ps_full_intersection.cpp:129-332,
@@ -164,176 +164,16 @@ __device__ __forceinline__ uint32_t probe(const DevDict& d, uint64_t h0, bool do
 // ---------------------------------------------------------------------------------------------
 // Outputs per read r (relative to `first`): nids[r], npos[r] (# positive k-mers), idoff[r] = r * stride
 // (fixed-stride slab: no allocation traffic between waves), and in the pools: ids ascending + how many
-// positive k-mers had each id.
-template <int KMAX>
-__global__ __launch_bounds__(256) void k1_lookup(DevDict d, const uint8_t* __restrict__ bases,
-                                                 const uint64_t* __restrict__ offs, const uint64_t* __restrict__ ends,
-                                                 uint64_t first, uint64_t n_reads,
-                                                 uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
-                                                 uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
-                                                 uint32_t* __restrict__ cnt_pool, uint32_t stride, unsigned int* tickets,
-                                                 uint32_t* __restrict__ kmer_out) {
-    __shared__ uint64_t s_hash[4][80];
-    __shared__ uint32_t s_ids[4][KMAX];
-    __shared__ uint32_t s_uid[4][KMAX];
-    __shared__ uint32_t s_ucnt[4][KMAX];
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
-    uint64_t* hsh = s_hash[wv];
-    uint32_t* ids = s_ids[wv];
-    uint32_t* uid = s_uid[wv];
-    uint32_t* ucnt = s_ucnt[wv];
-    const uint32_t k = d.k, m = d.m, W = k - m + 1;
-    const WorkQueue wq{tickets, n_reads, 8};
-    uint64_t t_first;
-    uint32_t t_count;
-
-    while (wq.pull(t_first, t_count))
-    for (uint64_t r = t_first; r < t_first + t_count; ++r) {
-        const uint64_t rb = offs[first + r];
-        // `ends` is given when the units are overlapping segments of long reads (host-side split)
-        const uint32_t len = (uint32_t)((ends ? ends[first + r] : offs[first + r + 1]) - rb);
-        const uint32_t nk = len >= k ? min(len - k + 1, (uint32_t)KMAX) : 0;  // host guarantees <= KMAX
-        const uint8_t* seq = bases + rb;
-
-        // bit planes of bases [w0, w0+64) (A) and [w0+64, w0+128) (B), built with ballots
-        uint64_t loA, hiA, nvA;
-        {
-            uint32_t c = (uint32_t)lane < len ? base_code(seq[lane]) : 0xFFu;
-            loA = __ballot(c <= 3 && (c & 1));
-            hiA = __ballot(c <= 3 && (c & 2));
-            nvA = __ballot(c > 3);
-        }
-        for (uint32_t w0 = 0; w0 < nk; w0 += 64) {
-            const uint32_t p1 = w0 + 64 + lane;
-            const uint32_t c1 = p1 < len ? base_code(seq[p1]) : 0xFFu;
-            const uint64_t loB = __ballot(c1 <= 3 && (c1 & 1));
-            const uint64_t hiB = __ballot(c1 <= 3 && (c1 & 2));
-            const uint64_t nvB = __ballot(c1 > 3);
-
-            // hash of the canonical m-mer starting at every base of the window (+ k-m extra on the right)
-            hsh[lane] = canonical_key(extract128(loA, loB, lane, m), extract128(hiA, hiB, lane, m), m);
-            if ((uint32_t)lane < k - m) {
-                uint32_t l2 = (uint32_t)(loB >> lane) & low_mask32(m), h2 = (uint32_t)(hiB >> lane) & low_mask32(m);
-                hsh[64 + lane] = canonical_key(l2, h2, m);
-            }
-            wave_lds_sync();
-
-            const bool active = w0 + lane < nk;
-            uint32_t csid = NEG;
-            const uint32_t knv = extract128(nvA, nvB, lane, k);
-            if (active && knv == 0) {
-                const uint32_t klo = extract128(loA, loB, lane, k), khi = extract128(hiA, hiB, lane, k);
-                uint32_t bestL = 0xFFFFFFFFu, bestR = 0xFFFFFFFFu;
-                for (uint32_t j = 0; j < W; ++j) {
-                    const uint32_t o = order24(hsh[lane + j]) << 4;
-                    bestL = min(bestL, o | j);          // leftmost smallest
-                    bestR = min(bestR, o | (15u - j));  // rightmost smallest
-                }
-                const uint32_t jL = bestL & 15u, jR = 15u - (bestR & 15u);
-                const uint64_t hL = hsh[lane + jL], hR = hsh[lane + jR];
-                const uint32_t rlo = rc_plane(klo, k), rhi = rc_plane(khi, k);
-                csid = probe(d, hL, true, hL == hR, jL, k - m - jR, klo, khi, rlo, rhi);
-                if (csid == NEG && hL != hR) csid = probe(d, hR, false, true, jL, k - m - jR, klo, khi, rlo, rhi);
-            }
-            if (active) ids[w0 + lane] = csid;
-            wave_lds_sync();
-            loA = loB; hiA = hiB; nvA = nvB;
-        }
-
-        // optional: colour-set id of every k-mer (0xFFFFFFFF = negative), the input of the reference's
-        // kmer_conservation / kmer_matches queries (src/kmer_conservation.cpp:7-54, src/kmer_matches.cpp:7-30)
-        if (kmer_out)
-            for (uint32_t i = lane; i < nk; i += 64) kmer_out[r * (uint64_t)stride + i] = ids[i];
-        // ---- sorted distinct ids + multiplicities -------------------------------------------------
-        // Consecutive k-mers mostly sit on the same unitig, so first compress runs: a "head" is a positive
-        // k-mer whose id differs from its left neighbour (or that starts a 64-lane chunk); heads and run
-        // lengths are compacted into LDS with ballot + mbcnt. Typically < 12 heads per read.
-        uint32_t H = 0, positives = 0;
-        for (uint32_t b0 = 0; b0 < nk; b0 += 64) {
-            const uint32_t i = b0 + lane;
-            const uint32_t clen = min(64u, nk - b0);
-            const uint32_t v = i < nk ? ids[i] : NEG;
-            const uint32_t pv = (lane > 0 && i < nk) ? ids[i - 1] : NEG;
-            const bool change = lane == 0 || v != pv || (uint32_t)lane >= clen;
-            const uint64_t C = __ballot(change);
-            const bool head = v != NEG && change;
-            const uint64_t Hm = __ballot(head);
-            positives += __popcll(__ballot(v != NEG));
-            const uint64_t rest = lane == 63 ? 0ull : (C >> (lane + 1));
-            const uint32_t next = rest ? (uint32_t)__builtin_ctzll(rest) + lane + 1 : 64u;
-            if (head && H + mask_rank(Hm) < (uint32_t)KMAX) {
-                uid[H + mask_rank(Hm)] = v;
-                ucnt[H + mask_rank(Hm)] = min(next, clen) - lane;
-            }
-            H += __popcll(Hm);
-        }
-        wave_lds_sync();
-        uint32_t cnt = 0;
-        const uint64_t base = r * (uint64_t)stride;
-        if (H <= 64) {
-            // lane j owns head j: total multiplicity of its id, whether it is the first head with that id,
-            // and its rank among the distinct ids
-            const uint32_t vj = (uint32_t)lane < H ? uid[lane] : NEG;
-            uint32_t total = 0;
-            bool first = (uint32_t)lane < H;
-            for (uint32_t i = 0; i < H; ++i) {
-                const uint32_t vi = uid[i], li = ucnt[i];
-                if (vi == vj) {
-                    total += li;
-                    if (i < (uint32_t)lane) first = false;
-                }
-            }
-            uint64_t reps = __ballot(first);
-            cnt = __popcll(reps);
-            uint32_t pos = 0;
-            while (reps) {
-                const int i = __builtin_ctzll(reps);
-                reps &= reps - 1;
-                pos += uid[i] < vj;
-            }
-            if (first) {
-                ids_pool[base + pos] = vj;
-                cnt_pool[base + pos] = total;
-            }
-        } else {
-            // many heads (only possible for long or very fragmented reads): repeated minimum extraction
-            uint32_t last = 0;
-            bool have_last = false;
-            for (;;) {
-                uint32_t lm = NEG;
-                for (uint32_t i = lane; i < nk; i += 64) {
-                    uint32_t v = ids[i];
-                    if (v != NEG && (!have_last || v > last)) lm = min(lm, v);
-                }
-                const uint32_t wm = wave_min_u32(lm);
-                if (wm == NEG) break;
-                uint32_t c = 0;
-                for (uint32_t i = lane; i < nk; i += 64) c += (ids[i] == wm);
-                c = wave_sum_u32(c);
-                if (lane == 0) {
-                    ids_pool[base + cnt] = wm;
-                    cnt_pool[base + cnt] = c;
-                }
-                last = wm;
-                have_last = true;
-                ++cnt;
-            }
-        }
-        if (lane == 0) {
-            nids[r] = cnt;
-            npos[r] = positives;
-            idoff[r] = base;
-        }
-        wave_lds_sync();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1 for short reads (at most 128 k-mers, i.e. <= 158 bases at k = 31): same results as k1_lookup, but
-// organised for memory-level parallelism: read offsets are fetched once per ticket, the bases of the
+// positive k-mers had each id; optionally the colour-set id of every k-mer (0xFFFFFFFF = negative), the input of
+// the reference's kmer_conservation / kmer_matches queries (src/kmer_conservation.cpp:7-54, src/kmer_matches.cpp:7-30).
+// A unit (a read, or a segment of a read longer than 512 k-mers) is processed in windows of 128 k-mers, i.e. 158
+// bases at k = 31, organised for memory-level parallelism: read offsets are fetched once per ticket, the bases of the
 // NEXT read are requested before the current one is processed, each lane owns two k-mers (i and i+64)
 // and the dependent probe steps are issued for both together: 2 pilots -> 2 slots -> 2 overflow pairs
 // -> up to 8 string fetches in flight.
+// Distinct ids: consecutive k-mers mostly sit on the same unitig, so first compress runs: a "head" is a positive
+// k-mer whose id differs from its left neighbour (or that starts a 64-lane chunk); heads and run
+// lengths are compacted into LDS with ballot + mbcnt. Typically < 12 heads per read.
 // ---------------------------------------------------------------------------------------------
 // W13 = true fixes the number of m-mers per k-mer at 13 (k - m = 12, e.g. k = 31, m = 19) so that the
 // minimizer scan unrolls completely. The probe section is written without branches: every load is issued
@@ -565,7 +405,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? 8 : (HALVES == 3 ? 6 : 5)) void 
             }  // window
             const uint32_t nk = nk_read;
 
-            // ---- sorted distinct ids + multiplicities (run heads, see k1_lookup) ----
+            // ---- sorted distinct ids + multiplicities (run heads) ----
             uint32_t H = 0, positives = 0;
             for (uint32_t b0i = 0; b0i < nk; b0i += 64) {
                 const uint32_t i = b0i + lane;
@@ -643,10 +483,10 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? 8 : (HALVES == 3 ? 6 : 5)) void 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Long reads: the lookup kernel ran on segments of at most 1024 k-mers; this kernel merges the sorted id
+// Long reads: the lookup kernel ran on segments of at most 512 k-mers; this kernel merges the sorted id
 // lists of the segments of every read into what one pass over the whole read would have produced: sorted
 // distinct ids, summed multiplicities, summed positive counts (fetch_color_set_ids sorts and deduplicates
-// over the whole read: ps_full_intersection.cpp:361-373). One wave per read. Up to 64 segments (65536
+// over the whole read: ps_full_intersection.cpp:361-373). One wave per read. Up to 64 segments (32768
 // k-mers): lane = one segment with a cursor into its sorted list, every step emits the smallest id under
 // the cursors. More segments: repeated minimum extraction over all the lists (quadratic, very long reads only).
 // The merged list of read r is written to out_ids/out_cnt at the slab offset of its first segment.
