@@ -488,16 +488,22 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? 8 : (HALVES == 3 ? 6 : 5)) void 
 // distinct ids, summed multiplicities, summed positive counts (fetch_color_set_ids sorts and deduplicates
 // over the whole read: ps_full_intersection.cpp:361-373). One wave per read. Up to 64 segments (32768
 // k-mers): lane = one segment with a cursor into its sorted list, every step emits the smallest id under
-// the cursors. More segments: repeated minimum extraction over all the lists (quadratic, very long reads only).
+// the cursors. Up to 512 segments: the same with the cursors in LDS, several segments per lane. More segments:
+// repeated minimum extraction over all the lists (quadratic, reads beyond 262144 k-mers only).
 // The merged list of read r is written to out_ids/out_cnt at the slab offset of its first segment.
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t MERGE_MAX_SEGMENTS = 512;  // 262144 k-mers; longer reads: repeated minimum extraction
 __global__ __launch_bounds__(256) void k_merge_segments(const uint32_t* __restrict__ seg_nids, const uint32_t* __restrict__ seg_npos,
                                                         const uint32_t* __restrict__ seg_ids, const uint32_t* __restrict__ seg_cnt,
                                                         uint32_t stride, const uint64_t* __restrict__ seg_first, uint64_t first,
                                                         uint64_t n_reads, uint32_t* __restrict__ out_nids,
                                                         uint32_t* __restrict__ out_npos, uint64_t* __restrict__ out_idoff,
                                                         uint32_t* __restrict__ out_ids, uint32_t* __restrict__ out_cnt) {
+    __shared__ uint32_t s_cur[4][MERGE_MAX_SEGMENTS];
+    __shared__ uint32_t s_len[4][MERGE_MAX_SEGMENTS];
     const int lane = lane_id();
+    uint32_t* cur = s_cur[threadIdx.x >> 6];
+    uint32_t* len = s_len[threadIdx.x >> 6];
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t u_first = seg_first[first];
@@ -523,6 +529,36 @@ __global__ __launch_bounds__(256) void k_merge_segments(const uint32_t* __restri
                 if (lane == 0) {
                     out_ids[base + out] = wm;
                     out_cnt[base + out] = total;
+                }
+                ++out;
+            }
+        } else if (u1 - u0 <= MERGE_MAX_SEGMENTS) {
+            // the same merge with the cursors in LDS: lane l owns segments l, l + 64, ...
+            const uint32_t nseg = (uint32_t)(u1 - u0);
+            for (uint32_t sg = lane; sg < nseg; sg += 64) {
+                cur[sg] = 0;
+                len[sg] = seg_nids[u0 + sg];
+            }
+            for (;;) {
+                uint32_t lm = NEG;
+                for (uint32_t sg = lane; sg < nseg; sg += 64) {
+                    const uint32_t c = cur[sg];
+                    if (c < len[sg]) lm = min(lm, seg_ids[(u0 + sg) * stride + c]);
+                }
+                const uint32_t wm = wave_min_u32(lm);
+                if (wm == NEG) break;
+                uint32_t c_sum = 0;
+                for (uint32_t sg = lane; sg < nseg; sg += 64) {
+                    const uint32_t c = cur[sg];
+                    if (c < len[sg] && seg_ids[(u0 + sg) * stride + c] == wm) {
+                        c_sum += seg_cnt[(u0 + sg) * stride + c];
+                        cur[sg] = c + 1;
+                    }
+                }
+                c_sum = wave_sum_u32(c_sum);
+                if (lane == 0) {
+                    out_ids[base + out] = wm;
+                    out_cnt[base + out] = c_sum;
                 }
                 ++out;
             }

@@ -172,14 +172,15 @@ def test_gpu_threshold_union_reads_of_128_to_255_kmers(s10_gpu, s10_oracle):
 
 
 def test_gpu_reads_of_any_length(s10_gpu, s10_oracle):
-    """ragged batch: 31 bp .. 100 kbp. Reads above 1024 k-mers are cut into overlapping segments by the host
+    """ragged batch: 31 bp .. 300 kbp. Reads above 512 k-mers are cut into overlapping segments by the host
     and their id lists merged on the device (k_merge_segments); answers must not depend on that."""
     from oracle.kmer_oracle import read_fasta
     src = max(read_fasta(S10_GENOMES[5]), key=len)
     lens = [1054, 700, 300, 151, 1000, 31, 64, 95, 96, 159, 1055, 2078, 5000, 60000, 30, 0, 1100]
     reads = [src[i * 1000:i * 1000 + l] for i, l in enumerate(lens)]
     reads.append(src[200000:203000].replace(b"A", b"N", 3))  # long read with invalid windows
-    reads.append(src[300000:400000])  # 98 segments: more than one lane per segment in the device merge
+    reads.append(src[300000:400000])  # 196 segments of 512 k-mers: several segments per lane in the device merge
+    reads.append(src[50000:350000])  # 586 segments: beyond the LDS cursors of the merge kernel
     reads.append(src[300000:330000] + b"N" + src[300000:330000])  # every id list occurs in two groups of segments
     b, o = pack_reads(reads)
     for got, want in ((s10_gpu.pseudoalign_full_intersection_batch(b, o), s10_oracle.full_intersection(b, o)),
