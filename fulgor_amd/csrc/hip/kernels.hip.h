@@ -182,10 +182,10 @@ __device__ __forceinline__ uint32_t probe(const DevDict& d, uint64_t h0, bool do
 // the limiter.
 // HALVES = 2, 3, 4 take reads of up to 256 / 384 / 512 k-mers (286 / 414 / 542 bases at k = 31) as overlapping windows of
 // 128 k-mers (k-mers [0,128) from bases [0,158), k-mers [128,256) from bases [128,286), ...): the window minima and the
-// probe run once per window, the distinct-id step once per read. Occupancy: 8 waves/SIMD up to two windows (64 VGPRs, the
-// two-window variant with 24 bytes of scratch), then bounded by the LDS id arrays (6 and 5 waves).
+// probe run once per window, the distinct-id step once per read. Occupancy: 8 waves/SIMD for every window count (64 VGPRs; 24 / 40 / 60
+// bytes of scratch with 2 / 3 / 4 windows measured faster than the spill-free 7, 6 or 5 waves).
 template <bool W13, int HALVES>
-__global__ __launch_bounds__(256, HALVES <= 2 ? 8 : (HALVES == 3 ? 6 : 5)) void k1_lookup_short(DevDict d, const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(256, 8) void k1_lookup_short(DevDict d, const uint8_t* __restrict__ bases,
                                                        const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
                                                        uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
                                                        uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
@@ -198,8 +198,10 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? 8 : (HALVES == 3 ? 6 : 5)) void 
     __shared__ uint32_t s_minL[4][152];
     __shared__ uint32_t s_minR[4][152];
     __shared__ uint32_t s_ids[4][KMAX];
-    __shared__ uint32_t s_uid[4][KMAX];
-    __shared__ uint32_t s_ucnt[4][KMAX];
+    // run heads: only the first 64 are ever read (more heads take the extraction path below, which reads `ids`)
+    constexpr int UCAP = HALVES == 1 ? KMAX : 64;
+    __shared__ uint32_t s_uid[4][UCAP];
+    __shared__ uint32_t s_ucnt[4][UCAP];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     uint32_t* mL = s_minL[wv];
     uint32_t* mR = s_minR[wv];
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? 8 : (HALVES == 3 ? 6 : 5)) void 
                 positives += __popcll(__ballot(v != NEG));
                 const uint64_t rest = lane == 63 ? 0ull : (C >> (lane + 1));
                 const uint32_t next = rest ? (uint32_t)__builtin_ctzll(rest) + lane + 1 : 64u;
-                if (head) {
+                if (head && (HALVES == 1 || H + mask_rank(Hm) < (uint32_t)UCAP)) {
                     uid[H + mask_rank(Hm)] = v;
                     ucnt[H + mask_rank(Hm)] = min(next, clen) - lane;
                 }
