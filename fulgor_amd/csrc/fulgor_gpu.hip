@@ -362,7 +362,7 @@ void stage_descriptors(fgpu_index* ix, fgpu_result* res, uint64_t max_total_ids,
     res->d_desc.ensure(std::max<uint64_t>(1, res->total_ids) * sizeof(ListDesc));
     Timed t(ix, res, FGPU_K_DESC);
     const uint64_t threads = n * 16;
-    hipLaunchKernelGGL(k_desc, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, ix->dc, res->d_nids.as<uint32_t>(),
+    hipLaunchKernelGGL(k_desc, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, res->d_nids.as<uint32_t>(),
                        res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(),
                        res->have_ids ? res->d_cnt_pool.as<uint32_t>() : (const uint32_t*)nullptr, res->d_idcsr.as<uint64_t>(), n,
                        res->d_desc.as<ListDesc>());

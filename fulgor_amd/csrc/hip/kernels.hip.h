@@ -626,7 +626,7 @@ struct __attribute__((aligned(16))) ListDesc {
 __device__ __forceinline__ int desc_type(const ListDesc& d) { return (int)(d.meta & 0xFFu); }
 __device__ __forceinline__ uint64_t desc_body(const ListDesc& d) { return d.begin + (d.meta >> 8); }
 
-__global__ __launch_bounds__(256) void k_desc(DevColors c, const uint32_t* __restrict__ nids,
+__global__ __launch_bounds__(256) void k_desc(const uint32_t* __restrict__ nids,
                                               const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ ids_src,
                                               const uint32_t* __restrict__ cnt_src, const uint64_t* __restrict__ dst_off,
                                               uint64_t n_reads, ListDesc* __restrict__ out) {
