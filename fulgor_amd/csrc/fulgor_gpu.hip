@@ -388,7 +388,8 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         if (!uni && algo != FGPU_FULL_INTERSECTION) throw std::runtime_error("unknown algorithm");
         if (uni && res->max_kmers_in_batch > 32767)  // biased 16-bit score counters at most
             throw std::runtime_error("threshold-union on the meta / differential codecs supports reads of at most 32767 k-mers");
-        const int bits = res->max_kmers_in_batch <= 127 ? 8 : 16;
+        const bool plain8 = res->max_kmers_in_batch > 127 && res->max_kmers_in_batch <= 255;  // (as for the hybrid union)
+        const int bits = res->max_kmers_in_batch <= 255 ? 8 : 16;
         const size_t per_wave = wave_scratch_bytes_compact() + (size_t)(uni ? G_SETS_UNION : G_SETS) * W * 4 +
                                 (uni ? (size_t)W * 4 * bits : (size_t)W * 4);
         uint32_t* scores_out = nullptr;
@@ -406,6 +407,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
             HIP_TRY(hipGetLastError());
         };
         if (!uni) launch(k_generic<false, 16>);
+        else if (plain8) launch(k_generic<true, 8, false>);
         else if (bits == 8) launch(k_generic<true, 8>);
         else launch(k_generic<true, 16>);
     } else if (algo == FGPU_FULL_INTERSECTION) {

@@ -1161,13 +1161,14 @@ constexpr uint32_t G_BLOCK_REF = 0x80000000u;
 constexpr uint32_t G_SETS = 4;  // colour sets of a read rebuilt concurrently (one LDS plane each)
 constexpr uint32_t G_SETS_UNION = 2;  // fewer for the union: its score planes take most of the LDS
 
-template <bool UNION, int BITS>
+template <bool UNION, int BITS, bool BIASED = true>
 __global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 5 : 4) : 7) void k_generic(DevGeneric g, const uint32_t* __restrict__ npos, const uint64_t* __restrict__ id_csr,
                           const ListDesc* __restrict__ desc, double tau, uint64_t n_reads,
                           uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count, unsigned int* tickets,
                           uint32_t* __restrict__ scores_out) {
     // scores_out (UNION only): also store score[c] for every colour, n u32 per read (index::kmer_matches)
-    // score counters as in k3a: biased BITS-bit fields (8 for reads of at most 127 k-mers, else 16),
+    // score counters as in k3a: biased BITS-bit fields (8 for reads of at most 127 k-mers, else 16), or plain 8-bit
+    // fields compared byte-wise with min_score for reads of 128 to 255 k-mers (BIASED = false);
     // colour c -> plane c % PLANES, word c / 32, field (c % 32) / PLANES
     constexpr uint32_t PLANES = BITS, HALF = 1u << (BITS - 1), ONES = BITS == 8 ? 0x01010101u : 0x00010001u;
     constexpr uint32_t FIELD = (1u << BITS) - 1u;
@@ -1203,7 +1204,7 @@ __global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 5 : 4) : 7) void k_generi
         }
         const uint32_t min_score = UNION ? (uint32_t)(unsigned long long)((double)npos[r] * tau) : 0u;
         if (UNION) {
-            const uint32_t start = (HALF - min_score) * ONES;  // score >= min_score  <=>  top bit of the field
+            const uint32_t start = BIASED ? (HALF - min_score) * ONES : 0u;  // biased: score >= min_score  <=>  top bit of the field
             for (uint32_t i = lane; i < W4 * PLANES; i += 64) EX4[i] = make_uint4(start, start, start, start);
         } else {
             for (uint32_t g4 = lane; g4 < W4; g4 += 64) {  // colours >= n start excluded
@@ -1312,13 +1313,26 @@ __global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 5 : 4) : 7) void k_generi
             if (scores_out) {  // counter = HALF - min_score + score
                 for (uint32_t cc = lane; cc < n; cc += 64) {
                     const uint32_t x = ACC[(cc % PLANES) * W + (cc >> 5)];
-                    scores_out[r * (uint64_t)n + cc] = ((x >> (BITS * ((cc & 31u) / PLANES))) & FIELD) - HALF + min_score;
+                    const uint32_t field = (x >> (BITS * ((cc & 31u) / PLANES))) & FIELD;
+                    scores_out[r * (uint64_t)n + cc] = BIASED ? field - HALF + min_score : field;
                 }
             }
+            const uint32_t thr_c = (256u - min_score) & 0xFFu;  // (plain counters only, as in k3a)
+            const uint32_t add7 = (thr_c & 0x7Fu) * 0x01010101u, top7 = (thr_c & 0x80u) ? 0xFFFFFFFFu : 0u;
+            const uint32_t all_pass = min_score == 0 ? 0xFFFFFFFFu : 0u;
             for (uint32_t w = lane; w < W; w += 64) {
                 uint32_t m = 0;
 #pragma unroll
-                for (uint32_t q = 0; q < PLANES; ++q) m |= ((ACC[q * W + w] >> (BITS - 1)) & ONES) << q;
+                for (uint32_t q = 0; q < PLANES; ++q) {
+                    const uint32_t x = ACC[q * W + w];
+                    if (BIASED) {
+                        m |= ((x >> (BITS - 1)) & ONES) << q;
+                    } else {
+                        const uint32_t low = (x & 0x7F7F7F7Fu) + add7;
+                        const uint32_t out = (x & low) | ((x ^ low) & top7);
+                        m |= (((out | all_pass) >> 7) & ONES) << q;
+                    }
+                }
                 const uint32_t lo = w * 32;
                 m &= lo >= n ? 0u : (n - lo >= 32 ? 0xFFFFFFFFu : ((1u << (n - lo)) - 1u));
                 bm[w] = m;

@@ -285,6 +285,21 @@ def test_s4546_threshold_union_equals_oracle(s4546, tau):
     orc.threshold_union(b[:150 * 300], o[:301], tau, threads=8, self_check=True)
 
 
+@pytest.mark.parametrize("read_len", [250, 300, 500])
+def test_s4546_longer_reads_equal_oracle(s4546, read_len):
+    """4546 colours, reads of 220 / 270 / 470 k-mers: the windowed lookup kernel (2, 3, 4 windows) and the threshold union's
+    plain 8-bit (250) and 16-bit (300, 500) counters against the oracle"""
+    ix, orc, gen = s4546
+    b, o = gen.generate(300000, 6000, read_len, 42)
+    go, gc = ix.pseudoalign_full_intersection_batch(b, o)
+    oo, oc = orc.full_intersection(b, o, threads=32)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+    for tau in (0.8, 0.3):
+        go, gc = ix.pseudoalign_threshold_union_batch(b, o, tau)
+        oo, oc = orc.threshold_union(b, o, tau, threads=32)
+        assert np.array_equal(go, oo) and np.array_equal(gc, oc), tau
+
+
 def test_s4546_random_id_lists(s4546):
     """intersections of arbitrary colour-set ids: many sparse lists, > 64 lists per read, all encodings"""
     ix, orc, _ = s4546
@@ -378,6 +393,14 @@ def test_s4546_codecs_equal_hybrid(s4546, index_type, psize, csize):
     got_tu = iy.pseudoalign_threshold_union_batch(b, o, 0.8)
     assert np.array_equal(got_fi[0], want_fi[0]) and np.array_equal(got_fi[1], want_fi[1])
     assert np.array_equal(got_tu[0], want_tu[0]) and np.array_equal(got_tu[1], want_tu[1])
+    # 250-base reads: both engines keep plain 8-bit score counters (128..255 k-mers)
+    b2, o2 = gen.generate(900000, 3000, 250, 42)
+    for tau in (0.8, 0.3, 0.001):
+        w, g_ = ix.pseudoalign_threshold_union_batch(b2, o2, tau), iy.pseudoalign_threshold_union_batch(b2, o2, tau)
+        assert np.array_equal(g_[0], w[0]) and np.array_equal(g_[1], w[1]), tau
+    bs, os_ = b2[:int(o2[40])], o2[:41]
+    for x, y in zip(ix.kmer_matches_batch(bs, os_), iy.kmer_matches_batch(bs, os_)):
+        assert np.array_equal(x, y)
 
 
 def test_deduplicated_path_equals_direct_path(s4546):
