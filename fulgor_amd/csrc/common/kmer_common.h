@@ -4,8 +4,8 @@
 // (call sites: src/ps_full_intersection.cpp:341-352, src/ps_threshold_union.cpp:330-346).
 // The reference's SSHash sources are not vendored (external/sshash is empty), and per SURVEY F7 the
 // per-read result does not depend on the dictionary's internals; this layout is therefore designed
-// for the GPU: bit-plane packed unitig strings, one 8-byte record per super-k-mer, a
-// pilot-displaced perfect hash over canonical minimizers.
+// for the GPU: one open-addressing table of 64-byte buckets keyed by the canonical minimizer, whose
+// 16-byte super-k-mer records carry their own unitig context (one line fetch per lookup).
 //
 // Everything in this header compiles for both host (g++) and device (hipcc).
 #pragma once
@@ -79,65 +79,67 @@ FG_HD uint64_t mix64(uint64_t x) {
 
 FG_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 
-// Minimizer order: a cheap 24-bit multiplicative hash of the canonical m-mer key, smaller first; ties are
-// broken by position (leftmost in the orientation in which the window is read), so that reading the same
-// window on the other strand selects the rightmost tie. Packed as (order << 4 | position) in a u32 min.
-// (The order only has to be the same on host and device and reasonably random; the perfect hash below is
-// keyed by the canonical key itself through the 64-bit mixer.)
-FG_HD uint32_t order24(uint64_t canonical) {
+// Minimizer order: a cheap 22-bit multiplicative hash of the canonical m-mer key, smaller first (22 bits so that
+// order << 10 | position packs into one u32 min for reads of up to 1024 m-mers per unit). A query breaks ties by
+// position (leftmost in the orientation in which it reads the window); the dictionary covers a k-mer under every
+// tied occurrence, so either strand finds it. (The order only has to be the same on host and device and
+// reasonably random; buckets are addressed by dict_hash of the canonical key.)
+constexpr uint32_t ORDER_POS_BITS = 10;
+FG_HD uint32_t minimizer_order(uint64_t canonical) {
     uint32_t x = (uint32_t)canonical * 0x9E3779B1u ^ (uint32_t)(canonical >> 32) * 0x85EBCA77u;
     x ^= x >> 15;
     x *= 0x2C1B3C6Du;
-    return x >> 8;
+    return x >> ORDER_POS_BITS;
 }
 
-// ---- perfect hash over canonical minimizer keys ------------------------------------------------
-// Minimizers are the m-mers with the SMALLEST order hash, so mix64(key) itself is far from uniform
-// over the selected keys; the perfect hash therefore uses a second, seeded mix of it:
-//   h = phf_hash(canonical key, seed); bucket = fastrange(high32(h), num_buckets);
-//   slot = fastrange(mix32(low32(h) ^ pilot * PHI32), num_slots)
-FG_HD uint64_t phf_hash(uint64_t key, uint64_t seed) { return mix64(key ^ (seed * 0x9E3779B97F4A7C15ULL + 0x632BE59BD9B4E019ULL)); }
-constexpr uint32_t PHI32 = 0x9E3779B1u;
-FG_HD uint32_t phf_bucket(uint64_t h, uint32_t num_buckets) { return mulhi32((uint32_t)(h >> 32), num_buckets); }
-FG_HD uint32_t phf_slot(uint64_t h, uint32_t pilot, uint32_t num_slots) {
-    uint32_t v = (uint32_t)h ^ (pilot * PHI32);
-    v ^= v >> 15;
-    v *= 0x2c1b3c6du;
-    v ^= v >> 12;
-    return mulhi32(v, num_slots);
+// ---- bucket hash of a canonical minimizer key ----------------------------------------------------
+// Minimizers are the m-mers with the SMALLEST order hash, so the bucket hash must not be correlated
+// with minimizer_order: other multipliers, other mixing. bucket = mulhi32(dict_hash(key, seed), num_buckets).
+FG_HD uint32_t dict_hash(uint64_t canonical, uint32_t seed) {
+    uint32_t x = ((uint32_t)canonical ^ seed) * 0xCC9E2D51u ^ (uint32_t)(canonical >> 32) * 0x1B873593u;
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    return x;
 }
 
-// ---- 8-byte super-k-mer record -----------------------------------------------------------------
-// bits  0..30  pos   : absolute base offset of the minimizer occurrence in the concatenated unitigs
-// bit   31     fwd   : the m-mer at pos, read in unitig orientation, is its own canonical form (key(fwd) <=
-//                      key(rc)). A query whose minimizer m-mer has the same flag lies on the unitig's strand,
-//                      otherwise on the opposite one (m-mers of odd length are never palindromes), so only
-//                      ONE orientation has to be compared against the string.
-// bits 32..35  jmin  : smallest offset (minimizer start - k-mer start) of a k-mer of this super-k-mer
-// bits 36..39  jmax  : largest such offset                       (requires k - m <= 15)
-// bits 40..62  csid  : colour-set id of the unitig (u2c folded in; index.hpp:37 in the reference)
-// bit  63      tag   : 0 = record, 1 = reference into the overflow array {offset:32, count:31}
-constexpr uint64_t REC_TAG = 1ULL << 63;
-constexpr uint32_t REC_MAX_CSID = (1u << 23) - 1;
-// empty slot: jmin=15 > jmax=0 never matches
-constexpr uint64_t REC_EMPTY = (15ULL << 32);
-
-FG_HD uint64_t rec_pack(uint32_t pos, bool fwd_canonical, uint32_t jmin, uint32_t jmax, uint32_t csid) {
-    return (uint64_t)(pos & 0x7FFFFFFFu) | ((uint64_t)fwd_canonical << 31) | ((uint64_t)jmin << 32) | ((uint64_t)jmax << 36) |
-           ((uint64_t)csid << 40);
+// ---- 16-byte super-k-mer record, four per 64-byte bucket ------------------------------------------
+// The dictionary is ONE open-addressing table of 64-byte buckets keyed by the canonical minimizer: a lookup
+// is one line fetch, nothing else (no pilot table, no string fetch). A record is self-contained: it carries
+// the CONTEXT of its minimizer occurrence, the CL = 2k - m unitig bases [pos - (k - m), pos + k) (bit planes,
+// unitig orientation; bases outside the unitig are 0 and outside every valid window), so a k-mer is verified
+// against the record alone. Window s (0 <= s <= k - m) of the context is the k-mer starting at context base s;
+// the record is valid for windows smin..smax: those are the k-mers of the unitig in which the occurrence is a
+// smallest-order m-mer (leftmost, rightmost or in between: on ties a k-mer is covered by the record of every
+// tied occurrence, so that a query may pick its own leftmost minimum on either strand).
+//   w0  context, lo plane, bases 0..31
+//   w1  context, hi plane, bases 0..31
+//   w2  lo plane bases 32..42 | hi plane bases 32..42 << 11 | smin << 22 | smax << 26 | fwd << 30
+//   w3  colour-set id (31 bits; u2c folded in, index.hpp:37 of the reference) | spill << 31
+// fwd: the minimizer m-mer, read in unitig orientation, is its own canonical form (a query whose minimizer has
+// the same flag lies on the unitig's strand, otherwise on the opposite one; a palindromic m-mer, even m only,
+// gets one record per flag). spill (last record of a bucket only): some record whose home is this bucket or an
+// earlier one lives in a later bucket: the query goes on to the next bucket. An empty slot has smin > smax.
+// Needs 2k - m <= 43 and k - m <= 15 (k = 31, m = 19: exactly 43 bases).
+constexpr uint32_t REC_WORDS = 4;
+constexpr uint32_t BUCKET_RECS = 4;
+constexpr uint32_t BUCKET_WORDS = REC_WORDS * BUCKET_RECS;
+constexpr uint32_t REC_CTX_MAX = 43;
+constexpr uint32_t REC_MAX_CSID = 0x7FFFFFFFu;
+constexpr uint32_t REC_SPILL = 0x80000000u;
+constexpr uint32_t REC_W2_EMPTY = 15u << 22;  // smin = 15 > smax = 0
+FG_HD uint32_t rec_w2(uint64_t ctx_lo, uint64_t ctx_hi, uint32_t smin, uint32_t smax, bool fwd) {
+    return (uint32_t)(ctx_lo >> 32) | ((uint32_t)(ctx_hi >> 32) << 11) | (smin << 22) | (smax << 26) | ((uint32_t)fwd << 30);
 }
-FG_HD uint32_t rec_pos(uint64_t r) { return (uint32_t)r & 0x7FFFFFFFu; }
-FG_HD bool rec_fwd(uint64_t r) { return (r >> 31) & 1u; }
+FG_HD uint32_t rec_smin(uint32_t w2) { return (w2 >> 22) & 15u; }
+FG_HD uint32_t rec_smax(uint32_t w2) { return (w2 >> 26) & 15u; }
+FG_HD bool rec_fwd(uint32_t w2) { return (w2 >> 30) & 1u; }
+FG_HD uint64_t rec_ctx_lo(uint32_t w0, uint32_t w2) { return (uint64_t)w0 | ((uint64_t)(w2 & 0x7FFu) << 32); }
+FG_HD uint64_t rec_ctx_hi(uint32_t w1, uint32_t w2) { return (uint64_t)w1 | ((uint64_t)((w2 >> 11) & 0x7FFu) << 32); }
 // is the L-mer its own canonical form?
 FG_HD bool is_fwd_canonical(uint32_t lo, uint32_t hi, uint32_t L) {
     return lmer_key(lo, hi) <= lmer_key(rc_plane(lo, L), rc_plane(hi, L));
 }
-FG_HD uint32_t rec_jmin(uint64_t r) { return (uint32_t)(r >> 32) & 15u; }
-FG_HD uint32_t rec_jmax(uint64_t r) { return (uint32_t)(r >> 36) & 15u; }
-FG_HD uint32_t rec_csid(uint64_t r) { return (uint32_t)(r >> 40) & REC_MAX_CSID; }
-FG_HD uint64_t ovf_pack(uint32_t off, uint32_t cnt) { return REC_TAG | (uint64_t)off | ((uint64_t)cnt << 32); }
-FG_HD uint32_t ovf_off(uint64_t r) { return (uint32_t)r; }
-FG_HD uint32_t ovf_cnt(uint64_t r) { return (uint32_t)(r >> 32) & 0x7FFFFFFFu; }
 
 // ---- unitig strings ----------------------------------------------------------------------------
 // word w holds bases [32w, 32w+32): low 32 bits = lo plane, high 32 bits = hi plane.

@@ -72,7 +72,7 @@ struct fgpu_index {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 256;
-    DevBuf d_strings, d_pilots, d_slots, d_overflow, d_bits, d_offsets, d_set_desc, d_blk_words;
+    DevBuf d_table, d_bits, d_offsets, d_set_desc, d_blk_words;
     DevBuf d_gops, d_gset_ops_off, d_gset_ops, d_garena, d_gblk_hdr, d_gblk_words, d_gset_bytes;
     DevDict dd{};
     DevColors dc{};
@@ -171,10 +171,7 @@ void upload_index(fgpu_index* ix) {
     const Dict& d = ix->host.dict;
     const HybridSets& h = ix->host.hybrid;
     hipStream_t s = ix->stream;
-    upload(ix->d_strings, d.strings, s);
-    upload(ix->d_pilots, d.pilots, s);
-    upload(ix->d_slots, d.slots, s);
-    upload(ix->d_overflow, d.overflow, s);
+    upload(ix->d_table, d.table, s);  // the whole k-mer dictionary: one table of 64-byte buckets
     upload(ix->d_bits, h.bits, s);
     upload(ix->d_offsets, h.offsets, s);
     {  // one resolved descriptor per colour set: everything a kernel needs about a list behind one gather
@@ -201,8 +198,7 @@ void upload_index(fgpu_index* ix) {
     }
     upload(ix->d_blk_words, h.blk_words, s);
     HIP_TRY(hipStreamSynchronize(s));
-    ix->dd = DevDict{ix->d_strings.as<uint64_t>(), ix->d_pilots.as<uint16_t>(), ix->d_slots.as<uint64_t>(),
-                     ix->d_overflow.as<uint64_t>(), d.num_buckets, d.num_slots, d.k, d.m, d.seed};
+    ix->dd = DevDict{ix->d_table.as<uint32_t>(), d.num_buckets, d.k, d.m, d.seed};
     const uint32_t w32 = ((h.num_colors + 31) / 32 + 3) & ~3u;  // result bitmaps move as 128-bit groups
     ix->dc = DevColors{ix->d_bits.as<uint64_t>(), ix->d_offsets.as<uint64_t>(), ix->d_set_desc.as<ListDesc>(),
                        ix->d_blk_words.as<uint32_t>(), h.num_colors, h.sparse_thr, h.dense_thr, w32};
@@ -290,14 +286,19 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
                                res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(), stride, res->d_tickets.as<unsigned int>(),
                                kmer_out);
         };
-        if (halves == 1 && w13) launch_short(k1_lookup_short<true, 1>);
-        else if (halves == 1) launch_short(k1_lookup_short<false, 1>);
-        else if (halves == 2 && w13) launch_short(k1_lookup_short<true, 2>);
-        else if (halves == 2) launch_short(k1_lookup_short<false, 2>);
-        else if (halves == 3 && w13) launch_short(k1_lookup_short<true, 3>);
-        else if (halves == 3) launch_short(k1_lookup_short<false, 3>);
-        else if (halves == 4 && w13) launch_short(k1_lookup_short<true, 4>);
-        else if (halves == 4) launch_short(k1_lookup_short<false, 4>);
+        const bool ko = kmer_out != nullptr;
+        if (halves == 1 && w13 && !ko) launch_short(k1_lookup<true, 1, false>);
+        else if (halves == 1 && w13) launch_short(k1_lookup<true, 1, true>);
+        else if (halves == 1 && !ko) launch_short(k1_lookup<false, 1, false>);
+        else if (halves == 1) launch_short(k1_lookup<false, 1, true>);
+        else if (halves == 2 && w13 && !ko) launch_short(k1_lookup<true, 2, false>);
+        else if (halves == 2 && w13) launch_short(k1_lookup<true, 2, true>);
+        else if (halves == 2 && !ko) launch_short(k1_lookup<false, 2, false>);
+        else if (halves == 2) launch_short(k1_lookup<false, 2, true>);
+        else if (halves <= 4 && w13 && !ko) launch_short(k1_lookup<true, 4, false>);
+        else if (halves <= 4 && w13) launch_short(k1_lookup<true, 4, true>);
+        else if (halves <= 4 && !ko) launch_short(k1_lookup<false, 4, false>);
+        else if (halves <= 4) launch_short(k1_lookup<false, 4, true>);
         else throw std::runtime_error("internal error: lookup unit longer than 512 k-mers");
         HIP_TRY(hipGetLastError());
     }
@@ -535,7 +536,7 @@ void fgpu_close(fgpu_index* ix) {
     if (!ix) return;
     if (ix->device == FGPU_HOST_ONLY) { delete ix; return; }
     (void)hipSetDevice(ix->device);
-    for (DevBuf* b : {&ix->d_strings, &ix->d_pilots, &ix->d_slots, &ix->d_overflow, &ix->d_bits, &ix->d_offsets,
+    for (DevBuf* b : {&ix->d_table, &ix->d_bits, &ix->d_offsets,
                       &ix->d_set_desc, &ix->d_blk_words, &ix->d_gops, &ix->d_gset_ops_off, &ix->d_gset_ops,
                       &ix->d_garena, &ix->d_gblk_hdr, &ix->d_gblk_words, &ix->d_gset_bytes})
         b->release();

@@ -1,7 +1,7 @@
 // HIP kernels of the pseudoalignment hot path for gfx950 (CDNA4, wave64). Integer/bit work only.
 //
-//   k1_lookup      read -> k-mers -> minimizer perfect-hash lookup -> sorted distinct colour-set ids
-//                  (+ multiplicities). Replaces index::fetch_color_set_ids and the k-mer streaming half
+//   k1_lookup      (k1_lookup.hip.h) read -> minimizer runs -> one bucket fetch per run -> sorted distinct
+//                  colour-set ids (+ multiplicities). Replaces index::fetch_color_set_ids and the k-mer streaming half
 //                  of pseudoalign_threshold_union (ps_full_intersection.cpp:334-374,
 //                  ps_threshold_union.cpp:327-387) including u2c (index.hpp:37).
 //   k_merge_segments  reads longer than 512 k-mers: id lists of their segments -> one list per read
@@ -22,15 +22,6 @@
 #include "../common/kmer_common.h"
 
 namespace fg {
-
-struct DevDict {
-    const uint64_t* strings;
-    const uint16_t* pilots;
-    const uint64_t* slots;
-    const uint64_t* overflow;
-    uint32_t num_buckets, num_slots, k, m;
-    uint64_t seed;
-};
 
 struct DevColors {
     const uint64_t* bits;       // the hybrid bit stream (bitmap lists are read from it)
@@ -118,371 +109,9 @@ __device__ __forceinline__ uint32_t extract128(uint64_t A, uint64_t B, uint32_t 
     return (uint32_t)v & low_mask32(L);
 }
 
-// ---------------------------------------------------------------------------------------------
-// k-mer dictionary probe
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t try_record(const DevDict& d, uint64_t rec, uint32_t jd, uint32_t qlo, uint32_t qhi) {
-    if (jd < rec_jmin(rec) || jd > rec_jmax(rec)) return NEG;
-    const uint32_t s = rec_pos(rec) - jd;
-    const uint64_t* w = d.strings + (s >> 5);
-    uint32_t lo, hi;
-    string_lmer(w[0], w[1], s & 31u, d.k, lo, hi);
-    return (lo == qlo && hi == qhi) ? rec_csid(rec) : NEG;
-}
-
-// Probe the bucket of minimizer hash h. A: query strand == unitig strand, minimizer at offset jA;
-// B: query is the reverse complement, minimizer at offset jB of the reverse-complemented k-mer.
-__device__ __forceinline__ uint32_t probe(const DevDict& d, uint64_t h0, bool doA, bool doB, uint32_t jA, uint32_t jB,
-                                          uint32_t klo, uint32_t khi, uint32_t rlo, uint32_t rhi) {
-    const uint64_t h = phf_hash(h0, d.seed);
-    const uint32_t pilot = d.pilots[phf_bucket(h, d.num_buckets)];
-    uint64_t e = d.slots[phf_slot(h, pilot, d.num_slots)];
-    const uint64_t* p = nullptr;
-    uint32_t cnt = 1;
-    if (e & REC_TAG) {
-        p = d.overflow + ovf_off(e);
-        cnt = ovf_cnt(e);
-        e = p[0];
-    }
-    for (uint32_t i = 0;;) {
-        if (doA) {
-            uint32_t c = try_record(d, e, jA, klo, khi);
-            if (c != NEG) return c;
-        }
-        if (doB) {
-            uint32_t c = try_record(d, e, jB, rlo, rhi);
-            if (c != NEG) return c;
-        }
-        if (++i >= cnt) break;
-        e = p[i];
-    }
-    return NEG;
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1: reads -> sorted distinct colour-set ids with multiplicities
-// ---------------------------------------------------------------------------------------------
-// Outputs per read r (relative to `first`): nids[r], npos[r] (# positive k-mers), idoff[r] = r * stride
-// (fixed-stride slab: no allocation traffic between waves), and in the pools: ids ascending + how many
-// positive k-mers had each id; optionally the colour-set id of every k-mer (0xFFFFFFFF = negative), the input of
-// the reference's kmer_conservation / kmer_matches queries (src/kmer_conservation.cpp:7-54, src/kmer_matches.cpp:7-30).
-// A unit (a read, or a segment of a read longer than 512 k-mers) is processed in windows of 128 k-mers, i.e. 158
-// bases at k = 31, organised for memory-level parallelism: read offsets are fetched once per ticket, the bases of the
-// NEXT read are requested before the current one is processed, each lane owns two k-mers (i and i+64)
-// and the dependent probe steps are issued for both together: 2 pilots -> 2 slots -> 2 overflow pairs
-// -> up to 8 string fetches in flight.
-// Distinct ids: consecutive k-mers mostly sit on the same unitig, so first compress runs: a "head" is a positive
-// k-mer whose id differs from its left neighbour (or that starts a 64-lane chunk); heads and run
-// lengths are compacted into LDS with ballot + mbcnt. Typically < 12 heads per read.
-// ---------------------------------------------------------------------------------------------
-// W13 = true fixes the number of m-mers per k-mer at 13 (k - m = 12, e.g. k = 31, m = 19) so that the
-// minimizer scan unrolls completely. The probe section is written without branches: every load is issued
-// unconditionally from an in-bounds address (inactive candidates read word 0) and results are selected,
-// because on this kernel the scalar unit (exec-mask bookkeeping of divergent branches), not memory, was
-// the limiter.
-// HALVES = 2, 3, 4 take reads of up to 256 / 384 / 512 k-mers (286 / 414 / 542 bases at k = 31) as overlapping windows of
-// 128 k-mers (k-mers [0,128) from bases [0,158), k-mers [128,256) from bases [128,286), ...): the window minima and the
-// probe run once per window, the distinct-id step once per read. Occupancy: 8 waves/SIMD for every window count (64 VGPRs; 24 / 40 / 60
-// bytes of scratch with 2 / 3 / 4 windows measured faster than the spill-free 7, 6 or 5 waves).
-template <bool W13, int HALVES>
-__global__ __launch_bounds__(256, 8) void k1_lookup_short(DevDict d, const uint8_t* __restrict__ bases,
-                                                       const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
-                                                       uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
-                                                       uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
-                                                       uint32_t* __restrict__ cnt_pool, uint32_t stride, unsigned int* tickets,
-                                                       uint32_t* __restrict__ kmer_out) {
-    constexpr int KMAX = 128 * HALVES;
-    constexpr int NB = 2 * HALVES + 1;  // 64-base groups fetched per read
-    // sliding-window minima by doubling: entry p = (24-bit order << 8 | tie-break position) of the best m-mer in
-    // [p, p + span), span = 1, 2, 4, 8; L breaks ties to the left (position p), R to the right (255 - p)
-    __shared__ uint32_t s_minL[4][152];
-    __shared__ uint32_t s_minR[4][152];
-    __shared__ uint32_t s_ids[4][KMAX];
-    // run heads: only the first 64 are ever read (more heads take the extraction path below, which reads `ids`)
-    constexpr int UCAP = HALVES == 1 ? KMAX : 64;
-    __shared__ uint32_t s_uid[4][UCAP];
-    __shared__ uint32_t s_ucnt[4][UCAP];
-    const int lane = lane_id(), wv = threadIdx.x >> 6;
-    uint32_t* mL = s_minL[wv];
-    uint32_t* mR = s_minR[wv];
-    uint32_t* ids = s_ids[wv];
-    uint32_t* uid = s_uid[wv];
-    uint32_t* ucnt = s_ucnt[wv];
-    const uint32_t k = d.k, m = d.m, W = W13 ? 13u : k - m + 1;
-    const uint32_t span = W13 ? 8u : 1u << (31 - __builtin_clz(W));  // largest power of two <= W (W <= 16)
-    const uint32_t km = k - m;
-    const WorkQueue wq{tickets, n_reads, 8};
-    uint64_t t_first;
-    uint32_t t_count;
-
-    while (wq.pull(t_first, t_count)) {
-        const uint64_t myoff = (uint32_t)lane <= t_count ? offs[first + t_first + lane] : 0;
-        uint64_t rb = readlane_u64(myoff, 0), re = readlane_u64(myoff, 1);  // wave-uniform: scalar registers
-        uint32_t len = (uint32_t)(re - rb);
-        const uint8_t* seq = bases + rb;
-        // reads are padded by the host buffer: positions past the read end are masked below, not branched on
-        uint32_t bb[NB];
-#pragma unroll
-        for (int g = 0; g < NB; ++g) bb[g] = seq[lane + 64 * g];
-        for (uint32_t j = 0; j < t_count; ++j) {
-            const uint64_t r = t_first + j;
-            const uint32_t cur_len = len;
-            uint32_t cc[NB];
-#pragma unroll
-            for (int g = 0; g < NB; ++g) cc[g] = (uint32_t)lane + 64 * g < cur_len ? base_code_fast(bb[g]) : 0xFFu;
-            if (j + 1 < t_count) {  // request the next read's bases now; they are consumed next iteration
-                rb = re;
-                re = readlane_u64(myoff, j + 2);
-                len = (uint32_t)(re - rb);
-                seq = bases + rb;
-#pragma unroll
-                for (int g = 0; g < NB; ++g) bb[g] = seq[lane + 64 * g];
-            }
-            const uint32_t nk_read = cur_len >= k ? min(cur_len - k + 1, (uint32_t)KMAX) : 0;
-#pragma unroll
-            for (int half = 0; half < HALVES; ++half) {
-            const uint32_t c0 = cc[2 * half], c1 = cc[2 * half + 1], c2 = cc[2 * half + 2];
-            const uint32_t nk = nk_read > 128u * half ? min(nk_read - 128u * half, 128u) : 0u;  // k-mers of this window
-            if (half > 0 && nk == 0) continue;  // (wave-uniform) a shorter read of the batch: nothing reads this window's ids
-            const uint64_t loA = __ballot(c0 <= 3 && (c0 & 1)), hiA = __ballot(c0 <= 3 && (c0 & 2)), nvA = __ballot(c0 > 3);
-            const uint64_t loB = __ballot(c1 <= 3 && (c1 & 1)), hiB = __ballot(c1 <= 3 && (c1 & 2)), nvB = __ballot(c1 > 3);
-            const uint64_t loC = __ballot(c2 <= 3 && (c2 & 1)), hiC = __ballot(c2 <= 3 && (c2 & 2)), nvC = __ballot(c2 > 3);
-
-            // window minima of the m-mer order over [i, i + W): W - 1 comparisons per k-mer become log2(span) + 1
-            uint32_t l0, l1, l2 = 0, r0, r1, r2 = 0;
-            {
-                const uint32_t o0 = order24(canonical_key(extract128(loA, loB, lane, m), extract128(hiA, hiB, lane, m), m)) << 8;
-                const uint32_t o1 = order24(canonical_key(extract128(loB, loC, lane, m), extract128(hiB, hiC, lane, m), m)) << 8;
-                l0 = o0 | (uint32_t)lane; r0 = o0 | (255u - lane);
-                l1 = o1 | (64u + lane); r1 = o1 | (191u - lane);
-                mL[lane] = l0; mR[lane] = r0;
-                mL[64 + lane] = l1; mR[64 + lane] = r1;
-                if (lane < 16) {
-                    const uint32_t o2 = order24(canonical_key((uint32_t)(loC >> lane) & low_mask32(m), (uint32_t)(hiC >> lane) & low_mask32(m), m)) << 8;
-                    l2 = o2 | (128u + lane); r2 = o2 | (127u - lane);
-                    mL[128 + lane] = l2; mR[128 + lane] = r2;
-                }
-            }
-            wave_lds_sync();
-#pragma unroll
-            for (uint32_t st = 1; st < span; st <<= 1) {  // in place: every lane reads before any lane writes
-                const uint32_t a0 = mL[lane + st], a1 = mL[64 + lane + st], b0 = mR[lane + st], b1 = mR[64 + lane + st];
-                uint32_t a2 = 0, b2 = 0;
-                if (lane < 16) { a2 = mL[128 + lane + st]; b2 = mR[128 + lane + st]; }
-                l0 = min(l0, a0); l1 = min(l1, a1); r0 = min(r0, b0); r1 = min(r1, b1);
-                mL[lane] = l0; mR[lane] = r0;
-                mL[64 + lane] = l1; mR[64 + lane] = r1;
-                if (lane < 16) {
-                    l2 = min(l2, a2); r2 = min(r2, b2);
-                    mL[128 + lane] = l2; mR[128 + lane] = r2;
-                }
-                wave_lds_sync();
-            }
-
-            bool valid[2];
-            uint32_t klo[2], khi[2], rlo[2], rhi[2], jL[2], jR[2], csid[2];
-            uint64_t hL[2], hR[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const uint64_t lx = a ? loB : loA, ly = a ? loC : loB, hx = a ? hiB : hiA, hy = a ? hiC : hiB;
-                const uint64_t nx = a ? nvB : nvA, ny = a ? nvC : nvB;
-                valid[a] = (uint32_t)(64 * a + lane) < nk && extract128(nx, ny, lane, k) == 0;
-                klo[a] = extract128(lx, ly, lane, k);
-                khi[a] = extract128(hx, hy, lane, k);
-                rlo[a] = rc_plane(klo[a], k);
-                rhi[a] = rc_plane(khi[a], k);
-            }
-            {
-                const uint32_t tail = W - span;  // [i, i + span) and [i + W - span, i + W) cover the window
-                const uint32_t bL0 = min(l0, mL[lane + tail]), bL1 = min(l1, mL[64 + lane + tail]);
-                const uint32_t bR0 = min(r0, mR[lane + tail]), bR1 = min(r1, mR[64 + lane + tail]);
-                jL[0] = (bL0 & 255u) - (uint32_t)lane;
-                jL[1] = (bL1 & 255u) - (64u + lane);
-                jR[0] = (255u - (bR0 & 255u)) - (uint32_t)lane;
-                jR[1] = (255u - (bR1 & 255u)) - (64u + lane);
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                // canonical keys of the leftmost / rightmost smallest m-mer, cut out of the k-mer itself
-                hL[a] = canonical_key((klo[a] >> jL[a]) & low_mask32(m), (khi[a] >> jL[a]) & low_mask32(m), m);
-                hR[a] = jR[a] == jL[a] ? hL[a]
-                                       : canonical_key((klo[a] >> jR[a]) & low_mask32(m), (khi[a] >> jR[a]) & low_mask32(m), m);
-            }
-            // ---- staged, branch-free probe of the leftmost-minimizer key for both k-mers ----
-            uint64_t hp[2], e[2], p0[2], p1[2];
-            uint32_t pil[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) hp[a] = phf_hash(hL[a], d.seed);
-#pragma unroll
-            for (int a = 0; a < 2; ++a) pil[a] = d.pilots[phf_bucket(hp[a], d.num_buckets)];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) e[a] = d.slots[phf_slot(hp[a], pil[a], d.num_slots)];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const uint64_t* p = d.overflow + ((e[a] & REC_TAG) ? ovf_off(e[a]) : 0u);
-                p0[a] = p[0];
-                p1[a] = p[1];
-            }
-            // First candidate: the slot's record, or the first record of its overflow list. A second record, when the
-            // slot has one and the first did not match, is tried in a second short step: keeping both candidates alive
-            // through the fetches costs 16 VGPRs, i.e. a wave per SIMD. The strand bit of the record against the
-            // canonical flag of the query's minimizer tells whether the k-mer (offset jL) or its reverse complement
-            // (offset jB) can sit on that super-k-mer.
-            bool slow[2], qfwd[2], simple[2], try2[2];
-            auto candidate = [&](int a, uint64_t rec, bool wanted, bool& con, bool& rcq, uint32_t& cs, uint32_t& csh,
-                                 uint64_t& w0, uint64_t& w1) {
-                rcq = rec_fwd(rec) != qfwd[a];  // opposite strand: compare the reverse complement
-                const uint32_t jd = rcq ? km - jR[a] : jL[a];
-                con = wanted && jd >= rec_jmin(rec) && jd <= rec_jmax(rec);
-                const uint32_t sp = con ? rec_pos(rec) - jd : 0u;
-                csh = sp & 31u;
-                cs = rec_csid(rec);
-                const uint64_t* w = d.strings + (sp >> 5);
-                w0 = w[0];
-                w1 = w[1];
-            };
-            auto matches = [&](int a, bool con, bool rcq, uint32_t csh, uint64_t w0, uint64_t w1) -> bool {
-                uint32_t lo, hi;
-                string_lmer(w0, w1, csh, k, lo, hi);
-                return con && lo == (rcq ? rlo[a] : klo[a]) && hi == (rcq ? rhi[a] : khi[a]);
-            };
-            {
-                uint64_t w0[2], w1[2];
-                uint32_t cs[2], csh[2];
-                bool con[2], rcq[2];
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const bool tag = (e[a] & REC_TAG) != 0;
-                    const bool same = hL[a] == hR[a];
-                    const uint32_t mlo = (klo[a] >> jL[a]) & low_mask32(m), mhi = (khi[a] >> jL[a]) & low_mask32(m);
-                    const uint64_t kf = lmer_key(mlo, mhi), kr = lmer_key(rc_plane(mlo, m), rc_plane(mhi, m));
-                    qfwd[a] = kf <= kr;
-                    // leave to the slow path: a palindromic minimizer (even m only), distinct tied minimizers, or the
-                    // same canonical m-mer occurring twice in the k-mer (then jL != jR and the two occurrences may
-                    // have opposite orientations, so one flag cannot decide the strand)
-                    simple[a] = same && kf != kr && jL[a] == jR[a];
-                    slow[a] = valid[a] && !simple[a];
-                    candidate(a, tag ? p0[a] : e[a], valid[a] && simple[a], con[a], rcq[a], cs[a], csh[a], w0[a], w1[a]);
-                }
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const bool hit = matches(a, con[a], rcq[a], csh[a], w0[a], w1[a]);
-                    csid[a] = hit ? cs[a] : NEG;
-                    try2[a] = valid[a] && simple[a] && !hit && (e[a] & REC_TAG) && ovf_cnt(e[a]) >= 2;
-                }
-            }
-            if (__any(try2[0] || try2[1])) {
-                uint64_t w0[2], w1[2];
-                uint32_t cs[2], csh[2];
-                bool con[2], rcq[2];
-#pragma unroll
-                for (int a = 0; a < 2; ++a) candidate(a, p1[a], try2[a], con[a], rcq[a], cs[a], csh[a], w0[a], w1[a]);
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-                    if (matches(a, con[a], rcq[a], csh[a], w0[a], w1[a])) csid[a] = cs[a];
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-                slow[a] = slow[a] || (valid[a] && csid[a] == NEG && (e[a] & REC_TAG) && ovf_cnt(e[a]) > 2);
-            // rare continuations: more than two records under the key, or a different rightmost key
-            if (__any(slow[0] || slow[1])) {
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    if (slow[a] && csid[a] == NEG) {  // the generic probe tries both orientations on every record
-                        const bool same = hL[a] == hR[a];
-                        const uint32_t jB = km - jR[a];
-                        csid[a] = probe(d, hL[a], true, same, jL[a], jB, klo[a], khi[a], rlo[a], rhi[a]);
-                        if (csid[a] == NEG && !same)
-                            csid[a] = probe(d, hR[a], false, true, jL[a], jB, klo[a], khi[a], rlo[a], rhi[a]);
-                    }
-                }
-            }
-            ids[128 * half + lane] = (uint32_t)lane < nk ? csid[0] : NEG;
-            ids[128 * half + 64 + lane] = (uint32_t)(64 + lane) < nk ? csid[1] : NEG;
-            if (kmer_out) {
-                if ((uint32_t)lane < nk) kmer_out[r * (uint64_t)stride + 128 * half + lane] = csid[0];
-                if ((uint32_t)(64 + lane) < nk) kmer_out[r * (uint64_t)stride + 128 * half + 64 + lane] = csid[1];
-            }
-            wave_lds_sync();
-            }  // window
-            const uint32_t nk = nk_read;
-
-            // ---- sorted distinct ids + multiplicities (run heads) ----
-            uint32_t H = 0, positives = 0;
-            for (uint32_t b0i = 0; b0i < nk; b0i += 64) {
-                const uint32_t i = b0i + lane;
-                const uint32_t clen = min(64u, nk - b0i);
-                const uint32_t v = ids[i];
-                const uint32_t pv = lane > 0 ? ids[i - 1] : NEG;
-                const bool change = lane == 0 || v != pv || (uint32_t)lane >= clen;
-                const uint64_t C = __ballot(change);
-                const bool head = v != NEG && change;
-                const uint64_t Hm = __ballot(head);
-                positives += __popcll(__ballot(v != NEG));
-                const uint64_t rest = lane == 63 ? 0ull : (C >> (lane + 1));
-                const uint32_t next = rest ? (uint32_t)__builtin_ctzll(rest) + lane + 1 : 64u;
-                if (head && (HALVES == 1 || H + mask_rank(Hm) < (uint32_t)UCAP)) {
-                    uid[H + mask_rank(Hm)] = v;
-                    ucnt[H + mask_rank(Hm)] = min(next, clen) - lane;
-                }
-                H += __popcll(Hm);
-            }
-            wave_lds_sync();
-            uint32_t cnt = 0;
-            const uint64_t base = r * (uint64_t)stride;
-            if (H <= 64) {
-                const uint32_t vj = (uint32_t)lane < H ? uid[lane] : NEG;
-                uint32_t total = 0;
-                bool firsth = (uint32_t)lane < H;
-                for (uint32_t i = 0; i < H; ++i) {
-                    const uint32_t vi = uid[i], li = ucnt[i];
-                    total += vi == vj ? li : 0u;
-                    firsth = firsth && !(vi == vj && i < (uint32_t)lane);
-                }
-                uint64_t reps = __ballot(firsth);
-                cnt = __popcll(reps);
-                uint32_t pos = 0;
-                while (reps) {
-                    const int i = __builtin_ctzll(reps);
-                    reps &= reps - 1;
-                    pos += uid[i] < vj;
-                }
-                if (firsth) {
-                    ids_pool[base + pos] = vj;
-                    cnt_pool[base + pos] = total;
-                }
-            } else {
-                uint32_t last = 0;
-                bool have_last = false;
-                for (;;) {
-                    uint32_t lm = NEG;
-                    for (uint32_t i = lane; i < nk; i += 64) {
-                        uint32_t v = ids[i];
-                        if (v != NEG && (!have_last || v > last)) lm = min(lm, v);
-                    }
-                    const uint32_t wm = wave_min_u32(lm);
-                    if (wm == NEG) break;
-                    uint32_t cc = 0;
-                    for (uint32_t i = lane; i < nk; i += 64) cc += (ids[i] == wm);
-                    cc = wave_sum_u32(cc);
-                    if (lane == 0) {
-                        ids_pool[base + cnt] = wm;
-                        cnt_pool[base + cnt] = cc;
-                    }
-                    last = wm;
-                    have_last = true;
-                    ++cnt;
-                }
-            }
-            if (lane == 0) {
-                nids[r] = cnt;
-                npos[r] = positives;
-                idoff[r] = base;
-            }
-            wave_lds_sync();
-        }
-    }
-}
+}  // namespace fg
+#include "k1_lookup.hip.h"
+namespace fg {
 
 // ---------------------------------------------------------------------------------------------
 // Long reads: the lookup kernel ran on segments of at most 512 k-mers; this kernel merges the sorted id

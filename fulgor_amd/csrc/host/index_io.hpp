@@ -51,8 +51,11 @@ inline void load_dump(const std::string& base, HostIndex& idx, uint32_t m = 0, u
         std::ifstream in(base + ".filenames.txt");
         if (!in.is_open()) throw std::runtime_error("cannot open filenames file");
         idx.filenames.clear();
-        std::string f;
-        for (uint64_t i = 0; i < num_colors && (in >> f); ++i) idx.filenames.push_back(f);
+        std::string f;  // one filename per line (src/index.cpp:76); a path may contain blanks
+        for (uint64_t i = 0; i < num_colors && std::getline(in, f); ++i) {
+            while (!f.empty() && (f.back() == '\r' || f.back() == '\n')) f.pop_back();
+            idx.filenames.push_back(f);
+        }
         if (idx.filenames.size() != num_colors) throw std::runtime_error("filenames file is short");
     }
     // colour sets
@@ -114,7 +117,7 @@ inline void load_dump(const std::string& base, HostIndex& idx, uint32_t m = 0, u
 
 // ---- own binary container ------------------------------------------------------------------------
 namespace detail {
-static const char FGIDX_MAGIC[8] = {'F', 'G', 'I', 'D', 'X', '0', '0', '5'};  // 005: 24-bit multiplicative minimizer order, PHF keyed by the canonical key
+static const char FGIDX_MAGIC[8] = {'F', 'G', 'I', 'D', 'X', '0', '0', '6'};  // 006: self-contained 16-byte super-k-mer records in 64-byte buckets
 template <typename T>
 void wr(std::ofstream& o, const T& v) { o.write(reinterpret_cast<const char*>(&v), sizeof(T)); }
 template <typename T>
@@ -148,8 +151,7 @@ inline void save_binary(const HostIndex& idx, const std::string& path) {
     wr(o, type);
     const Dict& d = idx.dict;
     wr(o, d.k); wr(o, d.m); wr(o, d.num_kmers); wr(o, d.total_bases); wr(o, d.seed);
-    wr(o, d.num_buckets); wr(o, d.num_slots);
-    wrv(o, d.strings); wrv(o, d.pilots); wrv(o, d.slots); wrv(o, d.overflow);
+    wrv(o, d.strings); wrv(o, d.records);  // the bucket table is rebuilt from the records at load
     wrv(o, d.unitig_off); wrv(o, d.unitig_csid);
     const HybridSets& h = idx.hybrid;
     wr(o, h.num_colors); wr(o, h.sparse_thr); wr(o, h.dense_thr); wr(o, h.nbits);
@@ -181,12 +183,32 @@ inline void load_binary(const std::string& path, HostIndex& idx) {
     idx.type = type;
     Dict& d = idx.dict;
     rd(i, d.k); rd(i, d.m); rd(i, d.num_kmers); rd(i, d.total_bases); rd(i, d.seed);
-    rd(i, d.num_buckets); rd(i, d.num_slots);
-    rdv(i, d.strings); rdv(i, d.pilots); rdv(i, d.slots); rdv(i, d.overflow);
+    rdv(i, d.strings); rdv(i, d.records);
     rdv(i, d.unitig_off); rdv(i, d.unitig_csid);
     HybridSets& h = idx.hybrid;
     rd(i, h.num_colors); rd(i, h.sparse_thr); rd(i, h.dense_thr); rd(i, h.nbits);
     rdv(i, h.offsets); rdv(i, h.bits);
+    {   // a truncated, stale or corrupt container must fail here, not index out of bounds later
+        auto bad = [](const char* what) { throw std::runtime_error(std::string("corrupt index file: ") + what); };
+        try { check_dict_params(d.k, d.m); } catch (std::exception&) { bad("k / m"); }
+        if (d.strings.size() < (d.total_bases + 31) / 32 + 2) bad("unitig strings shorter than total_bases");
+        if (d.records.size() % REC_WORDS) bad("record array");
+        if (d.unitig_off.size() != d.unitig_csid.size() + 1 || d.unitig_off.empty() || d.unitig_off[0] != 0 ||
+            d.unitig_off.back() != d.total_bases) bad("unitig table");
+        for (size_t u = 0; u + 1 < d.unitig_off.size(); ++u)
+            if (d.unitig_off[u + 1] < d.unitig_off[u] + d.k) bad("unitig offsets");
+        if (h.offsets.empty() || h.offsets[0] > h.offsets.back() || h.offsets.back() != h.nbits) bad("colour-set offsets");
+        for (size_t s = 0; s + 1 < h.offsets.size(); ++s)
+            if (h.offsets[s + 1] <= h.offsets[s]) bad("colour-set offsets are not increasing");
+        if (h.bits.size() * 64 < h.nbits) bad("colour-set stream shorter than nbits");
+        if (h.num_colors == 0 || h.num_colors > BLK_MAX_COLORS) bad("num_colors");
+        const uint64_t nsets = h.offsets.size() - 1;
+        for (uint32_t c : d.unitig_csid)
+            if (c >= nsets) bad("unitig colour-set id");
+        for (uint64_t r = 0; r < d.num_records(); ++r)
+            if ((d.records[r * REC_WORDS + 3] & REC_MAX_CSID) >= nsets) bad("record colour-set id");
+    }
+    build_dict_table(d);
     h.bits.resize((h.nbits + 63) / 64 + 4, 0);  // the device reads up to 256 bits past a bitmap list
     hybrid_build_blocks(h);
     if (idx.type != IDX_HYBRID) {
@@ -195,6 +217,20 @@ inline void load_binary(const std::string& path, HostIndex& idx) {
         rd(i, g.num_colors); rd(i, g.partition_size); rd(i, g.cluster_size); rd(i, g.num_partitions);
         rd(i, g.num_partial_sets); rd(i, g.num_clusters); rd(i, g.nbits);
         rdv(i, g.bits); rdv(i, g.ops); rdv(i, g.set_ops_off); rdv(i, g.set_ops); rdv(i, g.set_bytes);
+        {
+            auto bad = [](const char* what) { throw std::runtime_error(std::string("corrupt index file: ") + what); };
+            if (g.num_colors != h.num_colors) bad("codec colour count");
+            if (g.bits.size() * 64 < g.nbits) bad("codec arena shorter than nbits");
+            if (g.set_ops_off.size() != h.offsets.size() || g.set_ops_off[0] != 0 || g.set_ops_off.back() != g.set_ops.size())
+                bad("codec op lists");
+            for (size_t s = 0; s + 1 < g.set_ops_off.size(); ++s)
+                if (g.set_ops_off[s + 1] < g.set_ops_off[s]) bad("codec op offsets are not monotone");
+            for (uint32_t o : g.set_ops)
+                if (o >= g.ops.size()) bad("codec op index");
+            for (const SetOp& o : g.ops)
+                if (o.body > g.nbits || (uint64_t)o.base + o.np > g.num_colors || o.kind > OP_XOR_GAPS) bad("codec op");
+            if (g.set_bytes.size() + 1 != g.set_ops_off.size()) bad("codec byte table");
+        }
         build_generic_device(g);
     }
     uint64_t nf;

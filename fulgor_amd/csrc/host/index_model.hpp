@@ -41,17 +41,19 @@ struct Dict {
     uint32_t k = 0, m = 0;
     uint64_t num_kmers = 0;
     uint64_t total_bases = 0;
-    std::vector<uint64_t> strings;  // bit-plane words, padded with 2 zero words
-    uint64_t seed = 0;
-    uint32_t num_buckets = 0, num_slots = 0;
-    std::vector<uint16_t> pilots;   // 16-bit displacement per bucket (~6 keys per bucket): the table stays L2 resident
-    std::vector<uint64_t> slots;
-    std::vector<uint64_t> overflow;
+    std::vector<uint64_t> strings;  // bit-plane words of the unitig concatenation, padded with 2 zero words (host only:
+                                    // export / dump / self check; the records carry their own context)
+    uint32_t seed = 0;
+    std::vector<uint32_t> records;  // REC_WORDS words per super-k-mer record, in unitig order (saved; spill bits clear)
+    uint32_t num_buckets = 0;       // hashed buckets; the table holds DICT_TAIL_BUCKETS more for probe chains at the end
+    std::vector<uint32_t> table;    // BUCKET_WORDS words per bucket: the records placed by linear probing (rebuilt at load)
     // unitig table (export / u2c)
     std::vector<uint64_t> unitig_off;    // num_unitigs + 1 base offsets into the concatenation
     std::vector<uint32_t> unitig_csid;   // u2c
     uint64_t num_unitigs() const { return unitig_csid.size(); }
+    uint64_t num_records() const { return records.size() / REC_WORDS; }
 };
+constexpr uint32_t DICT_TAIL_BUCKETS = 1024;
 
 // ---- meta / differential / meta-differential colour sets (see codecs_build.hpp) ----------------------
 enum OpKind : uint32_t { OP_OR_GAPS = 0, OP_OR_BITMAP = 1, OP_OR_COMP = 2, OP_XOR_GAPS = 3 };
