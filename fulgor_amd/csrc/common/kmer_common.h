@@ -4,7 +4,7 @@
 // (call sites: src/ps_full_intersection.cpp:341-352, src/ps_threshold_union.cpp:330-346).
 // The reference's SSHash sources are not vendored (external/sshash is empty), and per SURVEY F7 the
 // per-read result does not depend on the dictionary's internals; this layout is therefore designed
-// for the GPU: one open-addressing table of 64-byte buckets keyed by the canonical minimizer, whose
+// for the GPU: one table of 64-byte buckets keyed by the minimizer, both strands of every unitig, whose
 // 16-byte super-k-mer records carry their own unitig context (one line fetch per lookup).
 //
 // Everything in this header compiles for both host (g++) and device (hipcc).
@@ -79,47 +79,59 @@ FG_HD uint64_t mix64(uint64_t x) {
 
 FG_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 
-// Minimizer order: a cheap 22-bit multiplicative hash of the canonical m-mer key, smaller first (22 bits so that
-// order << 10 | position packs into one u32 min for reads of up to 1024 m-mers per unit). A query breaks ties by
-// position (leftmost in the orientation in which it reads the window); the dictionary covers a k-mer under every
-// tied occurrence, so either strand finds it. (The order only has to be the same on host and device and
-// reasonably random; buckets are addressed by dict_hash of the canonical key.)
+// Minimizer order: a cheap 22-bit multiplicative hash of the m-mer AS READ (not of its canonical form), smaller
+// first, ties to the left (22 bits so that order << 10 | position packs into one u32 min for units of up to 1024
+// m-mers). The dictionary holds every unitig on BOTH strands, so a read is always compared in its own
+// orientation: no canonical forms, no reverse complements and no strand cases in the lookup kernel; memory
+// (twice the records) is what the 288 GB of HBM are for. (The order only has to be the same on host and device
+// and reasonably random; buckets are addressed by dict_hash of the m-mer.)
 constexpr uint32_t ORDER_POS_BITS = 10;
-FG_HD uint32_t minimizer_order(uint64_t canonical) {
-    uint32_t x = (uint32_t)canonical * 0x9E3779B1u ^ (uint32_t)(canonical >> 32) * 0x85EBCA77u;
+FG_HD uint32_t minimizer_order(uint32_t lo, uint32_t hi) {
+    uint32_t x = lo * 0x9E3779B1u ^ hi * 0x85EBCA77u;
     x ^= x >> 15;
     x *= 0x2C1B3C6Du;
     return x >> ORDER_POS_BITS;
 }
 
-// ---- bucket hash of a canonical minimizer key ----------------------------------------------------
+// ---- bucket hash of a minimizer (the m-mer as read: planes lo, hi) ---------------------------------------
 // Minimizers are the m-mers with the SMALLEST order hash, so the bucket hash must not be correlated
-// with minimizer_order: other multipliers, other mixing. bucket = mulhi32(dict_hash(key, seed), num_buckets).
-FG_HD uint32_t dict_hash(uint64_t canonical, uint32_t seed) {
-    uint32_t x = ((uint32_t)canonical ^ seed) * 0xCC9E2D51u ^ (uint32_t)(canonical >> 32) * 0x1B873593u;
+// with minimizer_order: other multipliers, other mixing. bucket = mulhi32(dict_hash(lo, hi, seed), num_buckets).
+FG_HD uint32_t dict_hash(uint32_t lo, uint32_t hi, uint32_t seed) {
+    uint32_t x = (lo ^ seed) * 0xCC9E2D51u ^ hi * 0x1B873593u;
     x ^= x >> 16;
     x *= 0x85EBCA6Bu;
     x ^= x >> 13;
     return x;
 }
+// second, independent hash of the key: tells a key's redirect slot from those of its bucket neighbours
+FG_HD uint32_t dict_tag(uint32_t lo, uint32_t hi) {
+    uint32_t x = lo * 0x27D4EB2Fu ^ hi * 0x165667B1u;
+    x ^= x >> 15;
+    x *= 0x2C1B3C6Du;
+    x ^= x >> 12;
+    return x;
+}
 
 // ---- 16-byte super-k-mer record, four per 64-byte bucket ------------------------------------------
-// The dictionary is ONE open-addressing table of 64-byte buckets keyed by the canonical minimizer: a lookup
-// is one line fetch, nothing else (no pilot table, no string fetch). A record is self-contained: it carries
-// the CONTEXT of its minimizer occurrence, the CL = 2k - m unitig bases [pos - (k - m), pos + k) (bit planes,
-// unitig orientation; bases outside the unitig are 0 and outside every valid window), so a k-mer is verified
-// against the record alone. Window s (0 <= s <= k - m) of the context is the k-mer starting at context base s;
-// the record is valid for windows smin..smax: those are the k-mers of the unitig in which the occurrence is a
-// smallest-order m-mer (leftmost, rightmost or in between: on ties a k-mer is covered by the record of every
-// tied occurrence, so that a query may pick its own leftmost minimum on either strand).
+// The dictionary is ONE table of 64-byte buckets: a hashed region addressed by the minimizer and, behind it, an
+// overflow region. A lookup is one line fetch, nothing else (no pilot table, no string fetch), plus one more for
+// the few keys that do not fit their bucket. A record is self-contained: it carries the CONTEXT of its minimizer
+// occurrence, the CL = 2k - m bases [pos - (k - m), pos + k) of the unitig strand it was cut from (bit planes; bases
+// outside the unitig are 0 and outside every valid window), so a k-mer is verified against the record alone.
+// Window s (0 <= s <= k - m) of the context is the k-mer starting at context base s; the record is valid for windows
+// smin..smax: the k-mers of that strand whose leftmost smallest-order m-mer is this occurrence (a super-k-mer).
 //   w0  context, lo plane, bases 0..31
 //   w1  context, hi plane, bases 0..31
-//   w2  lo plane bases 32..42 | hi plane bases 32..42 << 11 | smin << 22 | smax << 26 | fwd << 30
+//   w2  lo plane bases 32..42 | hi plane bases 32..42 << 11 | smin << 22 | smax << 26
 //   w3  colour-set id (31 bits; u2c folded in, index.hpp:37 of the reference) | spill << 31
-// fwd: the minimizer m-mer, read in unitig orientation, is its own canonical form (a query whose minimizer has
-// the same flag lies on the unitig's strand, otherwise on the opposite one; a palindromic m-mer, even m only,
-// gets one record per flag). spill (last record of a bucket only): some record whose home is this bucket or an
-// earlier one lives in a later bucket: the query goes on to the next bucket. An empty slot has smin > smax.
+// An empty slot has smin > smax.
+// A key whose records do not fit its home bucket next to the other keys living there (or that has more than four)
+// keeps ONE slot in the home bucket, a REDIRECT: w0 = dict_tag of the key, w1 = its first overflow bucket,
+// w2 = empty | redirect flag, w3 = number of overflow buckets. Its records fill consecutive overflow buckets; the
+// query reads the first REDIRECT_DIRECT of them at once.
+// spill (bit 31 of w3 of a bucket's last slot): the query goes on with the next bucket. Set on the overflow
+// buckets of a key from the REDIRECT_DIRECT-th on (but the last), and on a hashed bucket when more than four keys
+// live there (rare), whose surplus slots then sit in the following buckets.
 // Needs 2k - m <= 43 and k - m <= 15 (k = 31, m = 19: exactly 43 bases).
 constexpr uint32_t REC_WORDS = 4;
 constexpr uint32_t BUCKET_RECS = 4;
@@ -128,19 +140,16 @@ constexpr uint32_t REC_CTX_MAX = 43;
 constexpr uint32_t REC_MAX_CSID = 0x7FFFFFFFu;
 constexpr uint32_t REC_SPILL = 0x80000000u;
 constexpr uint32_t REC_W2_EMPTY = 15u << 22;  // smin = 15 > smax = 0
-FG_HD uint32_t rec_w2(uint64_t ctx_lo, uint64_t ctx_hi, uint32_t smin, uint32_t smax, bool fwd) {
-    return (uint32_t)(ctx_lo >> 32) | ((uint32_t)(ctx_hi >> 32) << 11) | (smin << 22) | (smax << 26) | ((uint32_t)fwd << 30);
+constexpr uint32_t REC_W2_REDIRECT = REC_W2_EMPTY | 0x80000000u;
+constexpr uint32_t DICT_MAX_BUCKETS = 1u << 26;  // a (source lane, bucket) pair of the lookup kernel packs into 32 bits
+constexpr uint32_t REDIRECT_DIRECT = 3;
+FG_HD uint32_t rec_w2(uint64_t ctx_lo, uint64_t ctx_hi, uint32_t smin, uint32_t smax) {
+    return (uint32_t)(ctx_lo >> 32) | ((uint32_t)(ctx_hi >> 32) << 11) | (smin << 22) | (smax << 26);
 }
 FG_HD uint32_t rec_smin(uint32_t w2) { return (w2 >> 22) & 15u; }
 FG_HD uint32_t rec_smax(uint32_t w2) { return (w2 >> 26) & 15u; }
-FG_HD bool rec_fwd(uint32_t w2) { return (w2 >> 30) & 1u; }
 FG_HD uint64_t rec_ctx_lo(uint32_t w0, uint32_t w2) { return (uint64_t)w0 | ((uint64_t)(w2 & 0x7FFu) << 32); }
 FG_HD uint64_t rec_ctx_hi(uint32_t w1, uint32_t w2) { return (uint64_t)w1 | ((uint64_t)((w2 >> 11) & 0x7FFu) << 32); }
-// is the L-mer its own canonical form?
-FG_HD bool is_fwd_canonical(uint32_t lo, uint32_t hi, uint32_t L) {
-    return lmer_key(lo, hi) <= lmer_key(rc_plane(lo, L), rc_plane(hi, L));
-}
-
 // ---- unitig strings ----------------------------------------------------------------------------
 // word w holds bases [32w, 32w+32): low 32 bits = lo plane, high 32 bits = hi plane.
 // extract an L-mer (L<=32) starting at base s from two consecutive words

@@ -589,6 +589,17 @@ int fgpu_convert(fgpu_index* ix, int index_type, uint32_t partition_size, uint32
     });
 }
 
+#ifdef FG_K1_STATS
+int fgpu_debug_k1_stats(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fg::k1_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return -EIO;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(fg::k1_stats), z, sizeof(z)) != hipSuccess) return -EIO;
+    }
+    return 0;
+}
+#endif
+
 int fgpu_selfcheck(const fgpu_index* ix, uint64_t unitig_stride) {
     if (!ix) return fail(-EINVAL, "null argument");
     return guarded([&] { verify_dict(ix->host.dict, unitig_stride ? unitig_stride : 1); });

@@ -2,17 +2,15 @@
 //
 // Role in the reference: sshash::dictionary::build over the unitig FASTA (src/index.cpp:268-276,
 // include/builders/builder.hpp:191-199) followed by u2c (include/index.hpp:37). Design (own, see
-// common/kmer_common.h): the minimizer of a k-mer is its canonical m-mer with the smallest hash order;
-// consecutive k-mers of a unitig sharing a minimizer occurrence form a super-k-mer, stored as ONE 16-byte
-// record that carries the unitig context of the occurrence (so a lookup never touches the strings) and the
-// colour-set id; records live in an open-addressing table of 64-byte buckets addressed by a hash of the
-// canonical minimizer. One lookup = one line fetch.
+// common/kmer_common.h): the minimizer of a k-mer is its m-mer with the smallest hash order, leftmost on ties;
+// consecutive k-mers sharing a minimizer occurrence form a super-k-mer, stored as ONE 16-byte record that
+// carries the context of the occurrence (so a lookup never touches the strings) and the colour-set id; records
+// live in a table of 64-byte buckets addressed by a hash of the minimizer. One lookup = one line fetch.
 //
-// Ties and strands are settled HERE so that the lookup kernel has no special cases: a query takes the
-// leftmost smallest m-mer of its k-mer in its own orientation, which is the rightmost one in unitig
-// orientation when the read lies on the other strand; a record therefore covers every k-mer in which its
-// occurrence is A smallest-order m-mer (on ties a k-mer is covered by several records, each under its own
-// occurrence). A palindromic minimizer (even m only) cannot tell the strand: it gets a record per strand flag.
+// Every unitig is indexed on BOTH strands (the unitig and its reverse complement are cut into super-k-mers
+// independently), so that a query is compared in its own orientation only: the lookup kernel never forms a
+// canonical m-mer or a reverse complement and has no strand, tie or palindrome cases. A k-mer that is its own
+// reverse complement (even k only) is kept on the unitig's strand only, so that it is found once.
 #pragma once
 #include <algorithm>
 #include <stdexcept>
@@ -50,37 +48,96 @@ inline void check_dict_params(uint32_t k, uint32_t m) {
     if (2 * k - m > REC_CTX_MAX) throw std::runtime_error("need 2k - m <= 43 (the record's context)");
 }
 
-// canonical key of the minimizer of a record, cut out of its context
-inline uint64_t record_key(const uint32_t* w, uint32_t k, uint32_t m) {
+// the minimizer of a record, cut out of its context
+inline void record_minimizer(const uint32_t* w, uint32_t k, uint32_t m, uint32_t& lo, uint32_t& hi) {
     const uint32_t km = k - m;
-    const uint32_t lo = (uint32_t)(rec_ctx_lo(w[0], w[2]) >> km) & low_mask32(m);
-    const uint32_t hi = (uint32_t)(rec_ctx_hi(w[1], w[2]) >> km) & low_mask32(m);
-    return canonical_key(lo, hi, m);
+    lo = (uint32_t)(rec_ctx_lo(w[0], w[2]) >> km) & low_mask32(m);
+    hi = (uint32_t)(rec_ctx_hi(w[1], w[2]) >> km) & low_mask32(m);
+}
+inline uint64_t record_key(const uint32_t* w, uint32_t k, uint32_t m) {
+    uint32_t lo, hi;
+    record_minimizer(w, k, m, lo, hi);
+    return lmer_key(lo, hi);
 }
 
-// Places the records into the bucket table by linear probing at record granularity: a record goes to the
-// first free slot at or after its home bucket; every full bucket passed on the way is marked `spill`, which
-// is what tells a query to read on. ~0.6 records per bucket on average: a query rarely needs a second line.
+// Places the records into the bucket table. Hashed region: a sweep over the buckets in order; the keys living
+// in a bucket (those hashed to it, plus slots carried over from a bucket with more than four keys) each get
+// one slot at least, a key with several records all of them while the bucket has room (keys with fewer records
+// first), a REDIRECT to the overflow region otherwise. ~0.6 records per bucket on average.
 inline void build_dict_table(Dict& d) {
     const uint64_t nrec = d.num_records();
     if (nrec >= (1ULL << 31)) throw std::runtime_error("too many super-k-mer records");
     d.num_buckets = (uint32_t)std::max<uint64_t>(16, nrec + nrec / 2 + nrec / 8);
-    const uint64_t nb_total = (uint64_t)d.num_buckets + DICT_TAIL_BUCKETS;
-    d.table.assign(nb_total * BUCKET_WORDS, 0);
-    for (uint64_t b = 0; b < nb_total; ++b)
-        for (uint32_t r = 0; r < BUCKET_RECS; ++r) d.table[b * BUCKET_WORDS + r * REC_WORDS + 2] = REC_W2_EMPTY;
-    std::vector<uint8_t> fill(nb_total, 0);
+    const uint64_t nb_hashed = (uint64_t)d.num_buckets + DICT_TAIL_BUCKETS;
+    struct Ref { uint32_t home; uint32_t rec; uint64_t key; };
+    std::vector<Ref> refs(nrec);
     for (uint64_t i = 0; i < nrec; ++i) {
-        const uint32_t* w = &d.records[i * REC_WORDS];
-        uint64_t b = mulhi32(dict_hash(record_key(w, d.k, d.m), d.seed), d.num_buckets);
-        while (fill[b] == BUCKET_RECS) {
-            d.table[b * BUCKET_WORDS + (BUCKET_RECS - 1) * REC_WORDS + 3] |= REC_SPILL;
-            if (++b >= nb_total) throw std::runtime_error("dictionary table: probe chain ran past the tail buckets");
-        }
-        uint32_t* dst = &d.table[b * BUCKET_WORDS + fill[b] * REC_WORDS];
-        dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3] & REC_MAX_CSID;
-        ++fill[b];
+        uint32_t lo, hi;
+        record_minimizer(&d.records[i * REC_WORDS], d.k, d.m, lo, hi);
+        refs[i] = Ref{mulhi32(dict_hash(lo, hi, d.seed), d.num_buckets), (uint32_t)i, lmer_key(lo, hi)};
     }
+    std::sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) {
+        return a.home != b.home ? a.home < b.home : (a.key != b.key ? a.key < b.key : a.rec < b.rec);
+    });
+    d.table.clear();
+    d.table.reserve((nb_hashed + nrec / 16 + 1024) * BUCKET_WORDS);  // room for the overflow region without a second copy
+    d.table.assign(nb_hashed * BUCKET_WORDS, 0);
+    for (uint64_t b = 0; b < nb_hashed; ++b)
+        for (uint32_t r = 0; r < BUCKET_RECS; ++r) d.table[b * BUCKET_WORDS + r * REC_WORDS + 2] = REC_W2_EMPTY;
+    struct Item { uint64_t first, count; };  // a key: refs[first, first + count)
+    std::vector<Item> carry, items;
+    std::vector<uint32_t> overflow;  // the overflow region, appended behind the hashed region at the end
+    auto put = [&](uint32_t* dst, uint32_t rec) {
+        const uint32_t* w = &d.records[(uint64_t)rec * REC_WORDS];
+        dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3] & REC_MAX_CSID;
+    };
+    uint64_t at = 0;
+    for (uint64_t b = 0; b < nb_hashed; ++b) {
+        items.swap(carry);
+        carry.clear();
+        while (at < nrec && refs[at].home == b) {
+            uint64_t e = at;
+            while (e < nrec && refs[e].home == b && refs[e].key == refs[at].key) ++e;
+            items.push_back(Item{at, e - at});
+            at = e;
+        }
+        if (items.empty()) continue;
+        uint32_t* bw = &d.table[b * BUCKET_WORDS];
+        if (items.size() > BUCKET_RECS) {  // more keys than slots: the surplus keys move on to the next bucket
+            carry.assign(items.begin() + BUCKET_RECS, items.end());
+            items.resize(BUCKET_RECS);
+        }
+        // every key one slot; then whole keys while they fit, fewest records first
+        std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.count < y.count; });
+        uint32_t left = BUCKET_RECS - (uint32_t)items.size(), slot = 0;
+        for (const Item& it : items) {
+            if (it.count - 1 <= left && it.count <= BUCKET_RECS) {
+                for (uint64_t j = 0; j < it.count; ++j) put(bw + (slot++) * REC_WORDS, refs[it.first + j].rec);
+                left -= (uint32_t)(it.count - 1);
+            } else {
+                const uint64_t nb = (it.count + BUCKET_RECS - 1) / BUCKET_RECS;
+                const uint64_t ob = nb_hashed + overflow.size() / BUCKET_WORDS;
+                if (ob + nb >= DICT_MAX_BUCKETS) throw std::runtime_error("dictionary table exceeds 2^26 buckets");
+                const size_t o0 = overflow.size();
+                overflow.resize(o0 + nb * BUCKET_WORDS, 0);
+                for (uint64_t j = 0; j < nb * BUCKET_RECS; ++j) {
+                    uint32_t* dst = &overflow[o0 + j * REC_WORDS];
+                    if (j < it.count) put(dst, refs[it.first + j].rec);
+                    else dst[2] = REC_W2_EMPTY;
+                }
+                // the query reads the first REDIRECT_DIRECT buckets at once; further ones hang on spill flags
+                for (uint64_t j = REDIRECT_DIRECT - 1; j + 1 < nb; ++j) overflow[o0 + j * BUCKET_WORDS + (BUCKET_RECS - 1) * REC_WORDS + 3] |= REC_SPILL;
+                uint32_t* dst = bw + (slot++) * REC_WORDS;
+                dst[0] = dict_tag((uint32_t)refs[it.first].key, (uint32_t)(refs[it.first].key >> 32));
+                dst[1] = (uint32_t)ob;
+                dst[2] = REC_W2_REDIRECT;
+                dst[3] = (uint32_t)nb;
+            }
+        }
+        if (!carry.empty()) bw[(BUCKET_RECS - 1) * REC_WORDS + 3] |= REC_SPILL;
+    }
+    if (!carry.empty()) throw std::runtime_error("dictionary table: keys carried past the tail buckets");
+    d.table.insert(d.table.end(), overflow.begin(), overflow.end());
 }
 
 inline void build_dict(Dict& d, uint32_t k, uint32_t m, const char* bases, uint64_t total_bases,
@@ -114,7 +171,7 @@ inline void build_dict(Dict& d, uint32_t k, uint32_t m, const char* bases, uint6
         for (unsigned t = 0; t < nthreads; ++t) {
             th.emplace_back([&, t]() {
                 std::vector<uint32_t> ord;
-                std::vector<uint8_t> fw, pal;
+                std::vector<uint8_t> code;  // the unitig strand being cut, one base per byte
                 auto& out = parts[t];
                 for (uint64_t u = cut[t]; u < cut[t + 1]; ++u) {
                     const uint64_t b = unitig_off[u], e = unitig_off[u + 1];
@@ -122,59 +179,61 @@ inline void build_dict(Dict& d, uint32_t k, uint32_t m, const char* bases, uint6
                     if (len < (int64_t)k) { errors[t] = "unitig shorter than k"; return; }
                     if (unitig_csid[u] > REC_MAX_CSID) { errors[t] = "colour-set id exceeds record width"; return; }
                     const int64_t nm = len - m + 1, nk = len - k + 1;
-                    ord.resize(nm);
-                    fw.resize(nm);
-                    pal.resize(nm);
-                    for (int64_t i = 0; i < nm; ++i) {
-                        const uint64_t s = b + i;
-                        uint32_t lo, hi;
-                        string_lmer(d.strings[s >> 5], d.strings[(s >> 5) + 1], (uint32_t)(s & 31), m, lo, hi);
-                        ord[i] = minimizer_order(canonical_key(lo, hi, m));
-                        const uint64_t kf = lmer_key(lo, hi), kr = lmer_key(rc_plane(lo, m), rc_plane(hi, m));
-                        fw[i] = kf <= kr;
-                        pal[i] = kf == kr;
-                    }
                     nk_parts[t] += nk;
-                    for (int64_t p = 0; p < nm; ++p) {
-                        // k-mers [sa, sb] of the unitig contain m-mer p and no m-mer of smaller order
-                        int64_t sa = std::max<int64_t>(0, p - km), sb = std::min<int64_t>(p, nk - 1);
-                        for (int64_t q = p - 1; q >= sa; --q)
-                            if (ord[q] < ord[p]) { sa = q + 1; break; }
-                        for (int64_t q = p + 1; q <= sb + km; ++q)
-                            if (ord[q] < ord[p]) { sb = q - km - 1; break; }
-                        if (sa > sb) continue;
-                        uint64_t clo = 0, chi = 0;  // context base c = unitig base p - km + c
-                        for (uint32_t c = 0; c < CL; ++c) {
-                            const int64_t x = p - km + c;
-                            if (x < 0 || x >= len) continue;
-                            const uint32_t code = detail::string_base(d.strings, b + x);
-                            clo |= (uint64_t)(code & 1u) << c;
-                            chi |= (uint64_t)(code >> 1) << c;
+                    code.resize(len);
+                    ord.resize(nm);
+                    for (int strand = 0; strand < 2; ++strand) {
+                        for (int64_t i = 0; i < len; ++i)
+                            code[i] = strand == 0 ? (uint8_t)detail::string_base(d.strings, b + i)
+                                                  : (uint8_t)(3u - detail::string_base(d.strings, b + (len - 1 - i)));
+                        uint32_t lo = 0, hi = 0;  // rolling m-mer, base i of the m-mer at bit i
+                        for (int64_t i = 0; i < len; ++i) {
+                            lo = (lo >> 1) | ((uint32_t)(code[i] & 1u) << (m - 1));
+                            hi = (hi >> 1) | ((uint32_t)(code[i] >> 1) << (m - 1));
+                            if (i + 1 >= (int64_t)m) ord[i + 1 - m] = minimizer_order(lo & low_mask32(m), hi & low_mask32(m));
                         }
-                        const uint32_t smin = (uint32_t)(sa - (p - km)), smax = (uint32_t)(sb - (p - km));
-                        auto emit = [&](uint32_t s0, uint32_t s1, bool fwd) {
-                            out.push_back((uint32_t)clo);
-                            out.push_back((uint32_t)chi);
-                            out.push_back(rec_w2(clo, chi, s0, s1, fwd));
-                            out.push_back(unitig_csid[u]);
-                        };
-                        if (!pal[p]) {
-                            emit(smin, smax, fw[p] != 0);
-                        } else {
-                            // palindromic minimizer: the flag cannot tell the strand, so one record per flag. A k-mer that is its
-                            // own reverse complement (even k) would match both: the second record skips those windows.
-                            emit(smin, smax, true);
-                            uint32_t s0 = smin;
-                            for (uint32_t s = smin; s <= smax + 1; ++s) {
+                        auto emit = [&](int64_t p, int64_t sa, int64_t sb) {  // k-mers sa..sb of the strand share the minimizer occurrence p
+                            uint64_t clo = 0, chi = 0;  // context base c = strand base p - km + c
+                            for (uint32_t c = 0; c < CL; ++c) {
+                                const int64_t x = p - km + c;
+                                if (x < 0 || x >= len) continue;
+                                clo |= (uint64_t)(code[x] & 1u) << c;
+                                chi |= (uint64_t)(code[x] >> 1) << c;
+                            }
+                            uint32_t s0 = (uint32_t)(sa - (p - km));
+                            const uint32_t s1 = (uint32_t)(sb - (p - km));
+                            auto put = [&](uint32_t a, uint32_t z) {
+                                out.push_back((uint32_t)clo);
+                                out.push_back((uint32_t)chi);
+                                out.push_back(rec_w2(clo, chi, a, z));
+                                out.push_back(unitig_csid[u]);
+                            };
+                            if (strand == 0 || (k & 1u)) { put(s0, s1); return; }
+                            // reverse strand, even k: a k-mer equal to its own reverse complement is already there
+                            for (uint32_t sw = s0; sw <= s1 + 1; ++sw) {
                                 bool self_rc = false;
-                                if (s <= smax) {
-                                    const uint32_t lo = (uint32_t)(clo >> s) & low_mask32(k), hi = (uint32_t)(chi >> s) & low_mask32(k);
-                                    self_rc = lo == rc_plane(lo, k) && hi == rc_plane(hi, k);
+                                if (sw <= s1) {
+                                    const uint32_t wl = (uint32_t)(clo >> sw) & low_mask32(k), wh = (uint32_t)(chi >> sw) & low_mask32(k);
+                                    self_rc = wl == rc_plane(wl, k) && wh == rc_plane(wh, k);
                                 }
-                                if (s > smax || self_rc) {
-                                    if (s > s0) emit(s0, s - 1, false);
-                                    s0 = s + 1;
+                                if (sw > s1 || self_rc) {
+                                    if (sw > s0) put(s0, sw - 1);
+                                    s0 = sw + 1;
                                 }
+                            }
+                        };
+                        int64_t run_p = -1, run_first = 0;
+                        for (int64_t sk = 0; sk <= nk; ++sk) {
+                            int64_t p = -1;
+                            if (sk < nk) {
+                                p = sk;
+                                for (uint32_t jj = 1; jj <= km; ++jj)
+                                    if (ord[sk + jj] < ord[p]) p = sk + jj;  // leftmost smallest order
+                            }
+                            if (p != run_p) {
+                                if (run_p >= 0) emit(run_p, run_first, sk - 1);
+                                run_p = p;
+                                run_first = sk;
                             }
                         }
                     }
@@ -202,36 +261,37 @@ inline void build_dict(Dict& d, uint32_t k, uint32_t m, const char* bases, uint6
 
 // Host walk of the same structure, used ONLY by the build-time self check (verify_dict below, the
 // analogue of the reference's `--check`, builder.hpp:221-277); queries never run here. It follows the
-// lookup kernel step by step: leftmost smallest m-mer of the k-mer as given, bucket chain, every record
-// compared on the strand its flag selects. Returns the number of matching records; *csid = the last match.
+// lookup kernel step by step: leftmost smallest m-mer of the k-mer as given, home bucket, redirect and spill
+// chains, every record compared in the k-mer's own orientation. Returns the number of matching records;
+// *csid = the last match.
 inline uint32_t dict_lookup(const Dict& d, uint32_t klo, uint32_t khi, uint32_t* csid) {
     const uint32_t k = d.k, m = d.m, km = k - m;
     uint32_t best = 0xFFFFFFFFu;
     for (uint32_t j = 0; j <= km; ++j) {
         const uint32_t lo = (klo >> j) & low_mask32(m), hi = (khi >> j) & low_mask32(m);
-        best = std::min(best, (minimizer_order(canonical_key(lo, hi, m)) << ORDER_POS_BITS) | j);
+        best = std::min(best, (minimizer_order(lo, hi) << ORDER_POS_BITS) | j);
     }
     const uint32_t pm = best & ((1u << ORDER_POS_BITS) - 1u);
     const uint32_t mlo = (klo >> pm) & low_mask32(m), mhi = (khi >> pm) & low_mask32(m);
-    const bool qfwd = is_fwd_canonical(mlo, mhi, m);
-    const uint32_t rlo = rc_plane(klo, k), rhi = rc_plane(khi, k);
     uint32_t found = 0;
-    uint64_t b = mulhi32(dict_hash(canonical_key(mlo, mhi, m), d.seed), d.num_buckets);
-    for (;; ++b) {
-        const uint32_t* bw = &d.table[b * BUCKET_WORDS];
+    const uint32_t tag = dict_tag(mlo, mhi);
+    const uint32_t s = km - pm;  // window of this k-mer in a record's context
+    std::vector<uint64_t> visit(1, mulhi32(dict_hash(mlo, mhi, d.seed), d.num_buckets));
+    for (size_t v = 0; v < visit.size(); ++v) {
+        const uint32_t* bw = &d.table[visit[v] * BUCKET_WORDS];
         for (uint32_t r = 0; r < BUCKET_RECS; ++r) {
             const uint32_t* w = bw + r * REC_WORDS;
-            const bool same = rec_fwd(w[2]) == qfwd;
-            const uint32_t s = same ? km - pm : pm;  // window of this k-mer in the record's context
+            if ((w[2] & 0x80000000u) && w[0] == tag)  // this key's redirect (or a tag collision: harmless)
+                for (uint32_t j = 0; j < std::min(w[3] & REC_MAX_CSID, REDIRECT_DIRECT); ++j) visit.push_back((uint64_t)w[1] + j);
             if (s < rec_smin(w[2]) || s > rec_smax(w[2])) continue;
             const uint32_t lo = (uint32_t)(rec_ctx_lo(w[0], w[2]) >> s) & low_mask32(k);
             const uint32_t hi = (uint32_t)(rec_ctx_hi(w[1], w[2]) >> s) & low_mask32(k);
-            if (lo == (same ? klo : rlo) && hi == (same ? khi : rhi)) {
+            if (lo == klo && hi == khi) {
                 ++found;
                 *csid = w[3] & REC_MAX_CSID;
             }
         }
-        if (!(bw[(BUCKET_RECS - 1) * REC_WORDS + 3] & REC_SPILL)) break;
+        if (bw[(BUCKET_RECS - 1) * REC_WORDS + 3] & REC_SPILL) visit.push_back(visit[v] + 1);
     }
     return found;
 }
@@ -250,22 +310,20 @@ inline void verify_dict(const Dict& d, uint64_t stride = 1) {
     }
 }
 
-// bucket statistics (tools / logs): records per bucket chain as a query sees them
+// bucket statistics (tools / logs)
 struct DictStats {
-    uint64_t records = 0, buckets = 0, spill_buckets = 0, max_chain = 0;
+    uint64_t records = 0, buckets = 0, redirects = 0, overflow_buckets = 0, spill_buckets = 0;
 };
 inline DictStats dict_stats(const Dict& d) {
     DictStats s;
     s.records = d.num_records();
     s.buckets = d.num_buckets;
-    uint64_t chain = 0;
-    for (uint64_t b = 0; b < (uint64_t)d.num_buckets + DICT_TAIL_BUCKETS; ++b) {
-        if (d.table[b * BUCKET_WORDS + (BUCKET_RECS - 1) * REC_WORDS + 3] & REC_SPILL) {
-            ++s.spill_buckets;
-            s.max_chain = std::max(s.max_chain, ++chain);
-        } else {
-            chain = 0;
-        }
+    const uint64_t nb_hashed = (uint64_t)d.num_buckets + DICT_TAIL_BUCKETS;
+    s.overflow_buckets = d.table.size() / BUCKET_WORDS - nb_hashed;
+    for (uint64_t b = 0; b < nb_hashed; ++b) {
+        const uint32_t* bw = &d.table[b * BUCKET_WORDS];
+        for (uint32_t r = 0; r < BUCKET_RECS; ++r) s.redirects += (bw[r * REC_WORDS + 2] & 0x80000000u) != 0;
+        s.spill_buckets += (bw[(BUCKET_RECS - 1) * REC_WORDS + 3] & REC_SPILL) != 0;
     }
     return s;
 }

@@ -45,7 +45,7 @@ struct Dict {
                                     // export / dump / self check; the records carry their own context)
     uint32_t seed = 0;
     std::vector<uint32_t> records;  // REC_WORDS words per super-k-mer record, in unitig order (saved; spill bits clear)
-    uint32_t num_buckets = 0;       // hashed buckets; the table holds DICT_TAIL_BUCKETS more for probe chains at the end
+    uint32_t num_buckets = 0;       // hashed buckets; behind them DICT_TAIL_BUCKETS more (slots carried past the last one), then the overflow region
     std::vector<uint32_t> table;    // BUCKET_WORDS words per bucket: the records placed by linear probing (rebuilt at load)
     // unitig table (export / u2c)
     std::vector<uint64_t> unitig_off;    // num_unitigs + 1 base offsets into the concatenation

@@ -275,9 +275,10 @@ int main(int argc, char** argv) {
         std::string().swap(seqs);
         build_dict(idx.dict, K, 19, bases.data(), bases.size(), off, csid);
         const DictStats ds = dict_stats(idx.dict);
-        fprintf(stderr, "dictionary: %llu k-mers, %llu super-k-mer records in %llu buckets of 64 bytes (%.0f MB), %llu spill buckets, longest chain %llu\n",
+        fprintf(stderr, "dictionary: %llu k-mers, %llu super-k-mer records in %llu hashed buckets of 64 bytes (%.0f MB with %llu overflow buckets), %llu redirects, %llu spill buckets\n",
                 (unsigned long long)idx.dict.num_kmers, (unsigned long long)ds.records, (unsigned long long)ds.buckets,
-                idx.dict.table.size() * 4e-6, (unsigned long long)ds.spill_buckets, (unsigned long long)ds.max_chain);
+                idx.dict.table.size() * 4e-6, (unsigned long long)ds.overflow_buckets, (unsigned long long)ds.redirects,
+                (unsigned long long)ds.spill_buckets);
     }
     verify_dict(idx.dict, 997);
     for (uint32_t c = 0; c < N; ++c) idx.filenames.push_back("synthetic_strain_" + std::to_string(c) + ".fasta");

@@ -28,7 +28,7 @@ def build_tool():
 
 def ensure_s4546(data_dir, s10_genomes):
     """returns (path of the .fgidx, [accessory sequence as uint8 array]); generates them if missing"""
-    fg = os.path.join(data_dir, "s4546syn.v6.fgidx")
+    fg = os.path.join(data_dir, "s4546syn.v7.fgidx")
     acc = os.path.join(data_dir, "s4546syn.accessory.txt")
     if not (os.path.exists(fg) and os.path.exists(acc)):
         os.makedirs(data_dir, exist_ok=True)
