@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
         uint32_t planes[NSLOT][3][PW];   // bases of the reads in flight: lo, hi, invalid
         uint32_t queue[QCAP];            // run descriptors
         uint32_t hid[HCAP];              // heads: colour-set id
-        uint32_t hcnt[HCAP];             //        k-mers | read slot << 16
-        uint32_t hres[HCAP];             //        total of the id within its read | FIRST, 0 for repeats
+        uint32_t hcnt[HCAP];             //        k-mers | read slot << 16 | place of the slot in the pass << 20
+        uint32_t hres[HCAP];             // heads sorted by (read, id): id  (long passes: total of the id within its read | FIRST, 0 for repeats)
+        uint32_t hsrt[HCAP];             //                             k-mers | tags
         uint32_t meta[NSLOT][M_WORDS];
         uint32_t offs[2 * (K1_TICKET + 1)];  // read offsets of the ticket
     };
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
     uint32_t* hid = L.hid;
     uint32_t* hcnt = L.hcnt;
     uint32_t* hres = L.hres;
+    uint32_t* hsrt = L.hsrt;
     uint32_t (*meta)[M_WORDS] = L.meta;
     const uint32_t k = d.k, m = d.m, km = k - m, W = W13 ? 13u : km + 1, CL = 2 * k - m;
     const uint32_t span = W13 ? 8u : 1u << (31 - __builtin_clz(W));  // largest power of two <= W (W <= 16)
@@ -346,6 +348,8 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                         const bool live = ovf || (firstb && act);
                         const uint32_t desc = T[6];
                         const uint32_t pm = desc & POSM, i0 = (desc >> 10) & POSM, cnt = (desc >> 20) & 31u, g = (desc >> 25) & 7u;
+                        // what a head carries besides its k-mers: read slot << 16 | place of the slot in this pass << 20
+                        const uint32_t gtag = (g << 16) | ((g >= gs ? g - gs : g + (uint32_t)NSLOT - gs) << 20);
                         // windows of the run: window s of a record's context is k-mer i0 + s - runlo
                         const uint32_t runlo = i0 + km - pm, runhi = runlo + cnt - 1u;
                         uint32_t hv[BUCKET_RECS], hc[BUCKET_RECS];
@@ -401,12 +405,12 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                         uint32_t at = hcount + (incl & 0xFFFFu) - emit;
                         if (lead && !follower) {
                             const uint32_t tot = s_last - (incl >> 16) + msum;
-                            if (at < (uint32_t)HCAP) { hid[at] = mid; hcnt[at] = tot | (g << 16); }
+                            if (at < (uint32_t)HCAP) { hid[at] = mid; hcnt[at] = tot | gtag; }
                         } else if (emit) {
 #pragma unroll
                             for (int r = 0; r < (int)BUCKET_RECS; ++r) {
                                 if (hc[r]) {
-                                    if (at < (uint32_t)HCAP) { hid[at] = hv[r]; hcnt[at] = hc[r] | (g << 16); }
+                                    if (at < (uint32_t)HCAP) { hid[at] = hv[r]; hcnt[at] = hc[r] | gtag; }
                                     ++at;
                                 }
                             }
@@ -442,51 +446,112 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                     maxseg = max(maxseg, (uint32_t)__builtin_amdgcn_readfirstlane((int)(meta[g][M_HB] - meta[g][M_HA])));
                 }
                 K1_STAT(7, maxseg);
-                // pass 1: total of the head's id within its read; FIRST = no earlier head of the read has that id. A head is
-                // compared with the heads of its own slot and with the few heads that came out of overflow buckets.
-                for (uint32_t h0 = 0; h0 < hcount; h0 += 64) {
-                    const uint32_t h = h0 + lane;
-                    const bool hact = h < hcount;
-                    const uint32_t vv = hact ? hid[h] : 0u, gsel = hact ? hcnt[h] >> 16 : gfirst;
+                if (hcount <= 64u) {
+                    // One pass of up to 64 heads. Every head finds its place among the heads of its read by counting those that sort
+                    // before it (smaller id, or the same id further left), in its own slot's stretch and among the few heads that came
+                    // out of overflow buckets; scattered to that place, equal ids are neighbours and the rest is lane-local.
+                    const bool hact = (uint32_t)lane < hcount;
+                    const uint32_t vv = hact ? hid[lane] : 0u, hw = hact ? hcnt[lane] : (gfirst << 16);
+                    const uint32_t gsel = (hw >> 16) & 7u, tsel = hw >> 20;
                     const uint32_t ha = meta[gsel][M_HA], hb = meta[gsel][M_HB];
-                    uint32_t tot = 0;
-                    bool firsth = hact;
-                    for (uint32_t t = 0; t < maxseg; ++t) {
-                        const uint32_t i = ha + t;
-                        const uint32_t vi = hid[min(i, (uint32_t)HCAP - 1u)], ci = hcnt[min(i, (uint32_t)HCAP - 1u)];
-                        const bool eq = i < hb && vi == vv;
-                        tot += eq ? (ci & 0xFFFFu) : 0u;
-                        firsth = firsth && !(eq && i < h);
-                    }
-                    for (uint32_t i = hmain; i < hcount; ++i) {
-                        const uint32_t vi = hid[i], ci = hcnt[i];
-                        const bool eq = vi == vv && (ci >> 16) == gsel;
-                        tot += eq ? (ci & 0xFFFFu) : 0u;
-                        firsth = firsth && !(eq && i < h);
-                    }
-                    if (hact) hres[h] = firsth ? (tot | FIRST) : 0u;
-                }
-                wave_lds_sync();
-                // pass 2: rank of every first head among the first heads of its read = its place in the sorted list
-                for (uint32_t h0 = 0; h0 < hcount; h0 += 64) {
-                    const uint32_t h = h0 + lane;
-                    const bool hact = h < hcount;
-                    const uint32_t vv = hact ? hid[h] : 0u, gsel = hact ? hcnt[h] >> 16 : gfirst;
-                    const uint32_t ha = meta[gsel][M_HA], hb = meta[gsel][M_HB];
-                    const uint32_t res = hact ? hres[h] : 0u;
                     uint32_t rank = 0;
                     for (uint32_t t = 0; t < maxseg; ++t) {
-                        const uint32_t i = min(ha + t, (uint32_t)HCAP - 1u);
-                        rank += (ha + t < hb && (hres[i] & FIRST) != 0 && hid[i] < vv) ? 1u : 0u;
+                        const uint32_t i = ha + t;
+                        const uint32_t vi = hid[min(i, (uint32_t)HCAP - 1u)];
+                        rank += (i < hb && (vi < vv || (vi == vv && i < (uint32_t)lane))) ? 1u : 0u;
                     }
-                    for (uint32_t i = hmain; i < hcount; ++i)
-                        rank += ((hres[i] & FIRST) != 0 && (hcnt[i] >> 16) == gsel && hid[i] < vv) ? 1u : 0u;
-                    if (res & FIRST) {
-                        const uint64_t rbase = (t_first + meta[gsel][M_UNIT]) * (uint64_t)stride;
-                        ids_pool[rbase + rank] = vv;
-                        cnt_pool[rbase + rank] = res & ~FIRST;
-                        atomicAdd(&meta[gsel][M_NIDS], 1u);
-                        atomicAdd(&meta[gsel][M_NPOS], res & ~FIRST);
+                    uint32_t before = 0;  // heads from overflow buckets that belong to earlier reads of the pass
+                    for (uint32_t i = hmain; i < hcount; ++i) {
+                        const uint32_t vi = hid[i], ti = hcnt[i] >> 20;
+                        rank += (ti == tsel && (vi < vv || (vi == vv && i < (uint32_t)lane))) ? 1u : 0u;
+                        before += ti < tsel ? 1u : 0u;
+                    }
+                    if (hact) {
+                        const uint32_t p = ha + before + rank;
+                        hres[p] = vv;
+                        hsrt[p] = hw;
+                    }
+                    wave_lds_sync();
+                    // lane = sorted place: runs of equal ids within a read -> one output entry with the sum of their k-mers
+                    const uint32_t sv = hact ? hres[lane] : 0u, sw = hact ? hsrt[lane] : 0xFFFFFFFFu;
+                    const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)sv, 0x138, 0xF, 0xF, false);  // wave_shr:1
+                    const uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)sw, 0x138, 0xF, 0xF, false);
+                    const bool rstart = hact && (lane == 0 || (pw >> 20) != (sw >> 20));
+                    const bool start = hact && (rstart || pv != sv);
+                    const uint64_t tailm = hcount == 64u ? 0ull : ~0ull << hcount;  // lanes past the heads end every run
+                    const uint64_t St = __ballot(start) | tailm, Rt = __ballot(rstart) | tailm;
+                    const uint32_t cs = wave_incl_scan_u32(hact ? sw & 0xFFFFu : 0u);
+                    // last lane of my run / of my read: the lane before the next start (64-bit masks shifted by lane + 1)
+                    const uint64_t sa = lane == 63 ? 1ull : St >> (lane + 1), ra = lane == 63 ? 1ull : Rt >> (lane + 1);
+                    const uint32_t run_last = (uint32_t)lane + (sa ? (uint32_t)__builtin_ctzll(sa) : 63u - (uint32_t)lane);
+                    const uint32_t read_last = (uint32_t)lane + (ra ? (uint32_t)__builtin_ctzll(ra) : 63u - (uint32_t)lane);
+                    const uint32_t cs_run = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(run_last << 2), (int)cs);
+                    const uint32_t cs_read = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(read_last << 2), (int)cs);
+                    const uint32_t own = hact ? sw & 0xFFFFu : 0u;
+                    // place of my run in the read's output: starts between the read's first lane and mine. For a read-start lane that is 0.
+                    const uint64_t below = St & ((1ull << lane) - 1ull);
+                    const uint64_t rbelow = Rt & ((2ull << lane) - 1ull);  // (a read start at or below me exists for every head)
+                    const uint32_t rs = 63u - (uint32_t)__builtin_clzll(rbelow | 1ull);
+                    const uint32_t idx = (uint32_t)__popcll(below >> rs);
+                    if (start) {
+                        const uint32_t g = (sw >> 16) & 7u;
+                        const uint64_t rbase = (t_first + meta[g][M_UNIT]) * (uint64_t)stride;
+                        ids_pool[rbase + idx] = sv;
+                        cnt_pool[rbase + idx] = cs_run - cs + own;
+                        if (rstart) {
+                            const uint64_t mine = (St & ~tailm) >> lane;  // starts from my lane on
+                            const uint32_t span_ = read_last - (uint32_t)lane + 1u;
+                            meta[g][M_NIDS] = (uint32_t)__popcll(span_ >= 64u ? mine : mine & ((1ull << span_) - 1ull));
+                            meta[g][M_NPOS] = cs_read - cs + own;
+                        }
+                    }
+                } else {
+                    // pass 1: total of the head's id within its read; FIRST = no earlier head of the read has that id. A head is
+                    // compared with the heads of its own slot and with the few heads that came out of overflow buckets.
+                    for (uint32_t h0 = 0; h0 < hcount; h0 += 64) {
+                        const uint32_t h = h0 + lane;
+                        const bool hact = h < hcount;
+                        const uint32_t vv = hact ? hid[h] : 0u, gsel = hact ? (hcnt[h] >> 16) & 7u : gfirst;
+                        const uint32_t ha = meta[gsel][M_HA], hb = meta[gsel][M_HB];
+                        uint32_t tot = 0;
+                        bool firsth = hact;
+                        for (uint32_t t = 0; t < maxseg; ++t) {
+                            const uint32_t i = ha + t;
+                            const uint32_t vi = hid[min(i, (uint32_t)HCAP - 1u)], ci = hcnt[min(i, (uint32_t)HCAP - 1u)];
+                            const bool eq = i < hb && vi == vv;
+                            tot += eq ? (ci & 0xFFFFu) : 0u;
+                            firsth = firsth && !(eq && i < h);
+                        }
+                        for (uint32_t i = hmain; i < hcount; ++i) {
+                            const uint32_t vi = hid[i], ci = hcnt[i];
+                            const bool eq = vi == vv && ((ci >> 16) & 7u) == gsel;
+                            tot += eq ? (ci & 0xFFFFu) : 0u;
+                            firsth = firsth && !(eq && i < h);
+                        }
+                        if (hact) hres[h] = firsth ? (tot | FIRST) : 0u;
+                    }
+                    wave_lds_sync();
+                    // pass 2: rank of every first head among the first heads of its read = its place in the sorted list
+                    for (uint32_t h0 = 0; h0 < hcount; h0 += 64) {
+                        const uint32_t h = h0 + lane;
+                        const bool hact = h < hcount;
+                        const uint32_t vv = hact ? hid[h] : 0u, gsel = hact ? (hcnt[h] >> 16) & 7u : gfirst;
+                        const uint32_t ha = meta[gsel][M_HA], hb = meta[gsel][M_HB];
+                        const uint32_t res = hact ? hres[h] : 0u;
+                        uint32_t rank = 0;
+                        for (uint32_t t = 0; t < maxseg; ++t) {
+                            const uint32_t i = min(ha + t, (uint32_t)HCAP - 1u);
+                            rank += (ha + t < hb && (hres[i] & FIRST) != 0 && hid[i] < vv) ? 1u : 0u;
+                        }
+                        for (uint32_t i = hmain; i < hcount; ++i)
+                            rank += ((hres[i] & FIRST) != 0 && ((hcnt[i] >> 16) & 7u) == gsel && hid[i] < vv) ? 1u : 0u;
+                        if (res & FIRST) {
+                            const uint64_t rbase = (t_first + meta[gsel][M_UNIT]) * (uint64_t)stride;
+                            ids_pool[rbase + rank] = vv;
+                            cnt_pool[rbase + rank] = res & ~FIRST;
+                            atomicAdd(&meta[gsel][M_NIDS], 1u);
+                            atomicAdd(&meta[gsel][M_NPOS], res & ~FIRST);
+                        }
                     }
                 }
                 wave_lds_sync();
