@@ -458,8 +458,16 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     const size_t stage_lds = (K2B_THREADS / 64) * K2B_STAGE_ENTRIES * 2;
     res->hits_folded = stage_lds + (size_t)W * 64 <= 80 * 1024;  // two blocks per CU
     const size_t lds = res->hits_folded ? stage_lds + (size_t)W * 64 : stage_lds;
-    // a block must see fewer than 65536 reads (16-bit hit counters): true for any resident grid >= n / 65535
-    const uint32_t grid = std::max<uint32_t>(resident_grid(k2b_expand, n, K2B_THREADS / 64, ix->num_cus, K2B_THREADS, lds), (uint32_t)(n / 60000 + 1));
+    // 16-bit hit counters: a block takes tickets for at most block_cap reads (k2b_expand), and the grid is large enough for
+    // the caps of the blocks of every ticket partition to exceed its reads by a quarter
+    static const uint32_t block_cap = [] {
+        const char* e = getenv("FULGOR_EXPAND_BLOCK_CAP");  // test knob: a small cap exercises the limit on small batches
+        const long v = e ? atol(e) : 0;
+        return (uint32_t)(v >= 32 && v <= 65504 ? v : 65504);
+    }();
+    const uint32_t cap_grid = (uint32_t)(n / (block_cap - block_cap / 4) + 1) + 8;
+    const uint32_t grid = std::max<uint32_t>(resident_grid(k2b_expand, n, K2B_THREADS / 64, ix->num_cus, K2B_THREADS, lds),
+                                             res->hits_folded ? cap_grid : 1u);
     if (res->hits_folded) res->d_partial.ensure((size_t)grid * W * 32 * 4);
     res->d_colors.ensure(16);
     auto expand = [&] {
@@ -468,7 +476,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
                            res->d_offsets.as<uint64_t>(), n, W, res->d_colors.as<uint32_t>(),
                            res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE,
                            res->hits_folded ? res->d_partial.as<uint32_t>() : (uint32_t*)nullptr, res->d_totals.as<uint64_t>(),
-                           (uint64_t)(res->d_colors.cap / 4));
+                           (uint64_t)(res->d_colors.cap / 4), block_cap);
         HIP_TRY(hipGetLastError());
     };
     expand();

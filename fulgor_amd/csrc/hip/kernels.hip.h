@@ -1076,25 +1076,36 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
                                                   const uint64_t* __restrict__ out_off, uint64_t n_reads, uint32_t W,
                                                   uint32_t* __restrict__ colors, unsigned int* tickets,
                                                   uint32_t* __restrict__ hit_partial, const uint64_t* __restrict__ totals,
-                                                  uint64_t capacity) {
+                                                  uint64_t capacity, uint32_t block_cap) {
     // launched behind the scan without a host round trip: if the colours of the pass do not fit `colors`
     // (capacity in u32), do nothing — the host enlarges the buffer and launches again
     if (totals[0] > capacity) return;
     // hit_partial != nullptr: also count, per colour, the reads of this launch that contain it. Each block
-    // keeps 16-bit counters in LDS (a block sees far fewer than 65536 reads) and stores them as one row of
-    // hit_partial[gridDim.x][W*32] at the end; k_hits_reduce sums the rows.
+    // keeps 16-bit counters in LDS and stores them as one row of hit_partial[gridDim.x][W*32] at the end;
+    // k_hits_reduce sums the rows. A block stops pulling tickets once it has taken block_cap (< 65536) reads, whatever
+    // the other blocks do (tickets are dynamic: blocks that start late, or share the GPU with another stream, leave
+    // more reads to the early ones): no counter can wrap. The host sizes the grid so that the caps add up to more
+    // than the reads of every partition.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_x[];
     uint16_t* stage_all = (uint16_t*)smem_x;                                           // one stage per wave
     uint32_t* hist = (uint32_t*)(smem_x + (K2B_THREADS / 64) * K2B_STAGE_ENTRIES * 2);  // W*16 words (two counters per word)
     const int lane = lane_id();
     unsigned char* stage = (unsigned char*)(stage_all + (threadIdx.x >> 6) * K2B_STAGE_ENTRIES);
+    __shared__ uint32_t s_taken;  // reads this block has taken tickets for
     if (hit_partial) {
         for (uint32_t i = threadIdx.x; i < W * 16; i += blockDim.x) hist[i] = 0;
+        if (threadIdx.x == 0) s_taken = 0;
         __syncthreads();
     }
     const WorkQueue wq{tickets, n_reads, 32};
     uint64_t t_first;
     uint32_t t_count;
+    auto may_pull = [&]() -> bool {
+        if (!hit_partial) return true;
+        uint32_t before = 0;
+        if (lane == 0) before = atomicAdd(&s_taken, 32u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)before) + 32u <= block_cap;
+    };
     // the first three 64-word rounds of a read's bitmap (all of it up to 6144 colours) are requested one read
     // ahead, its size and output offset once per ticket: the per-read fetch chain is off the critical path
     auto fetch3 = [&](uint64_t r, uint32_t (&x)[3]) {
@@ -1102,7 +1113,7 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
 #pragma unroll
         for (uint32_t q = 0; q < 3; ++q) x[q] = q * 64 + lane < W ? __builtin_nontemporal_load(&bm[q * 64 + lane]) : 0u;  // read once
     };
-    while (wq.pull(t_first, t_count)) {
+    while (may_pull() && wq.pull(t_first, t_count)) {
     const uint64_t rl = t_first + min((uint32_t)lane, t_count - 1);
     const uint32_t cnt_l = (uint32_t)lane < t_count ? counts[rl] : 0u;
     const uint64_t off_l = out_off[rl];

@@ -1,4 +1,4 @@
-// Test-data tool: builds a coloured compacted de Bruijn graph from <= 64 FASTA genomes and writes it
+// Test-data tool: builds a coloured compacted de Bruijn graph from a few hundred FASTA genomes at most and writes it
 // in the reference's dump format (src/index.cpp:59-120). It stands in for GGCAT + `fulgor build`
 // (Rust, not available here) for SMALL collections such as test_data/salmonella_10; it is not part
 // of the query engine. Per SURVEY F7 any valid decomposition of the k-mer set into monochromatic
@@ -40,12 +40,15 @@ static std::vector<std::string> read_fasta(const char* path) {
     return seqs;
 }
 
-struct Table {  // open addressing: canonical k-mer -> colour mask
+struct Table {  // open addressing: canonical k-mer -> colour mask of W words
     std::vector<uint64_t> key, val;
     std::vector<uint8_t> used, visited;
     uint64_t mask;
-    explicit Table(unsigned log2cap) : key(1ULL << log2cap), val(1ULL << log2cap, 0), used(1ULL << log2cap, 0),
-                                       visited(1ULL << log2cap, 0), mask((1ULL << log2cap) - 1) {}
+    uint32_t W;
+    Table(unsigned log2cap, uint32_t words) : key(1ULL << log2cap), val((1ULL << log2cap) * words, 0), used(1ULL << log2cap, 0),
+                                              visited(1ULL << log2cap, 0), mask((1ULL << log2cap) - 1), W(words) {}
+    std::vector<uint64_t> colour(uint64_t i) const { return std::vector<uint64_t>(val.begin() + i * W, val.begin() + (i + 1) * W); }
+    bool same_colour(uint64_t i, uint64_t j) const { return std::equal(val.begin() + i * W, val.begin() + (i + 1) * W, val.begin() + j * W); }
     static uint64_t h(uint64_t x) {
         x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
         return x;
@@ -80,7 +83,7 @@ int main(int argc, char** argv) {
     KMASK = (1ULL << (2 * K)) - 1;
     std::string base = argv[2];
     const int ng = argc - 3;
-    if (ng > 64) { fprintf(stderr, "at most 64 genomes\n"); return 1; }
+    const uint32_t W = (uint32_t)(ng + 63) / 64;
 
     uint64_t total = 0;
     std::vector<std::vector<std::string>> genomes;
@@ -91,7 +94,7 @@ int main(int argc, char** argv) {
     unsigned lg = 10;
     while ((1ULL << lg) < total * 2) ++lg;  // generous: distinct k-mers <= total bases
     if (lg > 30) lg = 30;
-    Table T(lg);
+    Table T(lg, W);
     uint64_t distinct = 0;
     for (int g = 0; g < ng; ++g)
         for (auto& s : genomes[g]) {
@@ -104,17 +107,19 @@ int main(int argc, char** argv) {
                 r = (r >> 2) | ((uint64_t)(3 - c) << (2 * (K - 1)));
                 if (++run >= K) {
                     uint64_t i = T.insert(f < r ? f : r);
-                    if (T.val[i] == 0) ++distinct;
-                    T.val[i] |= 1ULL << g;
+                    bool fresh = true;
+                    for (uint32_t w = 0; w < W; ++w) fresh = fresh && T.val[i * W + w] == 0;
+                    if (fresh) ++distinct;
+                    T.val[i * W + (g >> 6)] |= 1ULL << (g & 63);
                 }
             }
         }
     fprintf(stderr, "distinct canonical %u-mers: %llu\n", K, (unsigned long long)distinct);
 
-    // colour sets: distinct masks, numbered by increasing mask value
-    std::map<uint64_t, uint32_t> set_id;
+    // colour sets: distinct masks, numbered by increasing mask value (word 0 first)
+    std::map<std::vector<uint64_t>, uint32_t> set_id;
     for (uint64_t i = 0; i <= T.mask; ++i)
-        if (T.used[i]) set_id.emplace(T.val[i], 0);
+        if (T.used[i]) set_id.emplace(T.colour(i), 0);
     { uint32_t id = 0; for (auto& kv : set_id) kv.second = id++; }
     fprintf(stderr, "distinct colour sets: %zu\n", set_id.size());
 
@@ -129,13 +134,13 @@ int main(int argc, char** argv) {
     };
     auto extend = [&](uint64_t start, std::vector<uint64_t>& path) {
         uint64_t cur = start;
-        const uint64_t colour = T.val[T.find(canon(cur))];
+        const uint64_t colour_of = (uint64_t)T.find(canon(cur));
         for (;;) {
             uint64_t nxt, back;
             if (!unique_succ(cur, nxt)) break;
             if (!unique_succ(rc(nxt), back) || back != rc(cur)) break;
             int64_t ni = T.find(canon(nxt));
-            if (T.visited[ni] || T.val[ni] != colour) break;
+            if (T.visited[ni] || !T.same_colour((uint64_t)ni, colour_of)) break;
             T.visited[ni] = 1;
             path.push_back(nxt);
             cur = nxt;
@@ -164,7 +169,7 @@ int main(int argc, char** argv) {
         std::string seq = kmer_str(path[0]);
         for (size_t j = 1; j < path.size(); ++j) seq.push_back(ALPHA[path[j] & 3]);
         nk_check += path.size();
-        unitigs.push_back({set_id[T.val[i]], std::move(seq)});
+        unitigs.push_back({set_id[T.colour(i)], std::move(seq)});
     }
     if (nk_check != distinct) { fprintf(stderr, "internal error: %llu k-mers in unitigs\n", (unsigned long long)nk_check); return 1; }
     std::stable_sort(unitigs.begin(), unitigs.end(), [](const Unitig& a, const Unitig& b) { return a.set < b.set; });
@@ -189,9 +194,11 @@ int main(int argc, char** argv) {
     {
         std::ofstream o(base + ".color_sets.txt");
         for (auto& kv : set_id) {
-            o << "size=" << __builtin_popcountll(kv.first);
+            int size = 0;
+            for (uint64_t w : kv.first) size += __builtin_popcountll(w);
+            o << "size=" << size;
             for (int g = 0; g < ng; ++g)
-                if ((kv.first >> g) & 1) o << ' ' << g;
+                if ((kv.first[g >> 6] >> (g & 63)) & 1) o << ' ' << g;
             o << '\n';
         }
     }

@@ -17,7 +17,9 @@
 // Reads for the benchmark are drawn from the 10 real genomes and from the accessory sequence, so reads
 // cross several unitigs with nested colour sets, as real reads do.
 //
-// usage: synth_s4546 <s10_dump_base> <out.fgidx> <out_accessory.txt> [seed]
+// usage: synth_s4546 <s10_dump_base> <out.fgidx> <out_accessory.txt> [seed [core_stride [target_kmers]]]
+//        core_stride > 1 keeps every core_stride-th salmonella_10 unitig only and target_kmers shrinks the accessory part: a small
+//        index with the same 4546 colours and list shapes, for tests that move the whole index through text files
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -34,7 +36,8 @@ namespace {
 constexpr uint32_t N = 4546;
 constexpr uint32_t NW = (N + 63) / 64;
 constexpr uint32_t K = 31;
-constexpr uint64_t TARGET_KMERS = 43788757;
+uint64_t TARGET_KMERS = 43788757;
+uint64_t CORE_STRIDE = 1;
 
 uint64_t rng_state;
 inline uint64_t rnd() {
@@ -116,6 +119,8 @@ int main(int argc, char** argv) {
     if (argc < 4) { fprintf(stderr, "usage: %s <s10_dump_base> <out.fgidx> <out_accessory.txt> [seed]\n", argv[0]); return 1; }
     const std::string base = argv[1];
     rng_state = argc > 4 ? strtoull(argv[4], nullptr, 10) : 4546;
+    if (argc > 5) CORE_STRIDE = std::max<uint64_t>(1, strtoull(argv[5], nullptr, 10));
+    if (argc > 6) TARGET_KMERS = strtoull(argv[6], nullptr, 10);
 
     // ---- phylogeny ----
     tree.reserve(2 * N);
@@ -175,7 +180,9 @@ int main(int argc, char** argv) {
         std::ifstream in(base + ".unitigs.fa");
         if (!in.is_open()) { fprintf(stderr, "cannot open %s.unitigs.fa\n", base.c_str()); return 1; }
         std::string header, seq;
+        uint64_t unitig_no = 0;
         while (std::getline(in, header) && std::getline(in, seq)) {
+            if (unitig_no++ % CORE_STRIDE) continue;
             const uint32_t sid = (uint32_t)strtoul(header.c_str() + header.find("color_set_id=") + 13, nullptr, 10);
             Bitmap carriers;
             memset(&carriers, 0, sizeof(carriers));

@@ -41,3 +41,21 @@ def ensure_s4546(data_dir, s10_genomes):
         subprocess.run([BIN, base, tmp, acc], check=True)
         os.replace(tmp, fg)
     return fg, [np.fromfile(acc, dtype=np.uint8)]
+
+
+def ensure_s4546_small(data_dir, s10_genomes):
+    """a small index with the same 4546 colours and list shapes (every 24th salmonella_10 unitig, 2.2 M k-mers): for tests
+    that move the whole index through the reference's text dump. Returns (path of the .fgidx, [accessory sequence])."""
+    fg = os.path.join(data_dir, "s4546small.v7.fgidx")
+    acc = os.path.join(data_dir, "s4546small.accessory.txt")
+    if not (os.path.exists(fg) and os.path.exists(acc)):
+        os.makedirs(data_dir, exist_ok=True)
+        _build.build_tools()
+        base = os.path.join(data_dir, "s10")
+        if not os.path.exists(base + ".unitigs.fa"):
+            subprocess.run([_build.BIN_CCDBG, "31", base] + list(s10_genomes), check=True)
+        build_tool()
+        tmp = fg + ".tmp"
+        subprocess.run([BIN, base, tmp, acc, "4546", "24", "2200000"], check=True)
+        os.replace(tmp, fg)
+    return fg, [np.fromfile(acc, dtype=np.uint8)]

@@ -10,7 +10,8 @@ ids, no compressed lists and no code shared with either the product or oracle/fu
   threshold-union(read,t)  = colours c with #positive k-mers containing c >= uint64(double(P) * t),
                              P = #positive k-mers (src/ps_threshold_union.cpp:320-402, include/util.hpp:160-208)
 
-Used by tests/golden/make_golden.py to produce the committed golden vectors. Supports <= 64 genomes.
+Used by tests/golden/make_golden*.py to produce the committed golden vectors. Any number of genomes (masks are
+rows of 64-bit words).
 """
 import gzip
 
@@ -56,42 +57,48 @@ def canonical_kmers(seq, k):
 
 
 class KmerOracle:
-    def __init__(self, genome_paths, k=31):
+    def __init__(self, genomes, k=31):
+        """genomes: FASTA paths, or lists of contigs (bytes) per genome"""
         self.k = k
-        self.n = len(genome_paths)
-        assert self.n <= 64
-        keys, bits = [], []
-        for g, p in enumerate(genome_paths):
+        self.n = len(genomes)
+        self.W = (self.n + 63) // 64
+        keys, owner = [], []
+        for g, p in enumerate(genomes):
             ks = []
-            for contig in read_fasta(p):
+            for contig in (read_fasta(p) if isinstance(p, str) else p):
                 km, ok = canonical_kmers(contig, k)
                 ks.append(km[ok])
-            u = np.unique(np.concatenate(ks))
+            u = np.unique(np.concatenate(ks)) if ks else np.zeros(0, dtype=np.uint64)
             keys.append(u)
-            bits.append(np.full(len(u), 1 << g, dtype=np.uint64))
+            owner.append(np.full(len(u), g, dtype=np.uint32))
         keys = np.concatenate(keys)
-        bits = np.concatenate(bits)
+        owner = np.concatenate(owner)
         order = np.argsort(keys, kind="stable")
-        keys, bits = keys[order], bits[order]
-        starts = np.flatnonzero(np.concatenate(([True], keys[1:] != keys[:-1])))
-        self.keys = keys[starts]
-        self.masks = np.bitwise_or.reduceat(bits, starts)
+        keys, owner = keys[order], owner[order]
+        first = np.concatenate(([True], keys[1:] != keys[:-1]))
+        self.keys = keys[first]
+        row = np.cumsum(first) - 1  # index of the distinct k-mer of every (k-mer, genome) pair
+        self.masks = np.zeros((len(self.keys), self.W), dtype=np.uint64)
+        np.bitwise_or.at(self.masks, (row, owner >> 6), np.uint64(1) << (owner & 63).astype(np.uint64))
 
     def kmer_masks(self, read):
+        """masks of the read's positive k-mers: array [P, W]"""
         km, ok = canonical_kmers(read, self.k)
-        if len(km) == 0:
-            return np.zeros(0, dtype=np.uint64)
+        if len(km) == 0 or len(self.keys) == 0:
+            return np.zeros((0, self.W), dtype=np.uint64)
         idx = np.searchsorted(self.keys, km)
         idx[idx >= len(self.keys)] = 0
         hit = ok & (self.keys[idx] == km)
         return self.masks[idx[hit]]
 
+    def _colours(self, words):
+        return [c for c in range(self.n) if (int(words[c >> 6]) >> (c & 63)) & 1]
+
     def full_intersection(self, read):
         m = self.kmer_masks(read)
         if len(m) == 0:
             return []
-        a = int(np.bitwise_and.reduce(m))
-        return [c for c in range(self.n) if (a >> c) & 1]
+        return self._colours(np.bitwise_and.reduce(m, axis=0))
 
     def threshold_union(self, read, tau):
         m = self.kmer_masks(read)
@@ -101,6 +108,6 @@ class KmerOracle:
         min_score = int(float(P) * tau)
         out = []
         for c in range(self.n):
-            if int(((m >> np.uint64(c)) & np.uint64(1)).sum()) >= min_score:
+            if int(((m[:, c >> 6] >> np.uint64(c & 63)) & np.uint64(1)).sum()) >= min_score:
                 out.append(c)
         return out

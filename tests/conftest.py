@@ -62,9 +62,27 @@ def s10_gpu(built, s10_fgidx):
     return fulgor_amd.Index(s10_fgidx, device=0)
 
 
-def load_golden_reads():
+@pytest.fixture(scope="session")
+def c256_dump(built):
+    """the seeded 256-genome collection of tests/golden/synth_c256.py in the reference's dump format (colour = genome number)"""
+    sys.path.insert(0, GOLDEN)
+    import synth_c256
+    base = os.path.join(DATA, "c256")
+    if not os.path.exists(base + ".unitigs.fa"):
+        paths = synth_c256.write_fasta(synth_c256.genomes(), os.path.join(DATA, "c256_genomes"))
+        subprocess.run([built.BIN_CCDBG, "31", base] + paths, check=True)
+    return base
+
+
+@pytest.fixture(scope="session")
+def c256_oracle(built, c256_dump):
+    from oracle.pyoracle import OracleIndex
+    return OracleIndex.from_dump(c256_dump)
+
+
+def load_golden_reads(name="s10_reads.fa"):
     from fulgor_amd.reads import parse_fastx
-    return parse_fastx(os.path.join(GOLDEN, "s10_reads.fa"))
+    return parse_fastx(os.path.join(GOLDEN, name))
 
 
 def load_golden_tsv(name):

@@ -74,7 +74,7 @@ def main():
             idx = np.searchsorted(orc.keys, km)
             idx[idx >= len(orc.keys)] = 0
             hit = ok & (orc.keys[idx] == km)
-            masks = np.where(hit, orc.masks[idx], np.uint64(0))
+            masks = np.where(hit, orc.masks[idx, 0], np.uint64(0))
             counts = [int(((masks >> np.uint64(c)) & np.uint64(1)).sum()) for c in range(orc.n)]
             runs, p = [], 0
             while p < len(masks):

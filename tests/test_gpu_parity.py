@@ -1,11 +1,14 @@
 """GPU suite: the HIP path, called through the C ABI, against (1) the committed golden vectors of the
 independent k-mer oracle, (2) the oracle (CPU restatement of the reference) on seeded reads, bit-exact,
 (3) size-independent properties at BASELINE config size (1M reads on salmonella_10)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
 import fulgor_amd
-from conftest import S10_GENOMES, csr_to_lists, load_golden_reads, load_golden_tsv
+from conftest import ROOT, S10_GENOMES, csr_to_lists, load_golden_reads, load_golden_tsv
 from fulgor_amd import pack_reads
 
 pytestmark = pytest.mark.gpu
@@ -824,3 +827,108 @@ def test_s4546_reads_with_many_colour_sets(s4546):
     go, gc = ix.pseudoalign_full_intersection_batch(bb, oo_)
     wo, wc = orc.full_intersection(bb, oo_, threads=16)
     assert np.array_equal(go, wo) and np.array_equal(gc, wc)
+
+
+def test_gpu_hit_counts_with_capped_blocks(s10_fgidx):
+    """the expand kernel keeps its per-colour hit histogram in 16-bit LDS counters, so a block must never take
+    more than 65535 reads although tickets are handed out dynamically. Blocks stop pulling at a cap; with the cap lowered to
+    64 reads (test knob, read once per process, hence the subprocess) most blocks hit it on a 60000-read pass, and the hit
+    vector must still equal the column sums of the downloaded results."""
+    import subprocess
+    code = r'''
+import glob, os, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+import fulgor_amd
+from fulgor_amd.reads import ReadGenerator
+g = sorted(glob.glob(os.path.join(%r, "tests", "data", "salmonella_10", "*.fasta.gz")))
+b, o = ReadGenerator(g).generate(7, 60000, 150, 11)
+ix = fulgor_amd.Index(%r, device=0)
+reads = ix.upload_reads(b, o)
+res = ix.new_result()
+n = ix.num_colors()
+for algo, tau in ((fulgor_amd.FULL_INTERSECTION, 0.0), (fulgor_amd.THRESHOLD_UNION, 0.5)):
+    ix.run(reads, res, algo, tau)
+    hits = torch.zeros(n + 2, dtype=torch.int64, device="cuda:0")
+    res.accumulate_hits(hits.data_ptr())
+    go, gc = res.download()
+    got = hits.cpu().numpy()
+    assert np.array_equal(got[:n], np.bincount(gc, minlength=n)), "hit vector differs"
+    assert got[n] == 60000 and got[n + 1] == int((np.diff(go.astype(np.int64)) > 0).sum())
+print("ok")
+''' % (ROOT, ROOT, s10_fgidx)
+    env = dict(os.environ, FULGOR_EXPAND_BLOCK_CAP="64")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+# ---- round 2: parity evidence without shared inputs ---------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def s4546small(built):
+    """4546 colours, list shapes of the big synthetic index, small enough to travel as text: the index is written with
+    `fulgor dump`'s format (fgpu_dump) and the oracle builds itself from those files, ENCODING the colour sets with its own
+    encoder: the two sides share no encoded stream and no unitig table."""
+    from conftest import DATA
+    from fulgor_amd import synth
+    from fulgor_amd.reads import ReadGenerator
+    from oracle.pyoracle import OracleIndex
+    fg, extra = synth.ensure_s4546_small(DATA, S10_GENOMES)
+    ix = fulgor_amd.Index(fg, device=0)
+    base = os.path.join(DATA, "s4546small_dump")
+    if not os.path.exists(base + ".unitigs.fa"):
+        ix.dump(base)
+    orc = OracleIndex.from_dump(base)
+    gen = ReadGenerator(S10_GENOMES[:1], raw_sequences=extra)
+    return ix, orc, gen, fg, base
+
+
+def test_s4546small_dump_feeds_the_oracle(s4546small):
+    ix, orc, gen, _, _ = s4546small
+    ex = ix.export()
+    words, offs = orc.encoded_colors()  # encoded by the oracle from the text lists
+    assert np.array_equal(offs, ex["color_offsets"])
+    assert np.array_equal(words, ex["color_words"][:len(words)])
+    b, o = gen.generate(0, 20000, 150, 42)
+    i1, d1 = ix.fetch_color_set_ids_batch(b, o)
+    i2, d2 = orc.fetch_color_set_ids(b, o, threads=32)
+    assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+    assert int(np.diff(i1.astype(np.int64)).max()) >= 3  # reads do cross unitigs of different colour sets
+    go, gc = ix.pseudoalign_full_intersection_batch(b, o)
+    oo, oc = orc.full_intersection(b, o, threads=32)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+    for tau in (0.8, 0.3):
+        go, gc = ix.pseudoalign_threshold_union_batch(b, o, tau)
+        oo, oc = orc.threshold_union(b, o, tau, threads=32)
+        assert np.array_equal(go, oo) and np.array_equal(gc, oc), tau
+
+
+@pytest.mark.parametrize("index_type,psize,csize", [(fulgor_amd.DIFF, 4546, 16), (fulgor_amd.META, 160, 1), (fulgor_amd.META_DIFF, 160, 16)])
+def test_s4546small_codecs_equal_oracle_convert(s4546small, index_type, psize, csize):
+    """meta / differential / meta-differential at 4546 colours DIRECTLY against the oracle's restated cursors and
+    meta_intersect / diff_intersect / merge_* (round 1 compared them with the hybrid HIP path only)"""
+    from oracle.pyoracle import OracleIndex
+    _, _, gen, fg, base = s4546small
+    iy = fulgor_amd.Index(fg, device=0).convert(index_type, psize, csize)
+    orc = OracleIndex.from_dump(base).convert(index_type, psize, csize)
+    b, o = gen.generate(50000, 12000, 150, 42)
+    go, gc = iy.pseudoalign_full_intersection_batch(b, o)
+    oo, oc = orc.full_intersection(b, o, threads=32)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+    go, gc = iy.pseudoalign_threshold_union_batch(b, o, 0.8)
+    oo, oc = orc.threshold_union(b, o, 0.8, threads=32)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+
+
+@pytest.mark.parametrize("index_type,psize,csize", [(fulgor_amd.HYBRID, 0, 0), (fulgor_amd.DIFF, 16, 4), (fulgor_amd.META, 48, 8), (fulgor_amd.META_DIFF, 48, 8)])
+def test_gpu_matches_golden_at_256_colours(c256_dump, index_type, psize, csize):
+    """golden vectors ABOVE 64 colours: computed by the independent k-mer oracle straight from the 256 seeded genomes
+    (tests/golden/make_golden_c256.py); nothing of the restatement is involved"""
+    ix = fulgor_amd.Index(c256_dump, device=0)
+    if index_type != fulgor_amd.HYBRID:
+        ix.convert(index_type, psize, csize)
+    b, o = pack_reads(load_golden_reads("c256_reads.fa"))
+    offs, cols = ix.pseudoalign_full_intersection_batch(b, o)
+    assert csr_to_lists(offs, cols) == load_golden_tsv("c256_full_intersection.tsv")
+    for tau in (0.8, 0.3):
+        offs, cols = ix.pseudoalign_threshold_union_batch(b, o, tau)
+        assert csr_to_lists(offs, cols) == load_golden_tsv("c256_threshold_union_%s.tsv" % tau)

@@ -80,3 +80,20 @@ def test_oracle_kmer_level_queries_match_golden(s10_oracle):
         assert np.array_equal(pos, flags) and np.array_equal(cnt, counts if len(flags) else np.zeros(10, np.uint32)), rid
         got = [(s, n, _mask_of_set(s10_oracle, cs)) for s, n, cs in s10_oracle.kmer_conservation(reads[rid])]
         assert got == runs, rid
+
+
+# ---- above 64 colours: the seeded 256-genome collection (tests/golden/synth_c256.py, make_golden_c256.py) --------------
+@pytest.mark.parametrize("index_type,psize,csize", [(0, 0, 0), (1, 16, 4), (2, 48, 8), (3, 48, 8)])
+def test_oracle_matches_golden_at_256_colours(c256_dump, index_type, psize, csize):
+    """the restatement (hybrid lists of all three kinds at n = 256, and the three other codecs) against vectors that the
+    independent k-mer oracle computed straight from the 256 genomes"""
+    from oracle.pyoracle import OracleIndex
+    orc = OracleIndex.from_dump(c256_dump)
+    if index_type:
+        orc.convert(index_type, psize, csize)
+    b, o = pack_reads(load_golden_reads("c256_reads.fa"))
+    offs, cols = orc.full_intersection(b, o, threads=4, self_check=index_type == 0)
+    assert csr_to_lists(offs, cols) == load_golden_tsv("c256_full_intersection.tsv")
+    for tau in (0.8, 0.3):
+        offs, cols = orc.threshold_union(b, o, tau, threads=4, self_check=index_type == 0)
+        assert csr_to_lists(offs, cols) == load_golden_tsv("c256_threshold_union_%s.tsv" % tau)
