@@ -226,6 +226,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["end_to_end"] = end_to_end(ix, bases, offs, algo, args.tau, min(n_reads, 1 << 20), 0)
             out["end_to_end_compressed"] = end_to_end(ix, bases, offs, algo, args.tau, min(n_reads, 1 << 20), 2)
+            out["cli_end_to_end"] = cli_end_to_end(ix, bases, offs, algo, args.tau, min(n_reads, 10_000_000), args.read_len)
             out["cpu_baseline"] = cpu_baseline(ix, bases, offs, algo, args.tau, itype, args.partition_size, args.cluster_size)
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -254,6 +255,44 @@ def end_to_end(ix, bases, offs, algo, tau, n, fmt):
     return {"value": round(n / best, 1), "unit": "reads/s", "reads": int(n), "output_bytes": int(out_bytes),
             "includes": "H2D of the reads, all kernels, device-side %s formatting, D2H of the output into a pinned, recycled "
                         "host buffer" % ("ascii" if fmt == 0 else "compressed")}
+
+
+def cli_end_to_end(ix, bases, offs, algo, tau, n, read_len):
+    """Wall clock of the command-line path (`python -m fulgor_amd pseudoalign`: driver.pseudoalign_sharded) on a bounded
+    sample: an uncompressed FASTQ file on tmpfs -> parallel parse into pinned batches -> H2D -> kernels -> records in the
+    reference's compressed format built on the device -> D2H -> /dev/null, three passes in flight. What the reference's own
+    published figure measures (tools/pseudoalign.cpp:76-88), reported beside `value`, never as it. The index is open already."""
+    import tempfile
+    from fulgor_amd import driver
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    path = os.path.join(d, "fulgor_bench_%d.fq" % os.getpid())
+    try:
+        width = 1 + 1 + 9 + 1  # "@r%09d\n"
+        rec = np.empty((n, width + read_len + 3 + read_len + 1), dtype=np.uint8)
+        ids = np.arange(n, dtype=np.int64)
+        rec[:, 0], rec[:, 1], rec[:, width - 1] = ord("@"), ord("r"), ord("\n")
+        for dgt in range(9):
+            rec[:, 2 + dgt] = ord("0") + (ids // 10 ** (8 - dgt)) % 10
+        rec[:, width:width + read_len] = np.asarray(bases[:n * read_len]).reshape(n, read_len)
+        rec[:, width + read_len:width + read_len + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+        rec[:, width + read_len + 3:-1] = ord("I")
+        rec[:, -1] = ord("\n")
+        rec.tofile(path)
+        size = os.path.getsize(path)
+        del rec
+        best = None
+        for _ in range(2):  # the second run finds warm buffers
+            t0 = time.perf_counter()
+            got, mapped = driver.pseudoalign_sharded(lambda: ix, path, "/dev/null", algo, tau, "compressed")
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        assert got == n
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+    return {"value": round(n / best, 1), "unit": "reads/s", "reads": int(n), "fastq_bytes": int(size),
+            "includes": "FASTQ file on tmpfs -> parse (parallel, native) -> pinned batches -> H2D -> kernels -> compressed records "
+                        "built on the device -> D2H -> /dev/null; index already resident"}
 
 
 def cpu_baseline(ix, bases, offs, algo, tau, itype=0, psize=160, csize=16):

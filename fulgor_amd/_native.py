@@ -69,6 +69,8 @@ def lib():
     L.fgpu_result_format.argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(vp), u64p]
     L.fgpu_result_format_view.argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(vp), u64p]
     L.fgpu_fastx_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.fgpu_fastx_open_part.argtypes = [C.c_char_p, C.c_uint, C.c_uint64, C.c_uint64, C.POINTER(vp)]
+    L.fgpu_fastx_count.argtypes = [C.c_char_p, C.c_uint, C.c_uint64, C.c_uint64, u64p]
     L.fgpu_fastx_next.argtypes = [vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp), u64p]
     L.fgpu_fastx_names.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.fgpu_fastx_close.argtypes = [vp]

@@ -13,18 +13,40 @@ from .index import FULL_INTERSECTION, THRESHOLD_UNION, Index
 from .reads import FastxReader
 
 
+def _launch_ranks(argv, gpus):
+    """--gpus N outside a launcher: start one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torchrun
+    exports them) running this same command line, wait for all of them"""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-m", "fulgor_amd", "pseudoalign"] + list(argv), env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return 1 if rc else 0
+
+
 def pseudoalign(argv):
     ap = argparse.ArgumentParser(prog="fulgor pseudoalign", add_help=True)
     ap.add_argument("-i", dest="index_filename", required=True, help="The Fulgor index (dump basename or .fgidx).")
     ap.add_argument("-q", dest="query_filename", required=True, help="Query filename in FASTA/FASTQ format (optionally gzipped).")
     ap.add_argument("-o", dest="output_filename", required=True, help="File where output will be written.")
-    ap.add_argument("-t", dest="num_threads", type=int, default=1, help="Accepted for compatibility; reads are batched on the GPU.")
+    ap.add_argument("-t", dest="num_threads", type=int, default=0,
+                    help="Threads that parse the query file (the reference's parser / worker threads); 0 = half of the host's.")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("-r", dest="threshold", type=float, default=None,
                     help="Threshold for threshold_union algorithm. It must be a float in (0.0,1.0].")
     ap.add_argument("--deduplicate", action="store_true")
     ap.add_argument("--format", dest="format", default="ascii")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="GPUs of this node to use: one process per GPU, the index replicated, every GPU takes one part of the query file.")
     try:
         a = ap.parse_args(argv)
     except SystemExit:
@@ -41,26 +63,58 @@ def pseudoalign(argv):
     if a.format not in driver.FORMATS:
         print("Unknown output format. Supported formats: ascii, binary, compressed.")  # tools/pseudoalign.cpp:317-320
         return 1
-    if a.verbose:
+    if a.gpus < 1:
+        print("--gpus must be positive", file=sys.stderr)
+        return 1
+    rank, world, local = driver.rank_env()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        if a.deduplicate:
+            print("--deduplicate runs on one GPU", file=sys.stderr)
+            return 1
+        return _launch_ranks(argv, a.gpus)
+    if world != a.gpus:
+        print("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
+        return 1
+    if a.verbose and rank == 0:
         print(" ".join(["fulgor", "pseudoalign"] + list(argv)))
-    t0 = time.time()
-    try:
-        index = Index(a.index_filename, device=a.device)
-    except RuntimeError as e:
-        print(str(e), file=sys.stderr)
+    if not os.path.exists(a.query_filename):
+        print("cannot open " + a.query_filename, file=sys.stderr)
         return 1
-    try:  # read id = 0-based file order (src/ps_utils.cpp:276,286); parsing overlaps with the GPU passes
-        batches = FastxReader(a.query_filename, batch=1 << 20, copy=False)
-    except RuntimeError as e:
-        print(str(e), file=sys.stderr)
-        return 1
+    # FULGOR_SHARE_GPU=1 (test only): all ranks use --device and gloo, to exercise the multi-rank path on a one-GPU box
+    share = os.environ.get("FULGOR_SHARE_GPU") == "1"
+    device = a.device if (world == 1 or share) else local
+    reduce_device = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if share or not torch.cuda.is_available():
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))  # RCCL on ROCm
+            reduce_device = "cuda:%d" % device
     t1 = time.time()
-    with open(a.output_filename, "wb") as out:
-        n, mapped = driver.pseudoalign_stream(index, batches, algo, a.threshold or 0.0, sink=out, fmt=a.format,
-                                              deduplicate=a.deduplicate)
-    batches.close()
+    try:
+        if a.deduplicate:
+            index = Index(a.index_filename, device=device)
+            batches = FastxReader(a.query_filename, batch=1 << 19, copy=False, threads=a.num_threads)
+            with open(a.output_filename, "wb") as out:
+                n, mapped = driver.pseudoalign_stream(index, batches, algo, 0.0, sink=out, fmt=a.format, deduplicate=True)
+            batches.close()
+        else:  # read id = 0-based file order (src/ps_utils.cpp:276,286); parsing overlaps with the GPU passes
+            n, mapped = driver.pseudoalign_sharded(lambda: Index(a.index_filename, device=device), a.query_filename,
+                                                   a.output_filename, algo, a.threshold or 0.0, a.format, rank, world,
+                                                   io_threads=a.num_threads, device_for_reduce=reduce_device)
+    except (RuntimeError, ValueError) as e:
+        print(str(e), file=sys.stderr)
+        return 1
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
     el = (time.time() - t1) * 1000.0
-    if a.verbose:  # tools/pseudoalign.cpp:79-88
+    if a.verbose and rank == 0:  # tools/pseudoalign.cpp:79-88
         print("processed %d reads" % n)
         print("elapsed = %d millisec / %d sec / %d min / %g musec/read" % (el, el / 1000, el / 60000, el * 1000 / max(1, n)))
         print("num_mapped_reads %d/%d (%g%%)" % (mapped, n, mapped * 100.0 / max(1, n)))
@@ -162,6 +216,6 @@ def main(argv=None):
              "kmer-matches": lambda av: _query_tool(av, "kmer-matches", _emit_matches)}
     if not argv or argv[0] not in tools:
         print("usage: python -m fulgor_amd <pseudoalign|kmer-conservation|kmer-matches|dump> -i <index> -q <reads> -o <out> "
-              "[-r tau] [--format ascii|binary|compressed] [--deduplicate] [--verbose]")
+              "[-r tau] [--format ascii|binary|compressed] [--deduplicate] [--verbose] [--gpus N] [-t io threads]")
         return 1
     return tools[argv[0]](argv[1:])

@@ -1157,41 +1157,95 @@ int fgpu_formatter_finish(fgpu_formatter* f, char** out, uint64_t* out_len) {
 }
 
 // ---- query reader -------------------------------------------------------------------------------------------
+namespace {
+// grow-only byte buffer in pinned host memory (H2D copies out of it run at PCIe speed and overlap with kernels); plain
+// memory when there is no HIP device (host-only tools, CPU tests)
+struct PinnedBytes {
+    char* p = nullptr;
+    size_t n = 0, cap = 0;
+    bool pinned = false;
+    ~PinnedBytes() { release(); }
+    void release() {
+        if (p) { if (pinned) (void)hipHostFree(p); else free(p); }
+        p = nullptr;
+        n = cap = 0;
+    }
+    void clear() { n = 0; }
+    size_t size() const { return n; }
+    char* data() { return p; }
+    void reserve(size_t want) {
+        want += 1024;  // slack: the lookup kernel over-reads padded reads
+        if (want <= cap) return;
+        want += want / 4 + 4096;
+        char* q = nullptr;
+        bool pin = hipHostMalloc((void**)&q, want, hipHostMallocDefault) == hipSuccess && q;
+        if (!pin) {
+            (void)hipGetLastError();
+            q = (char*)malloc(want);
+            if (!q) throw std::bad_alloc();
+        }
+        if (n) memcpy(q, p, n);
+        const size_t keep = n;
+        release();
+        p = q;
+        n = keep;
+        cap = want;
+        pinned = pin;
+    }
+    void set_size(size_t len) { n = len; }
+};
+}  // namespace
+
 struct fgpu_fastx {
+    static constexpr int RING = 4;  // batches alive at a time: a worker loop keeps several passes in flight
     FastxReader reader;
-    std::vector<char> bases;     // the current batch (owned by the reader, recycled)
-    std::vector<uint64_t> offs;
+    PinnedBytes bases[RING];
+    std::vector<uint64_t> offs[RING];
     std::vector<char> names;
     std::vector<uint64_t> name_offs{0};
-    explicit fgpu_fastx(const char* path) : reader(path) {}
+    int cur = RING - 1;
+    fgpu_fastx(const char* path, unsigned threads, uint64_t begin, uint64_t end) : reader(path, threads, begin, end) {}
 };
 
-int fgpu_fastx_open(const char* path, fgpu_fastx** out) {
+int fgpu_fastx_open(const char* path, fgpu_fastx** out) { return fgpu_fastx_open_part(path, 0, 0, ~0ULL, out); }
+
+int fgpu_fastx_open_part(const char* path, unsigned threads, uint64_t begin, uint64_t end, fgpu_fastx** out) {
     if (!path || !out) return fail(-EINVAL, "null argument");
     *out = nullptr;
-    return guarded([&] { *out = new fgpu_fastx(path); });
+    return guarded([&] { *out = new fgpu_fastx(path, threads, begin, end); });
+}
+
+int fgpu_fastx_count(const char* path, unsigned threads, uint64_t begin, uint64_t end, uint64_t* num_reads) {
+    if (!path || !num_reads) return fail(-EINVAL, "null argument");
+    return guarded([&] {
+        FastxReader r(path, threads, begin, end);
+        const uint64_t total = r.count();
+        *num_reads = total;
+    });
 }
 
 int fgpu_fastx_next(fgpu_fastx* f, uint64_t max_reads, const char** bases, const uint64_t** offs, uint64_t* n) {
     if (!f || !bases || !offs || !n) return fail(-EINVAL, "null argument");
     if (max_reads == 0) return fail(-EINVAL, "max_reads must be positive");
     return guarded([&] {
-        f->reader.next(max_reads, f->bases, f->offs, &f->names, &f->name_offs);
-        *n = f->offs.size() - 1;
-        const size_t len = f->bases.size();
-        f->bases.resize(len + 256, 0);  // slack: the lookup kernel over-reads padded reads
-        f->bases.resize(len);
-        *bases = f->bases.data();
-        *offs = f->offs.data();
+        f->cur = (f->cur + 1) % fgpu_fastx::RING;
+        PinnedBytes& b = f->bases[f->cur];
+        f->reader.next(max_reads, b, f->offs[f->cur]);
+        *n = f->offs[f->cur].size() - 1;
+        b.reserve(b.size());
+        *bases = b.data();
+        *offs = f->offs[f->cur].data();
     });
 }
 
 int fgpu_fastx_names(fgpu_fastx* f, const char** names, const uint64_t** name_offs) {
     if (!f || !names || !name_offs) return fail(-EINVAL, "null argument");
-    f->names.reserve(f->names.size() + 1);
-    *names = f->names.data();
-    *name_offs = f->name_offs.data();
-    return 0;
+    return guarded([&] {
+        f->reader.names(f->names, f->name_offs);
+        f->names.reserve(f->names.size() + 1);
+        *names = f->names.data();
+        *name_offs = f->name_offs.data();
+    });
 }
 
 void fgpu_fastx_close(fgpu_fastx* f) { delete f; }

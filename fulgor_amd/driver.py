@@ -157,36 +157,118 @@ def pseudoalign_reads(index, bases, offs, algo=FULL_INTERSECTION, threshold=0.0,
 
 
 def pseudoalign_stream(index, batches, algo=FULL_INTERSECTION, threshold=0.0, sink=None, fmt="ascii", deduplicate=False,
-                       first_id=0):
-    """the worker loop over a stream of read batches (reads.FastxReader): while a batch is on the GPU the reader's
-    thread inflates and parses the next ones. Read ids follow file order. returns (num_reads, num_mapped_reads)"""
+                       first_id=0, write_header=True, inflight=3):
+    """the worker loop over a stream of read batches (reads.FastxReader): parsing, upload, kernels, device-side formatting
+    and the copy of the formatted records back to the host overlap. `inflight` batches are in the pipeline at a time, each
+    driven by its own host thread on its own result (= its own HIP stream; the C calls release the GIL); records are written
+    in file order. Read ids follow file order from first_id on. returns (num_reads, num_mapped_reads)"""
     if deduplicate and algo != FULL_INTERSECTION:
         raise ValueError("Deduplication not available for threshold < 1.0. Remove --deduplicate flag.")
     f = Formatter(fmt, index.num_colors()) if sink is not None else None
-    if f is not None:
+    if f is not None and write_header:
         sink.write(f.header)
-    res = index.new_result()
     n = mapped = 0
-    for bases, offs in batches:
-        cnt = len(offs) - 1
-        if deduplicate:
+    if deduplicate:
+        for bases, offs in batches:
             o, c = deduplicated_full_intersection(index, bases, offs)
             mapped += int((np.diff(o.astype(np.int64)) > 0).sum())
             if f is not None:
                 sink.write(f.add(first_id + n, o, c))
-        else:
-            reads = index.upload_reads(bases, offs)
-            index.run(reads, res, algo, threshold)
-            mapped += res.sizes()[2]
-            if f is not None:
-                sink.write(res.format_view(FORMATS[fmt], first_id + n))
-            reads.close()
-        n += cnt
+            n += len(offs) - 1
+        if f is not None:
+            sink.write(f.finish())  # the deduplicated path formats on the host: flush its last compressed block
+        return n, mapped
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    inflight = max(1, min(3, int(inflight)))  # the reader keeps four batches alive
+    results = [index.new_result() for _ in range(inflight)]
+
+    def one_pass(slot, bases, offs, id0):
+        res = results[slot]
+        reads = index.upload_reads(bases, offs)
+        index.run(reads, res, algo, threshold)
+        m = res.sizes()[2]
+        view = res.format_view(FORMATS[fmt], id0) if f is not None else None  # valid until this result formats again
+        reads.close()
+        return m, view
+
+    pending = deque()
+
+    def retire():
+        nonlocal mapped
+        m, view = pending.popleft().result()
+        mapped += m
+        if view is not None:
+            sink.write(view)
+
+    with ThreadPoolExecutor(max_workers=inflight) as pool:
+        slot = 0
+        for bases, offs in batches:
+            if len(pending) == inflight:
+                retire()  # frees the slot that is taken next: slots are used round robin
+            pending.append(pool.submit(one_pass, slot, bases, offs, first_id + n))
+            slot = (slot + 1) % inflight
+            n += len(offs) - 1
+        while pending:
+            retire()
     if f is not None:
-        tail = f.finish()
-        if deduplicate:  # the deduplicated path formats on the host: flush its last compressed block
-            sink.write(tail)
-    res.close()
+        f.finish()  # (the host formatter only supplied the file header)
+    for r in results:
+        r.close()
+    return n, mapped
+
+
+# ---- several GPUs: one process per GPU, every rank takes one part of the query file (SURVEY 8e) --------------------------
+def rank_env():
+    """(rank, world size, local rank) as torchrun / the CLI's own launcher export them"""
+    import os
+    rank = int(os.environ.get("RANK", "0"))
+    return rank, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", str(rank)))
+
+
+def pseudoalign_sharded(open_index, query, output, algo=FULL_INTERSECTION, threshold=0.0, fmt="ascii", rank=0, world=1,
+                        io_threads=0, device_for_reduce=None, batch=1 << 19):
+    """One rank of a multi-GPU `pseudoalign`. Reads are independent units (tools/pseudoalign.cpp:22-51 keeps no state across
+    reads but two counters): rank r parses and processes the records that start in the r-th of `world` byte ranges of the
+    (plain) query file, numbers them in file order (the ranks exchange the record counts of their parts), writes
+    <output>.part<r>, and the two counters are all-reduced (RCCL when the tensor lives on a GPU, gloo on the CPU). Rank 0 then
+    concatenates the parts in rank order = read-id order. open_index() opens this rank's replica of the index.
+    returns (num_reads, num_mapped_reads) of the whole job."""
+    import os
+    import shutil
+    import torch
+    import torch.distributed as dist
+    from .reads import FastxReader, count_reads, is_gzip
+    size = os.path.getsize(query)
+    if world > 1 and is_gzip(query):
+        raise ValueError("a gzip stream cannot be read in parts: decompress the query file for a multi-GPU run")
+    begin, end = size * rank // world, size * (rank + 1) // world
+    first_id = 0
+    if world > 1:
+        mine = torch.tensor([count_reads(query, begin, end, io_threads)], dtype=torch.int64, device=device_for_reduce)
+        counts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(counts, mine)
+        first_id = int(sum(int(c.item()) for c in counts[:rank]))
+    index = open_index()
+    batches = FastxReader(query, batch=batch, copy=False, threads=io_threads, begin=begin, end=end if world > 1 else (1 << 64) - 1)
+    part = output if world == 1 else "%s.part%d" % (output, rank)
+    with open(part, "wb") as out:
+        n, mapped = pseudoalign_stream(index, batches, algo, threshold, sink=out, fmt=fmt, first_id=first_id,
+                                       write_header=rank == 0)
+    batches.close()
+    if world > 1:
+        t = torch.tensor([n, mapped], dtype=torch.int64, device=device_for_reduce)
+        dist.all_reduce(t)
+        n, mapped = int(t[0].item()), int(t[1].item())
+        dist.barrier()
+        if rank == 0:
+            with open(output, "wb") as out:
+                for r in range(world):
+                    p = "%s.part%d" % (output, r)
+                    with open(p, "rb") as src:
+                        shutil.copyfileobj(src, out, 64 << 20)
+                    os.remove(p)
+        dist.barrier()
     return n, mapped
 
 

@@ -84,20 +84,38 @@ def parse_fastx(path):
     return seqs
 
 
-class FastxReader:
-    """native FASTA/FASTQ(.gz) reader (fgpu_fastx_*): a background thread inflates and parses while the caller works.
-    Iterating yields (bases uint8 array, offsets uint64 array) batches of at most `batch` reads in file order.
-    copy=False hands out views of the reader's own recycled buffers, valid until the next batch is requested (what
-    the worker loop wants: the batch goes straight to the GPU)."""
+ALL = (1 << 64) - 1
 
-    def __init__(self, path, batch=1 << 20, copy=True):
+
+def count_reads(path, begin=0, end=ALL, threads=0):
+    """number of records that start in the byte range [begin, end) of a plain FASTA/FASTQ file (fgpu_fastx_count)"""
+    import ctypes as C
+    from . import _native
+    n = C.c_uint64()
+    _native.check(_native.lib().fgpu_fastx_count(str(path).encode(), int(threads), int(begin), int(end), C.byref(n)))
+    return n.value
+
+
+def is_gzip(path):
+    with open(path, "rb") as f:
+        return f.read(2) == b"\x1f\x8b"
+
+
+class FastxReader:
+    """native FASTA/FASTQ(.gz) reader (fgpu_fastx_*): plain files are parsed by `threads` threads at once, a gzip stream by
+    one, off the caller's thread in both cases. Iterating yields (bases uint8 array, offsets uint64 array) batches of at
+    most `batch` reads in file order. copy=False hands out views of the reader's own pinned, recycled buffers, valid until
+    THREE more batches have been requested (what the worker loop wants: batches go straight to the GPU, a few in flight).
+    begin / end: only the records starting in that byte range of a plain file (one part per GPU)."""
+
+    def __init__(self, path, batch=1 << 20, copy=True, threads=0, begin=0, end=ALL):
         import ctypes as C
         from . import _native
         self._C, self._N, self._L = C, _native, _native.lib()
         self.batch = int(batch)
         self.copy = bool(copy)
         h = C.c_void_p()
-        _native.check(self._L.fgpu_fastx_open(str(path).encode(), C.byref(h)))
+        _native.check(self._L.fgpu_fastx_open_part(str(path).encode(), int(threads), int(begin), int(end), C.byref(h)))
         self._h = h
 
     def __iter__(self):

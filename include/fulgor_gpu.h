@@ -129,13 +129,20 @@ int fgpu_formatter_add(fgpu_formatter* f, uint32_t first_id, const uint64_t* off
                        char** out, uint64_t* out_len);
 int fgpu_formatter_finish(fgpu_formatter* f, char** out, uint64_t* out_len);
 
-/* Query reader (src/ps_utils.cpp:245-305): FASTA / FASTQ, plain or gzip, parsed natively by a background
- * thread (inflate + parse overlap with the GPU passes). fgpu_fastx_next returns the next at most max_reads reads in
+/* Query reader (src/ps_utils.cpp:245-305): FASTA / FASTQ, plain or gzip, parsed natively off the caller's thread
+ * (inflate + parse overlap with the GPU passes). Plain files are mapped and parsed by `threads` threads at once, byte range by
+ * byte range; a gzip stream is inflated and parsed by one thread. fgpu_fastx_next returns the next at most max_reads reads in
  * file order (read id = position in the file, as FQFeeder numbers them) as concatenated bases + (n + 1) offsets.
- * The two buffers belong to the reader and stay valid until the next call on it (they are recycled: no allocation
- * per batch); *n = 0 at end of file. */
+ * The two buffers belong to the reader (pinned host memory when a HIP device is present) and stay valid for the next THREE
+ * calls on it (a ring of four batches: a worker loop keeps several passes in flight); *n = 0 at end of file.
+ * fgpu_fastx_open_part reads only the records that start in the byte range [begin, end) of a PLAIN file (both ends are
+ * moved forward to the next record boundary, so consecutive ranges partition the file): every GPU of a multi-GPU run takes
+ * one part; fgpu_fastx_count returns the number of records of such a part (their global read ids follow from the counts of
+ * the parts in front). threads = 0: half of the host's hardware threads, at most 32. */
 typedef struct fgpu_fastx fgpu_fastx;
 int fgpu_fastx_open(const char* path, fgpu_fastx** out);
+int fgpu_fastx_open_part(const char* path, unsigned threads, uint64_t begin, uint64_t end, fgpu_fastx** out);
+int fgpu_fastx_count(const char* path, unsigned threads, uint64_t begin, uint64_t end, uint64_t* num_reads);
 int fgpu_fastx_next(fgpu_fastx* f, uint64_t max_reads, const char** bases, const uint64_t** offs, uint64_t* n);
 /* names of the records of the last batch (kseq's name: the header up to the first blank), concatenated + (n + 1) offsets;
  * same lifetime as the batch */

@@ -181,3 +181,102 @@ def test_native_fastx_reader_matches_python_parser(built, tmp_path):
     assert names == ["r%d" % i for i in range(len(seqs))]
     with pytest.raises(RuntimeError):
         FastxReader(str(tmp_path / "missing.fq"))
+
+
+def test_parallel_reader_ranges_parts_and_batch_limit(built, tmp_path):
+    """plain files are parsed range by range by several threads (8 MB ranges: a 40 MB FASTQ has five), parts of a file
+    partition its records whatever the cut points, and a batch never holds more than max_reads reads"""
+    from fulgor_amd.reads import FastxReader, count_reads
+    rng = np.random.default_rng(11)
+    alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    seqs = [bytes(alpha[rng.integers(0, 5, size=int(l))]) for l in rng.integers(100, 220, size=120000)]
+    quals = [bytes(rng.integers(33, 75, size=len(s), dtype=np.uint8)) for s in seqs]  # '@' and '+' occur at line starts
+    p = str(tmp_path / "big.fq")
+    with open(p, "wb") as f:
+        for i, (s, q) in enumerate(zip(seqs, quals)):
+            f.write(b"@read%d/1\n%s\n+\n%s\n" % (i, s, q))
+    size = os.path.getsize(p)
+    assert size > 36 << 20
+
+    def collect(**kw):
+        got, sizes = [], []
+        rd = FastxReader(p, copy=True, **kw)
+        for bases, offs in rd:
+            b = bytes(bases)
+            got += [b[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+            sizes.append(len(offs) - 1)
+        rd.close()
+        return got, sizes
+
+    got, sizes = collect(batch=4096, threads=6)
+    assert got == seqs and max(sizes) <= 4096 and sizes[:-1] == [4096] * (len(sizes) - 1)
+    got, sizes = collect(batch=1 << 20, threads=2)
+    assert got == seqs and len(sizes) == 1
+    cuts = [0, size // 3 + 17, size // 3 + 18, (2 * size) // 3, size]  # arbitrary byte positions, one range nearly empty
+    total, joined = 0, []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        part, _ = collect(batch=50000, threads=3, begin=a, end=b)
+        assert count_reads(p, a, b, 3) == len(part)
+        joined += part
+        total += len(part)
+    assert total == len(seqs) and joined == seqs
+
+
+MULTI_RANK_CLI_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch.distributed as dist
+from fulgor_amd import driver
+from oracle.pyoracle import OracleIndex
+
+class Reads:
+    def __init__(self, b, o): self.b, self.o = np.array(b), np.array(o)
+    def close(self): pass
+
+class Result:
+    """stands in for the GPU result of a pass in this CPU test of the sharding logic: computed by the oracle"""
+    def __init__(self, orc): self.orc = orc
+    def sizes(self): return len(self.o) - 1, len(self.c), int((np.diff(self.o.astype(np.int64)) > 0).sum())
+    def format_view(self, fmt, first_id): return driver.format_ascii(first_id, self.o, self.c)
+    def close(self): pass
+
+class Index:
+    def __init__(self, base): self.orc = OracleIndex.from_dump(base)
+    def num_colors(self): return 10
+    def new_result(self): return Result(self.orc)
+    def upload_reads(self, b, o): return Reads(b, o)
+    def run(self, reads, res, algo, tau): res.o, res.c = self.orc.full_intersection(reads.b, reads.o, threads=2)
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n, mapped = driver.pseudoalign_sharded(lambda: Index(os.path.join(sys.argv[1], "data", "s10")), sys.argv[2], sys.argv[3],
+                                       rank=rank, world=world, io_threads=2, batch=300)
+if rank == 0:
+    open(sys.argv[3] + ".counters", "w").write("%d %d" % (n, mapped))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_cli_path_on_gloo(s10_dump, tmp_path, world):
+    """driver.pseudoalign_sharded, the body of `pseudoalign --gpus N`, launched by torchrun on gloo: every rank takes a byte range
+    of the query file, numbers its reads from the all-gathered counts, writes its part; the parts are joined in rank order
+    and the counters all-reduced. The passes themselves are computed by the oracle here (no GPU in this suite); the
+    result must be the golden ascii output, byte for byte."""
+    script = tmp_path / "worker.py"
+    script.write_text(MULTI_RANK_CLI_WORKER)
+    reads = load_golden_reads()
+    q = tmp_path / "reads.fq"
+    with open(q, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)))
+    out = tmp_path / "out.txt"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+                    "--master-addr", "127.0.0.1", "--master-port", str(29550 + world), str(script), ROOT, str(q), str(out)],
+                   check=True, env=env, timeout=600)
+    want = open(os.path.join(ROOT, "tests", "golden", "s10_full_intersection.tsv"), "rb").read()
+    assert open(out, "rb").read() == want
+    n, mapped = map(int, open(str(out) + ".counters").read().split())
+    assert n == len(reads) and mapped == sum(1 for l in want.splitlines() if l.split(b"\t")[1] != b"0")
+    assert not [p for p in os.listdir(tmp_path) if ".part" in p]

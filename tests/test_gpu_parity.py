@@ -785,6 +785,50 @@ def test_s4546_config_size_10M_reads_properties(s4546):
         assert np.array_equal(go, oo) and np.array_equal(gc, oc)
 
 
+def test_s4546_config_metadiff_12M5_reads_per_gpu_properties(s4546):
+    """BASELINE configs[4] at its PER-GPU size: meta-differential colour sets, 12.5 M reads (100 M reads over 8 GPUs), one GPU.
+    Size-independent properties: the hit vector (what RCCL all-reduces) does not depend on how the reads are cut into passes
+    and equals the hybrid index's on the same reads; slices far apart are bit-exact against the oracle's restated
+    meta-differential cursors (merge_metadiff / meta_intersect<is_diff>)."""
+    import torch
+    from conftest import DATA
+    from fulgor_amd import synth
+    ix, orc_h, gen = s4546
+    fg, _ = synth.ensure_s4546(DATA, S10_GENOMES)
+    iy = fulgor_amd.Index(fg, device=0).convert(fulgor_amd.META_DIFF, 160, 16)
+    N = 12_500_000
+    b, o = gen.generate(3 * N, N, 150, 42)  # the slice rank 3 of the 8-GPU job owns
+    nc = iy.num_colors()
+
+    def hit_vector(index, chunk):
+        reads = index.upload_reads(b, o)
+        res = index.new_result()
+        hits = torch.zeros(nc + 2, dtype=torch.int64, device="cuda:0")
+        for first in range(0, N, chunk):
+            index.run(reads, res, fulgor_amd.FULL_INTERSECTION, 0.0, first, min(chunk, N - first))
+            res.accumulate_hits(hits.data_ptr())
+        res.close()
+        reads.close()
+        return hits.cpu().numpy()
+
+    md_a = hit_vector(iy, 2_500_000)
+    md_b = hit_vector(iy, 1_700_000)  # ragged last pass
+    assert np.array_equal(md_a, md_b) and md_a[nc] == N
+    assert np.array_equal(md_a, hit_vector(ix, 2_500_000))  # codecs do not change results
+    from oracle.pyoracle import OracleIndex
+    orc = OracleIndex.from_export(ix.export()).convert(fulgor_amd.META_DIFF, 160, 16)
+    for first in (0, 6_000_000, N - 10_000):
+        cnt = 10_000
+        lo, hi = int(o[first]), int(o[first + cnt])
+        sb, so = b[lo:hi], o[first:first + cnt + 1] - o[first]
+        go, gc = iy.pseudoalign_full_intersection_batch(sb, so)
+        oo, oc = orc.full_intersection(sb, so, threads=32)
+        assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+        go, gc = iy.pseudoalign_threshold_union_batch(sb, so, 0.8)
+        oo, oc = orc.threshold_union(sb, so, 0.8, threads=32)
+        assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+
+
 @pytest.mark.parametrize("k", [21, 27])
 def test_gpu_other_kmer_lengths(built, tmp_path, k):
     """k != 31 (the dictionary derives m = k - 12): a 3-genome index built at that k, lookups and both algorithms
@@ -932,3 +976,35 @@ def test_gpu_matches_golden_at_256_colours(c256_dump, index_type, psize, csize):
     for tau in (0.8, 0.3):
         offs, cols = ix.pseudoalign_threshold_union_batch(b, o, tau)
         assert csr_to_lists(offs, cols) == load_golden_tsv("c256_threshold_union_%s.tsv" % tau)
+
+
+def test_cli_two_ranks_share_the_gpu(s10_fgidx, s10_oracle, tmp_path):
+    """`pseudoalign --gpus 2` (own launcher, one process per rank; FULGOR_SHARE_GPU=1 puts both ranks on the one GPU of this
+    box and the counters on gloo): the joined output equals the single-process output byte for byte (ascii), parses back to
+    the same records (compressed), and the pipelined single-process output equals the oracle's."""
+    import subprocess
+    from fulgor_amd.reads import ReadGenerator
+    from oracle.pyoracle import parse_compressed
+    n = 150_000
+    b, o = ReadGenerator(S10_GENOMES).generate(9, n, 150, 5)
+    q = tmp_path / "reads.fq"
+    with open(q, "wb") as f:
+        for i in range(n):
+            f.write(b"@r%d\n%s\n+\n%s\n" % (i, bytes(b[int(o[i]):int(o[i + 1])]), b"I" * 150))
+    base = [sys.executable, "-m", "fulgor_amd", "pseudoalign", "-i", s10_fgidx, "-q", str(q), "--verbose"]
+    outs = {}
+    for fmt in ("ascii", "compressed"):
+        for gpus in (1, 2):
+            out = tmp_path / ("out_%s_%d" % (fmt, gpus))
+            env = dict(os.environ, FULGOR_SHARE_GPU="1")
+            r = subprocess.run(base + ["-o", str(out), "--format", fmt, "--gpus", str(gpus)], cwd=ROOT, env=env,
+                               capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stdout + r.stderr
+            assert "processed %d reads" % n in r.stdout
+            outs[fmt, gpus] = open(out, "rb").read()
+    assert outs["ascii", 1] == outs["ascii", 2]
+    oo, oc = s10_oracle.full_intersection(b, o, threads=32)
+    assert outs["ascii", 1] == s10_oracle.format_ascii(oo, oc)
+    for gpus in (1, 2):
+        ids, po, pc = parse_compressed(outs["compressed", gpus])
+        assert np.array_equal(ids, np.arange(n)) and np.array_equal(po, oo) and np.array_equal(pc, oc)
