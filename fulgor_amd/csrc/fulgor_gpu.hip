@@ -555,7 +555,10 @@ void fgpu_close(fgpu_index* ix) {
 
 int fgpu_save(const fgpu_index* ix, const char* path) {
     if (!ix || !path) return fail(-EINVAL, "null argument");
-    return guarded([&] { save_binary(ix->host, path); });
+    return guarded([&] {
+        if (ends_with(path, "fur")) save_fur(ix->host, path);  // the reference's layout (fur_format.hpp: not validated on a real file)
+        else save_binary(ix->host, path);
+    });
 }
 
 int fgpu_info(const fgpu_index* ix, uint64_t* k, uint64_t* num_colors, uint64_t* num_color_sets, uint64_t* num_unitigs,

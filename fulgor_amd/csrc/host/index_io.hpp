@@ -19,13 +19,10 @@
 #include <sstream>
 #include "codecs_build.hpp"
 #include "dict_build.hpp"
+#include "fur_format.hpp"
 #include "hybrid_codec.hpp"
 
 namespace fg {
-
-inline bool ends_with(const std::string& s, const std::string& suf) {
-    return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
-}
 
 inline void load_dump(const std::string& base, HostIndex& idx, uint32_t m = 0, unsigned nthreads = 0) {
     uint64_t k = 0, num_kmers = 0, num_colors = 0, num_unitigs = 0, num_color_sets = 0;
@@ -243,14 +240,42 @@ inline void load_binary(const std::string& path, HostIndex& idx) {
     }
 }
 
-// path dispatch: ".fgidx" container, a reference binary index (rejected), or a dump basename
+// A file in the reference's binary layout (fur_format.hpp: Fulgor-owned sections from the reference, primitive layouts from
+// memory of upstream and NOT validated on a real file, k2u section = the engine's own block): what fgpu_save writes under
+// a .fur / .mfur / .dfur / .mdfur name. A file written by the reference itself stops at its SSHash section.
+inline void load_fur(const std::string& path, HostIndex& idx, unsigned nthreads = 0) {
+    uint32_t psize = 0, csize = 0;
+    fur::read_fur(path, idx, psize, csize);
+    Dict& d = idx.dict;
+    check_dict_params(d.k, d.m);
+    if (d.unitig_off.empty() || d.unitig_off.back() != d.total_bases || d.strings.size() < (d.total_bases + 31) / 32)
+        throw std::runtime_error("corrupt index file (unitigs)");
+    std::string bases(d.total_bases, 'A');
+    for (uint64_t i = 0; i < d.total_bases; ++i) bases[i] = "ACGT"[detail::string_base(d.strings, i)];
+    const std::vector<uint64_t> off = d.unitig_off;
+    const std::vector<uint32_t> csid = d.unitig_csid;
+    const uint64_t num_kmers = d.num_kmers;
+    build_dict(d, d.k, d.m, bases.data(), bases.size(), off, csid, nthreads);
+    if (d.num_kmers != num_kmers) throw std::runtime_error("corrupt index file (num_kmers)");
+    hybrid_build_blocks(idx.hybrid, nthreads);
+    const int type = idx.type;
+    if (type != IDX_HYBRID) {
+        convert_sets(idx.hybrid, type, psize ? psize : idx.hybrid.num_colors, csize ? csize : 1, idx.generic);
+        idx.generic.type = type;
+    }
+}
+
+inline void save_fur(const HostIndex& idx, const std::string& path) {
+    const bool have = idx.type != IDX_HYBRID;
+    fur::write_fur(idx, path, have && idx.generic.partition_size ? idx.generic.partition_size : 160,
+                   have && idx.generic.cluster_size ? idx.generic.cluster_size : 16);
+}
+
+// path dispatch: ".fgidx" container, a binary index in the reference's layout, or a dump basename
 inline void open_index(const std::string& path, HostIndex& idx, unsigned nthreads = 0) {
     if (ends_with(path, ".fgidx")) { load_binary(path, idx); return; }
     // suffix sniffing order of the reference CLI: mdfur, mfur, dfur, fur (tools/pseudoalign.cpp:294-306)
-    if (ends_with(path, "fur"))
-        throw std::runtime_error(
-            "binary Fulgor index files embed an SSHash dictionary whose on-disk layout is not available "
-            "to this build; run `fulgor dump -i " + path + " -o <base>` with the reference and open <base> instead");
+    if (ends_with(path, "fur")) { load_fur(path, idx, nthreads); return; }
     load_dump(path, idx, 0, nthreads);
 }
 

@@ -1008,3 +1008,24 @@ def test_cli_two_ranks_share_the_gpu(s10_fgidx, s10_oracle, tmp_path):
     for gpus in (1, 2):
         ids, po, pc = parse_compressed(outs["compressed", gpus])
         assert np.array_equal(ids, np.arange(n)) and np.array_equal(po, oo) and np.array_equal(pc, oc)
+
+
+@pytest.mark.parametrize("suffix,index_type,psize,csize", [("fur", 0, 0, 0), ("mdfur", 3, 4, 2)])
+def test_gpu_queries_on_an_index_loaded_from_the_fur_layout(s10_fgidx, s10_oracle, seeded_reads, tmp_path, suffix, index_type, psize, csize):
+    """an index written in the reference's section layout (fur_format.hpp; own k2u block) and opened again answers like the
+    index it was written from"""
+    ix = fulgor_amd.Index(s10_fgidx, device=-1)
+    if index_type:
+        ix.convert(index_type, psize, csize)
+    p = str(tmp_path / ("x." + suffix))
+    ix.save(p)
+    iy = fulgor_amd.Index(p, device=0)
+    assert iy.index_type == index_type
+    b, o = seeded_reads
+    b, o = b[:int(o[8000])], o[:8001]
+    go, gc = iy.pseudoalign_full_intersection_batch(b, o)
+    oo, oc = s10_oracle.full_intersection(b, o, threads=16)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+    go, gc = iy.pseudoalign_threshold_union_batch(b, o, 0.8)
+    oo, oc = s10_oracle.threshold_union(b, o, 0.8, threads=16)
+    assert np.array_equal(go, oo) and np.array_equal(gc, oc)

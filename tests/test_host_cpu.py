@@ -78,11 +78,49 @@ def test_open_on_device_fails_without_gpu(s10_fgidx):
         fulgor_amd.Index(s10_fgidx, device=0)
 
 
-def test_reference_binary_index_is_rejected(tmp_path):
+def test_reference_binary_index_stops_at_the_sshash_section(tmp_path):
+    """a file written by the reference carries an sshash::dictionary behind the version number: its layout is not available
+    here, the loader says so instead of guessing"""
     p = tmp_path / "x.mdfur"
-    p.write_bytes(b"\x04\x02\x00")
+    p.write_bytes(b"\x04\x02\x00" + bytes(range(64)))
     with pytest.raises(RuntimeError, match="fulgor dump"):
         fulgor_amd.Index(str(p), device=-1)
+    q = tmp_path / "y.fur"
+    q.write_bytes(b"\x03\x00\x00" + bytes(64))
+    with pytest.raises(RuntimeError, match="MAJOR index version"):  # include/util.hpp:91-95
+        fulgor_amd.Index(str(q), device=-1)
+
+
+@pytest.mark.parametrize("suffix,index_type,psize,csize", [("fur", 0, 0, 0), ("mfur", 2, 3, 1), ("dfur", 1, 10, 4), ("mdfur", 3, 4, 2)])
+def test_fur_layout_roundtrip(s10_fgidx, s10_dump, tmp_path, suffix, index_type, psize, csize):
+    """f1, the unblocked half: the Fulgor-owned sections in the reference's visit order (version, [k2u], u2c + rank9, the
+    colour-set container of the suffix's codec, filenames) written and parsed back. The k2u section is the engine's own
+    block (no SSHash), the primitive layouts are from memory of upstream: a round trip of OUR files, not .fur support."""
+    import filecmp
+    ix = fulgor_amd.Index(s10_fgidx, device=-1)
+    if index_type:
+        ix.convert(index_type, psize, csize)  # fixes the partition / cluster shape that is written
+    p = str(tmp_path / ("x." + suffix))
+    ix.save(p)
+    iy = fulgor_amd.Index(p, device=-1)
+    assert iy.index_type == index_type
+    a, b = ix.export(), iy.export()
+    for key in ("unitig_bases", "unitig_off", "unitig_csid", "color_words", "color_offsets", "thresholds"):
+        assert np.array_equal(a[key], b[key]), key
+    assert a["k"] == b["k"] and a["color_bits"] == b["color_bits"]
+    iy.selfcheck(unitig_stride=101)
+    base = str(tmp_path / "dump")
+    iy.dump(base)
+    for sfx in (".metadata.txt", ".filenames.txt", ".unitigs.fa", ".color_sets.txt"):
+        assert filecmp.cmp(base + sfx, s10_dump + sfx, shallow=False), sfx
+    # the sections sit where the reference's visit order puts them: version first, filenames last
+    raw = open(p, "rb").read()
+    assert raw[:3] == b"\x04\x02\x00" and raw[3:11] == b"FGK2U001"
+    assert raw.endswith(b"SAL_HA8462AA.fasta.gz")
+    with open(p, "r+b") as f:  # a damaged file fails cleanly
+        f.truncate(len(raw) - 100)
+    with pytest.raises(RuntimeError):
+        fulgor_amd.Index(p, device=-1)
 
 
 def test_bad_container_is_rejected(tmp_path):
