@@ -969,22 +969,29 @@ int fgpu_fetch_color_set_ids(fgpu_index* ix, const char* bases, const uint64_t* 
         stage_lookup(ix, rd, 0, n, res);
         HIP_TRY(hipStreamSynchronize(res->stream));
         if (ix->timing) ix->collect_timing(res->pending);
-        std::vector<uint32_t> nids(n);
-        if (n) HIP_TRY(hipMemcpy(nids.data(), res->d_nids.p, n * 4, hipMemcpyDeviceToHost));
+        // dense CSR on the device first (scan of the list sizes + gather): only the ids that exist cross PCIe
+        hipStream_t s = res->stream;
+        res->d_idcsr.ensure((n + 1) * 8 + 16);
         uint64_t used = 0;
-        for (uint64_t r = 0; r < n; ++r) used += nids[r];
-        // every read's list sits at d_idoff[r] in the slab pool (its own slab, or its first segment's)
-        std::vector<uint32_t> pool(res->pool_units * res->id_stride);
-        if (!pool.empty()) HIP_TRY(hipMemcpy(pool.data(), res->d_ids_pool.p, pool.size() * 4, hipMemcpyDeviceToHost));
-        std::vector<uint64_t> src(n);
-        if (n) HIP_TRY(hipMemcpy(src.data(), res->d_idoff.p, n * 8, hipMemcpyDeviceToHost));
+        if (n) {
+            run_scan(ix, res, res->d_nids.as<uint32_t>(), n, res->d_idcsr.as<uint64_t>());
+            HIP_TRY(hipMemcpyAsync(res->h_totals, res->d_totals.p, 16, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            used = res->h_totals[0];
+        }
         uint64_t* o = (uint64_t*)malloc((n + 1) * 8);
         uint32_t* v = (uint32_t*)malloc(std::max<uint64_t>(1, used) * 4);
         if (!o || !v) { free(o); free(v); throw std::bad_alloc(); }
         o[0] = 0;
-        for (uint64_t r = 0; r < n; ++r) {
-            memcpy(v + o[r], pool.data() + src[r], (size_t)nids[r] * 4);
-            o[r + 1] = o[r] + nids[r];
+        if (n) {
+            res->d_colors.ensure(std::max<uint64_t>(1, used) * 4);
+            hipLaunchKernelGGL(k_gather_ids, dim3((uint32_t)((n * 16 + 255) / 256)), dim3(256), 0, s, res->d_nids.as<uint32_t>(),
+                               res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), res->d_idcsr.as<uint64_t>(), n,
+                               res->d_colors.as<uint32_t>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(o, res->d_idcsr.p, (n + 1) * 8, hipMemcpyDeviceToHost, s));
+            if (used) HIP_TRY(hipMemcpyAsync(v, res->d_colors.p, used * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
         }
         *out_offsets = o;
         *out_ids = v;

@@ -255,6 +255,19 @@ struct __attribute__((aligned(16))) ListDesc {
 __device__ __forceinline__ int desc_type(const ListDesc& d) { return (int)(d.meta & 0xFFu); }
 __device__ __forceinline__ uint64_t desc_body(const ListDesc& d) { return d.begin + (d.meta >> 8); }
 
+// per-read id lists out of the lookup kernel's fixed-stride slabs into one dense CSR (what fetch_color_set_ids hands to the
+// host: only the ids that exist cross PCIe, not the slab pool). 16 threads per read.
+__global__ __launch_bounds__(256) void k_gather_ids(const uint32_t* __restrict__ nids, const uint64_t* __restrict__ src_off,
+                                                    const uint32_t* __restrict__ ids_src, const uint64_t* __restrict__ dst_off,
+                                                    uint64_t n_reads, uint32_t* __restrict__ out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t r = t >> 4;
+    if (r >= n_reads) return;
+    const uint32_t cnt = nids[r];
+    const uint64_t so = src_off[r], dso = dst_off[r];
+    for (uint32_t j = (uint32_t)t & 15u; j < cnt; j += 16) out[dso + j] = ids_src[so + j];
+}
+
 __global__ __launch_bounds__(256) void k_desc(const uint32_t* __restrict__ nids,
                                               const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ ids_src,
                                               const uint32_t* __restrict__ cnt_src, const uint64_t* __restrict__ dst_off,
