@@ -302,22 +302,25 @@ def cpu_baseline(ix, bases, offs, algo, tau, itype=0, psize=160, csize=16):
     orc = OracleIndex.from_export(ix.export())
     if itype:
         orc.convert(itype, psize, csize)
-    cores = os.cpu_count() or 1
+    host = os.cpu_count() or 1
     probe = min(len(offs) - 1, 20000)
-    sec, _, _ = orc.time_pseudoalign(bases[:int(offs[probe])], offs[:probe + 1], algo, tau, cores)
-    n = int(min(len(offs) - 1, max(probe, probe * 12.0 / max(sec, 1e-6))))
+    # the port does not scale to every hardware thread of a big host (it allocates per read, as the reference does): probe a
+    # few thread counts on 20000 reads each and time the sample at the best one
+    rates = {}
+    for t in sorted({host, max(1, host // 2), max(1, host // 4), max(1, host // 8), 8}, reverse=True):
+        sec, _, _ = orc.time_pseudoalign(bases[:int(offs[probe])], offs[:probe + 1], algo, tau, t)
+        rates[t] = probe / max(sec, 1e-9)
+    cores = max(rates, key=rates.get)
+    n = int(min(len(offs) - 1, max(probe, rates[cores] * 12.0)))
     sec, mapped, _ = orc.time_pseudoalign(bases[:int(offs[n])], offs[:n + 1], algo, tau, cores)
-    # the same port at the reference's own published setting (-t 8: one parser + 7 workers, README.md:171-175: 50.6 k reads/s
-    # = 6-7 k reads/s per worker on SRR801268 / salmonella_4546, other reads and hardware: context only)
-    n8 = int(min(len(offs) - 1, max(2000, probe * 6.0 / max(sec / max(n, 1) * probe * cores / 8.0, 1e-6))))
-    sec8, _, _ = orc.time_pseudoalign(bases[:int(offs[n8])], offs[:n8 + 1], algo, tau, 8)
     return {"value": round(n / sec, 1), "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "first %d reads of rank 0's read set, %d worker threads, output discarded (%.1f s)" % (n, cores, sec),
+            "sample": "first %d reads of rank 0's read set, %d worker threads (the best of the probed thread counts on this "
+                      "%d-thread host), output discarded (%.1f s)" % (n, cores, host, sec),
             "per_thread": round(n / sec / cores, 1),
-            "at_8_threads": {"value": round(n8 / sec8, 1), "per_thread": round(n8 / sec8 / 8, 1), "reads": n8,
-                             "context": "the reference's README quotes 50.6 k reads/s at -t 8 (about 7 k reads/s per worker) for its own "
-                                        "binary on real reads and unnamed hardware; this port is a restatement with an exact k-mer "
-                                        "hash map in place of SSHash, not the reference binary"}}
+            "thread_probe": {str(t): round(r, 1) for t, r in sorted(rates.items())},
+            "context": "the reference's README quotes 50.6 k reads/s at -t 8 (about 7 k reads/s per worker) for its own binary on "
+                       "real reads and unnamed hardware; this port is a restatement with an exact k-mer hash map in place of SSHash, "
+                       "not the reference binary"}
 
 
 if __name__ == "__main__":
