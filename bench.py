@@ -69,8 +69,24 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import __graft_entry__ as ge
+    # Rank 0 builds the library and the index caches BEFORE any rank joins the process group; the other ranks wait for a marker
+    # file, not inside a collective: a slow build (cold box, 40 s to minutes for the synthetic index) cannot run into the
+    # process-group timeout.
+    marker = os.path.join(ROOT, "data", ".bench_ready_%s_%s" % (args.workload, os.environ.get("MASTER_PORT", "0")))
     if rank == 0:
+        if os.path.exists(marker):
+            os.remove(marker)
         ge.build()
+        fg, gen, desc = prepare_workload(args.workload, rank)
+        os.makedirs(os.path.dirname(marker), exist_ok=True)
+        open(marker, "w").close()
+    else:
+        t_wait = time.time()
+        while not os.path.exists(marker):
+            if time.time() - t_wait > 3600:
+                raise SystemExit("rank 0 did not finish preparing the workload within an hour")
+            time.sleep(0.5)
+        fg, gen, desc = prepare_workload(args.workload, rank)
     import fulgor_amd  # binds libfulgor_gpu.so to torch's HIP runtime (fulgor_amd/_native.py)
     import torch
     import torch.distributed as dist
@@ -81,20 +97,17 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
+        import datetime
         if share:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=30))
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=30))
         dist.barrier()
+        if rank == 0 and os.path.exists(marker):
+            os.remove(marker)
 
     default_reads = {"s10": 1_000_000, "s4546syn": 10_000_000}
     n_reads = args.reads or default_reads[args.workload]
-    if rank == 0:
-        fg, gen, desc = prepare_workload(args.workload, rank)
-    if world > 1:
-        dist.barrier()
-    if rank != 0:
-        fg, gen, desc = prepare_workload(args.workload, rank)
 
     ix = fulgor_amd.Index(fg, device=local_rank)
     itype = {"hybrid": 0, "diff": 1, "meta": 2, "meta-diff": 3}[args.index_type]

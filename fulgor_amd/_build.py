@@ -10,7 +10,6 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_GPU = os.path.join(PKG, "libfulgor_gpu.so")
 LIB_TOOLS = os.path.join(PKG, "libfgtools.so")
 BIN_CCDBG = os.path.join(PKG, "ccdbg_from_fasta")
-BIN_CLI = os.path.join(PKG, "fulgor")
 LIB_ORACLE = os.path.join(ROOT, "oracle", "liboracle.so")
 
 

@@ -59,13 +59,8 @@ FG_HD uint32_t brev32(uint32_t x) {
 // reverse complement of one plane of an L-mer: reverse the L bits, then flip them
 FG_HD uint32_t rc_plane(uint32_t p, uint32_t L) { return (~brev32(p) >> (32 - L)) & low_mask32(L); }
 
-// 64-bit key of an L-mer and its canonical (strand independent) form
+// 64-bit key of an L-mer
 FG_HD uint64_t lmer_key(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
-FG_HD uint64_t canonical_key(uint32_t lo, uint32_t hi, uint32_t L) {
-    uint64_t f = lmer_key(lo, hi);
-    uint64_t r = lmer_key(rc_plane(lo, L), rc_plane(hi, L));
-    return f < r ? f : r;
-}
 
 // murmur3 finalizer: a bijection on u64
 FG_HD uint64_t mix64(uint64_t x) {

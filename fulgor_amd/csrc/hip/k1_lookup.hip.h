@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t run_pack(uint32_t pm, uint32_t i0, uint32_t 
 
 constexpr uint32_t K1_TICKET = 8;  // reads per pull from the work queue
 
-#ifdef FG_K1_STATS  // instrumented build (profiles/k1_stats.sh): how often every loop of the kernel runs
+#ifdef FG_K1_STATS  // instrumented build (profiles/k1_stats.py): how often every loop of the kernel runs
 __device__ unsigned long long k1_stats[16];
 #define K1_STAT(i, v) do { if (lane == 0) atomicAdd(&k1_stats[i], (unsigned long long)(v)); } while (0)
 #else

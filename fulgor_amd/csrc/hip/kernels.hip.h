@@ -103,12 +103,6 @@ struct WorkQueue {
     }
 };
 
-// bits [off, off+L) of the 128-bit value B:A (off in [0,63], L <= 32)
-__device__ __forceinline__ uint32_t extract128(uint64_t A, uint64_t B, uint32_t off, uint32_t L) {
-    uint64_t v = off ? ((A >> off) | (B << (64 - off))) : A;
-    return (uint32_t)v & low_mask32(L);
-}
-
 }  // namespace fg
 #include "k1_lookup.hip.h"
 namespace fg {

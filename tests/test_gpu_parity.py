@@ -1029,3 +1029,42 @@ def test_gpu_queries_on_an_index_loaded_from_the_fur_layout(s10_fgidx, s10_oracl
     go, gc = iy.pseudoalign_threshold_union_batch(b, o, 0.8)
     oo, oc = s10_oracle.threshold_union(b, o, 0.8, threads=16)
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+
+
+def test_rccl_all_reduce_of_the_hit_vector_single_rank(s10_fgidx, seeded_reads, tmp_path):
+    """the reduction `bench.py` and `pseudoalign --gpus N` run at the end of a step, on the backend they use on a multi-GPU
+    node ("nccl" = RCCL on ROCm), with the one rank this box offers: process-group set-up on the device, all-reduce of the
+    device-resident hit vector that fgpu_result_accumulate_hits filled, result unchanged. (What a single GPU can show of
+    the RCCL path; the ranks' control flow is covered on gloo.)"""
+    import subprocess
+    code = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import fulgor_amd
+from fulgor_amd import driver
+from fulgor_amd.reads import ReadGenerator
+import glob
+g = sorted(glob.glob(os.path.join(%r, "tests", "data", "salmonella_10", "*.fasta.gz")))
+b, o = ReadGenerator(g).generate(0, 20000, 150, 7)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+ix = fulgor_amd.Index(%r, device=0)
+reads = ix.upload_reads(b, o)
+res = ix.new_result()
+ix.run(reads, res, fulgor_amd.FULL_INTERSECTION)
+n = ix.num_colors()
+hits = torch.zeros(n + 2, dtype=torch.int64, device="cuda:0")
+res.accumulate_hits(hits.data_ptr())
+before = hits.cpu().numpy().copy()
+driver.all_reduce_hits(hits)
+dist.barrier()
+torch.cuda.synchronize()
+go, gc = res.download()
+assert np.array_equal(hits.cpu().numpy(), before) and np.array_equal(before[:n], np.bincount(gc, minlength=n))
+dist.destroy_process_group()
+print("ok")
+''' % (ROOT, ROOT, s10_fgidx)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout.split(), r.stdout + r.stderr  # (the runtime may print after the script's last line)
