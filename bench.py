@@ -239,7 +239,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["end_to_end"] = end_to_end(ix, bases, offs, algo, args.tau, min(n_reads, 1 << 20), 0)
             out["end_to_end_compressed"] = end_to_end(ix, bases, offs, algo, args.tau, min(n_reads, 1 << 20), 2)
-            out["cli_end_to_end"] = cli_end_to_end(ix, bases, offs, algo, args.tau, min(n_reads, 10_000_000), args.read_len)
+            try:
+                out["cli_end_to_end"] = cli_end_to_end(ix, bases, offs, algo, args.tau, min(n_reads, 10_000_000), args.read_len)
+            except Exception as e:  # (no room for the FASTQ file, ...): the bench line must not depend on this leg
+                out["cli_end_to_end"] = {"value": None, "error": str(e)[:200]}
             out["cpu_baseline"] = cpu_baseline(ix, bases, offs, algo, args.tau, itype, args.partition_size, args.cluster_size)
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -277,7 +280,12 @@ def cli_end_to_end(ix, bases, offs, algo, tau, n, read_len):
     published figure measures (tools/pseudoalign.cpp:76-88), reported beside `value`, never as it. The index is open already."""
     import tempfile
     from fulgor_amd import driver
-    d = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    import shutil
+    need = n * (12 + 2 * read_len + 4) + (64 << 20)
+    d = next((x for x in ("/dev/shm", tempfile.gettempdir(), os.path.join(ROOT, "data"))
+              if os.path.isdir(x) and shutil.disk_usage(x).free > need), None)
+    if d is None:
+        raise RuntimeError("no directory with %d MB free for the FASTQ sample" % (need >> 20))
     path = os.path.join(d, "fulgor_bench_%d.fq" % os.getpid())
     try:
         width = 1 + 1 + 9 + 1  # "@r%09d\n"
