@@ -453,11 +453,11 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     // The expand kernel is launched right behind the scan, without waiting for the totals: it checks on the device
     // that the colours fit the buffer it was given and does nothing otherwise; only then (first passes, growing
     // results) the buffer is enlarged and the launch repeated. One host round trip per pass instead of two.
-    // the per-colour hit histogram rides along in LDS while it fits (16-bit counters, W * 64 bytes); for
+    // the per-colour hit histogram rides along in LDS while it fits (16-bit counters, about W * 64 bytes); for
     // larger collections the expand kernel runs without it and k_hits counts from the bitmaps on demand
-    const size_t stage_lds = (K2B_THREADS / 64) * K2B_STAGE_ENTRIES * 2;
-    res->hits_folded = stage_lds + (size_t)W * 64 <= 80 * 1024;  // two blocks per CU
-    const size_t lds = res->hits_folded ? stage_lds + (size_t)W * 64 : stage_lds;
+    const size_t stage_lds = (K2B_THREADS / 64) * K2B_STAGE_BYTES + 16;  // + the block's ticket counter
+    res->hits_folded = stage_lds + k2b_hist_region(W) <= 80 * 1024;  // two blocks per CU
+    const size_t lds = res->hits_folded ? stage_lds + k2b_hist_region(W) : stage_lds;
     // 16-bit hit counters: a block takes tickets for at most block_cap reads (k2b_expand), and the grid is large enough for
     // the caps of the blocks of every ticket partition to exceed its reads by a quarter
     static const uint32_t block_cap = [] {

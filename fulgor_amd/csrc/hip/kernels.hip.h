@@ -1076,9 +1076,33 @@ __global__ __launch_bounds__(256) void scan_apply(const uint32_t* __restrict__ c
 // full-width coalesced stores. 64 words (2048 colours) per round.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t K2B_THREADS = 1024;  // 16 waves share one LDS hit histogram: 2 blocks per CU = 8 waves/SIMD
-// per-wave stage of 16-bit entries: slot i lives at entry i + 2 * (i / 32) — dense words (prefix = 32 * lane) would
-// otherwise share 2 banks, and a skew of two entries keeps every aligned group of 4 slots contiguous and 4-byte aligned
-constexpr uint32_t K2B_STAGE_ENTRIES = 2048 + 2 * 64;
+// Per-wave stage of 16-bit entries: slot i lives at entry i + 2 * (i / 32) — dense words (prefix = 32 * lane) would
+// otherwise share 2 banks, and a skew of two entries keeps every aligned group of 4 slots contiguous and 4-byte aligned.
+// The skew comes out of the address itself: a slot has the VIRTUAL byte address V = v0 + 4096 * wave + 2 * i and lives at
+// LDS byte V + ((V >> 6) << 2) (two instructions per access, no slot counter besides V). With v0 a multiple of 1024 the
+// stages of the 16 waves are 4352 bytes each and start at LDS byte v0 * 17 / 16.
+constexpr uint32_t K2B_STAGE_BYTES = (2048 + 2 * 64) * 2;
+__device__ __forceinline__ uint32_t k2b_stage_skew(uint32_t v) {  // v + ((v >> 6) << 2) (kept from being rewritten as shift, mask, add)
+    uint32_t a;
+    asm("v_lshrrev_b32 %0, 6, %1\n\tv_lshl_add_u32 %0, %0, 2, %1" : "=&v"(a) : "v"(v));
+    return a;
+}
+// The hit histogram in front of the stages: 16-bit counters, two per word. The colours of rounds 2p and 2p + 1 share the
+// words [2048 p, 2048 p + 2048): low half = even round, high half = odd round. Within a round the increment is therefore
+// the same for all lanes and the counter's byte address is 4 * (stage entry) (+ 8192 p).
+__host__ __device__ __forceinline__ uint32_t k2b_hist_words(uint32_t W) {
+    const uint32_t rounds = (W + 63) / 64;
+    return (rounds / 2) * 2048 + ((rounds & 1u) ? (W - 64 * (rounds - 1)) * 32 : 0u);
+}
+// bytes in front of the stages (a multiple of 1088 = 1024 * 17 / 16) and the virtual address that lands there
+__host__ __device__ __forceinline__ uint32_t k2b_hist_region(uint32_t W) { return (k2b_hist_words(W) * 4 + 1087) / 1088 * 1088; }
+// LDS accesses by byte address (the kernel's only LDS is its dynamic block, which therefore starts at byte 0: checked on entry).
+// Plain pointers into the block would cost an addition of the block's (link-time) address per access.
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ lds_u16* lds16(uint32_t a) { return (lds_u16*)(uintptr_t)a; }
+__device__ __forceinline__ lds_u32* lds32(uint32_t a) { return (lds_u32*)(uintptr_t)a; }
+__device__ __forceinline__ void lds_add(uint32_t a, uint32_t v) { __hip_atomic_fetch_add(lds32(a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
                                                   const uint64_t* __restrict__ out_off, uint64_t n_reads, uint32_t W,
                                                   uint32_t* __restrict__ colors, unsigned int* tickets,
@@ -1094,13 +1118,16 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
     // more reads to the early ones): no counter can wrap. The host sizes the grid so that the caps add up to more
     // than the reads of every partition.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_x[];
-    uint16_t* stage_all = (uint16_t*)smem_x;                                           // one stage per wave
-    uint32_t* hist = (uint32_t*)(smem_x + (K2B_THREADS / 64) * K2B_STAGE_ENTRIES * 2);  // W*16 words (two counters per word)
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_x != 0u) __builtin_trap();
+    uint32_t* hist = (uint32_t*)smem_x;  // k2b_hist_words(W) words at LDS byte 0, the stages behind them
     const int lane = lane_id();
-    unsigned char* stage = (unsigned char*)(stage_all + (threadIdx.x >> 6) * K2B_STAGE_ENTRIES);
-    __shared__ uint32_t s_taken;  // reads this block has taken tickets for
+    const uint32_t hist_words = hit_partial ? k2b_hist_words(W) : 0u;
+    // virtual address of this wave's slot 0
+    const uint32_t v_wave = (hit_partial ? k2b_hist_region(W) / 1088u * 1024u : 0u) + 4096u * (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // reads this block has taken tickets for: one word behind the stages (no static LDS: the dynamic block starts at LDS byte 0)
+    uint32_t& s_taken = *(uint32_t*)(smem_x + (hit_partial ? k2b_hist_region(W) : 0u) + (K2B_THREADS / 64) * K2B_STAGE_BYTES);
     if (hit_partial) {
-        for (uint32_t i = threadIdx.x; i < W * 16; i += blockDim.x) hist[i] = 0;
+        for (uint32_t i = threadIdx.x; i < hist_words; i += blockDim.x) hist[i] = 0;
         if (threadIdx.x == 0) s_taken = 0;
         __syncthreads();
     }
@@ -1134,59 +1161,66 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
         if (__builtin_amdgcn_readlane((int)cnt_l, j) == 0) continue;
         uint32_t* out = colors + readlane_u64(off_l, j);
         const uint32_t* bm = bitmap + r * W;
-        for (uint32_t w0 = 0; w0 < W; w0 += 64) {
-            uint32_t x;
-            if (w0 == 0) x = cur[0];
-            else if (w0 == 64) x = cur[1];
-            else if (w0 == 128) x = cur[2];
-            else x = w0 + lane < W ? bm[w0 + lane] : 0u;
+        // one round = 64 words. The first three rounds have their words in registers and contain no loads: a load would make
+        // the wave wait for ALL its outstanding memory operations (one in-order counter), i.e. for the stores of the round
+        // before to reach L2, round after round. (Doing the same for the one wait per read that is left, with the requests
+        // issued and counted by hand so that the stores stay in flight, changed nothing: measured, profiles/r2.)
+        auto round = [&](const uint32_t w0, uint32_t x) {
             const uint32_t pc = __popc(x);
             const uint32_t incl = wave_incl_scan_u32(pc);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (total == 0) continue;
-            uint32_t at = incl - pc;
+            if (total == 0) return;
+            uint32_t va = v_wave + ((incl - pc) << 1);
             const uint32_t rel = (uint32_t)lane * 32;
             while (x) {
-                *(uint16_t*)(stage + (at << 1) + ((at >> 5) << 2)) = (uint16_t)(rel + __builtin_ctz(x));
-                ++at;
+                *lds16(k2b_stage_skew(va)) = (uint16_t)(rel | (uint32_t)__builtin_ctz(x));
+                va += 2;
                 x &= x - 1;
             }
             wave_lds_sync();
             const uint32_t cbase = w0 * 32;
+            // hit counters of this round: which half of the word, which 2048-word group
+            const uint32_t hinc = (w0 & 64u) ? 0x10000u : 1u;
+            const uint32_t hoff = (w0 >> 7) * 8192u;
             // copy-out: every lane takes 4 consecutive slots (two LDS words) and stores 4 colours at once; the last
             // total % 4 slots (all of them in a round of at most 64) go out one per lane
             const uint32_t full = total <= 64 ? 0u : total & ~3u;  // short rounds: one slot per lane, one pass
             for (uint32_t i = (uint32_t)lane * 4; i < full; i += 256) {
-                const uint32_t* sp = (const uint32_t*)(stage + (i << 1) + ((i >> 5) << 2));
+                const lds_u32* sp = lds32(k2b_stage_skew(v_wave + (i << 1)));
                 const uint32_t e01 = sp[0], e23 = sp[1];
-                const uint32_t c0 = cbase + (e01 & 0xFFFFu), c1 = cbase + (e01 >> 16), c2 = cbase + (e23 & 0xFFFFu),
-                               c3 = cbase + (e23 >> 16);
-                *(u32x4_a4*)(out + i) = u32x4{c0, c1, c2, c3};
+                const uint32_t e0 = e01 & 0xFFFFu, e1 = e01 >> 16, e2 = e23 & 0xFFFFu, e3 = e23 >> 16;
+                *(u32x4_a4*)(out + i) = u32x4{cbase + e0, cbase + e1, cbase + e2, cbase + e3};
                 if (hit_partial) {
-                    atomicAdd(&hist[c0 >> 1], (c0 & 1u) ? 0x10000u : 1u);
-                    atomicAdd(&hist[c1 >> 1], (c1 & 1u) ? 0x10000u : 1u);
-                    atomicAdd(&hist[c2 >> 1], (c2 & 1u) ? 0x10000u : 1u);
-                    atomicAdd(&hist[c3 >> 1], (c3 & 1u) ? 0x10000u : 1u);
+                    lds_add(hoff + (e0 << 2), hinc);
+                    lds_add(hoff + (e1 << 2), hinc);
+                    lds_add(hoff + (e2 << 2), hinc);
+                    lds_add(hoff + (e3 << 2), hinc);
                 }
             }
             if ((uint32_t)lane < total - full) {
                 const uint32_t i = full + lane;
-                const uint32_t col = cbase + *(const uint16_t*)(stage + (i << 1) + ((i >> 5) << 2));
-                out[i] = col;
-                if (hit_partial) atomicAdd(&hist[col >> 1], (col & 1u) ? 0x10000u : 1u);
+                const uint32_t e = *lds16(k2b_stage_skew(v_wave + (i << 1)));
+                out[i] = cbase + e;
+                if (hit_partial) lds_add(hoff + (e << 2), hinc);
             }
             out += total;
             wave_lds_sync();
-        }
+        };
+        round(0, cur[0]);
+        if (W > 64) round(64, cur[1]);
+        if (W > 128) round(128, cur[2]);
+        for (uint32_t w0 = 192; w0 < W; w0 += 64) round(w0, w0 + lane < W ? bm[w0 + lane] : 0u);
     }
     }
     if (hit_partial) {
         __syncthreads();
         uint32_t* row = hit_partial + (uint64_t)blockIdx.x * W * 32;
-        for (uint32_t i = threadIdx.x; i < W * 16; i += blockDim.x) {
+        const uint32_t ncol = W * 32;
+        for (uint32_t i = threadIdx.x; i < hist_words; i += blockDim.x) {
             const uint32_t v = hist[i];
-            row[2 * i] = v & 0xFFFFu;
-            row[2 * i + 1] = v >> 16;
+            const uint32_t c = (i >> 11) * 4096u + (i & 2047u);  // colour of the low half; the high half is 2048 further
+            row[c] = v & 0xFFFFu;
+            if (c + 2048u < ncol) row[c + 2048u] = v >> 16;
         }
     }
 }
