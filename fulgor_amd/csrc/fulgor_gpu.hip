@@ -72,7 +72,7 @@ struct fgpu_index {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 256;
-    DevBuf d_table, d_bits, d_offsets, d_set_desc, d_blk_words;
+    DevBuf d_table, d_bmp_rows, d_offsets, d_set_desc, d_blk_words;
     DevBuf d_gops, d_gset_ops_off, d_gset_ops, d_garena, d_gblk_hdr, d_gblk_words, d_gset_bytes;
     DevDict dd{};
     DevColors dc{};
@@ -172,20 +172,37 @@ void upload_index(fgpu_index* ix) {
     const HybridSets& h = ix->host.hybrid;
     hipStream_t s = ix->stream;
     upload(ix->d_table, d.table, s);  // the whole k-mer dictionary: one table of 64-byte buckets
-    upload(ix->d_bits, h.bits, s);
     upload(ix->d_offsets, h.offsets, s);
+    const uint32_t w32 = ((h.num_colors + 31) / 32 + 3) & ~3u;  // result bitmaps move as 128-bit groups
     {  // one resolved descriptor per colour set: everything a kernel needs about a list behind one gather
         std::vector<ListDesc> sd(h.num_sets());
+        // the bitmap lists leave the bit stream (arbitrary bit offsets) for aligned rows of w32 words
+        std::vector<uint32_t> rows;
+        {
+            uint64_t nb = 0;
+            for (uint64_t id = 0; id < sd.size(); ++id) nb += h.set_size[id] >= h.sparse_thr && h.set_size[id] < h.dense_thr;
+            rows.assign(nb * w32 + 4, 0u);
+        }
+        uint64_t next_row = 0;
+        const auto stream_bits = [&](uint64_t pos, uint32_t len) -> uint32_t {  // len <= 32 bits at bit `pos` of the stream
+            const uint64_t w = pos >> 6, sh = pos & 63;
+            uint64_t v = h.bits[w] >> sh;
+            if (sh + len > 64) v |= h.bits[w + 1] << (64 - sh);
+            return len == 32 ? (uint32_t)v : (uint32_t)v & ((1u << len) - 1u);
+        };
         for (uint64_t id = 0; id < sd.size(); ++id) {
             const uint32_t size = h.set_size[id];
             ListDesc& d = sd[id];
             d.score = 0;
             d.id = (uint32_t)id;
-            if (size >= h.sparse_thr && size < h.dense_thr) {  // bitmap list: bit offsets into the stream
-                d.begin = h.offsets[id];
+            if (size >= h.sparse_thr && size < h.dense_thr) {  // bitmap list: its row
+                const uint64_t body = h.offsets[id] + delta_code_bits(size);
+                uint32_t* row = rows.data() + next_row * w32;
+                for (uint32_t c0 = 0; c0 < h.num_colors; c0 += 32) row[c0 >> 5] = stream_bits(body + c0, std::min(32u, h.num_colors - c0));
+                d.begin = next_row++ * w32;
                 d.soff = 0;
                 d.ncodes = 0;
-                d.meta = (uint32_t)D_ENC_BITMAP | (delta_code_bits(size) << 8);
+                d.meta = (uint32_t)D_ENC_BITMAP;
             } else {  // gap-coded on the host, packed blocks here
                 d.begin = h.blk_wbase[id];
                 d.ncodes = (uint32_t)(h.blk_first[id + 1] - h.blk_first[id]);
@@ -194,13 +211,13 @@ void upload_index(fgpu_index* ix) {
             }
         }
         upload(ix->d_set_desc, sd, s);
-        HIP_TRY(hipStreamSynchronize(s));  // sd is released at the end of this block
+        upload(ix->d_bmp_rows, rows, s);
+        HIP_TRY(hipStreamSynchronize(s));  // sd and rows are released at the end of this block
     }
     upload(ix->d_blk_words, h.blk_words, s);
     HIP_TRY(hipStreamSynchronize(s));
     ix->dd = DevDict{ix->d_table.as<uint32_t>(), d.num_buckets, d.k, d.m, d.seed};
-    const uint32_t w32 = ((h.num_colors + 31) / 32 + 3) & ~3u;  // result bitmaps move as 128-bit groups
-    ix->dc = DevColors{ix->d_bits.as<uint64_t>(), ix->d_offsets.as<uint64_t>(), ix->d_set_desc.as<ListDesc>(),
+    ix->dc = DevColors{ix->d_bmp_rows.as<uint32_t>(), ix->d_offsets.as<uint64_t>(), ix->d_set_desc.as<ListDesc>(),
                        ix->d_blk_words.as<uint32_t>(), h.num_colors, h.sparse_thr, h.dense_thr, w32};
 }
 
@@ -544,7 +561,7 @@ void fgpu_close(fgpu_index* ix) {
     if (!ix) return;
     if (ix->device == FGPU_HOST_ONLY) { delete ix; return; }
     (void)hipSetDevice(ix->device);
-    for (DevBuf* b : {&ix->d_table, &ix->d_bits, &ix->d_offsets,
+    for (DevBuf* b : {&ix->d_table, &ix->d_bmp_rows, &ix->d_offsets,
                       &ix->d_set_desc, &ix->d_blk_words, &ix->d_gops, &ix->d_gset_ops_off, &ix->d_gset_ops,
                       &ix->d_garena, &ix->d_gblk_hdr, &ix->d_gblk_words, &ix->d_gset_bytes})
         b->release();

@@ -377,6 +377,12 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                                 for (uint32_t s = lo; s <= hi; ++s) kmer_out[row + s + pm - km] = hv[r];
                             }
                         }
+#ifdef FG_K1_STATS
+                        {
+                            const uint32_t st1 = (uint32_t)__popcll(__ballot(mine == 1)), st2 = (uint32_t)__popcll(__ballot(mine >= 2)), st3 = (uint32_t)__popcll(__ballot(live));
+                            K1_STAT(10, st1); K1_STAT(11, st2); K1_STAT(12, st2 ? 1 : 0); K1_STAT(13, st3);
+                        }
+#endif
                         // Heads in lane order: the runs first, pairs behind them. Among the run lanes of the first chunk a run with one
                         // matching record whose left neighbour (same read) matched the same id alone is folded into that neighbour:
                         // consecutive runs mostly sit on the same unitig, or on unitigs of one colour set.

@@ -24,7 +24,8 @@
 namespace fg {
 
 struct DevColors {
-    const uint64_t* bits;       // the hybrid bit stream (bitmap lists are read from it)
+    const uint32_t* bmp_words;  // the bitmap lists as rows of w32 words, 16-byte aligned, zero behind colour n - 1 (the
+                                // stream packs them at arbitrary bit offsets; a row moves as 128-bit groups without shifts)
     const uint64_t* offsets;
     const struct ListDesc* set_desc;  // one resolved descriptor per colour set (built at upload)
     const uint32_t* blk_words;        // packed blocks of the gap-coded lists, headers in front of the data (host/hybrid_codec.hpp)
@@ -239,10 +240,10 @@ struct ListHeader {
 // one thread per (read, list) pair, writes (id, score) descriptors in per-read order for the generic codecs;
 // the hybrid kernels gather set_desc themselves (the full intersection one read ahead).
 struct __attribute__((aligned(16))) ListDesc {
-    uint64_t begin;   // bitmap list: bit offset of the list; gap-coded list: first data word in blk_words
+    uint64_t begin;   // bitmap list: first word of its row in bmp_words; gap-coded list: first data word in blk_words
     uint64_t soff;    // gap-coded list: index of its first block header — or, for a single-block list, the header itself
     uint32_t ncodes;  // blocks of a gap-coded list (0 for bitmap lists)
-    uint32_t meta;    // encoding | (body - begin) << 8
+    uint32_t meta;    // encoding
     int32_t score;    // positive k-mers that produced this id (threshold-union)
     uint32_t id;      // colour-set id
 };
@@ -485,16 +486,8 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
                     while (mb) {
                         const int src = __builtin_ctzll(mb);
                         mb &= mb - 1;
-                        const uint64_t body = sc.h_soff[src];
-                        const uint32_t* words = (const uint32_t*)c.bits + (body >> 5);
-                        const uint32_t sh = (uint32_t)body & 31u;
-                        for (uint32_t g4 = lane; g4 * 128 < n; g4 += 64) {
-                            const uint32_t* p = words + 4 * g4;  // (c.bits carries 256 padding bits)
-                            const uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4];
-                            const uint4 x = make_uint4(__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh),
-                                                       __builtin_amdgcn_alignbit(w3, w2, sh), __builtin_amdgcn_alignbit(w4, w3, sh));
-                            EX4[g4] = or_not(EX4[g4], x);
-                        }
+                        const uint4* row = (const uint4*)(c.bmp_words + sc.h_soff[src]);
+                        for (uint32_t g4 = lane; g4 < W4; g4 += 64) EX4[g4] = or_not(EX4[g4], row[g4]);
                     }
                     wave_lds_sync();
 
@@ -695,13 +688,10 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 4 : 2)) void k3a
             while (mb) {
                 const int src = __builtin_ctzll(mb);
                 mb &= mb - 1;
-                const uint64_t body = sc.h_soff[src];
                 const uint32_t s = (uint32_t)sc.h_score[src];
-                const uint32_t* words = (const uint32_t*)c.bits + (body >> 5);
-                const uint32_t sh = (uint32_t)body & 31u;
-                for (uint32_t w = lane; w * 32 < n; w += 64) {  // one funnel shift per word (c.bits carries padding)
-                    uint32_t x = __builtin_amdgcn_alignbit(words[w + 1], words[w], sh);
-                    if (n - w * 32 < 32) x &= (1u << (n - w * 32)) - 1u;
+                const uint32_t* words = c.bmp_words + sc.h_soff[src];
+                for (uint32_t w = lane; w * 32 < n; w += 64) {
+                    const uint32_t x = words[w];
 #pragma unroll
                     for (uint32_t q = 0; q < PLANES; ++q)  // only this lane touches these words
                         atomicAdd(&SC[q * W + w], counter_spread<BITS>(x, q, s));

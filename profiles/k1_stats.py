@@ -25,6 +25,6 @@ out = (ctypes.c_ulonglong * 16)()
 lib.fgpu_debug_k1_stats(out, 1)
 ix.run(reads, res, fulgor_amd.FULL_INTERSECTION, 0.0, 0, n)
 lib.fgpu_debug_k1_stats(out, 0)
-names = ["reads", "passes", "chunks", "batches", "runs", "pairs", "heads", "sum of maxseg", "overflow retries", "heads from pairs"]
+names = ["reads", "passes", "chunks", "batches", "runs", "pairs", "heads", "sum of maxseg", "overflow retries", "heads from pairs", "lanes with one matching record", "lanes with several", "batches with such a lane", "live lanes"]
 for i, nm in enumerate(names):
     print("%-18s %12d   per read %.3f   per pass %.3f" % (nm, out[i], out[i] / max(1, out[0]), out[i] / max(1, out[1])))
