@@ -214,6 +214,7 @@ void upload_index(fgpu_index* ix) {
         upload(ix->d_bmp_rows, rows, s);
         HIP_TRY(hipStreamSynchronize(s));  // sd and rows are released at the end of this block
     }
+    if (h.blk_words.size() >= (1ull << 32)) throw std::runtime_error("colour sets too large: the packed blocks exceed 2^32 words");  // BlockLane::word
     upload(ix->d_blk_words, h.blk_words, s);
     HIP_TRY(hipStreamSynchronize(s));
     ix->dd = DevDict{ix->d_table.as<uint32_t>(), d.num_buckets, d.k, d.m, d.seed};
@@ -232,6 +233,7 @@ void upload_generic(fgpu_index* ix) {
     upload(ix->d_gset_ops, g.dev_set_ops, s);
     upload(ix->d_garena, g.dev_span, s);
     upload(ix->d_gblk_hdr, g.dev_blk_hdr, s);
+    if (g.dev_blk_words.size() >= (1ull << 32)) throw std::runtime_error("colour sets too large: the packed blocks exceed 2^32 words");  // BlockLane::word
     upload(ix->d_gblk_words, g.dev_blk_words, s);
     upload(ix->d_gset_bytes, g.set_bytes, s);
     HIP_TRY(hipStreamSynchronize(s));
@@ -429,7 +431,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         else if (bits == 8) launch(k_generic<true, 8>);
         else launch(k_generic<true, 16>);
     } else if (algo == FGPU_FULL_INTERSECTION) {
-        const size_t per_wave = (size_t)2 * W * 4 + wave_scratch_bytes_compact();
+        const size_t per_wave = (size_t)3 * W * 4 + wave_scratch_bytes_compact();  // EXCL, T, the initial EXCL
         const uint32_t wpb = pick_waves(per_wave, (const void*)k2a_intersect);
         const uint32_t grid = resident_grid(k2a_intersect, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
         Timed t(ix, res, FGPU_K_INTERSECT);

@@ -52,6 +52,23 @@ __device__ __forceinline__ void wave_lds_sync() {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_a4 __attribute__((aligned(4)));  // 16-byte global access at any 4-byte boundary
 
+// LDS accesses by byte address. Plain pointers into a kernel's dynamic LDS block cost an addition of the block's (link-time)
+// address per access, and `base[v >> 5]` becomes shift, mask, add; from an explicit byte address it is shift, shift-add.
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ lds_u16* lds16(uint32_t a) { return (lds_u16*)(uintptr_t)a; }
+__device__ __forceinline__ lds_u32* lds32(uint32_t a) { return (lds_u32*)(uintptr_t)a; }
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
+__device__ __forceinline__ void lds_add(uint32_t a, uint32_t v) { __hip_atomic_fetch_add(lds32(a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_or(uint32_t a, uint32_t v) { __hip_atomic_fetch_or(lds32(a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_xor(uint32_t a, uint32_t v) { __hip_atomic_fetch_xor(lds32(a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// byte address of the word that holds bit v of a bit plane at byte address `plane` (wave-uniform)
+__device__ __forceinline__ uint32_t lds_bit_word(uint32_t plane, uint32_t v) {
+    uint32_t a;
+    asm("v_lshrrev_b32 %0, 5, %1\n\tv_lshl_add_u32 %0, %0, 2, %2" : "=&v"(a) : "v"(v), "s"(plane));
+    return a;
+}
+
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
     for (int o = 32; o; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
@@ -289,7 +306,7 @@ __global__ __launch_bounds__(256) void k_desc(const uint32_t* __restrict__ nids,
 // they are scalars), lane i extracts value i with one funnel shift, and the data words of the next two
 // blocks are already in flight while a block is consumed.
 struct BlockLane {      // per lane: the flattened block this lane resolved
-    uint32_t a_lo, a_hi;  // address of its first data word
+    uint32_t word;        // its first data word, as an index into the block words (checked at upload: fewer than 2^32 words)
     uint32_t start;       // value of field 0 (plus a caller-defined bias, e.g. an LDS plane offset in bits)
     uint32_t meta;        // width | (count-1) << 5 | caller flags << 11
     uint32_t extra;       // caller-defined (the list's score for the threshold union)
@@ -320,20 +337,22 @@ __device__ __forceinline__ uint32_t owner_list(uint32_t excl, uint32_t nlists, u
 // Every lane requests the two words that hold its field of block q (word `lane` of a bitmap chunk). The
 // request is unconditional (lanes past the block's count read inside the 64 padding words of blk_words) so
 // that the number of loads in flight is known at compile time and the wait before a block is consumed leaves
-// the two younger requests outstanding.
-__device__ __forceinline__ uint2 block_fetch(const BlockLane& b, uint32_t q, int lane) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)b.a_lo, q), hi = (uint32_t)__builtin_amdgcn_readlane((int)b.a_hi, q);
-    uint32_t width = (uint32_t)__builtin_amdgcn_readlane((int)b.meta, q) & 31u;
+// the two younger requests outstanding. Returns the block's meta word (a scalar) for the step that consumes it.
+__device__ __forceinline__ uint32_t block_fetch(const uint32_t* words, const BlockLane& b, uint32_t q, int lane, uint2& w) {
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)b.word, q);
+    const uint32_t mt = (uint32_t)__builtin_amdgcn_readlane((int)b.meta, q);
+    uint32_t width = mt & 31u;
     width += width == BLK_CHUNK_WIDTH;  // a chunk is read as 32-bit fields
     typedef const uint32_t __attribute__((address_space(1))) * global_words;  // keeps the request a global_load (vmcnt only)
-    const global_words p = (global_words)((((uint64_t)hi << 32) | lo) + ((__umul24((uint32_t)lane, width) >> 3) & ~3u));
-    return make_uint2(p[0], p[1]);
+    // scalar base (words + first) plus a 32-bit lane offset: the address needs no vector arithmetic beyond the offset
+    const global_words p = (global_words)(words + first) + (__umul24((uint32_t)lane, width) >> 5);
+    w = make_uint2(p[0], p[1]);
+    return mt;
 }
 
 template <typename F, typename H, typename G>
-__device__ __forceinline__ void block_consume(const BlockLane& b, uint32_t q, int lane, uint2 w, F& per_value, H& per_word,
+__device__ __forceinline__ void block_consume(const BlockLane& b, uint32_t q, uint32_t mt, int lane, uint2 w, F& per_value, H& per_word,
                                               G& after_block) {
-    const uint32_t mt = (uint32_t)__builtin_amdgcn_readlane((int)b.meta, q);
     const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)b.start, q);
     const uint32_t ex = (uint32_t)__builtin_amdgcn_readlane((int)b.extra, q);
     const uint32_t width = mt & 31u;
@@ -350,22 +369,24 @@ __device__ __forceinline__ void block_consume(const BlockLane& b, uint32_t q, in
 
 // per_value(v, extra of the block) for every value of the offset blocks, per_word(word index, bits, extra) for
 // every word of the bitmap chunks among blocks [0, steps) held by the lanes of `b` (steps >= 1);
-// after_block(flags) once per block (wave-uniform). Three register pairs rotate by unrolling, not by moves,
-// so a block is consumed while the requests of the next two are in flight.
+// after_block(flags) once per block (wave-uniform). Three register pairs (and the blocks' meta words, scalars) rotate by
+// unrolling, not by moves, so a block is consumed while the requests of the next two are in flight.
 template <typename F, typename H, typename G>
-__device__ __forceinline__ void run_blocks(const BlockLane& b, uint32_t steps, int lane, F per_value, H per_word, G after_block) {
+__device__ __forceinline__ void run_blocks(const uint32_t* words, const BlockLane& b, uint32_t steps, int lane, F per_value, H per_word,
+                                           G after_block) {
     const uint32_t last = steps - 1;
-    uint2 c0 = block_fetch(b, 0, lane), c1 = block_fetch(b, min(1u, last), lane), c2;
+    uint2 c0, c1, c2;
+    uint32_t m0 = block_fetch(words, b, 0, lane, c0), m1 = block_fetch(words, b, min(1u, last), lane, c1), m2;
     uint32_t q = 0;
     while (true) {
-        c2 = block_fetch(b, min(q + 2, last), lane);
-        block_consume(b, q, lane, c0, per_value, per_word, after_block);
+        m2 = block_fetch(words, b, min(q + 2, last), lane, c2);
+        block_consume(b, q, m0, lane, c0, per_value, per_word, after_block);
         if (++q > last) break;
-        c0 = block_fetch(b, min(q + 2, last), lane);
-        block_consume(b, q, lane, c1, per_value, per_word, after_block);
+        m0 = block_fetch(words, b, min(q + 2, last), lane, c0);
+        block_consume(b, q, m1, lane, c1, per_value, per_word, after_block);
         if (++q > last) break;
-        c1 = block_fetch(b, min(q + 2, last), lane);
-        block_consume(b, q, lane, c2, per_value, per_word, after_block);
+        m1 = block_fetch(words, b, min(q + 2, last), lane, c1);
+        block_consume(b, q, m2, lane, c2, per_value, per_word, after_block);
         if (++q > last) break;
     }
 }
@@ -413,12 +434,14 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = c.w32, W4 = W >> 2;  // W is a multiple of 4: the bitmaps move as 128-bit groups
-    const uint32_t per_wave = 2 * W * 4 + wave_scratch_bytes_compact();
+    const uint32_t per_wave = 3 * W * 4 + wave_scratch_bytes_compact();
     unsigned char* mine = smem + (size_t)wv * per_wave;
     WaveScratch sc = carve_scratch(mine);
     uint32_t* EXCL = (uint32_t*)(mine + wave_scratch_bytes_compact());
     uint4* EX4 = (uint4*)EXCL;
-    uint4* T4 = EX4 + W4;  // the plane T, all zero between sparse lists
+    uint4* T4 = EX4 + W4;    // the plane T, all zero between sparse lists
+    uint4* INIT4 = T4 + W4;  // what EXCL starts from: colours >= n excluded
+    const uint32_t excl_at = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(EXCL));  // LDS byte address of EXCL
     constexpr uint32_t BATCH = 8;
     const WorkQueue wq{tickets, n_reads, BATCH};
     uint64_t t_first;
@@ -426,7 +449,14 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
     const uint32_t n = c.n, tail_word = n >> 5, tail_mask = ~((1u << (n & 31u)) - 1u);
     const ListDesc none{0, 0, 0, (uint32_t)D_ENC_NONE & 0xFFu, 0, 0};
 
-    for (uint32_t g4 = lane; g4 < W4; g4 += 64) T4[g4] = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t g4 = lane; g4 < W4; g4 += 64) {
+        T4[g4] = make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t w = 4 * g4;
+        INIT4[g4] = make_uint4(w < tail_word ? 0u : (w == tail_word ? tail_mask : 0xFFFFFFFFu),
+                               w + 1 < tail_word ? 0u : (w + 1 == tail_word ? tail_mask : 0xFFFFFFFFu),
+                               w + 2 < tail_word ? 0u : (w + 2 == tail_word ? tail_mask : 0xFFFFFFFFu),
+                               w + 3 < tail_word ? 0u : (w + 3 == tail_word ? tail_mask : 0xFFFFFFFFu));
+    }
     wave_lds_sync();
 
     while (wq.pull(t_first, t_count)) {
@@ -458,13 +488,7 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
                 for (uint32_t g4 = lane; g4 < W4; g4 += 64) bm4[g4] = make_uint4(0u, 0u, 0u, 0u);
                 if (lane == 0) out_count[r] = 0;
             } else {
-                for (uint32_t g4 = lane; g4 < W4; g4 += 64) {  // colours >= n start excluded
-                    const uint32_t w = 4 * g4;
-                    EX4[g4] = make_uint4(w < tail_word ? 0u : (w == tail_word ? tail_mask : 0xFFFFFFFFu),
-                                         w + 1 < tail_word ? 0u : (w + 1 == tail_word ? tail_mask : 0xFFFFFFFFu),
-                                         w + 2 < tail_word ? 0u : (w + 2 == tail_word ? tail_mask : 0xFFFFFFFFu),
-                                         w + 3 < tail_word ? 0u : (w + 3 == tail_word ? tail_mask : 0xFFFFFFFFu));
-                }
+                for (uint32_t g4 = lane; g4 < W4; g4 += 64) EX4[g4] = INIT4[g4];
                 for (uint32_t g = 0; g < cnt; g += 64) {
                     ListDesc d = dcur;
                     if (g) {  // more than 64 lists: rare, fetched in place
@@ -492,7 +516,7 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
                     wave_lds_sync();
 
                     for (uint32_t s0 = 0; s0 < total_blk; s0 += 64) {
-                        BlockLane bl{0u, 0u, 0u, 0u, 0u};
+                        BlockLane bl{0u, 0u, 0u, 0u};
                         const uint32_t s = s0 + lane;
                         if (s < total_blk) {
                             const uint32_t i = owner_list(excl, min(64u, cnt - g), s);
@@ -500,16 +524,14 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
                             const uint32_t j = s - (sc.pref[i] - (nb & 0x7FFFFFFFu));
                             // a single-block list carries its block header in the descriptor itself (one fetch less)
                             const uint64_t hd = (nb & 0x7FFFFFFFu) == 1 ? sc.h_soff[i] : ((const uint64_t*)(c.blk_words + sc.h_begin[i]))[j];
-                            const uint64_t a = (uint64_t)(c.blk_words + sc.h_begin[i] + blk_rel_word(hd));
                             const bool sparse = (nb >> 31) != 0;
-                            bl.a_lo = (uint32_t)a;
-                            bl.a_hi = (uint32_t)(a >> 32);
+                            bl.word = (uint32_t)sc.h_begin[i] + blk_rel_word(hd);
                             bl.start = blk_start(hd) + (sparse ? W * 32u : 0u);  // bit index relative to EXCL
                             bl.meta = blk_width(hd) | ((blk_count(hd) - 1u) << 5) |
                                       ((sparse && j + 1 == (nb & 0x7FFFFFFFu)) ? 1u << 11 : 0u);
                         }
-                        run_blocks(bl, min(64u, total_blk - s0), lane,
-                                   [&](uint32_t v, uint32_t) { atomicOr(&EXCL[v >> 5], 1u << (v & 31)); },
+                        run_blocks(c.blk_words, bl, min(64u, total_blk - s0), lane,
+                                   [&](uint32_t v, uint32_t) { lds_or(lds_bit_word(excl_at, v), 1u << (v & 31)); },
                                    [&](uint32_t wi, uint32_t x, uint32_t) { atomicOr(&EXCL[wi], x); },
                                    [&](uint32_t last_of_sparse) {
                                        if (last_of_sparse) {  // a colour absent from this sparse list is excluded; T goes back to zero
@@ -700,20 +722,18 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 4 : 2)) void k3a
             }
 
             for (uint32_t s0 = 0; s0 < total_blk; s0 += 64) {
-                BlockLane bl{0u, 0u, 0u, 0u, 0u};
+                BlockLane bl{0u, 0u, 0u, 0u};
                 const uint32_t s = s0 + lane;
                 if (s < total_blk) {
                     const uint32_t i = owner_list(excl, min(K3A_GROUP, cnt - g), s);
                     const uint32_t j = s - (sc.pref[i] - sc.h_ncodes[i]);
                     const uint64_t hd = sc.h_ncodes[i] == 1 ? sc.h_soff[i] : ((const uint64_t*)(c.blk_words + sc.h_begin[i]))[j];  // (as in k2a)
-                    const uint64_t a = (uint64_t)(c.blk_words + sc.h_begin[i] + blk_rel_word(hd));
-                    bl.a_lo = (uint32_t)a;
-                    bl.a_hi = (uint32_t)(a >> 32);
+                    bl.word = (uint32_t)sc.h_begin[i] + blk_rel_word(hd);
                     bl.start = blk_start(hd);
                     bl.meta = blk_width(hd) | ((blk_count(hd) - 1u) << 5);
                     bl.extra = (uint32_t)sc.h_score[i];
                 }
-                run_blocks(bl, min(64u, total_blk - s0), lane,
+                run_blocks(c.blk_words, bl, min(64u, total_blk - s0), lane,
                            [&](uint32_t v, uint32_t sv) {
                                atomicAdd(&SC[(v % PLANES) * W + (v >> 5)], sv << ((BITS & 31) * ((v & 31u) / PLANES)));
                            },
@@ -897,19 +917,17 @@ __global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 5 : 4) : 7) void k_generi
                     sc.pref[lane] = incl;
                     wave_lds_sync();
                     for (uint32_t s0 = 0; s0 < total_blk; s0 += 64) {
-                        BlockLane bl{0u, 0u, 0u, 0u, 0u};
+                        BlockLane bl{0u, 0u, 0u, 0u};
                         const uint32_t s = s0 + lane;
                         if (s < total_blk) {
                             const uint32_t i = upper_slot(sc.pref, s);
                             const uint32_t jb = s - (sc.pref[i] - sc.h_ncodes[i]);
                             const uint64_t hd = g.blk_hdr[sc.h_soff[i] + jb];
-                            const uint64_t a = (uint64_t)(g.blk_words + sc.h_begin[i] + blk_rel_word(hd));
-                            bl.a_lo = (uint32_t)a;
-                            bl.a_hi = (uint32_t)(a >> 32);
+                            bl.word = (uint32_t)sc.h_begin[i] + blk_rel_word(hd);
                             bl.start = blk_start(hd) + (uint32_t)sc.h_score[i];  // bit index relative to T
                             bl.meta = blk_width(hd) | ((blk_count(hd) - 1u) << 5);
                         }
-                        run_blocks(bl, min(64u, total_blk - s0), lane,
+                        run_blocks(g.blk_words, bl, min(64u, total_blk - s0), lane,
                                    [&](uint32_t v, uint32_t) { atomicXor(&T[v >> 5], 1u << (v & 31)); },
                                    [&](uint32_t wi, uint32_t x, uint32_t) { atomicXor(&T[wi], x); },
                                    [](uint32_t) {});
@@ -1086,13 +1104,6 @@ __host__ __device__ __forceinline__ uint32_t k2b_hist_words(uint32_t W) {
 }
 // bytes in front of the stages (a multiple of 1088 = 1024 * 17 / 16) and the virtual address that lands there
 __host__ __device__ __forceinline__ uint32_t k2b_hist_region(uint32_t W) { return (k2b_hist_words(W) * 4 + 1087) / 1088 * 1088; }
-// LDS accesses by byte address (the kernel's only LDS is its dynamic block, which therefore starts at byte 0: checked on entry).
-// Plain pointers into the block would cost an addition of the block's (link-time) address per access.
-typedef __attribute__((address_space(3))) uint16_t lds_u16;
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-__device__ __forceinline__ lds_u16* lds16(uint32_t a) { return (lds_u16*)(uintptr_t)a; }
-__device__ __forceinline__ lds_u32* lds32(uint32_t a) { return (lds_u32*)(uintptr_t)a; }
-__device__ __forceinline__ void lds_add(uint32_t a, uint32_t v) { __hip_atomic_fetch_add(lds32(a), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
                                                   const uint64_t* __restrict__ out_off, uint64_t n_reads, uint32_t W,
                                                   uint32_t* __restrict__ colors, unsigned int* tickets,
@@ -1108,7 +1119,7 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
     // more reads to the early ones): no counter can wrap. The host sizes the grid so that the caps add up to more
     // than the reads of every partition.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_x[];
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_x != 0u) __builtin_trap();
+    if (lds_addr(smem_x) != 0u) __builtin_trap();  // (no static LDS in this kernel: byte addresses count from the dynamic block)
     uint32_t* hist = (uint32_t*)smem_x;  // k2b_hist_words(W) words at LDS byte 0, the stages behind them
     const int lane = lane_id();
     const uint32_t hist_words = hit_partial ? k2b_hist_words(W) : 0u;
