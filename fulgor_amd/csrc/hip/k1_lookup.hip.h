@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
     constexpr uint32_t POSM = (1u << ORDER_POS_BITS) - 1u;
     constexpr uint32_t FIRST = 0x80000000u;
     constexpr uint32_t PAIRS = 256;         // ring of (bucket << 6 | source lane) pairs waiting for a lane (at most 4 new ones per lane and batch)
-    enum { M_UNIT = 0, M_QA = 1, M_QB = 2, M_NIDS = 3, M_NPOS = 4, M_HA = 5, M_HB = 6, M_WORDS = 8 };
+    enum { M_UNIT = 0, M_QA = 1, M_QB = 2, M_NIDS = 3, M_NPOS = 4, M_HA = 5, M_HB = 6, M_NK = 7, M_WORDS = 8 };
     // one block of LDS per wave, every array at a constant offset from the wave's base address (one address register
     // serves them all)
     struct WaveLds {
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
             uint32_t pairs[PAIRS];
         };
         uint32_t planes[NSLOT][3][PW];   // bases of the reads in flight: lo, hi, invalid
-        uint32_t queue[QCAP];            // run descriptors
+        uint32_t queue[QCAP + 1];        // run descriptors (+ one: a lane also looks at the entry behind its own)
         uint32_t hid[HCAP];              // heads: colour-set id
         uint32_t hcnt[HCAP];             //        k-mers | read slot << 16 | place of the slot in the pass << 20
         uint32_t hres[HCAP];             // heads sorted by (read, id): id  (long passes: total of the id within its read | FIRST, 0 for repeats)
@@ -219,19 +219,13 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                 }
                 if (lane == 0) {
                     uint32_t* M = meta[ws];
-                    M[M_UNIT] = j; M[M_QA] = q; M[M_QB] = q + R; M[M_NIDS] = 0; M[M_NPOS] = 0; M[M_HA] = 0; M[M_HB] = 0;
+                    M[M_UNIT] = j; M[M_QA] = q; M[M_QB] = q + R; M[M_NIDS] = 0; M[M_NPOS] = 0; M[M_HA] = 0; M[M_HB] = 0; M[M_NK] = nk;
                 }
-                uint32_t nh[NA];  // first run head at or after k-mer 64 a (nk if none)
-                nh[NA - 1] = nk;
-#pragma unroll
-                for (int a = NA - 2; a >= 0; --a) nh[a] = H[a] ? 64u * a + (uint32_t)__builtin_ctzll(H[a]) : nh[a + 1];
+                // (a run ends where the next one of the read begins, or with the read's last k-mer: phase C works its length out)
                 uint32_t before = q;
 #pragma unroll
                 for (int a = 0; a < NA - 1; ++a) {
-                    const uint32_t i = 64 * a + lane;
-                    const uint64_t rest = lane == 63 ? 0ull : (H[a] >> (lane + 1));
-                    const uint32_t next = rest ? i + 1u + (uint32_t)__builtin_ctzll(rest) : nh[a + 1];
-                    if ((H[a] >> lane) & 1ull) queue[before + mask_rank(H[a])] = run_pack(pos[a], i, next - i, ws);
+                    if ((H[a] >> lane) & 1ull) queue[before + mask_rank(H[a])] = run_pack(pos[a], 64 * a + lane, 0u, ws);
                     before += (uint32_t)__popcll(H[a]);
                 }
                 wave_lds_sync();
@@ -260,9 +254,19 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                     const bool act = (uint32_t)lane < qn;
                     // per-run state: the CL read bases around the minimizer (three planes, two words each), S[6] = descriptor
                     uint32_t S[7];
+                    uint32_t slot_qa = 0;
+                    bool slot_last = false;  // the last run of its read slot
                     {
-                        const uint32_t desc = act ? queue[e] : 0u;
+                        uint32_t desc = act ? queue[e] : 0u;
                         const uint32_t pm = desc & POSM, g = desc >> 25;
+                        // the run's k-mers: up to the next run of the same read slot, or to the read's last k-mer
+                        const uint32_t behind = queue[min(e + 1u, (uint32_t)QCAP)];
+                        const uint32_t slot_qb = single ? qb : meta[g][M_QB];
+                        if (!single) slot_qa = meta[g][M_QA];
+                        const uint32_t i0 = (desc >> 10) & POSM;
+                        const uint32_t iend = e + 1u == slot_qb ? meta[g][M_NK] : (behind >> 10) & POSM;
+                        desc |= (iend - i0) << 20;
+                        slot_last = e + 1u == slot_qb;
                         // base pm - km + c at field bit c (plane word 0 is padding)
                         const uint32_t o = pm + 32u - km;
                         const uint32_t* pl = L.planes[g][0] + (o >> 5);
@@ -285,8 +289,6 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
 #pragma unroll
                         for (int r = 0; r < (int)BUCKET_RECS; ++r) rec[r] = bp[r];
                     }
-                    uint32_t slot_qa = 0, slot_qb = 0;
-                    if (!single) { const uint32_t g = (S[6] >> 25) & 7u; slot_qa = meta[g][M_QA]; slot_qb = meta[g][M_QB]; }
 
                     // Buckets still to be looked at go through the ring `pairs` as (bucket << 6 | lane that owns the run): the overflow
                     // bucket behind this key's redirect slot, the next bucket behind a spill flag. found(...) is run on freshly loaded buckets.
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                             if (!single) {  // where the heads of every read slot begin and end
                                 const uint32_t begin = hcount + (incl & 0xFFFFu) - emit;
                                 if (act && e == slot_qa) meta[g][M_HA] = begin;
-                                if (act && e + 1 == slot_qb) meta[g][M_HB] = begin + emit;
+                                if (act && slot_last) meta[g][M_HB] = begin + emit;
                             }
                             // heads of the run lanes lie in per-slot order; what the pairs contribute comes behind them
                             hmain = hcount + ((uint32_t)__builtin_amdgcn_readlane((int)incl, (int)qn - 1) & 0xFFFFu);
@@ -460,11 +462,13 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                     const uint32_t vv = hact ? hid[lane] : 0u, hw = hact ? hcnt[lane] : (gfirst << 16);
                     const uint32_t gsel = (hw >> 16) & 7u, tsel = hw >> 20;
                     const uint32_t ha = meta[gsel][M_HA], hb = meta[gsel][M_HB];
+                    // (id, place) pairs compare as one 64-bit number; ha + maxseg <= 128 <= HCAP: no clamp, what lies past hb is not counted
+                    const uint64_t key = ((uint64_t)vv << 32) | (uint32_t)lane;
                     uint32_t rank = 0;
                     for (uint32_t t = 0; t < maxseg; ++t) {
                         const uint32_t i = ha + t;
-                        const uint32_t vi = hid[min(i, (uint32_t)HCAP - 1u)];
-                        rank += (i < hb && (vi < vv || (vi == vv && i < (uint32_t)lane))) ? 1u : 0u;
+                        const uint32_t vi = hid[i];
+                        rank += ((uint32_t)(i < hb) & (uint32_t)((((uint64_t)vi << 32) | i) < key));
                     }
                     uint32_t before = 0;  // heads from overflow buckets that belong to earlier reads of the pass
                     for (uint32_t i = hmain; i < hcount; ++i) {
