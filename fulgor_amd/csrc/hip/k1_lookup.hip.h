@@ -41,7 +41,10 @@ __device__ __forceinline__ uint32_t run_pack(uint32_t pm, uint32_t i0, uint32_t 
     return pm | (i0 << 10) | (cnt << 20) | (g << 25);
 }
 
-constexpr uint32_t K1_TICKET = 8;  // reads per pull from the work queue
+#ifndef FG_K1_TICKET
+#define FG_K1_TICKET 9  // three reads fill a pass of 64 runs (18 runs per 150-base read): tickets of 3 n reads leave no short pass behind
+#endif
+constexpr uint32_t K1_TICKET = FG_K1_TICKET;  // reads per pull from the work queue
 
 #ifdef FG_K1_STATS  // instrumented build (profiles/k1_stats.py): how often every loop of the kernel runs
 __device__ unsigned long long k1_stats[16];
@@ -173,23 +176,18 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                 // ---- A: order of every m-mer, window minima by doubling ----
                 mn[64 * (NA - 1) + 16 + lane] = 0xFFFFFFFFu;  // positions past the last round are "infinite"
                 uint32_t v[NA];
+                {
+                    // m-mer at position 64 a + lane: two words of each plane out of the read's slot, where lane 0 has just put them
+                    // (the ballot masks are scalars: cutting the window out of them costs a move per operand, a select per
+                    // plane and twice the shifts)
+                    const uint32_t* pw = P + 1 + (lane >> 5);
 #pragma unroll
-                for (int a = 0; a < NA; ++a) {
-                    // m-mer at position 64 a + lane out of a static word triple (alignbit shifts by lane & 31)
-                    const uint32_t l0 = (uint32_t)LO[a], l1 = (uint32_t)(LO[a] >> 32), l2 = a + 1 < NB ? (uint32_t)LO[a + 1 < NB ? a + 1 : a] : 0u;
-                    const uint32_t h0 = (uint32_t)HI[a], h1 = (uint32_t)(HI[a] >> 32), h2 = a + 1 < NB ? (uint32_t)HI[a + 1 < NB ? a + 1 : a] : 0u;
-                    uint32_t lo, hi;
-                    if (a == NA - 1) {  // 16 positions
-                        lo = __builtin_amdgcn_alignbit(l1, l0, lane);
-                        hi = __builtin_amdgcn_alignbit(h1, h0, lane);
-                    } else {
-                        const uint32_t la = __builtin_amdgcn_alignbit(l1, l0, lane), lb = __builtin_amdgcn_alignbit(l2, l1, lane);
-                        const uint32_t ha = __builtin_amdgcn_alignbit(h1, h0, lane), hb = __builtin_amdgcn_alignbit(h2, h1, lane);
-                        lo = lane < 32 ? la : lb;
-                        hi = lane < 32 ? ha : hb;
+                    for (int a = 0; a < NA; ++a) {
+                        const uint32_t lo = __builtin_amdgcn_alignbit(pw[2 * a + 1], pw[2 * a], lane);
+                        const uint32_t hi = __builtin_amdgcn_alignbit(pw[PW + 2 * a + 1], pw[PW + 2 * a], lane);
+                        v[a] = (minimizer_order(lo & maskm, hi & maskm) << ORDER_POS_BITS) | (uint32_t)(64 * a + lane);
+                        if (a < NA - 1 || lane < 16) mn[64 * a + lane] = v[a];
                     }
-                    v[a] = (minimizer_order(lo & maskm, hi & maskm) << ORDER_POS_BITS) | (uint32_t)(64 * a + lane);
-                    if (a < NA - 1 || lane < 16) mn[64 * a + lane] = v[a];
                 }
                 wave_lds_sync();
 #pragma unroll
