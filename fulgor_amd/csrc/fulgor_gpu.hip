@@ -431,14 +431,20 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         else if (bits == 8) launch(k_generic<true, 8>);
         else launch(k_generic<true, 16>);
     } else if (algo == FGPU_FULL_INTERSECTION) {
-        const size_t per_wave = (size_t)3 * W * 4 + wave_scratch_bytes_compact();  // EXCL, T, the initial EXCL
-        const uint32_t wpb = pick_waves(per_wave, (const void*)k2a_intersect);
-        const uint32_t grid = resident_grid(k2a_intersect, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
-        Timed t(ix, res, FGPU_K_INTERSECT);
-        hipLaunchKernelGGL(k2a_intersect, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_nids.as<uint32_t>(),
-                           res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), n, res->d_bitmap.as<uint32_t>(),
-                           res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
-        HIP_TRY(hipGetLastError());
+        // two reads per group (a second EXCL plane) while 8 waves per SIMD still fit the LDS with it
+        const bool pair = (size_t)32 * k2a_wave_bytes(W, true) <= 160 * 1024;
+        const size_t per_wave = k2a_wave_bytes(W, pair);
+        auto launch = [&](auto kernel) {
+            const uint32_t wpb = pick_waves(per_wave, (const void*)kernel);
+            const uint32_t grid = resident_grid(kernel, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
+            Timed t(ix, res, FGPU_K_INTERSECT);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_nids.as<uint32_t>(),
+                               res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), n, res->d_bitmap.as<uint32_t>(),
+                               res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
+            HIP_TRY(hipGetLastError());
+        };
+        if (pair) launch(k2a_intersect<true>);
+        else launch(k2a_intersect<false>);
     } else if (algo == FGPU_THRESHOLD_UNION) {
         // score counters from the longest read of the batch: biased 8-bit up to 127 k-mers, plain 8-bit up to 255, biased
         // 16-bit up to 32767, else 32-bit

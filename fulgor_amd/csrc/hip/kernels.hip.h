@@ -427,6 +427,13 @@ __device__ __forceinline__ WaveScratch carve_scratch(unsigned char* p) {
 // through one loop (run_blocks), one block of up to 64 values per step.
 __device__ __forceinline__ uint4 or_not(uint4 e, uint4 x) { return make_uint4(e.x | ~x.x, e.y | ~x.y, e.z | ~x.z, e.w | ~x.w); }
 
+// PAIR: two consecutive reads of a ticket with at most 64 lists between them go through the kernel as ONE group — their
+// descriptors arrive with one gather, their blocks run through one block loop into two EXCL planes — so that the fetch
+// chain ids -> descriptors -> block headers -> blocks, which bounds this kernel, is paid once for both.
+// (Without PAIR there is one EXCL plane: collections whose planes are too large for a fourth one.)
+__host__ __device__ inline uint32_t k2a_wave_bytes(uint32_t W, bool pair) { return ((pair ? 2u : 1u) + 2u) * W * 4u + wave_scratch_bytes_compact(); }
+
+template <bool PAIR>
 __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint32_t* __restrict__ nids,
                                                      const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
                                                      uint64_t n_reads, uint32_t* __restrict__ out_bitmap,
@@ -434,15 +441,16 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = c.w32, W4 = W >> 2;  // W is a multiple of 4: the bitmaps move as 128-bit groups
-    const uint32_t per_wave = 3 * W * 4 + wave_scratch_bytes_compact();
-    unsigned char* mine = smem + (size_t)wv * per_wave;
+    constexpr uint32_t NEX = PAIR ? 2u : 1u;  // EXCL planes (reads of a group)
+    unsigned char* mine = smem + (size_t)wv * k2a_wave_bytes(W, PAIR);
     WaveScratch sc = carve_scratch(mine);
     uint32_t* EXCL = (uint32_t*)(mine + wave_scratch_bytes_compact());
-    uint4* EX4 = (uint4*)EXCL;
-    uint4* T4 = EX4 + W4;    // the plane T, all zero between sparse lists
-    uint4* INIT4 = T4 + W4;  // what EXCL starts from: colours >= n excluded
+    uint4* EX4 = (uint4*)EXCL;     // plane p of the group at EX4 + p * W4
+    uint4* T4 = EX4 + NEX * W4;    // the plane T, all zero between sparse lists
+    uint4* INIT4 = T4 + W4;        // what EXCL starts from: colours >= n excluded
     const uint32_t excl_at = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(EXCL));  // LDS byte address of EXCL
     constexpr uint32_t BATCH = 8;
+    constexpr uint32_t SPARSE_FLAG = 0x80000000u, SECOND_FLAG = 0x40000000u, NBLK_MASK = 0x3FFFFFFFu;
     const WorkQueue wq{tickets, n_reads, BATCH};
     uint64_t t_first;
     uint32_t t_count;
@@ -460,40 +468,51 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
     wave_lds_sync();
 
     while (wq.pull(t_first, t_count)) {
-        // The colour-set ids of read i + 1 are requested while read i is processed; its descriptors (one 32-byte gather
-        // per list) are fetched at the top of the read. (Requesting the descriptors a read ahead as well costs 7 VGPRs,
-        // i.e. a wave per SIMD, and was slower.)
+        // The colour-set ids of the next group are requested while a group is processed; its descriptors (one 32-byte gather
+        // per list) are fetched at the top of the group. (Requesting the descriptors a group ahead as well was slower, in
+        // registers and through an LDS stage: DESIGN.md §8.)
         const uint64_t rl = min(t_first + (uint64_t)lane, n_reads - 1);
         const uint32_t cnt_l = (uint32_t)lane < t_count ? nids[rl] : 0u;  // lanes past the ticket: empty reads
         const uint64_t off_l = idoff[rl];
-        auto fetch_ids = [&](uint32_t i) -> uint32_t {  // ids of the ticket's read i (first 64)
-            const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, i);
-            return (uint32_t)lane < cn ? ids_pool[readlane_u64(off_l, i) + lane] : 0u;
+        // the group that starts with the ticket's read i: its list counts, and whether read i + 1 belongs to it
+        // (t_count <= BATCH < 62: the lanes exist and read as empty past the ticket)
+        auto group_at = [&](uint32_t i, uint32_t& a0, uint32_t& a1) -> bool {
+            a0 = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, i);
+            a1 = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, i + 1);
+            return PAIR && i + 1 < t_count && a0 != 0 && a1 != 0 && a0 + a1 <= 64u;
         };
-        auto fetch_desc = [&](uint32_t i, uint32_t id) -> ListDesc {
-            const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, i);
-            ListDesc dd = none;
-            if ((uint32_t)lane < cn) dd = c.set_desc[id];
-            return dd;
+        auto fetch_ids = [&](uint32_t i, uint32_t a0, uint32_t a1, bool two) -> uint32_t {  // lane = list of the group (first 64)
+            uint32_t id = 0;
+            if ((uint32_t)lane < a0) id = ids_pool[readlane_u64(off_l, i) + lane];
+            else if (two && (uint32_t)lane < a0 + a1) id = ids_pool[readlane_u64(off_l, i + 1) + lane - a0];
+            return id;
         };
-        uint32_t id1 = fetch_ids(0);
-        for (uint32_t ri = 0; ri < t_count; ++ri) {
+        uint32_t c0, c1;
+        bool pair = group_at(0, c0, c1);
+        uint32_t id1 = fetch_ids(0, c0, c1, pair);
+        for (uint32_t ri = 0; ri < t_count;) {
+            const uint32_t nr = pair ? 2u : 1u;
+            const uint32_t nlist = pair ? c0 + c1 : c0;  // lists of the group (a single read may have more than 64)
+            ListDesc dcur = none;
+            if ((uint32_t)lane < nlist) dcur = c.set_desc[id1];
+            uint32_t n0, n1;
+            const bool npair = group_at(ri + nr, n0, n1);
+            const uint32_t id2 = fetch_ids(ri + nr, n0, n1, npair);
             const uint64_t r = t_first + ri;
-            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, ri);
             const uint64_t off = readlane_u64(off_l, ri);
-            const ListDesc dcur = fetch_desc(ri, id1);
-            const uint32_t id2 = fetch_ids(ri + 1);  // (t_count <= BATCH < 62: lane i + 1 exists and reads as empty past the ticket)
-            uint4* bm4 = (uint4*)(out_bitmap + r * W);
-            if (cnt == 0) {
+            const uint32_t second = (pair && (uint32_t)lane >= c0) ? SECOND_FLAG : 0u;  // this lane's list belongs to read r + 1
+            if (nlist == 0) {
+                uint4* bm4 = (uint4*)(out_bitmap + r * W);
                 for (uint32_t g4 = lane; g4 < W4; g4 += 64) bm4[g4] = make_uint4(0u, 0u, 0u, 0u);
                 if (lane == 0) out_count[r] = 0;
             } else {
-                for (uint32_t g4 = lane; g4 < W4; g4 += 64) EX4[g4] = INIT4[g4];
-                for (uint32_t g = 0; g < cnt; g += 64) {
+                for (uint32_t p = 0; p < nr; ++p)
+                    for (uint32_t g4 = lane; g4 < W4; g4 += 64) EX4[p * W4 + g4] = INIT4[g4];
+                for (uint32_t g = 0; g < nlist; g += 64) {
                     ListDesc d = dcur;
-                    if (g) {  // more than 64 lists: rare, fetched in place
+                    if (g) {  // more than 64 lists (a read on its own): rare, fetched in place
                         d = none;
-                        if (g + lane < cnt) d = c.set_desc[ids_pool[off + g + lane]];
+                        if (g + lane < nlist) d = c.set_desc[ids_pool[off + g + lane]];
                     }
                     const int type = (int)(int8_t)(d.meta & 0xFFu);
                     const uint32_t nblk = d.ncodes;  // 0 for bitmap lists
@@ -501,7 +520,7 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
                     const uint32_t excl = incl - nblk;
                     const uint32_t total_blk = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     sc.h_begin[lane] = d.begin; sc.h_soff[lane] = type == D_ENC_BITMAP ? desc_body(d) : d.soff;
-                    sc.h_ncodes[lane] = nblk | (type == D_ENC_DELTA_GAPS ? 0x80000000u : 0u);
+                    sc.h_ncodes[lane] = nblk | (type == D_ENC_DELTA_GAPS ? SPARSE_FLAG : 0u) | second;
                     sc.pref[lane] = incl;
                     wave_lds_sync();
 
@@ -511,7 +530,8 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
                         const int src = __builtin_ctzll(mb);
                         mb &= mb - 1;
                         const uint4* row = (const uint4*)(c.bmp_words + sc.h_soff[src]);
-                        for (uint32_t g4 = lane; g4 < W4; g4 += 64) EX4[g4] = or_not(EX4[g4], row[g4]);
+                        uint4* ex = EX4 + ((PAIR && (sc.h_ncodes[src] & SECOND_FLAG)) ? W4 : 0u);
+                        for (uint32_t g4 = lane; g4 < W4; g4 += 64) ex[g4] = or_not(ex[g4], row[g4]);
                     }
                     wave_lds_sync();
 
@@ -519,25 +539,28 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
                         BlockLane bl{0u, 0u, 0u, 0u};
                         const uint32_t s = s0 + lane;
                         if (s < total_blk) {
-                            const uint32_t i = owner_list(excl, min(64u, cnt - g), s);
+                            const uint32_t i = owner_list(excl, min(64u, nlist - g), s);
                             const uint32_t nb = sc.h_ncodes[i];
-                            const uint32_t j = s - (sc.pref[i] - (nb & 0x7FFFFFFFu));
+                            const uint32_t j = s - (sc.pref[i] - (nb & NBLK_MASK));
                             // a single-block list carries its block header in the descriptor itself (one fetch less)
-                            const uint64_t hd = (nb & 0x7FFFFFFFu) == 1 ? sc.h_soff[i] : ((const uint64_t*)(c.blk_words + sc.h_begin[i]))[j];
-                            const bool sparse = (nb >> 31) != 0;
+                            const uint64_t hd = (nb & NBLK_MASK) == 1 ? sc.h_soff[i] : ((const uint64_t*)(c.blk_words + sc.h_begin[i]))[j];
+                            const bool sparse = (nb & SPARSE_FLAG) != 0;
+                            const uint32_t plane = (PAIR && (nb & SECOND_FLAG)) ? 1u : 0u;
                             bl.word = (uint32_t)sc.h_begin[i] + blk_rel_word(hd);
-                            bl.start = blk_start(hd) + (sparse ? W * 32u : 0u);  // bit index relative to EXCL
+                            // bit index relative to EXCL: the list's own plane, or T for a sparse list
+                            bl.start = blk_start(hd) + (sparse ? NEX : plane) * W * 32u;
                             bl.meta = blk_width(hd) | ((blk_count(hd) - 1u) << 5) |
-                                      ((sparse && j + 1 == (nb & 0x7FFFFFFFu)) ? 1u << 11 : 0u);
+                                      ((sparse && j + 1 == (nb & NBLK_MASK)) ? 1u << 11 : 0u) | (plane << 12);
                         }
                         run_blocks(c.blk_words, bl, min(64u, total_blk - s0), lane,
                                    [&](uint32_t v, uint32_t) { lds_or(lds_bit_word(excl_at, v), 1u << (v & 31)); },
                                    [&](uint32_t wi, uint32_t x, uint32_t) { atomicOr(&EXCL[wi], x); },
-                                   [&](uint32_t last_of_sparse) {
-                                       if (last_of_sparse) {  // a colour absent from this sparse list is excluded; T goes back to zero
+                                   [&](uint32_t flags) {  // bit 0: last block of a sparse list, bit 1: the list's plane
+                                       if (flags & 1u) {  // a colour absent from this sparse list is excluded; T goes back to zero
+                                           uint4* ex = EX4 + ((PAIR && (flags & 2u)) ? W4 : 0u);
                                            wave_lds_sync();
                                            for (uint32_t g4 = lane; g4 < W4; g4 += 64) {
-                                               EX4[g4] = or_not(EX4[g4], T4[g4]);
+                                               ex[g4] = or_not(ex[g4], T4[g4]);
                                                T4[g4] = make_uint4(0u, 0u, 0u, 0u);
                                            }
                                            wave_lds_sync();
@@ -546,19 +569,26 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
                     }
                     wave_lds_sync();
                 }
-                uint32_t pc = 0;
-                for (uint32_t g4 = lane; g4 < W4; g4 += 64) {
-                    const uint4 e = EX4[g4];
-                    const uint4 x = make_uint4(~e.x, ~e.y, ~e.z, ~e.w);
-                    // streamed past the L2 (nontemporal): the rows are read back by another kernel, the L2 is for the lists
-                    __builtin_nontemporal_store((u32x4){x.x, x.y, x.z, x.w}, (u32x4*)&bm4[g4]);
-                    pc += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
+                for (uint32_t p = 0; p < nr; ++p) {
+                    uint4* bm4 = (uint4*)(out_bitmap + (r + p) * W);
+                    uint32_t pc = 0;
+                    for (uint32_t g4 = lane; g4 < W4; g4 += 64) {
+                        const uint4 e = EX4[p * W4 + g4];
+                        const uint4 x = make_uint4(~e.x, ~e.y, ~e.z, ~e.w);
+                        // streamed past the L2 (nontemporal): the rows are read back by another kernel, the L2 is for the lists
+                        __builtin_nontemporal_store((u32x4){x.x, x.y, x.z, x.w}, (u32x4*)&bm4[g4]);
+                        pc += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
+                    }
+                    pc = wave_sum_u32(pc);
+                    if (lane == 0) out_count[r + p] = pc;
                 }
-                pc = wave_sum_u32(pc);
-                if (lane == 0) out_count[r] = pc;
                 wave_lds_sync();
             }
+            ri += nr;
             id1 = id2;
+            c0 = n0;
+            c1 = n1;
+            pair = npair;
         }
     }
 }
