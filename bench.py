@@ -51,7 +51,9 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the BASELINE config size)")
     ap.add_argument("--algo", default="full-intersection", choices=["full-intersection", "threshold-union"])
     ap.add_argument("--tau", type=float, default=0.8)
-    ap.add_argument("--chunk", type=int, default=2_500_000, help="reads per kernel pass (10M reads = 4 equal passes)")
+    ap.add_argument("--chunk", type=int, default=10_000_000,
+                    help="reads per kernel pass (default: the whole read set of the BASELINE config in one pass; the result buffers of a "
+                         "10 M-read pass take 40 GB (full intersection) to 95 GB (threshold union) of the 288 GB)")
     ap.add_argument("--index-type", default="hybrid", choices=["hybrid", "diff", "meta", "meta-diff"],
                     help="colour-set codec (fur / dfur / mfur / mdfur of the reference)")
     ap.add_argument("--partition-size", type=int, default=160)
