@@ -84,6 +84,11 @@ struct fgpu_index {
     struct Pending { int kernel; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
+    // device buffers of released read batches, kept for the next upload: the command-line path uploads and releases a batch
+    // every few milliseconds from several host threads, and hipMalloc / hipFree synchronise the whole device (every stream)
+    std::mutex reads_mu;
+    std::vector<std::pair<DevBuf, DevBuf>> reads_pool;  // (bases, offsets)
+    static constexpr size_t READS_POOL_MAX = 8;
     std::mutex tmu;  // results on different streams may be driven from different host threads
 
     hipEvent_t get_event() {
@@ -573,6 +578,7 @@ void fgpu_close(fgpu_index* ix) {
                       &ix->d_set_desc, &ix->d_blk_words, &ix->d_gops, &ix->d_gset_ops_off, &ix->d_gset_ops,
                       &ix->d_garena, &ix->d_gblk_hdr, &ix->d_gblk_words, &ix->d_gset_bytes})
         b->release();
+    for (auto& pr : ix->reads_pool) { pr.first.release(); pr.second.release(); }
     for (auto e : ix->event_pool) (void)hipEventDestroy(e);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
@@ -694,6 +700,24 @@ int fgpu_reads_upload(fgpu_index* ix, const char* bases, const uint64_t* offs, u
                 HIP_TRY(hipMemcpyAsync(rd->d_bases.p, seg_bases.data(), seg_bases.size(), hipMemcpyHostToDevice, ix->stream));
             HIP_TRY(hipStreamSynchronize(ix->stream));  // seg_bases / seg_offs are released at the end of this block
         } else {
+            {
+                std::lock_guard<std::mutex> g(ix->reads_mu);
+                // the smallest pooled pair that is large enough, else the largest one (it grows below)
+                size_t best = ix->reads_pool.size();
+                for (size_t i = 0; i < ix->reads_pool.size(); ++i) {
+                    const auto& c = ix->reads_pool[i];
+                    const bool fits = c.first.cap >= nb + 1024 && c.second.cap >= (n + 1) * 8;
+                    if (best == ix->reads_pool.size()) { best = i; continue; }
+                    const auto& b = ix->reads_pool[best];
+                    const bool bfits = b.first.cap >= nb + 1024 && b.second.cap >= (n + 1) * 8;
+                    if (fits != bfits ? fits : (fits ? c.first.cap < b.first.cap : c.first.cap > b.first.cap)) best = i;
+                }
+                if (best < ix->reads_pool.size()) {
+                    rd->d_bases = ix->reads_pool[best].first;
+                    rd->d_offs = ix->reads_pool[best].second;
+                    ix->reads_pool.erase(ix->reads_pool.begin() + best);
+                }
+            }
             rd->d_bases.ensure(nb + 1024);
             rd->d_offs.ensure((n + 1) * 8);
             if (nb) HIP_TRY(hipMemcpyAsync(rd->d_bases.p, bases, nb, hipMemcpyHostToDevice, ix->stream));
@@ -709,6 +733,14 @@ int fgpu_reads_upload(fgpu_index* ix, const char* bases, const uint64_t* offs, u
 void fgpu_reads_free(fgpu_reads* rd) {
     if (!rd) return;
     (void)hipSetDevice(rd->ix->device);
+    if (!rd->has_long && rd->d_bases.p && rd->d_offs.p) {  // back to the pool (the kernels that read them have completed: every pass ends with a stream synchronise)
+        std::lock_guard<std::mutex> g(rd->ix->reads_mu);
+        if (rd->ix->reads_pool.size() < fgpu_index::READS_POOL_MAX) {
+            rd->ix->reads_pool.emplace_back(rd->d_bases, rd->d_offs);
+            rd->d_bases = DevBuf();
+            rd->d_offs = DevBuf();
+        }
+    }
     rd->d_bases.release();
     rd->d_offs.release();
     rd->d_seg_offs.release();
@@ -1195,12 +1227,25 @@ int fgpu_formatter_finish(fgpu_formatter* f, char** out, uint64_t* out_len) {
 namespace {
 // grow-only byte buffer in pinned host memory (H2D copies out of it run at PCIe speed and overlap with kernels); plain
 // memory when there is no HIP device (host-only tools, CPU tests)
+// Pinning and unpinning 100 MB costs tens of milliseconds each (a reader has four such buffers: 63 ms of its close()), so
+// released pinned buffers wait in a process-wide pool for the next reader; what is still pooled at exit goes with the process.
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<std::pair<char*, size_t>> free_list;
+    static constexpr size_t MAX = 8;
+    static PinnedPool& get() { static PinnedPool* p = new PinnedPool(); return *p; }  // (never destroyed: no calls into HIP at exit)
+};
 struct PinnedBytes {
     char* p = nullptr;
     size_t n = 0, cap = 0;
     bool pinned = false;
     ~PinnedBytes() { release(); }
     void release() {
+        if (p && pinned) {
+            PinnedPool& pool = PinnedPool::get();
+            std::lock_guard<std::mutex> g(pool.mu);
+            if (pool.free_list.size() < PinnedPool::MAX) { pool.free_list.emplace_back(p, cap); p = nullptr; }
+        }
         if (p) { if (pinned) (void)hipHostFree(p); else free(p); }
         p = nullptr;
         n = cap = 0;
@@ -1213,7 +1258,19 @@ struct PinnedBytes {
         if (want <= cap) return;
         want += want / 4 + 4096;
         char* q = nullptr;
-        bool pin = hipHostMalloc((void**)&q, want, hipHostMallocDefault) == hipSuccess && q;
+        {
+            PinnedPool& pool = PinnedPool::get();
+            std::lock_guard<std::mutex> g(pool.mu);
+            size_t best = pool.free_list.size();
+            for (size_t i = 0; i < pool.free_list.size(); ++i)
+                if (pool.free_list[i].second >= want && (best == pool.free_list.size() || pool.free_list[i].second < pool.free_list[best].second)) best = i;
+            if (best < pool.free_list.size()) {
+                q = pool.free_list[best].first;
+                want = pool.free_list[best].second;
+                pool.free_list.erase(pool.free_list.begin() + best);
+            }
+        }
+        bool pin = q != nullptr || (hipHostMalloc((void**)&q, want, hipHostMallocDefault) == hipSuccess && q);
         if (!pin) {
             (void)hipGetLastError();
             q = (char*)malloc(want);

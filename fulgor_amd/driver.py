@@ -181,7 +181,12 @@ def pseudoalign_stream(index, batches, algo=FULL_INTERSECTION, threshold=0.0, si
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     inflight = max(1, min(3, int(inflight)))  # the reader keeps four batches alive
-    results = [index.new_result() for _ in range(inflight)]
+    # the results (device buffers sized for one batch, a stream each) stay with the index: a second stream of batches through
+    # the same index finds them allocated (allocating and freeing device memory synchronises the whole device)
+    results = getattr(index, "_stream_results", None) or []
+    while len(results) < inflight:
+        results.append(index.new_result())
+    index._stream_results = results
 
     def one_pass(slot, bases, offs, id0):
         res = results[slot]
@@ -213,8 +218,6 @@ def pseudoalign_stream(index, batches, algo=FULL_INTERSECTION, threshold=0.0, si
             retire()
     if f is not None:
         f.finish()  # (the host formatter only supplied the file header)
-    for r in results:
-        r.close()
     return n, mapped
 
 

@@ -171,6 +171,9 @@ class Index:
 
     def close(self):
         if getattr(self, "_h", None):
+            for r in getattr(self, "_stream_results", []):  # (driver.pseudoalign_stream keeps its results with the index)
+                r.close()
+            self._stream_results = []
             self._L.fgpu_close(self._h)
             self._h = None
 
