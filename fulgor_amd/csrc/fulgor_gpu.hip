@@ -562,8 +562,10 @@ int fgpu_open(const char* path, int device, fgpu_index** out) {
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         ix->num_cus = prop.multiProcessorCount;
         HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+        LoadClock clk;
         upload_index(ix);
         if (ix->host.type != IDX_HYBRID) upload_generic(ix);
+        clk.lap("descriptors, bitmap rows, upload");
     });
     if (rc) { delete ix; return rc; }
     *out = ix;

@@ -12,6 +12,7 @@
 // canonical m-mer or a reverse complement and has no strand, tie or palindrome cases. A k-mer that is its own
 // reverse complement (even k only) is kept on the unitig's strand only, so that it is found once.
 #pragma once
+#include <atomic>
 #include <algorithm>
 #include <stdexcept>
 #include <thread>
@@ -70,26 +71,84 @@ inline void build_dict_table(Dict& d) {
     d.num_buckets = (uint32_t)std::max<uint64_t>(16, nrec + nrec / 2 + nrec / 8);
     const uint64_t nb_hashed = (uint64_t)d.num_buckets + DICT_TAIL_BUCKETS;
     struct Ref { uint32_t home; uint32_t rec; uint64_t key; };
-    std::vector<Ref> refs(nrec);
-    for (uint64_t i = 0; i < nrec; ++i) {
-        uint32_t lo, hi;
-        record_minimizer(&d.records[i * REC_WORDS], d.k, d.m, lo, hi);
-        refs[i] = Ref{mulhi32(dict_hash(lo, hi, d.seed), d.num_buckets), (uint32_t)i, lmer_key(lo, hi)};
-    }
-    std::sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) {
+    // The table is rebuilt from the records whenever an index is opened: the sort of the records by (home bucket, key) is
+    // most of the time of opening one, so it runs on several threads — the records are dealt into ranges of home buckets
+    // (the hash spreads them evenly), every range is sorted on its own, and the ranges follow each other in the order.
+    const unsigned T = (unsigned)std::min<uint64_t>(std::max(1u, std::min(32u, std::thread::hardware_concurrency())), nrec / 65536 + 1);
+    auto parallel = [&](uint64_t n, auto fn) {  // fn(thread, begin, end) over [0, n) in T contiguous pieces
+        if (T == 1) { fn(0u, (uint64_t)0, n); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; ++t) th.emplace_back([&, t] { fn(t, n * t / T, n * (t + 1) / T); });
+        for (auto& x : th) x.join();
+    };
+    const auto less = [](const Ref& a, const Ref& b) {
         return a.home != b.home ? a.home < b.home : (a.key != b.key ? a.key < b.key : a.rec < b.rec);
-    });
+    };
+    std::vector<Ref> refs(nrec);
+    {
+        const uint32_t P = T == 1 ? 1u : 8u * T;  // ranges of home buckets
+        const auto part_of = [&](uint32_t home) { return (uint32_t)((uint64_t)home * P / d.num_buckets); };  // (home < num_buckets)
+        std::vector<Ref> tmp(T == 1 ? 0 : nrec);
+        std::vector<Ref>& first = T == 1 ? refs : tmp;
+        std::vector<uint64_t> count((size_t)T * P, 0);
+        parallel(nrec, [&](unsigned t, uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e; ++i) {
+                uint32_t lo, hi;
+                record_minimizer(&d.records[i * REC_WORDS], d.k, d.m, lo, hi);
+                first[i] = Ref{mulhi32(dict_hash(lo, hi, d.seed), d.num_buckets), (uint32_t)i, lmer_key(lo, hi)};
+                ++count[(size_t)t * P + part_of(first[i].home)];
+            }
+        });
+        if (T == 1) {
+            std::sort(refs.begin(), refs.end(), less);
+        } else {
+            std::vector<uint64_t> start((size_t)T * P), part_begin(P + 1, 0);
+            uint64_t run = 0;
+            for (uint32_t p = 0; p < P; ++p) {
+                part_begin[p] = run;
+                for (unsigned t = 0; t < T; ++t) { start[(size_t)t * P + p] = run; run += count[(size_t)t * P + p]; }
+            }
+            part_begin[P] = run;
+            parallel(nrec, [&](unsigned t, uint64_t b, uint64_t e) {
+                uint64_t* at = &start[(size_t)t * P];
+                for (uint64_t i = b; i < e; ++i) refs[at[part_of(tmp[i].home)]++] = tmp[i];
+            });
+            std::atomic<uint32_t> next{0};
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < T; ++t)
+                th.emplace_back([&] {
+                    for (uint32_t p; (p = next.fetch_add(1)) < P;) std::sort(refs.begin() + part_begin[p], refs.begin() + part_begin[p + 1], less);
+                });
+            for (auto& x : th) x.join();
+        }
+    }
     d.table.clear();
     d.table.reserve((nb_hashed + nrec / 16 + 1024) * BUCKET_WORDS);  // room for the overflow region without a second copy
-    d.table.assign(nb_hashed * BUCKET_WORDS, 0);
-    for (uint64_t b = 0; b < nb_hashed; ++b)
-        for (uint32_t r = 0; r < BUCKET_RECS; ++r) d.table[b * BUCKET_WORDS + r * REC_WORDS + 2] = REC_W2_EMPTY;
+    d.table.resize(nb_hashed * BUCKET_WORDS);
+    parallel(nb_hashed, [&](unsigned, uint64_t b0, uint64_t b1) {
+        for (uint64_t b = b0; b < b1; ++b)
+            for (uint32_t r = 0; r < BUCKET_RECS; ++r) {
+                uint32_t* w = &d.table[b * BUCKET_WORDS + r * REC_WORDS];
+                w[0] = w[1] = w[3] = 0;
+                w[2] = REC_W2_EMPTY;
+            }
+    });
     struct Item { uint64_t first, count; };  // a key: refs[first, first + count)
     std::vector<Item> carry, items;
     std::vector<uint32_t> overflow;  // the overflow region, appended behind the hashed region at the end
-    auto put = [&](uint32_t* dst, uint32_t rec) {
-        const uint32_t* w = &d.records[(uint64_t)rec * REC_WORDS];
-        dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3] & REC_MAX_CSID;
+    // the records in table order (gathered by all threads: the sweep below then reads them front to back instead of
+    // missing the cache once per record)
+    std::vector<uint32_t> ordered(nrec * REC_WORDS);
+    parallel(nrec, [&](unsigned, uint64_t b, uint64_t e) {
+        for (uint64_t i = b; i < e; ++i) {
+            const uint32_t* w = &d.records[(uint64_t)refs[i].rec * REC_WORDS];
+            uint32_t* o = &ordered[i * REC_WORDS];
+            o[0] = w[0]; o[1] = w[1]; o[2] = w[2]; o[3] = w[3] & REC_MAX_CSID;
+        }
+    });
+    auto put = [&](uint32_t* dst, uint64_t at_ref) {  // the record of refs[at_ref]
+        const uint32_t* w = &ordered[at_ref * REC_WORDS];
+        dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3];
     };
     uint64_t at = 0;
     for (uint64_t b = 0; b < nb_hashed; ++b) {
@@ -112,7 +171,7 @@ inline void build_dict_table(Dict& d) {
         uint32_t left = BUCKET_RECS - (uint32_t)items.size(), slot = 0;
         for (const Item& it : items) {
             if (it.count - 1 <= left && it.count <= BUCKET_RECS) {
-                for (uint64_t j = 0; j < it.count; ++j) put(bw + (slot++) * REC_WORDS, refs[it.first + j].rec);
+                for (uint64_t j = 0; j < it.count; ++j) put(bw + (slot++) * REC_WORDS, it.first + j);
                 left -= (uint32_t)(it.count - 1);
             } else {
                 const uint64_t nb = (it.count + BUCKET_RECS - 1) / BUCKET_RECS;
@@ -122,7 +181,7 @@ inline void build_dict_table(Dict& d) {
                 overflow.resize(o0 + nb * BUCKET_WORDS, 0);
                 for (uint64_t j = 0; j < nb * BUCKET_RECS; ++j) {
                     uint32_t* dst = &overflow[o0 + j * REC_WORDS];
-                    if (j < it.count) put(dst, refs[it.first + j].rec);
+                    if (j < it.count) put(dst, it.first + j);
                     else dst[2] = REC_W2_EMPTY;
                 }
                 // the query reads the first REDIRECT_DIRECT buckets at once; further ones hang on spill flags

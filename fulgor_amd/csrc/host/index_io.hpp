@@ -13,6 +13,7 @@
 // The reference's binary .fur/.mfur/.dfur/.mdfur files embed an SSHash dictionary whose layout is
 // defined by a submodule that is not vendored; they are rejected loudly by open_index().
 #pragma once
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -168,8 +169,20 @@ inline void save_binary(const HostIndex& idx, const std::string& path) {
     if (!o) throw std::runtime_error("write error on index file");
 }
 
+// FULGOR_VERBOSE_LOAD=1: the stages of opening an index, with their times, on stderr
+struct LoadClock {
+    bool on = getenv("FULGOR_VERBOSE_LOAD") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (on) fprintf(stderr, "  open: %-34s %7.3f s\n", what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
+
 inline void load_binary(const std::string& path, HostIndex& idx) {
     using namespace detail;
+    LoadClock clk;
     std::ifstream i(path, std::ios::binary);
     if (!i.is_open()) throw std::runtime_error("cannot open index file");
     char magic[8];
@@ -185,6 +198,7 @@ inline void load_binary(const std::string& path, HostIndex& idx) {
     HybridSets& h = idx.hybrid;
     rd(i, h.num_colors); rd(i, h.sparse_thr); rd(i, h.dense_thr); rd(i, h.nbits);
     rdv(i, h.offsets); rdv(i, h.bits);
+    clk.lap("read the container");
     {   // a truncated, stale or corrupt container must fail here, not index out of bounds later
         auto bad = [](const char* what) { throw std::runtime_error(std::string("corrupt index file: ") + what); };
         try { check_dict_params(d.k, d.m); } catch (std::exception&) { bad("k / m"); }
@@ -205,9 +219,12 @@ inline void load_binary(const std::string& path, HostIndex& idx) {
         for (uint64_t r = 0; r < d.num_records(); ++r)
             if ((d.records[r * REC_WORDS + 3] & REC_MAX_CSID) >= nsets) bad("record colour-set id");
     }
+    clk.lap("validate");
     build_dict_table(d);
+    clk.lap("dictionary table from the records");
     h.bits.resize((h.nbits + 63) / 64 + 4, 0);  // the device reads up to 256 bits past a bitmap list
     hybrid_build_blocks(h);
+    clk.lap("packed blocks of the gap lists");
     if (idx.type != IDX_HYBRID) {
         GenericSets& g = idx.generic;
         g.type = idx.type;
