@@ -180,14 +180,20 @@ inline void hybrid_build_blocks(HybridSets& h, unsigned nthreads = 0) {
     // per-set descriptor instead. Every list starts on an even word (headers are read as u64), rel_word counts from
     // the start of the list's region, headers included (a gap-coded list owns fewer than n/4 <= 2^25 codes of at most 27
     // bits and one header per 64 codes at most: always below 2^26 words).
+    uint64_t begin_of_next = 0;
     for (uint64_t i = 0; i < ns; ++i) {
         const uint64_t nb = h.blk_first[i + 1];
         uint64_t tot = nwords[i + 1] + (nb >= 2 ? 2 * nb : 0);
         tot += tot & 1;
         h.blk_first[i + 1] += h.blk_first[i];
-        nwords[i + 1] = nwords[i] + tot;
+        // The memory system moves 128-byte lines (32 words) and the intersection kernel is bound by the number of lines it
+        // requests: a region of at most one line does not straddle a line boundary, a longer one starts on one.
+        uint64_t at = begin_of_next;
+        if (tot > 32 ? (at & 31) != 0 : (at >> 5) != ((at + tot - 1) >> 5)) at = (at + 31) & ~(uint64_t)31;
+        h.blk_wbase[i] = at;
+        begin_of_next = at + tot;
+        nwords[i + 1] = begin_of_next;
     }
-    for (uint64_t i = 0; i < ns; ++i) h.blk_wbase[i] = nwords[i];
     h.blk_hdr.assign(h.blk_first[ns], 0);
     h.blk_words.assign(nwords[ns] + 64, 0);  // a wave reads up to 64 * 27 bits + 1 word past a block's start
     run([&](uint64_t a, uint64_t b) {
