@@ -1068,3 +1068,44 @@ print("ok")
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout.split(), r.stdout + r.stderr  # (the runtime may print after the script's last line)
+
+
+@pytest.mark.gpu
+def test_pooled_buffers_and_reused_stream_results(s10_gpu, s10_oracle, tmp_path):
+    """The command-line loop recycles what it used to allocate per batch: device read buffers (pool in the index), pinned
+    reader buffers (process-wide pool), the three results of the stream (kept with the index). Batches of growing and shrinking
+    size through the same index, and two streams over two files one after the other, must give the oracle's records."""
+    from fulgor_amd import driver
+    from fulgor_amd.reads import FastxReader, ReadGenerator
+    from conftest import S10_GENOMES
+    gen = ReadGenerator(S10_GENOMES)
+    for n, seed in ((3000, 5), (200, 6), (9000, 7), (1, 8), (4000, 9)):  # upload / free / upload: larger, smaller, larger again
+        bases, offs = gen.generate(0, n, 150, seed)
+        reads = s10_gpu.upload_reads(bases, offs)
+        res = s10_gpu.new_result()
+        s10_gpu.run(reads, res, 0, 0.0)
+        o, c = res.download()
+        reads.close()
+        res.close()
+        wo, wc = s10_oracle.full_intersection(bases, offs)
+        assert np.array_equal(np.asarray(o, dtype=np.int64), np.asarray(wo, dtype=np.int64)) and np.array_equal(c, wc)
+    outs = []
+    for n, seed in ((7000, 11), (2500, 12)):
+        bases, offs = gen.generate(0, n, 150, seed)
+        fq = tmp_path / ("q%d.fq" % seed)
+        with open(fq, "wb") as f:
+            for i in range(n):
+                s = bytes(bases[int(offs[i]):int(offs[i + 1])])
+                f.write(b"@r%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)))
+        out = tmp_path / ("o%d.tsv" % seed)
+        rd = FastxReader(str(fq), batch=1024, copy=False, threads=3)
+        with open(out, "wb") as sink:
+            got, mapped = driver.pseudoalign_stream(s10_gpu, rd, sink=sink, fmt="ascii")
+        rd.close()
+        assert got == n
+        wo, wc = s10_oracle.full_intersection(bases, offs)
+        wo = np.asarray(wo, dtype=np.int64)
+        want = "".join("%d\t%d%s\n" % (i, wo[i + 1] - wo[i], "".join("\t%d" % x for x in wc[wo[i]:wo[i + 1]])) for i in range(n))
+        assert out.read_bytes().decode() == want
+        outs.append(mapped)
+    assert len(getattr(s10_gpu, "_stream_results", [])) == 3  # the second stream found the results of the first
