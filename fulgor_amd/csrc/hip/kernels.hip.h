@@ -792,7 +792,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 4 : 2)) void k3a
             for (uint32_t q = 0; q < PLANES; ++q) {
                 const uint32_t x = SC[q * W + w];
                 if (BIASED) {
-                    m |= ((x >> (BITS - 1)) & ONES) << q;
+                    m = (m >> 1) | (x & (ONES << (BITS - 1)));  // plane q ends PLANES - 1 - q = BITS - 1 - q places below its field's top bit
                 } else {  // byte >= min_score  <=>  carry out of byte + (256 - min_score); min_score = 0 keeps every colour
                     const uint32_t low = (x & 0x7F7F7F7Fu) + add7;         // carry into bit 7 of every byte
                     const uint32_t out = (x & low) | ((x ^ low) & top7);   // majority(x7, low7, bit 7 of 256 - min_score)
@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 5 : 4) : 7) void k_generi
                 for (uint32_t q = 0; q < PLANES; ++q) {
                     const uint32_t x = ACC[q * W + w];
                     if (BIASED) {
-                        m |= ((x >> (BITS - 1)) & ONES) << q;
+                        m = (m >> 1) | (x & (ONES << (BITS - 1)));  // plane q ends PLANES - 1 - q = BITS - 1 - q places below its field's top bit
                     } else {
                         const uint32_t low = (x & 0x7F7F7F7Fu) + add7;
                         const uint32_t out = (x & low) | ((x ^ low) & top7);
