@@ -8,7 +8,11 @@
 //   * plain files are mapped and cut into byte ranges that a pool of threads parses concurrently (a range
 //     starts at the first record boundary at or behind its first byte: '>' at a line start, or '@' at a line
 //     start whose line after next starts with '+'), and the chunks are handed out in range order;
-//   * gzip streams cannot be entered in the middle: one thread inflates and parses.
+//   * gzip streams cannot be entered in the middle: one thread inflates and parses;
+//   * block-compressed gzip (BGZF, what bgzip / htslib write: a series of gzip members of at most 64 KB, each giving its
+//     compressed size in an extra field) can: the members are inflated by the pool of threads into an anonymous buffer as
+//     the ranges that need them come up, and the ranges are parsed as for a plain file. Any gzip reader, the reference's
+//     included, reads such a file as one stream.
 #pragma once
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -213,20 +217,10 @@ public:
             if (map_ == MAP_FAILED) { close(fd_); throw std::runtime_error("cannot map " + path); }
             madvise((void*)map_, size_, MADV_SEQUENTIAL);
         }
-        begin_ = std::min(begin, size_);
-        end_ = std::min(end, size_);
-        num_ranges_ = begin_ < end_ ? (end_ - begin_ + range_ - 1) / range_ : 0;
-        window_ = 2 * std::max(1u, threads) + 2;
-        for (unsigned t = 0; t < std::max(1u, threads) && t < num_ranges_; ++t) workers_.emplace_back([this] { work(); });
+        start(threads, begin, end);
     }
     ~MappedFastxSource() override {
-        {
-            std::lock_guard<std::mutex> g(m_);
-            stop_ = true;
-        }
-        cv_space_.notify_all();
-        cv_data_.notify_all();
-        for (auto& w : workers_) w.join();
+        shutdown();
         // tearing down the page tables of a multi-gigabyte mapping that hundreds of threads have touched takes tens of
         // milliseconds (60-90 ms for 3 GB on a 256-thread host): nobody has to wait for it
         if (map_ && size_) {
@@ -244,9 +238,10 @@ public:
         if (next_out_ >= num_ranges_) return false;
         c = std::move(done_[next_out_]);
         done_.erase(next_out_);
-        ++next_out_;
+        const uint64_t r = next_out_++;
         g.unlock();
         cv_space_.notify_all();
+        consumed(r);
         return true;
     }
     void recycle(FastxChunk&& c) override {
@@ -254,39 +249,88 @@ public:
         std::lock_guard<std::mutex> g(m_);
         if (pool_.size() < 64) pool_.push_back(std::move(c));
     }
-    // first record boundary at or behind byte p (size_ if none). A record starts at a line start with '>', or with '@' when the
+    // first record boundary at or behind byte p (size_ if none). A record starts at a line start with '>' (FASTA files), or with '@' when the
     // four lines from there look like a FASTQ record: third line '+...', fourth as long as the second (a quality line may
     // begin with '@', but then the line after next is a sequence). FASTQ files with wrapped sequences offer no such
     // boundaries: everything then falls to the first range, i.e. one thread parses the file with kseq's general grammar.
     uint64_t record_start(uint64_t p) const {
+        bool sure;
+        return record_start_in(p, size_, sure);
+    }
+    uint64_t size() const { return size_; }
+
+protected:
+    MappedFastxSource(uint64_t range_bytes) : range_(range_bytes) {}  // a derived source sets map_ / size_ and calls start()
+    // hooks of a source whose bytes come into being on demand
+    virtual void ensure(uint64_t, uint64_t) {}  // bytes [lo, hi) of map_ are about to be read
+    virtual void consumed(uint64_t) {}          // range r has been handed out
+    virtual bool lazy() const { return false; }
+    void start(unsigned threads, uint64_t begin, uint64_t end) {
+        if (size_) {  // FASTA or FASTQ, by the file's first character: which line starts can open a record
+            ensure(0, 1);
+            kind_ = map_[0] == '>' || map_[0] == '@' ? map_[0] : 0;
+        }
+        begin_ = std::min(begin, size_);
+        end_ = std::min(end, size_);
+        num_ranges_ = begin_ < end_ ? (end_ - begin_ + range_ - 1) / range_ : 0;
+        window_ = 2 * std::max(1u, threads) + 2;
+        for (unsigned t = 0; t < std::max(1u, threads) && t < num_ranges_; ++t) workers_.emplace_back([this] { work(); });
+    }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_space_.notify_all();
+        cv_data_.notify_all();
+        for (auto& w : workers_) w.join();
+        workers_.clear();
+    }
+    // record_start within the window [.., wend): sure = false when the window ended before the answer was certain
+    uint64_t record_start_in(uint64_t p, uint64_t wend, bool& sure) const {
+        sure = true;
         if (p == 0) return 0;
-        const char* nl = (const char*)memchr(map_ + p - 1, '\n', size_ - (p - 1));  // p - 1: p itself may be a line start
-        uint64_t q = nl ? (uint64_t)(nl - map_) + 1 : size_;
-        while (q < size_) {
-            if (map_[q] == '>') return q;
-            if (map_[q] == '@') {
-                const char* fin = map_ + size_;
-                const char* l1 = (const char*)memchr(map_ + q, '\n', size_ - q);                    // end of the header
+        const char* nl = (const char*)memchr(map_ + p - 1, '\n', wend - (p - 1));  // p - 1: p itself may be a line start
+        uint64_t q = nl ? (uint64_t)(nl - map_) + 1 : wend;
+        while (q < wend) {
+            if (map_[q] == '>' && kind_ != '@') return q;  // (in a FASTQ file a quality line may begin with '>')
+            if (map_[q] == '@' && kind_ != '>') {
+                const char* fin = map_ + wend;
+                const char* l1 = (const char*)memchr(map_ + q, '\n', wend - q);                    // end of the header
                 const char* l2 = l1 ? (const char*)memchr(l1 + 1, '\n', (size_t)(fin - l1 - 1)) : nullptr;  // end of the sequence
-                if (!l2) return q;  // a truncated last record
+                if (!l2) { sure = wend == size_; return q; }  // a truncated last record
                 if (l2 + 1 < fin && l2[1] == '+') {
                     const char* l3 = (const char*)memchr(l2 + 1, '\n', (size_t)(fin - l2 - 1));   // end of the '+' line
-                    if (!l3) return q;
+                    if (!l3) { sure = wend == size_; return q; }
                     const char* l4 = (const char*)memchr(l3 + 1, '\n', (size_t)(fin - l3 - 1));
+                    if (!l4 && wend != size_) { sure = false; return q; }
                     size_t ls = (size_t)(l2 - l1 - 1), lq = (size_t)((l4 ? l4 : fin) - l3 - 1);
                     if (ls && l1[ls] == '\r') --ls;
                     if (lq && l3[lq] == '\r') --lq;
                     if (ls == lq) return q;
+                } else if (l2 + 1 >= fin && wend != size_) {
+                    sure = false;
+                    return q;
                 }
             }
-            const char* e = (const char*)memchr(map_ + q, '\n', size_ - q);
-            q = e ? (uint64_t)(e - map_) + 1 : size_;
+            const char* e = (const char*)memchr(map_ + q, '\n', wend - q);
+            q = e ? (uint64_t)(e - map_) + 1 : wend;
         }
-        return size_;
+        sure = wend == size_;
+        return wend;
     }
-    uint64_t size() const { return size_; }
+    // first record boundary at or behind p, with the bytes it looks at made available first
+    uint64_t boundary(uint64_t p) {
+        if (!lazy()) return record_start(p);
+        for (uint64_t margin = 1u << 20;; margin *= 4) {
+            const uint64_t wend = std::min(size_, p + margin);
+            ensure(p ? p - 1 : 0, wend);
+            bool sure;
+            const uint64_t q = record_start_in(p, wend, sure);
+            if (sure || wend == size_) return q;
+        }
+    }
 
-private:
     void work() {
         for (;;) {
             uint64_t r;
@@ -299,8 +343,9 @@ private:
                 if (!pool_.empty()) { c = std::move(pool_.back()); pool_.pop_back(); }
             }
             try {
-                const uint64_t lo = record_start(begin_ + r * range_);
-                const uint64_t hi = r + 1 == num_ranges_ ? (end_ == size_ ? size_ : record_start(end_)) : record_start(begin_ + (r + 1) * range_);
+                const uint64_t lo = boundary(begin_ + r * range_);
+                const uint64_t hi = r + 1 == num_ranges_ ? (end_ == size_ ? size_ : boundary(end_)) : boundary(begin_ + (r + 1) * range_);
+                ensure(lo, hi);
                 uint64_t pos = lo;
                 c.bases.reserve((hi - lo) / 2 + 64);
                 parse_fastx_records(
@@ -326,9 +371,13 @@ private:
         }
     }
 
+protected:
     int fd_ = -1;
     const char* map_ = nullptr;
     uint64_t size_ = 0, begin_ = 0, end_ = 0, range_, num_ranges_ = 0, window_ = 4;
+    char kind_ = 0;  // '>' FASTA, '@' FASTQ, 0 unknown (both kinds of record start are looked for)
+
+private:
     std::vector<std::thread> workers_;
     std::mutex m_;
     std::condition_variable cv_data_, cv_space_;
@@ -337,6 +386,150 @@ private:
     uint64_t next_in_ = 0, next_out_ = 0;
     bool stop_ = false;
     std::string error_;
+};
+
+// ---- block-compressed gzip (BGZF): members inflated on demand by the same pool of threads -----------------------------
+// A BGZF member: 10-byte gzip header with FLG.FEXTRA, XLEN, an extra subfield 'B' 'C' of two bytes holding the member's
+// total size minus one, raw deflate data, CRC32, ISIZE (SAM specification, section 4.1; every member inflates to at most 64 KB).
+inline bool bgzf_member(const unsigned char* p, uint64_t avail, uint64_t& total, uint64_t& data_at, uint64_t& data_len, uint32_t& isize) {
+    if (avail < 28 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return false;
+    const uint32_t xlen = p[10] | (p[11] << 8);
+    if (avail < 12ull + xlen + 8) return false;
+    uint32_t at = 0;
+    total = 0;
+    while (at + 4 <= xlen) {
+        const unsigned char* f = p + 12 + at;
+        const uint32_t slen = f[2] | (f[3] << 8);
+        if (f[0] == 'B' && f[1] == 'C' && slen == 2 && at + 6 <= xlen) total = (uint64_t)(f[4] | (f[5] << 8)) + 1;
+        at += 4 + slen;
+    }
+    if (total < 12ull + xlen + 8 || total > avail) return false;
+    data_at = 12ull + xlen;
+    data_len = total - data_at - 8;
+    isize = p[total - 4] | (p[total - 3] << 8) | (p[total - 2] << 16) | ((uint32_t)p[total - 1] << 24);
+    return true;
+}
+
+inline bool is_bgzf_file(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    unsigned char h[4096];
+    const size_t got = fread(h, 1, sizeof h, f);
+    fclose(f);
+    if (got < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+    const uint32_t xlen = h[10] | (h[11] << 8);
+    for (uint32_t at = 0; at + 4 <= xlen && 12 + at + 4 <= got;) {
+        const unsigned char* s = h + 12 + at;
+        const uint32_t slen = s[2] | (s[3] << 8);
+        if (s[0] == 'B' && s[1] == 'C' && slen == 2) return true;
+        at += 4 + slen;
+    }
+    return false;
+}
+
+class BgzfFastxSource : public MappedFastxSource {
+public:
+    BgzfFastxSource(const std::string& path, unsigned threads, uint64_t range_bytes = 8u << 20) : MappedFastxSource(range_bytes) {
+        cfd_ = open(path.c_str(), O_RDONLY);
+        if (cfd_ < 0) throw std::runtime_error("cannot open " + path);
+        struct stat st;
+        if (fstat(cfd_, &st) != 0 || st.st_size == 0) { close(cfd_); throw std::runtime_error("cannot stat " + path); }
+        csize_ = (uint64_t)st.st_size;
+        cmap_ = (const unsigned char*)mmap(nullptr, csize_, PROT_READ, MAP_PRIVATE, cfd_, 0);
+        if (cmap_ == MAP_FAILED) { close(cfd_); throw std::runtime_error("cannot map " + path); }
+        try {
+            uint64_t at = 0, u = 0;
+            while (at < csize_) {  // the members: a hop per member through the size fields
+                Member m;
+                uint64_t total;
+                if (!bgzf_member(cmap_ + at, csize_ - at, total, m.data_at, m.data_len, m.isize))
+                    throw std::runtime_error("corrupt block-compressed gzip file (member header at byte " + std::to_string(at) + ")");
+                if (m.isize > 65536) throw std::runtime_error("corrupt block-compressed gzip file (member larger than 64 KB)");
+                m.data_at += at;
+                m.crc_at = at + total - 8;
+                m.uoff = u;
+                if (m.isize) members_.push_back(m);
+                u += m.isize;
+                at += total;
+            }
+            size_ = u;
+            state_.reset(new std::atomic<unsigned char>[members_.size() + 1]);
+            for (size_t i = 0; i <= members_.size(); ++i) state_[i].store(0);
+            if (size_) {
+                void* b = mmap(nullptr, size_ + 1, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+                if (b == MAP_FAILED) throw std::runtime_error("cannot reserve the buffer for the inflated file");
+                map_ = (const char*)b;
+            }
+        } catch (...) {
+            munmap((void*)cmap_, csize_);
+            close(cfd_);
+            throw;
+        }
+        start(threads, 0, ~0ULL);
+    }
+    ~BgzfFastxSource() override {
+        shutdown();  // (the workers use this object's hooks: they end before it does)
+        if (map_ && size_) munmap((void*)map_, size_ + 1);
+        map_ = nullptr;
+        size_ = 0;
+        munmap((void*)cmap_, csize_);
+        close(cfd_);
+    }
+
+protected:
+    bool lazy() const override { return true; }
+    void ensure(uint64_t lo, uint64_t hi) override {
+        if (lo >= hi || members_.empty()) return;
+        // first member that ends behind lo
+        size_t a = 0, b = members_.size();
+        while (a < b) {
+            const size_t mid = (a + b) / 2;
+            if (members_[mid].uoff + members_[mid].isize <= lo) a = mid + 1; else b = mid;
+        }
+        z_stream zs;
+        bool init = false;
+        for (size_t i = a; i < members_.size() && members_[i].uoff < hi; ++i) {
+            unsigned char st = 0;
+            if (state_[i].compare_exchange_strong(st, 1)) {
+                const Member& m = members_[i];
+                if (!init) {
+                    memset(&zs, 0, sizeof zs);
+                    if (inflateInit2(&zs, -15) != Z_OK) { state_[i].store(3); throw std::runtime_error("zlib: inflateInit2 failed"); }
+                    init = true;
+                } else {
+                    inflateReset(&zs);
+                }
+                zs.next_in = (Bytef*)(cmap_ + m.data_at);
+                zs.avail_in = (uInt)m.data_len;
+                zs.next_out = (Bytef*)(map_ + m.uoff);
+                zs.avail_out = m.isize;
+                const int rc = inflate(&zs, Z_FINISH);
+                const unsigned char* t = cmap_ + m.crc_at;
+                const uint32_t want_crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+                const bool ok = rc == Z_STREAM_END && zs.avail_out == 0 &&
+                                (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)(map_ + m.uoff), m.isize) == want_crc;
+                state_[i].store(ok ? 2 : 3);
+                if (!ok) { inflateEnd(&zs); throw std::runtime_error("corrupt block-compressed gzip file (member at inflated byte " + std::to_string(m.uoff) + ")"); }
+            } else {
+                while ((st = state_[i].load()) == 1) std::this_thread::yield();  // another thread is inflating it
+                if (st == 3) { if (init) inflateEnd(&zs); throw std::runtime_error("corrupt block-compressed gzip file"); }
+            }
+        }
+        if (init) inflateEnd(&zs);
+    }
+    void consumed(uint64_t r) override {  // the inflated bytes of ranges well behind the reader go back to the system
+        if (r < 2) return;
+        const uint64_t page = 4096, lo = (r - 2) * range_ / page * page, hi = (r - 1) * range_ / page * page;
+        if (hi > lo && hi <= size_) madvise((void*)(map_ + lo), hi - lo, MADV_DONTNEED);
+    }
+
+private:
+    struct Member { uint64_t data_at, data_len, crc_at, uoff; uint32_t isize; };
+    int cfd_ = -1;
+    const unsigned char* cmap_ = nullptr;
+    uint64_t csize_ = 0;
+    std::vector<Member> members_;
+    std::unique_ptr<std::atomic<unsigned char>[]> state_;
 };
 
 inline bool is_gzip_file(const std::string& path) {
@@ -358,7 +551,8 @@ public:
         threads_ = threads;
         if (is_gzip_file(path)) {
             if (begin != 0 || end != ~0ULL) throw std::runtime_error("a gzip stream cannot be read in parts");
-            src_.reset(new StreamFastxSource(path));
+            if (is_bgzf_file(path)) src_.reset(new BgzfFastxSource(path, threads));
+            else src_.reset(new StreamFastxSource(path));
         } else {
             src_.reset(new MappedFastxSource(path, threads, begin, end));
         }

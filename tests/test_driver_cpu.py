@@ -190,7 +190,8 @@ def test_parallel_reader_ranges_parts_and_batch_limit(built, tmp_path):
     rng = np.random.default_rng(11)
     alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
     seqs = [bytes(alpha[rng.integers(0, 5, size=int(l))]) for l in rng.integers(100, 220, size=120000)]
-    quals = [bytes(rng.integers(33, 75, size=len(s), dtype=np.uint8)) for s in seqs]  # '@' and '+' occur at line starts
+    quals = [bytes(rng.integers(33, 75, size=len(s), dtype=np.uint8)) for s in seqs]  # '@', '+' and '>' occur at line starts ...
+    quals = [(b">" if i % 3 == 0 else b"@" if i % 3 == 1 else b"+") + q[1:] for i, q in enumerate(quals)]  # ... of every quality line
     p = str(tmp_path / "big.fq")
     with open(p, "wb") as f:
         for i, (s, q) in enumerate(zip(seqs, quals)):
@@ -220,6 +221,101 @@ def test_parallel_reader_ranges_parts_and_batch_limit(built, tmp_path):
         joined += part
         total += len(part)
     assert total == len(seqs) and joined == seqs
+    # cut points inside the sequence line of records whose quality line begins with '>' / '@' / '+': the first line start
+    # behind such a cut that LOOKS like a header is that quality line; the part must begin at the record after it
+    starts = np.cumsum([0] + [len(b"@read%d/1\n" % i) + 2 * len(s) + 4 for i, s in enumerate(seqs)])
+    picks = [int(i) for i in rng.choice(len(seqs) - 1, size=30, replace=False)]
+    cuts = sorted(int(starts[i]) + len(b"@read%d/1\n" % i) + 10 for i in picks)
+    cuts = [0] + cuts + [size]
+    joined = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        joined += collect(batch=50000, threads=2, begin=a, end=b)[0]
+    assert joined == seqs
+    # every quality line begins with '>' (Phred 29): in a FASTQ file that is not a FASTA header, wherever a part is cut
+    small = [b"ACGT" * 30] * 2000
+    p2 = str(tmp_path / "gt.fq")
+    with open(p2, "wb") as f:
+        for i, sq in enumerate(small):
+            f.write(b"@r%d\n%s\n+\n>%s\n" % (i, sq, b"I" * (len(sq) - 1)))
+    sz = os.path.getsize(p2)
+    for cut in range(120000, 120000 + 300, 7):  # cut points in every kind of line
+        parts = []
+        for a, b in ((0, cut), (cut, sz)):
+            rd = FastxReader(p2, copy=True, batch=5000, threads=2, begin=a, end=b)
+            for bases, offs in rd:
+                bb = bytes(bases)
+                parts += [bb[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+            rd.close()
+        assert parts == small
+
+
+def _bgzf(data, rng, max_block=65280):
+    """block-compressed gzip as bgzip / htslib write it (SAM specification 4.1): members of at most 64 KB with their total size
+    in a 'BC' extra subfield, and the empty end-of-file member"""
+    import struct, zlib
+    out, at = [], 0
+    while True:
+        n = min(len(data) - at, int(rng.integers(1, max_block + 1)))
+        blk = data[at:at + n]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        cd = co.compress(blk) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cd) + 25) + cd +
+                   struct.pack("<II", zlib.crc32(blk) & 0xFFFFFFFF, len(blk)))
+        at += n
+        if n == 0:
+            break
+    return b"".join(out)
+
+
+def test_block_compressed_gzip_is_read_in_parallel(built, tmp_path):
+    """BGZF (bgzip) files are gzip files whose members can be inflated independently: the reader does so on all threads and
+    parses range by range as for a plain file. Same records as the plain file, whatever the member sizes (records, lines and
+    range boundaries fall anywhere inside members); an ordinary gzip reader sees the same stream; damage is reported."""
+    import gzip
+    from fulgor_amd.reads import FastxReader
+    rng = np.random.default_rng(5)
+    alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    seqs = [bytes(alpha[rng.integers(0, 5, size=int(l))]) for l in rng.integers(100, 220, size=90000)]
+    quals = [bytes(rng.integers(33, 75, size=len(s), dtype=np.uint8)) for s in seqs]
+    quals = [(b">" if i % 3 == 0 else b"@" if i % 3 == 1 else b"+") + q[1:] for i, q in enumerate(quals)]  # line starts that look like headers
+    plain = b"".join(b"@read%d extra\n%s\n+\n%s\n" % (i, s, q) for i, (s, q) in enumerate(zip(seqs, quals)))
+    assert len(plain) > 26 << 20  # four ranges of 8 MB
+
+    def collect(path, **kw):
+        got, names = [], []
+        rd = FastxReader(path, copy=True, **kw)
+        for bases, offs in rd:
+            b = bytes(bases)
+            got += [b[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+            names += rd.names()
+        rd.close()
+        return got, names
+
+    for tag, mb in (("a", 65280), ("b", 3000)):  # full-size members, and many small ones of random sizes
+        p = str(tmp_path / ("reads_%s.fq.gz" % tag))
+        comp = _bgzf(plain, rng, mb)
+        with open(p, "wb") as f:
+            f.write(comp)
+        assert gzip.decompress(comp) == plain  # (what the reference's gzip reader would see)
+        got, names = collect(p, batch=20000, threads=5)
+        assert got == seqs and names == ["read%d" % i for i in range(len(seqs))]
+        got, _ = collect(p, batch=1 << 20, threads=1)
+        assert got == seqs
+    fa = b"".join(b">s%d\n%s\n%s\n" % (i, s[:60], s[60:]) for i, s in enumerate(seqs[:5000]))  # wrapped FASTA
+    p = str(tmp_path / "seqs.fa.gz")
+    with open(p, "wb") as f:
+        f.write(_bgzf(fa, rng, 20000))
+    got, _ = collect(p, batch=1000, threads=3)
+    assert got == seqs[:5000]
+    with open(str(tmp_path / "empty.fq.gz"), "wb") as f:
+        f.write(_bgzf(b"", rng))
+    assert collect(str(tmp_path / "empty.fq.gz"), batch=10)[0] == []
+    bad = bytearray(comp)
+    bad[len(bad) // 2] ^= 0x55  # a flipped byte in the middle of the file
+    with open(str(tmp_path / "bad.fq.gz"), "wb") as f:
+        f.write(bytes(bad))
+    with pytest.raises(RuntimeError):
+        collect(str(tmp_path / "bad.fq.gz"), batch=20000, threads=4)
 
 
 MULTI_RANK_CLI_WORKER = r'''
