@@ -71,6 +71,7 @@ def lib():
     L.fgpu_fastx_open.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.fgpu_fastx_open_part.argtypes = [C.c_char_p, C.c_uint, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.fgpu_fastx_count.argtypes = [C.c_char_p, C.c_uint, C.c_uint64, C.c_uint64, u64p]
+    L.fgpu_fastx_text_size.argtypes = [C.c_char_p, u64p, C.POINTER(C.c_int)]
     L.fgpu_fastx_next.argtypes = [vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp), u64p]
     L.fgpu_fastx_names.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.fgpu_fastx_close.argtypes = [vp]

@@ -1309,6 +1309,15 @@ int fgpu_fastx_open_part(const char* path, unsigned threads, uint64_t begin, uin
     return guarded([&] { *out = new fgpu_fastx(path, threads, begin, end); });
 }
 
+int fgpu_fastx_text_size(const char* path, uint64_t* size, int* can_be_read_in_parts) {
+    if (!path || !size || !can_be_read_in_parts) return fail(-EINVAL, "null argument");
+    return guarded([&] {
+        bool parts = false;
+        *size = fastx_text_size(path, parts);
+        *can_be_read_in_parts = parts ? 1 : 0;
+    });
+}
+
 int fgpu_fastx_count(const char* path, unsigned threads, uint64_t begin, uint64_t end, uint64_t* num_reads) {
     if (!path || !num_reads) return fail(-EINVAL, "null argument");
     return guarded([&] {

@@ -427,9 +427,44 @@ inline bool is_bgzf_file(const std::string& path) {
     return false;
 }
 
+// length of the text that the parts [begin, end) of a query file refer to: the file size, or for a block-compressed gzip file
+// the inflated size (sum of the members' ISIZE fields); 0 with `parts = false` for an ordinary gzip stream
+inline uint64_t fastx_text_size(const std::string& path, bool& parts) {
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) throw std::runtime_error("cannot stat " + path);
+    parts = true;
+    FILE* f0 = fopen(path.c_str(), "rb");
+    if (!f0) throw std::runtime_error("cannot open " + path);
+    unsigned char m[2] = {0, 0};
+    const size_t got = fread(m, 1, 2, f0);
+    fclose(f0);
+    if (!(got == 2 && m[0] == 0x1f && m[1] == 0x8b)) return (uint64_t)st.st_size;
+    if (!is_bgzf_file(path)) { parts = false; return 0; }
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open " + path);
+    const uint64_t csize = (uint64_t)st.st_size;
+    const unsigned char* cm = (const unsigned char*)mmap(nullptr, csize, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (cm == MAP_FAILED) { close(fd); throw std::runtime_error("cannot map " + path); }
+    uint64_t at = 0, u = 0;
+    bool ok = true;
+    while (at < csize) {
+        uint64_t total, da, dl;
+        uint32_t isize;
+        if (!bgzf_member(cm + at, csize - at, total, da, dl, isize)) { ok = false; break; }
+        u += isize;
+        at += total;
+    }
+    munmap((void*)cm, csize);
+    close(fd);
+    if (!ok) throw std::runtime_error("corrupt block-compressed gzip file");
+    return u;
+}
+
 class BgzfFastxSource : public MappedFastxSource {
 public:
-    BgzfFastxSource(const std::string& path, unsigned threads, uint64_t range_bytes = 8u << 20) : MappedFastxSource(range_bytes) {
+    // [begin, end): positions in the INFLATED text (fastx_text_size gives its length), as for a plain file
+    BgzfFastxSource(const std::string& path, unsigned threads, uint64_t begin = 0, uint64_t end = ~0ULL, uint64_t range_bytes = 8u << 20)
+        : MappedFastxSource(range_bytes) {
         cfd_ = open(path.c_str(), O_RDONLY);
         if (cfd_ < 0) throw std::runtime_error("cannot open " + path);
         struct stat st;
@@ -465,7 +500,7 @@ public:
             close(cfd_);
             throw;
         }
-        start(threads, 0, ~0ULL);
+        start(threads, begin, end);
     }
     ~BgzfFastxSource() override {
         shutdown();  // (the workers use this object's hooks: they end before it does)
@@ -519,7 +554,7 @@ protected:
     }
     void consumed(uint64_t r) override {  // the inflated bytes of ranges well behind the reader go back to the system
         if (r < 2) return;
-        const uint64_t page = 4096, lo = (r - 2) * range_ / page * page, hi = (r - 1) * range_ / page * page;
+        const uint64_t page = 4096, lo = (begin_ + (r - 2) * range_ + page - 1) / page * page, hi = (begin_ + (r - 1) * range_) / page * page;
         if (hi > lo && hi <= size_) madvise((void*)(map_ + lo), hi - lo, MADV_DONTNEED);
     }
 
@@ -550,9 +585,12 @@ public:
         if (threads == 0) threads = std::min(32u, std::max(1u, std::thread::hardware_concurrency() / 2));
         threads_ = threads;
         if (is_gzip_file(path)) {
-            if (begin != 0 || end != ~0ULL) throw std::runtime_error("a gzip stream cannot be read in parts");
-            if (is_bgzf_file(path)) src_.reset(new BgzfFastxSource(path, threads));
-            else src_.reset(new StreamFastxSource(path));
+            if (is_bgzf_file(path)) {
+                src_.reset(new BgzfFastxSource(path, threads, begin, end));
+            } else {
+                if (begin != 0 || end != ~0ULL) throw std::runtime_error("a gzip stream cannot be read in parts (a block-compressed one, as bgzip writes it, can)");
+                src_.reset(new StreamFastxSource(path));
+            }
         } else {
             src_.reset(new MappedFastxSource(path, threads, begin, end));
         }

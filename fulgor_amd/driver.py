@@ -241,10 +241,11 @@ def pseudoalign_sharded(open_index, query, output, algo=FULL_INTERSECTION, thres
     import shutil
     import torch
     import torch.distributed as dist
-    from .reads import FastxReader, count_reads, is_gzip
-    size = os.path.getsize(query)
-    if world > 1 and is_gzip(query):
-        raise ValueError("a gzip stream cannot be read in parts: decompress the query file for a multi-GPU run")
+    from .reads import FastxReader, count_reads, text_size
+    size, in_parts = text_size(query)
+    if world > 1 and not in_parts:
+        raise ValueError("a gzip stream cannot be read in parts: decompress the query file for a multi-GPU run, or compress it "
+                         "in blocks (bgzip)")
     begin, end = size * rank // world, size * (rank + 1) // world
     first_id = 0
     if world > 1:

@@ -96,6 +96,16 @@ def count_reads(path, begin=0, end=ALL, threads=0):
     return n.value
 
 
+def text_size(path):
+    """(length of the text that parts [begin, end) of the query file refer to, whether it can be read in parts): the file size
+    for a plain file, the inflated size for a block-compressed gzip file, (0, False) for an ordinary gzip stream"""
+    import ctypes as C
+    from . import _native
+    n, ok = C.c_uint64(), C.c_int()
+    _native.check(_native.lib().fgpu_fastx_text_size(str(path).encode(), C.byref(n), C.byref(ok)))
+    return n.value, bool(ok.value)
+
+
 def is_gzip(path):
     with open(path, "rb") as f:
         return f.read(2) == b"\x1f\x8b"

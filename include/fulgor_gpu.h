@@ -135,13 +135,18 @@ int fgpu_formatter_finish(fgpu_formatter* f, char** out, uint64_t* out_len);
  * file order (read id = position in the file, as FQFeeder numbers them) as concatenated bases + (n + 1) offsets.
  * The two buffers belong to the reader (pinned host memory when a HIP device is present) and stay valid for the next THREE
  * calls on it (a ring of four batches: a worker loop keeps several passes in flight); *n = 0 at end of file.
- * fgpu_fastx_open_part reads only the records that start in the byte range [begin, end) of a PLAIN file (both ends are
- * moved forward to the next record boundary, so consecutive ranges partition the file): every GPU of a multi-GPU run takes
- * one part; fgpu_fastx_count returns the number of records of such a part (their global read ids follow from the counts of
- * the parts in front). threads = 0: half of the host's hardware threads, at most 32. */
+ * A block-compressed gzip file (BGZF, as bgzip writes it: gzip members of at most 64 KB that announce their size) is inflated
+ * member by member by the same threads and parsed like a plain file.
+ * fgpu_fastx_open_part reads only the records that start in the byte range [begin, end) of the TEXT of a plain or
+ * block-compressed file (both ends are moved forward to the next record boundary, so consecutive ranges partition the
+ * file): every GPU of a multi-GPU run takes one part; fgpu_fastx_text_size gives the length of that text (the file size, or
+ * the inflated size) and whether the file can be read in parts at all (an ordinary gzip stream cannot); fgpu_fastx_count
+ * returns the number of records of a part (their global read ids follow from the counts of the parts in front).
+ * threads = 0: half of the host's hardware threads, at most 32. */
 typedef struct fgpu_fastx fgpu_fastx;
 int fgpu_fastx_open(const char* path, fgpu_fastx** out);
 int fgpu_fastx_open_part(const char* path, unsigned threads, uint64_t begin, uint64_t end, fgpu_fastx** out);
+int fgpu_fastx_text_size(const char* path, uint64_t* size, int* can_be_read_in_parts);
 int fgpu_fastx_count(const char* path, unsigned threads, uint64_t begin, uint64_t end, uint64_t* num_reads);
 int fgpu_fastx_next(fgpu_fastx* f, uint64_t max_reads, const char** bases, const uint64_t** offs, uint64_t* n);
 /* names of the records of the last batch (kseq's name: the header up to the first blank), concatenated + (n + 1) offsets;

@@ -301,6 +301,22 @@ def test_block_compressed_gzip_is_read_in_parallel(built, tmp_path):
         assert got == seqs and names == ["read%d" % i for i in range(len(seqs))]
         got, _ = collect(p, batch=1 << 20, threads=1)
         assert got == seqs
+    # parts of the inflated text, as the ranks of a multi-GPU run take them (positions in the text, not in the file)
+    from fulgor_amd.reads import count_reads, text_size
+    assert text_size(p) == (len(plain), True)
+    cuts = [0, len(plain) // 3 + 5, len(plain) // 3 + 6, (2 * len(plain)) // 3, len(plain)]
+    joined = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        part, _ = collect(p, batch=50000, threads=3, begin=a, end=b)
+        assert count_reads(p, a, b, 3) == len(part)
+        joined += part
+    assert joined == seqs
+    pz = str(tmp_path / "stream.fq.gz")
+    with gzip.open(pz, "wb", compresslevel=1) as f:
+        f.write(plain[:1 << 20])
+    assert text_size(pz) == (0, False) and text_size(str(tmp_path / "reads_a.fq.gz"))[1]
+    with pytest.raises(RuntimeError):
+        FastxReader(pz, begin=100, end=5000)
     fa = b"".join(b">s%d\n%s\n%s\n" % (i, s[:60], s[60:]) for i, s in enumerate(seqs[:5000]))  # wrapped FASTA
     p = str(tmp_path / "seqs.fa.gz")
     with open(p, "wb") as f:
@@ -376,3 +392,11 @@ def test_multi_rank_cli_path_on_gloo(s10_dump, tmp_path, world):
     n, mapped = map(int, open(str(out) + ".counters").read().split())
     assert n == len(reads) and mapped == sum(1 for l in want.splitlines() if l.split(b"\t")[1] != b"0")
     assert not [p for p in os.listdir(tmp_path) if ".part" in p]
+    if world == 2:  # the same query file compressed in blocks (bgzip): the ranks take parts of the inflated text
+        qz = tmp_path / "reads.fq.gz"
+        qz.write_bytes(_bgzf(q.read_bytes(), np.random.default_rng(1), 4000))
+        out2 = tmp_path / "out_bgzf.txt"
+        subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29561", str(script), ROOT, str(qz), str(out2)],
+                       check=True, env=env, timeout=600)
+        assert open(out2, "rb").read() == want
