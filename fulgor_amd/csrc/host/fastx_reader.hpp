@@ -493,6 +493,7 @@ public:
             if (size_) {
                 void* b = mmap(nullptr, size_ + 1, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
                 if (b == MAP_FAILED) throw std::runtime_error("cannot reserve the buffer for the inflated file");
+                madvise(b, size_ + 1, MADV_HUGEPAGE);  // (first touch by page: fewer faults for the inflating threads)
                 map_ = (const char*)b;
             }
         } catch (...) {
