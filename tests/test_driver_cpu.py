@@ -400,3 +400,58 @@ def test_multi_rank_cli_path_on_gloo(s10_dump, tmp_path, world):
                         "--master-addr", "127.0.0.1", "--master-port", "29561", str(script), ROOT, str(qz), str(out2)],
                        check=True, env=env, timeout=600)
         assert open(out2, "rb").read() == want
+
+
+def test_reader_parts_fuzz(built, tmp_path):
+    """seeded fuzz of the range logic: 4-line FASTQ and single- or multi-line FASTA with every nasty line start (quality lines
+    beginning with '@', '>' or '+', names with blanks, CRLF, no final newline, empty sequences in FASTA), cut into parts at
+    random positions: the parts must partition the records, names included, whatever the cuts"""
+    from fulgor_amd.reads import FastxReader, count_reads
+    rng = np.random.default_rng(2024)
+    alpha = np.frombuffer(b"ACGTNacgt", dtype=np.uint8)
+    qual_first = b"@>+!I5#"
+
+    def collect(path, **kw):
+        seqs, names = [], []
+        rd = FastxReader(path, copy=True, batch=37, threads=3, **kw)
+        for bases, offs in rd:
+            b = bytes(bases)
+            seqs += [b[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+            names += rd.names()
+        rd.close()
+        return seqs, names
+
+    for trial in range(240):
+        fastq = trial % 2 == 0
+        eol = b"\r\n" if trial % 5 == 3 else b"\n"
+        n = int(rng.integers(1, 120))
+        want_s, want_n, text = [], [], []
+        for i in range(n):
+            ln = int(rng.integers(1 if fastq else 0, 90))
+            s = bytes(alpha[rng.integers(0, len(alpha), size=ln)])
+            name = b"rec%d_%d" % (trial, i)
+            hdr = name + (b" some comment" if i % 3 == 0 else b"")
+            if fastq:
+                q = bytes([qual_first[int(rng.integers(0, len(qual_first)))]]) + bytes(rng.integers(33, 75, size=ln - 1, dtype=np.uint8))
+                text.append(b"@" + hdr + eol + s + eol + (b"+" + (name if i % 4 == 0 else b"")) + eol + q + eol)
+            else:
+                w = int(rng.integers(1, 100))
+                lines = [s[j:j + w] for j in range(0, len(s), w)] if trial % 4 == 1 else [s]
+                text.append(b">" + hdr + eol + b"".join(l + eol for l in lines))
+            want_s.append(s)
+            want_n.append(name.decode())
+        data = b"".join(text)
+        if trial % 7 == 0 and data.endswith(eol):
+            data = data[:-len(eol)]  # no newline at the end of the file
+        p = str(tmp_path / ("f%d.%s" % (trial, "fq" if fastq else "fa")))
+        with open(p, "wb") as f:
+            f.write(data)
+        assert collect(p) == (want_s, want_n), trial
+        cuts = sorted(set([0, len(data)] + [int(x) for x in rng.integers(0, len(data) + 1, size=int(rng.integers(1, 9)))]))
+        js, jn, total = [], [], 0
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            s_, n_ = collect(p, begin=a, end=b)
+            assert count_reads(p, a, b, 2) == len(s_)
+            js += s_
+            jn += n_
+        assert (js, jn) == (want_s, want_n), (trial, cuts)
