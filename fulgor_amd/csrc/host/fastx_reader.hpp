@@ -298,7 +298,11 @@ protected:
                 const char* fin = map_ + wend;
                 const char* l1 = (const char*)memchr(map_ + q, '\n', wend - q);                    // end of the header
                 const char* l2 = l1 ? (const char*)memchr(l1 + 1, '\n', (size_t)(fin - l1 - 1)) : nullptr;  // end of the sequence
-                if (!l2) { sure = wend == size_; return q; }  // a truncated last record
+                if (!l2) {  // the text ends within two lines: a last quality line that begins with '@', or a record cut off behind its
+                    // header. Not taken for a record start: whoever parses the lines in front decides with the full grammar.
+                    if (wend != size_) { sure = false; return q; }
+                    return size_;
+                }
                 if (l2 + 1 < fin && l2[1] == '+') {
                     const char* l3 = (const char*)memchr(l2 + 1, '\n', (size_t)(fin - l2 - 1));   // end of the '+' line
                     if (!l3) { sure = wend == size_; return q; }

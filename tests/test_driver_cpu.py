@@ -421,7 +421,7 @@ def test_reader_parts_fuzz(built, tmp_path):
         rd.close()
         return seqs, names
 
-    for trial in range(240):
+    for trial in range(1500):
         fastq = trial % 2 == 0
         eol = b"\r\n" if trial % 5 == 3 else b"\n"
         n = int(rng.integers(1, 120))
