@@ -323,6 +323,22 @@ def test_block_compressed_gzip_is_read_in_parallel(built, tmp_path):
         f.write(_bgzf(fa, rng, 20000))
     got, _ = collect(p, batch=1000, threads=3)
     assert got == seqs[:5000]
+    # records far longer than the megabyte the boundary search inflates first (long reads): the window must grow
+    longs = [bytes(alpha[rng.integers(0, 4, size=int(l))]) for l in (2_600_000, 50, 1_300_000, 3_100_000, 700, 2_200_000)]
+    for kind in ("fq", "fa"):
+        if kind == "fq":
+            text = b"".join(b"@L%d\n%s\n+\n%s\n" % (i, s, b"@" + b"I" * (len(s) - 1)) for i, s in enumerate(longs))
+        else:
+            text = b"".join(b">L%d\n%s\n" % (i, s) for i, s in enumerate(longs))
+        p = str(tmp_path / ("long.%s.gz" % kind))
+        with open(p, "wb") as f:
+            f.write(_bgzf(text, rng, 65280))
+        assert collect(p, batch=4, threads=4)[0] == longs
+        cuts = sorted(set([0, len(text)] + [int(x) for x in rng.integers(0, len(text), size=6)]))
+        joined = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            joined += collect(p, batch=4, threads=2, begin=a, end=b)[0]
+        assert joined == longs, (kind, cuts)
     with open(str(tmp_path / "empty.fq.gz"), "wb") as f:
         f.write(_bgzf(b"", rng))
     assert collect(str(tmp_path / "empty.fq.gz"), batch=10)[0] == []
