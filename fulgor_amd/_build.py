@@ -37,7 +37,7 @@ def build_gpu(force=False):
     srcs = _walk(CSRC, (".hip", ".h", ".hpp")) + [os.path.join(ROOT, "include", "fulgor_gpu.h")]
     if force or _newer(LIB_GPU, srcs):
         _run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-              os.path.join(CSRC, "fulgor_gpu.hip"), "-o", LIB_GPU, "-lz"])
+              os.path.join(CSRC, "fulgor_gpu.hip"), "-o", LIB_GPU, "-lz", "-ldl"])
     return LIB_GPU
 
 

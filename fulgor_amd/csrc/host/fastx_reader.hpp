@@ -14,6 +14,7 @@
 //     the ranges that need them come up, and the ranges are parsed as for a plain file. Any gzip reader, the reference's
 //     included, reads such a file as one stream.
 #pragma once
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -464,6 +465,29 @@ inline uint64_t fastx_text_size(const std::string& path, bool& parts) {
     return u;
 }
 
+// libdeflate, when the host has it (looked up at run time: only the shared object ships with most systems, no header), inflates a
+// whole member 2-3 times faster than zlib's streaming inflate; without it zlib does the work.
+struct LibDeflate {
+    void* (*alloc)() = nullptr;
+    int (*decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    void (*release)(void*) = nullptr;
+    uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;
+    bool ok = false;
+    LibDeflate() {
+        if (getenv("FULGOR_NO_LIBDEFLATE")) return;
+        void* h = nullptr;
+        for (const char* name : {"libdeflate.so.0", "libdeflate.so", "libdeflate.so.1"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) return;
+        alloc = (void* (*)())dlsym(h, "libdeflate_alloc_decompressor");
+        decompress = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_deflate_decompress");
+        release = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
+        crc = (uint32_t (*)(uint32_t, const void*, size_t))dlsym(h, "libdeflate_crc32");
+        ok = alloc && decompress && release && crc;
+    }
+    static const LibDeflate& get() { static const LibDeflate l; return l; }
+};
+
 class BgzfFastxSource : public MappedFastxSource {
 public:
     // [begin, end): positions in the INFLATED text (fastx_text_size gives its length), as for a plain file
@@ -509,10 +533,19 @@ public:
     }
     ~BgzfFastxSource() override {
         shutdown();  // (the workers use this object's hooks: they end before it does)
-        if (map_ && size_) munmap((void*)map_, size_ + 1);
+        {   // (unmapping gigabytes that many threads have touched takes tens of milliseconds: not on the caller's time)
+            const void* m = map_;
+            const void* cm = cmap_;
+            const size_t sz = map_ && size_ ? size_ + 1 : 0, csz = csize_;
+            auto unmap = [m, sz, cm, csz] {
+                if (sz) munmap((void*)m, sz);
+                munmap((void*)cm, csz);
+            };
+            if (sz + csz >= ((size_t)64 << 20)) std::thread(unmap).detach();
+            else unmap();
+        }
         map_ = nullptr;
         size_ = 0;
-        munmap((void*)cmap_, csize_);
         close(cfd_);
     }
 
@@ -528,10 +561,26 @@ protected:
         }
         z_stream zs;
         bool init = false;
+        const LibDeflate& ld = LibDeflate::get();
+        void* fast = nullptr;
+        struct Release { const LibDeflate& l; void*& d; ~Release() { if (d) l.release(d); } } release_fast{ld, fast};
         for (size_t i = a; i < members_.size() && members_[i].uoff < hi; ++i) {
             unsigned char st = 0;
             if (state_[i].compare_exchange_strong(st, 1)) {
                 const Member& m = members_[i];
+                if (ld.ok && (fast || (fast = ld.alloc()))) {
+                    size_t got = 0;
+                    const int rc = ld.decompress(fast, cmap_ + m.data_at, m.data_len, (void*)(map_ + m.uoff), m.isize, &got);
+                    const unsigned char* t = cmap_ + m.crc_at;
+                    const uint32_t want_crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24);
+                    const bool good = rc == 0 && got == m.isize && ld.crc(0, map_ + m.uoff, m.isize) == want_crc;
+                    state_[i].store(good ? 2 : 3);
+                    if (!good) {
+                        if (init) inflateEnd(&zs);
+                        throw std::runtime_error("corrupt block-compressed gzip file (member at inflated byte " + std::to_string(m.uoff) + ")");
+                    }
+                    continue;
+                }
                 if (!init) {
                     memset(&zs, 0, sizeof zs);
                     if (inflateInit2(&zs, -15) != Z_OK) { state_[i].store(3); throw std::runtime_error("zlib: inflateInit2 failed"); }
