@@ -1,0 +1,54 @@
+"""One-off soak of the HIP path against the oracle on the bench index, far beyond the sizes the test suite affords: full
+intersection, threshold union, fetched ids on millions of seeded reads, plus dirty reads (random N, random lengths).
+usage (GPU box): python profiles/soak_parity.py [reads in millions, default 2]"""
+import glob, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import fulgor_amd
+from fulgor_amd import synth
+from fulgor_amd.reads import ReadGenerator
+from oracle.pyoracle import OracleIndex
+M = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
+g = sorted(glob.glob(os.path.join(ROOT, "tests", "data", "salmonella_10", "*.fasta.gz")))
+fg, extra = synth.ensure_s4546(os.path.join(ROOT, "data"), g)
+ix = fulgor_amd.Index(fg, device=0)
+orc = OracleIndex.from_export(ix.export())
+gen = ReadGenerator(g, raw_sequences=extra)
+T = min(64, os.cpu_count() or 8)
+bad = 0
+
+
+def check(tag, a, b):
+    global bad
+    ok = all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a, b))
+    bad += not ok
+    print("%-46s %s" % (tag, "equal" if ok else "DIFFERENT"), flush=True)
+
+
+n = int(M * 1e6)
+for seed, first in ((7, 50_000_000), (8, 90_000_000)):
+    b, o = gen.generate(first, n, 150, seed)
+    t0 = time.time()
+    check("full intersection, %d reads, seed %d" % (n, seed), ix.pseudoalign_full_intersection_batch(b, o), orc.full_intersection(b, o, threads=T))
+    check("fetched ids, %d reads, seed %d" % (n, seed), ix.fetch_color_set_ids_batch(b, o), orc.fetch_color_set_ids(b, o, threads=T))
+    print("  (%.0f s)" % (time.time() - t0), flush=True)
+b, o = gen.generate(123_000_000, n // 2, 150, 9)
+for tau in (0.8, 0.25):
+    check("threshold union tau %.2f, %d reads" % (tau, n // 2), ix.pseudoalign_threshold_union_batch(b, o, tau), orc.threshold_union(b, o, tau, threads=T))
+# dirty, ragged reads: random lengths 0..400, 3 % N, lower case
+rng = np.random.default_rng(5)
+b, o = gen.generate(7_000_000, 200_000, 400, 10)
+b = np.array(b)
+lens = rng.integers(0, 401, size=200_000)
+keep = np.concatenate([np.arange(int(o[i]), int(o[i]) + int(lens[i])) for i in range(200_000)])
+b2 = b[keep]
+o2 = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
+mask = rng.random(len(b2)) < 0.03
+b2[mask] = ord("N")
+low = rng.random(len(b2)) < 0.2
+b2[low] = np.char.lower(b2[low].view("S1")).view(np.uint8)
+check("dirty ragged reads, full intersection", ix.pseudoalign_full_intersection_batch(b2, o2), orc.full_intersection(b2, o2, threads=T))
+check("dirty ragged reads, threshold union 0.5", ix.pseudoalign_threshold_union_batch(b2, o2, 0.5), orc.threshold_union(b2, o2, 0.5, threads=T))
+print("SOAK", "FAILED" if bad else "PASSED")
+sys.exit(1 if bad else 0)
