@@ -471,3 +471,39 @@ def test_reader_parts_fuzz(built, tmp_path):
             js += s_
             jn += n_
         assert (js, jn) == (want_s, want_n), (trial, cuts)
+
+
+def test_reader_under_sanitizers(tmp_path):
+    """race / memory check of the multi-threaded query reader (SURVEY: race detection): the reader alone, built with
+    ThreadSanitizer and with AddressSanitizer + UBSan, reads a plain and a block-compressed FASTQ file (whole and in parts)
+    with a pool of threads; no report, and the same records every time"""
+    import shutil
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    src = os.path.join(ROOT, "tests", "reader_sanitize.cpp")
+    inc = os.path.join(ROOT, "fulgor_amd", "csrc")
+    rng = np.random.default_rng(1)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    recs = []
+    for i in range(60000):
+        l = int(rng.integers(80, 200))
+        q = bytes([b"@>+I"[i % 4]]) + bytes(rng.integers(35, 74, size=l - 1, dtype=np.uint8))
+        recs.append(b"@r%d x\n%s\n+\n%s\n" % (i, bytes(alpha[rng.integers(0, 4, size=l)]), q))
+    plain = b"".join(recs)
+    (tmp_path / "p.fq").write_bytes(plain)
+    (tmp_path / "p.fq.gz").write_bytes(_bgzf(plain, rng, 65280))
+    for tag, flags in (("tsan", ["-fsanitize=thread"]), ("asan", ["-fsanitize=address,undefined"])):
+        exe = str(tmp_path / ("h_" + tag))
+        r = subprocess.run(["g++", "-O1", "-g", "-std=c++17"] + flags + ["-I", inc, src, "-o", exe, "-lz", "-ldl", "-pthread"],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            pytest.skip("sanitizer build not available: " + r.stderr[-200:])
+        outs = set()
+        for f in ("p.fq", "p.fq.gz"):
+            for args in (["6"], ["3", "5000000", "14000000"]):
+                r = subprocess.run([exe, str(tmp_path / f)] + args, capture_output=True, text=True, timeout=600)
+                assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+                lines = r.stdout.strip().splitlines()
+                assert len(lines) == 3 and len(set(lines)) == 1
+                outs.add((tuple(args[1:]), lines[0]))
+        assert len(outs) == 2  # plain and block-compressed agree, whole and in parts
