@@ -166,3 +166,26 @@ def test_dump_writes_the_reference_interchange_files(host_index, s10_dump, tmp_p
     host_index.dump(base)
     for suffix in (".metadata.txt", ".filenames.txt", ".unitigs.fa", ".color_sets.txt"):
         assert filecmp.cmp(base + suffix, s10_dump + suffix, shallow=False), suffix
+
+
+def test_host_code_under_sanitizers(c256_dump, tmp_path):
+    """memory / race check of the host side of the library (SURVEY: race detection): dump ingestion, the multi-threaded
+    dictionary-table and packed-block builders, the container and .fur round trips and the three codec conversions on the
+    256-colour collection, built with AddressSanitizer + UBSan and with ThreadSanitizer; no report, tables identical after a
+    reload"""
+    import shutil, subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    from conftest import ROOT
+    src = os.path.join(ROOT, "tests", "host_sanitize.cpp")
+    for tag, flags in (("asan", ["-fsanitize=address,undefined"]), ("tsan", ["-fsanitize=thread"])):
+        exe = str(tmp_path / ("host_" + tag))
+        r = subprocess.run(["g++", "-O1", "-g", "-std=c++17"] + flags + ["-I", os.path.join(ROOT, "fulgor_amd", "csrc"), "-I",
+                            os.path.join(ROOT, "include"), src, "-o", exe, "-lz", "-ldl", "-pthread"], capture_output=True, text=True)
+        if r.returncode != 0:
+            pytest.skip("sanitizer build not available: " + r.stderr[-200:])
+        out = tmp_path / tag
+        out.mkdir()
+        r = subprocess.run([exe, c256_dump, str(out)], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.strip().endswith("host ok"), (r.stdout[-500:], r.stderr[-2000:])
+        assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
