@@ -50,5 +50,21 @@ low = rng.random(len(b2)) < 0.2
 b2[low] = np.char.lower(b2[low].view("S1")).view(np.uint8)
 check("dirty ragged reads, full intersection", ix.pseudoalign_full_intersection_batch(b2, o2), orc.full_intersection(b2, o2, threads=T))
 check("dirty ragged reads, threshold union 0.5", ix.pseudoalign_threshold_union_batch(b2, o2, 0.5), orc.threshold_union(b2, o2, 0.5, threads=T))
+# per-k-mer output (kmer-conservation): 20 k reads, one oracle call each
+from fulgor_amd.index import conservation_triples
+b, o = gen.generate(31_000_000, 20000, 150, 11)
+ko, ki = ix.kmer_color_set_ids_batch(b, o)
+bb = bytes(np.asarray(b))
+same = all(conservation_triples(ki[int(ko[j]):int(ko[j + 1])]) == orc.kmer_conservation(bb[int(o[j]):int(o[j + 1])]) for j in range(20000))
+bad += not same
+print("%-46s %s" % ("k-mer conservation triples, 20000 reads", "equal" if same else "DIFFERENT"), flush=True)
+# the other codecs against the hybrid result of the same reads (both HIP; the codecs meet the oracle on the small index)
+b, o = gen.generate(200_000_000, n // 2, 150, 12)
+ref_fi = ix.pseudoalign_full_intersection_batch(b, o)
+ref_tu = ix.pseudoalign_threshold_union_batch(b, o, 0.8)
+for t, name in ((3, "meta-differential"), (1, "differential"), (2, "meta")):
+    ix.convert(t, 128, 16)
+    check("%s, full intersection, %d reads" % (name, n // 2), ix.pseudoalign_full_intersection_batch(b, o), ref_fi)
+    check("%s, threshold union 0.8, %d reads" % (name, n // 2), ix.pseudoalign_threshold_union_batch(b, o, 0.8), ref_tu)
 print("SOAK", "FAILED" if bad else "PASSED")
 sys.exit(1 if bad else 0)
