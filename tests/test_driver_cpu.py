@@ -267,6 +267,41 @@ def _bgzf(data, rng, max_block=65280):
     return b"".join(out)
 
 
+def test_ordinary_gzip_whole_and_streamed(built, tmp_path, monkeypatch):
+    """an ordinary gzip file of moderate size is inflated in one go (libdeflate, when the host has it) and parsed by the pool;
+    otherwise, and for large files, zlib streams it. Same records either way: one member, several members, zero padding
+    behind the last member; a truncated file is an error either way"""
+    import gzip
+    from fulgor_amd.reads import FastxReader
+    rng = np.random.default_rng(8)
+    alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    seqs = [bytes(alpha[rng.integers(0, 5, size=int(l))]) for l in rng.integers(50, 300, size=70000)]
+    text = b"".join(b"@q%d\n%s\n+\n%s\n" % (i, s, b">" + b"F" * (len(s) - 1)) for i, s in enumerate(seqs))
+    half = text.index(b"\n@q35000\n") + 1
+    files = {"one.fq.gz": gzip.compress(text, 1), "two.fq.gz": gzip.compress(text[:half], 1) + gzip.compress(text[half:], 6),
+             "pad.fq.gz": gzip.compress(text, 1) + b"\0" * 700}
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+
+    def collect(path):
+        got = []
+        rd = FastxReader(str(path), copy=True, batch=30000, threads=4)
+        for bases, offs in rd:
+            b = bytes(bases)
+            got += [b[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+        rd.close()
+        return got
+
+    (tmp_path / "cut.fq.gz").write_bytes(files["one.fq.gz"][:len(files["one.fq.gz"]) // 2])
+    for stream in (False, True):
+        if stream:
+            monkeypatch.setenv("FULGOR_GZIP_STREAM", "1")
+        for name in ("one.fq.gz", "two.fq.gz") + (() if stream else ("pad.fq.gz",)):  # (zlib's gzread stops at the padding as well)
+            assert collect(tmp_path / name) == seqs, (name, stream)
+        with pytest.raises(RuntimeError):
+            collect(tmp_path / "cut.fq.gz")
+
+
 def test_block_compressed_gzip_is_read_in_parallel(built, tmp_path):
     """BGZF (bgzip) files are gzip files whose members can be inflated independently: the reader does so on all threads and
     parses range by range as for a plain file. Same records as the plain file, whatever the member sizes (records, lines and
