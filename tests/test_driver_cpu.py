@@ -527,6 +527,8 @@ def test_reader_under_sanitizers(tmp_path):
     plain = b"".join(recs)
     (tmp_path / "p.fq").write_bytes(plain)
     (tmp_path / "p.fq.gz").write_bytes(_bgzf(plain, rng, 65280))
+    import gzip
+    (tmp_path / "s.fq.gz").write_bytes(gzip.compress(plain, 1))
     for tag, flags in (("tsan", ["-fsanitize=thread"]), ("asan", ["-fsanitize=address,undefined"])):
         exe = str(tmp_path / ("h_" + tag))
         r = subprocess.run(["g++", "-O1", "-g", "-std=c++17"] + flags + ["-I", inc, src, "-o", exe, "-lz", "-ldl", "-pthread"],
@@ -534,8 +536,8 @@ def test_reader_under_sanitizers(tmp_path):
         if r.returncode != 0:
             pytest.skip("sanitizer build not available: " + r.stderr[-200:])
         outs = set()
-        for f in ("p.fq", "p.fq.gz"):
-            for args in (["6"], ["3", "5000000", "14000000"]):
+        for f in ("p.fq", "p.fq.gz", "s.fq.gz"):
+            for args in (["6"], ["3", "5000000", "14000000"])[:1 if f == "s.fq.gz" else 2]:  # (an ordinary gzip stream has no parts)
                 r = subprocess.run([exe, str(tmp_path / f)] + args, capture_output=True, text=True, timeout=600)
                 assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
                 lines = r.stdout.strip().splitlines()
