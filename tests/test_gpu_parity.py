@@ -340,6 +340,22 @@ def test_cli_output_is_byte_identical_to_reference_format(s10_gpu, s10_fgidx, tm
         assert raw[p] == i and raw[p + 1] == len(cols) and raw[p + 2:p + 2 + len(cols)].tolist() == cols
         p += 2 + len(cols)
     assert p == len(raw)
+    # the same query file gzipped, as an ordinary stream and in blocks (bgzip): same output
+    import gzip, struct, zlib
+    raw = open(q, "rb").read()
+    qg, qb = tmp_path / "q.fa.gz", tmp_path / "qb.fa.gz"
+    qg.write_bytes(gzip.compress(raw, 6))
+    with open(qb, "wb") as f:
+        for at in list(range(0, len(raw), 30000)) + [len(raw)]:
+            blk = raw[at:at + 30000]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            cd = co.compress(blk) + co.flush()
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cd) + 25) + cd +
+                    struct.pack("<II", zlib.crc32(blk) & 0xFFFFFFFF, len(blk)))
+    for qq in (qg, qb):
+        oz = tmp_path / (qq.name + ".tsv")
+        assert cli.main(["pseudoalign", "-i", s10_fgidx, "-q", str(qq), "-o", str(oz)]) == 0
+        assert oz.read_bytes() == out.read_bytes()
     out5 = tmp_path / "out_dedup.tsv"
     assert cli.main(["pseudoalign", "-i", s10_fgidx, "-q", q, "-o", str(out5), "--deduplicate"]) == 0
     assert out5.read_bytes() == out.read_bytes()
