@@ -799,8 +799,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 4 : 2)) void k3a
                     m |= (((out | all_pass) >> 7) & ONES) << q;
                 }
             }
-            const uint32_t lo = w * 32;
-            m &= lo >= n ? 0u : (n - lo >= 32 ? 0xFFFFFFFFu : ((1u << (n - lo)) - 1u));
+            if (w >= (n >> 5)) m &= w == (n >> 5) ? (1u << (n & 31u)) - 1u : 0u;  // (only the last words hold colours >= n)
             bm[w] = m;
             pc += __popc(m);
         }
@@ -1007,8 +1006,7 @@ __global__ __launch_bounds__(256, UNION ? (BITS == 8 ? 5 : 4) : 7) void k_generi
                         m |= (((out | all_pass) >> 7) & ONES) << q;
                     }
                 }
-                const uint32_t lo = w * 32;
-                m &= lo >= n ? 0u : (n - lo >= 32 ? 0xFFFFFFFFu : ((1u << (n - lo)) - 1u));
+                if (w >= (n >> 5)) m &= w == (n >> 5) ? (1u << (n & 31u)) - 1u : 0u;  // (only the last words hold colours >= n)
                 bm[w] = m;
                 pc += __popc(m);
             }
