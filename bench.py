@@ -62,6 +62,8 @@ def main():
                     help="passes in flight per GPU: chunk i runs on stream i %% streams (own result buffers, own host thread)")
     ap.add_argument("--read-len", type=int, default=150, help="read length in bases (the metric is quoted on 150)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--order", type=int, default=1, help="0: take the reads of a pass in file order (fgpu_tune; A/B measurements)")
+    ap.add_argument("--small", type=int, default=1, help="0: a bitmap row for every result (fgpu_tune; A/B measurements)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,6 +114,8 @@ def main():
     n_reads = args.reads or default_reads[args.workload]
 
     ix = fulgor_amd.Index(fg, device=local_rank)
+    if not args.order or not args.small:
+        ix.tune(order_min_reads=None if args.order else -1, small_results=bool(args.small))
     itype = {"hybrid": 0, "diff": 1, "meta": 2, "meta-diff": 3}[args.index_type]
     if itype:
         ix.convert(itype, args.partition_size, args.cluster_size)
@@ -198,7 +202,7 @@ def main():
         avg_ms = dom_ms / dom_launches
         achieved = kbytes[dom] / launches_per_step / (avg_ms * 1e-3) / 1e9
         kernels = {k_: {"avg_ms": round(v[0] / v[1], 4), "launches": v[1]} for k_, v in timing.items() if v[1]}
-        stage_ms = sum(timing[k_][0] for k_ in (stage_kernel, "scan", "k2b_expand")) / args.steps
+        stage_ms = sum(timing[k_][0] for k_ in (stage_kernel, "k_order", "scan", "k2b_expand")) / args.steps
         # HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
         # build (profiles/traffic.json, made by profiles/traffic_from_pmc.py); only quoted for the configuration the
         # counters were collected on (same workload, codec and reads per launch), otherwise null.
@@ -233,7 +237,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(kbytes[dom] / launches_per_step),
                          "avg_launch_ms": round(avg_ms, 4),
-                         "stage": {"kernels": [stage_kernel, "scan", "k2b_expand"],
+                         "stage": {"kernels": [stage_kernel, "k_order", "scan", "k2b_expand"],
                                    "bytes_per_step": acct["lists"] + acct["output"], "ms_per_step": round(stage_ms, 4),
                                    "achieved": round((acct["lists"] + acct["output"]) / (stage_ms * 1e-3) / 1e9, 2)}},
             "kernels": kernels,

@@ -77,6 +77,7 @@ def lib():
     L.fgpu_fastx_close.argtypes = [vp]
     L.fgpu_fastx_close.restype = None
     L.fgpu_result_algorithmic_bytes.argtypes = [vp, u64p, u64p, u64p]
+    L.fgpu_tune.argtypes = [vp, C.c_int, C.c_uint64]
     L.fgpu_timing_enable.argtypes = [vp, C.c_int]
     L.fgpu_timing_reset.argtypes = [vp]
     L.fgpu_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), u64p]

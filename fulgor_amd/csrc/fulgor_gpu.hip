@@ -63,7 +63,14 @@ void upload(DevBuf& b, const std::vector<T>& v, hipStream_t s) {
 
 constexpr size_t TICKET_BYTES = 3 * 8 * TICKET_STRIDE * sizeof(unsigned int);
 
-const char* KERNEL_NAMES[FGPU_K_COUNT] = {"k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits", "k_desc", "k_format"};
+const char* KERNEL_NAMES[FGPU_K_COUNT] = {"k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits", "k_desc", "k_format", "k_order"};
+
+// defaults of the fgpu_tune knobs from the environment (measurement: FULGOR_ORDER=0 takes the reads of a pass in file order,
+// FULGOR_ORDER_MIN_READS sets the smallest pass that is ordered, FULGOR_SMALL=0 writes a bitmap row for every result)
+uint64_t env_u64(const char* name, uint64_t dflt) {
+    const char* e = getenv(name);
+    return e && *e ? strtoull(e, nullptr, 10) : dflt;
+}
 
 }  // namespace
 
@@ -72,7 +79,10 @@ struct fgpu_index {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 256;
-    DevBuf d_table, d_bmp_rows, d_offsets, d_set_desc, d_blk_words;
+    // fgpu_tune
+    uint64_t order_min_reads = env_u64("FULGOR_ORDER", 1) ? env_u64("FULGOR_ORDER_MIN_READS", 16384) : ~0ull;
+    bool small_results = env_u64("FULGOR_SMALL", 1) != 0;
+    DevBuf d_table, d_bmp_rows, d_offsets, d_set_desc, d_blk_words, d_set_rank;
     DevBuf d_gops, d_gset_ops_off, d_gset_ops, d_garena, d_gblk_hdr, d_gblk_words, d_gset_bytes;
     DevDict dd{};
     DevColors dc{};
@@ -121,9 +131,10 @@ struct Timed {
     hipStream_t stream;
     std::vector<fgpu_index::Pending>* sink;
     hipEvent_t a = nullptr, b = nullptr;
+    bool on = false;  // (kernel < 0: a launch inside another bracket)
     Timed(fgpu_index* i, fgpu_result* r, int k);
     ~Timed() {
-        if (ix->timing) { (void)hipEventRecord(b, stream); sink->push_back({kernel, a, b}); }
+        if (on) { (void)hipEventRecord(b, stream); sink->push_back({kernel, a, b}); }
     }
 };
 
@@ -151,6 +162,10 @@ struct fgpu_result {
     DevBuf d_nids, d_npos, d_idoff, d_ids_pool, d_cnt_pool, d_cursor, d_bitmap, d_counts, d_offsets, d_block_sums,
         d_block_mapped, d_totals, d_colors, d_acct, d_partial, d_tickets, d_idcsr, d_desc, d_kmer_ids, d_scores;
     DevBuf d_nids2, d_npos2, d_idoff2, d_ids_pool2, d_cnt_pool2;  // long reads: merged per-read lists (stage_lookup)
+    DevBuf d_order_keys, d_order_hist, d_order_off, d_order;      // locality order of a pass (k_order_*)
+    uint64_t order_hist_sets = 0;  // entries of d_order_hist that are known to be zero
+    DevBuf d_small;                // results of at most SMALL_RESULT colours as colours (small_mode)
+    bool small_mode = false;       // the last pass left no bitmap row for results of 0..SMALL_RESULT colours
     bool want_kmer_ids = false, want_scores = false;
     uint64_t total_ids = 0;
     uint64_t* h_totals = nullptr;  // pinned {total colours, mapped reads, ids used}
@@ -167,7 +182,8 @@ struct fgpu_result {
 };
 
 Timed::Timed(fgpu_index* i, fgpu_result* r, int k) : ix(i), kernel(k), stream(r->stream), sink(&r->pending) {
-    if (ix->timing) { a = ix->get_event(); b = ix->get_event(); HIP_TRY(hipEventRecord(a, stream)); }
+    on = ix->timing && k >= 0;
+    if (on) { a = ix->get_event(); b = ix->get_event(); HIP_TRY(hipEventRecord(a, stream)); }
 }
 
 namespace {
@@ -221,6 +237,18 @@ void upload_index(fgpu_index* ix) {
     }
     if (h.blk_words.size() >= (1ull << 32)) throw std::runtime_error("colour sets too large: the packed blocks exceed 2^32 words");  // BlockLane::word
     upload(ix->d_blk_words, h.blk_words, s);
+    {  // rank of every colour set by the number of k-mers that carry it (rarest first): the sort key of k_order_keys
+        const uint64_t ns = h.num_sets();
+        std::vector<uint64_t> weight(ns, 0);
+        for (uint64_t u = 0; u < d.num_unitigs(); ++u)
+            if (d.unitig_csid[u] < ns) weight[d.unitig_csid[u]] += d.unitig_off[u + 1] - d.unitig_off[u] - d.k + 1;
+        std::vector<uint32_t> by_weight(ns), rank(ns);
+        for (uint64_t i = 0; i < ns; ++i) by_weight[i] = (uint32_t)i;
+        std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t a, uint32_t b) { return weight[a] < weight[b]; });
+        for (uint64_t i = 0; i < ns; ++i) rank[by_weight[i]] = (uint32_t)i;
+        upload(ix->d_set_rank, rank, s);
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     HIP_TRY(hipStreamSynchronize(s));
     ix->dd = DevDict{ix->d_table.as<uint32_t>(), d.num_buckets, d.k, d.m, d.seed};
     ix->dc = DevColors{ix->d_bmp_rows.as<uint32_t>(), ix->d_offsets.as<uint64_t>(), ix->d_set_desc.as<ListDesc>(),
@@ -351,13 +379,14 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
 }
 
 // exclusive scan of n u32 sizes into n+1 u64 offsets; totals -> d_totals {sum, #nonzero}
-void run_scan(fgpu_index* ix, fgpu_result* res, const uint32_t* sizes, uint64_t n, uint64_t* offsets, uint64_t* totals = nullptr) {
+void run_scan(fgpu_index* ix, fgpu_result* res, const uint32_t* sizes, uint64_t n, uint64_t* offsets, uint64_t* totals = nullptr,
+              int timed_as = FGPU_K_SCAN) {
     hipStream_t s = res->stream;
     const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     res->d_block_sums.ensure(std::max<uint64_t>(1, nb) * 8);
     res->d_block_mapped.ensure(std::max<uint64_t>(1, nb) * 8);
     res->d_totals.ensure(32);
-    Timed t(ix, res, FGPU_K_SCAN);
+    Timed t(ix, res, timed_as);
     hipLaunchKernelGGL(scan_block_sums, dim3((uint32_t)nb), dim3(256), 0, s, sizes, n, res->d_block_sums.as<uint64_t>(),
                        res->d_block_mapped.as<uint64_t>());
     hipLaunchKernelGGL(scan_top, dim3(1), dim3(256), 0, s, res->d_block_sums.as<uint64_t>(), res->d_block_mapped.as<uint64_t>(), nb,
@@ -394,6 +423,34 @@ void stage_descriptors(fgpu_index* ix, fgpu_result* res, uint64_t max_total_ids,
     HIP_TRY(hipGetLastError());
 }
 
+// Locality order of the pass (k_order_*): the reads sorted by the rarest colour set among their ids. nullptr when the pass
+// is too small to gain from it (or FULGOR_ORDER=0).
+const uint32_t* stage_order(fgpu_index* ix, fgpu_result* res) {
+    const uint64_t n = res->n;
+    if (n < ix->order_min_reads || n >= (1ull << 32)) return nullptr;
+    hipStream_t s = res->stream;
+    const uint64_t ns = ix->host.hybrid.num_sets();
+    res->d_order_keys.ensure(n * 4 + 16);
+    res->d_order.ensure(n * 4 + 16);
+    res->d_order_off.ensure((ns + 2) * 8 + 64);
+    if (res->order_hist_sets < ns + 1) {  // (the scatter leaves the histogram all zero)
+        res->d_order_hist.ensure((ns + 1) * 4 + 16);
+        HIP_TRY(hipMemsetAsync(res->d_order_hist.p, 0, (ns + 1) * 4, s));
+        res->order_hist_sets = ns + 1;
+    }
+    uint64_t* totals = res->d_order_off.as<uint64_t>() + (ns + 2);  // scratch behind the offsets (keeps d_totals intact)
+    Timed t(ix, res, FGPU_K_ORDER);
+    const uint32_t grid = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(k_order_keys, dim3(grid), dim3(256), 0, s, res->d_nids.as<uint32_t>(), res->d_idoff.as<uint64_t>(),
+                       res->d_ids_pool.as<uint32_t>(), ix->d_set_rank.as<uint32_t>(), (uint32_t)ns, n, res->d_order_keys.as<uint32_t>(),
+                       res->d_order_hist.as<uint32_t>());
+    run_scan(ix, res, res->d_order_hist.as<uint32_t>(), ns + 1, res->d_order_off.as<uint64_t>(), totals, -1);  // (inside this bracket)
+    hipLaunchKernelGGL(k_order_scatter, dim3(grid), dim3(256), 0, s, res->d_order_keys.as<uint32_t>(), n,
+                       res->d_order_off.as<uint64_t>(), res->d_order_hist.as<uint32_t>(), res->d_order.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    return res->d_order.as<uint32_t>();
+}
+
 void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     hipStream_t s = res->stream;
     const uint64_t n = res->n;
@@ -403,11 +460,16 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     res->d_offsets.ensure((n + 1) * 8 + 16);
     res->total = res->mapped = 0;
     res->hit_rows = 0;
+    res->small_mode = false;
     if (n == 0) {
         HIP_TRY(hipMemsetAsync(res->d_offsets.p, 0, 8, s));
         HIP_TRY(hipStreamSynchronize(s));
         return;
     }
+    // the per-colour hit histogram rides along in the expand kernel's LDS while it fits (16-bit counters, about W * 64 bytes);
+    // for larger collections the expand kernel runs without it and k_hits counts from the bitmaps on demand
+    const size_t stage_lds = (K2B_THREADS / 64) * K2B_STAGE_BYTES + 16;  // + the block's ticket counter
+    const bool hits_fold = stage_lds + k2b_hist_region(W) <= 80 * 1024;  // two blocks per CU
     if (ix->host.type != IDX_HYBRID) {
         const bool uni = algo == FGPU_THRESHOLD_UNION;
         if (!uni && algo != FGPU_FULL_INTERSECTION) throw std::runtime_error("unknown algorithm");
@@ -439,13 +501,23 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         // two reads per group (a second EXCL plane) while 8 waves per SIMD still fit the LDS with it
         const bool pair = (size_t)32 * k2a_wave_bytes(W, true) <= 160 * 1024;
         const size_t per_wave = k2a_wave_bytes(W, pair);
+        const uint32_t* order = stage_order(ix, res);
+        // small results travel as colours when a row is much larger than SMALL_RESULT colours, every such result is of the
+        // sparse kind of the compressed formatter, and nobody needs the rows (k_hits counts from them when the expand
+        // kernel's histogram does not fit)
+        res->small_mode = ix->small_results && W >= 32 && SMALL_RESULT < ix->host.hybrid.sparse_thr && hits_fold;
+        uint32_t* small_out = nullptr;
+        if (res->small_mode) {
+            res->d_small.ensure(n * SMALL_RESULT * 4 + 16);
+            small_out = res->d_small.as<uint32_t>();
+        }
         auto launch = [&](auto kernel) {
             const uint32_t wpb = pick_waves(per_wave, (const void*)kernel);
             const uint32_t grid = resident_grid(kernel, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
             Timed t(ix, res, FGPU_K_INTERSECT);
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_nids.as<uint32_t>(),
                                res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), n, res->d_bitmap.as<uint32_t>(),
-                               res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE);
+                               res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, order, small_out);
             HIP_TRY(hipGetLastError());
         };
         if (pair) launch(k2a_intersect<true>);
@@ -483,10 +555,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     // The expand kernel is launched right behind the scan, without waiting for the totals: it checks on the device
     // that the colours fit the buffer it was given and does nothing otherwise; only then (first passes, growing
     // results) the buffer is enlarged and the launch repeated. One host round trip per pass instead of two.
-    // the per-colour hit histogram rides along in LDS while it fits (16-bit counters, about W * 64 bytes); for
-    // larger collections the expand kernel runs without it and k_hits counts from the bitmaps on demand
-    const size_t stage_lds = (K2B_THREADS / 64) * K2B_STAGE_BYTES + 16;  // + the block's ticket counter
-    res->hits_folded = stage_lds + k2b_hist_region(W) <= 80 * 1024;  // two blocks per CU
+    res->hits_folded = hits_fold;
     const size_t lds = res->hits_folded ? stage_lds + k2b_hist_region(W) : stage_lds;
     // 16-bit hit counters: a block takes tickets for at most block_cap reads (k2b_expand), and the grid is large enough for
     // the caps of the blocks of every ticket partition to exceed its reads by a quarter
@@ -506,7 +575,8 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
                            res->d_offsets.as<uint64_t>(), n, W, res->d_colors.as<uint32_t>(),
                            res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE,
                            res->hits_folded ? res->d_partial.as<uint32_t>() : (uint32_t*)nullptr, res->d_totals.as<uint64_t>(),
-                           (uint64_t)(res->d_colors.cap / 4), block_cap);
+                           (uint64_t)(res->d_colors.cap / 4), block_cap,
+                           res->small_mode ? res->d_small.as<uint32_t>() : (const uint32_t*)nullptr);
         HIP_TRY(hipGetLastError());
     };
     expand();
@@ -576,7 +646,7 @@ void fgpu_close(fgpu_index* ix) {
     if (!ix) return;
     if (ix->device == FGPU_HOST_ONLY) { delete ix; return; }
     (void)hipSetDevice(ix->device);
-    for (DevBuf* b : {&ix->d_table, &ix->d_bmp_rows, &ix->d_offsets,
+    for (DevBuf* b : {&ix->d_table, &ix->d_bmp_rows, &ix->d_offsets, &ix->d_set_rank,
                       &ix->d_set_desc, &ix->d_blk_words, &ix->d_gops, &ix->d_gset_ops_off, &ix->d_gset_ops,
                       &ix->d_garena, &ix->d_gblk_hdr, &ix->d_gblk_words, &ix->d_gset_bytes})
         b->release();
@@ -771,7 +841,8 @@ void fgpu_result_free(fgpu_result* r) {
     (void)hipSetDevice(r->ix->device);
     for (DevBuf* b : {&r->d_nids, &r->d_npos, &r->d_idoff, &r->d_ids_pool, &r->d_cnt_pool, &r->d_cursor, &r->d_bitmap,
                       &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct, &r->d_partial, &r->d_tickets, &r->d_idcsr, &r->d_desc, &r->d_kmer_ids, &r->d_scores, &r->d_fmt_sizes, &r->d_fmt_off, &r->d_fmt_out,
-                      &r->d_nids2, &r->d_npos2, &r->d_idoff2, &r->d_ids_pool2, &r->d_cnt_pool2})
+                      &r->d_nids2, &r->d_npos2, &r->d_idoff2, &r->d_ids_pool2, &r->d_cnt_pool2, &r->d_order_keys, &r->d_order_hist,
+                      &r->d_order_off, &r->d_order, &r->d_small})
         b->release();
     if (r->h_totals) (void)hipHostFree(r->h_totals);
     if (r->h_fmt) (void)hipHostFree(r->h_fmt);
@@ -837,7 +908,8 @@ int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_rea
             {
                 Timed t(ix, res, FGPU_K_FORMAT);
                 hipLaunchKernelGGL(k_cfmt_sizes, dim3(grid), dim3(256), 0, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
-                                   n, W, nc, sthr, dthr, first_read_id, bits);
+                                   n, W, nc, sthr, dthr, first_read_id, bits, res->small_mode ? res->d_offsets.as<uint64_t>() : (const uint64_t*)nullptr,
+                                   res->d_colors.as<uint32_t>());
                 hipLaunchKernelGGL(k_cfmt_blocks, dim3((uint32_t)nb), dim3(CFMT_BLOCK_READS), 0, s, bits, n, rec_off, block_bits,
                                    block_bytes);
             }
@@ -854,7 +926,8 @@ int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_rea
             const uint32_t cap_words = (uint32_t)std::min<uint64_t>(((uint64_t)nc * 3 / 2 + 256 + 63) / 64, 1024);
             hipLaunchKernelGGL(k_cfmt_write, dim3(grid), dim3(256), (size_t)4 * cap_words * 8, s, res->d_bitmap.as<uint32_t>(),
                                res->d_counts.as<uint32_t>(), n, W, nc, sthr, dthr, first_read_id, bits, rec_off, block_bits, block_off,
-                               res->d_fmt_out.as<unsigned long long>(), cap_words);
+                               res->d_fmt_out.as<unsigned long long>(), cap_words,
+                               res->small_mode ? res->d_offsets.as<uint64_t>() : (const uint64_t*)nullptr, res->d_colors.as<uint32_t>());
             HIP_TRY(hipGetLastError());
         } else if (n && format == FGPU_FMT_BINARY) {
             bytes = 8 * n + 4 * res->total;
@@ -960,6 +1033,14 @@ int fgpu_result_algorithmic_bytes(const fgpu_result* r, uint64_t* list_bytes, ui
         // ceil(L/4) bytes of 2-bit read + one 8-byte record per k-mer
         if (lookup_bytes) *lookup_bytes = (r->total_bases + 3) / 4 + 8 * r->total_kmers;
     });
+}
+
+int fgpu_tune(fgpu_index* ix, int knob, uint64_t value) {
+    if (!ix) return fail(-EINVAL, "null argument");
+    if (knob == FGPU_TUNE_ORDER_MIN_READS) ix->order_min_reads = value;
+    else if (knob == FGPU_TUNE_SMALL_RESULTS) ix->small_results = value != 0;
+    else return fail(-EINVAL, "unknown knob");
+    return 0;
 }
 
 int fgpu_timing_enable(fgpu_index* ix, int on) {

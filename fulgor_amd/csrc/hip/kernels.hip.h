@@ -34,6 +34,7 @@ struct DevColors {
 };
 
 constexpr uint32_t NEG = 0xFFFFFFFFu;
+constexpr uint32_t SMALL_RESULT = 16;  // results of at most this many colours may travel as colours, not as a bitmap row (k2a -> k2b)
 enum { D_ENC_NONE = -1, D_ENC_DELTA_GAPS = 0, D_ENC_BITMAP = 1, D_ENC_COMPLEMENT = 2 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -100,7 +101,9 @@ __device__ __forceinline__ uint32_t mask_rank(uint64_t m) {
 // Dynamic work distribution for the persistent one-wave-per-read kernels. The batch is cut into 8
 // static partitions (label = blockIdx & 7, which the dispatcher happens to place on one XCD each; only
 // speed depends on that) and every wave pulls `batch` reads at a time from its partition's
-// counter. No tail from uneven reads or from a grid larger than what is actually resident.
+// counter; a wave whose partition is used up goes on with the partitions behind it (the partitions of a pass
+// taken in locality order differ a lot in cost: all unmapped reads sit in the last one). No tail from uneven
+// reads or from a grid larger than what is actually resident.
 constexpr uint32_t TICKET_STRIDE = 64;  // counters live 256 bytes apart (separate L2 channels)
 struct WorkQueue {
     unsigned int* counters;  // 8 * TICKET_STRIDE words, zeroed before every launch
@@ -108,16 +111,21 @@ struct WorkQueue {
     uint32_t batch;          // reads per pull
     __device__ __forceinline__ bool pull(uint64_t& first, uint32_t& count) const {
         const uint32_t parts = min(8u, gridDim.x);
-        const uint32_t part = blockIdx.x % parts;
         const uint64_t per = (n + parts - 1) / parts;
-        const uint64_t lo = min(n, part * per), hi = min(n, lo + per);
-        unsigned int t = 0;
-        if (lane_id() == 0) t = atomicAdd(&counters[part * TICKET_STRIDE], batch);
-        t = __builtin_amdgcn_readfirstlane(t);
-        first = lo + t;
-        if (first >= hi) return false;
-        count = (uint32_t)min((uint64_t)batch, hi - first);
-        return true;
+        uint32_t part = blockIdx.x % parts;
+        for (uint32_t tries = 0; tries < parts; ++tries) {
+            const uint64_t lo = min(n, part * per), hi = min(n, lo + per);
+            unsigned int t = 0;
+            if (lane_id() == 0) t = atomicAdd(&counters[part * TICKET_STRIDE], batch);
+            t = __builtin_amdgcn_readfirstlane(t);
+            first = lo + t;
+            if (first < hi) {
+                count = (uint32_t)min((uint64_t)batch, hi - first);
+                return true;
+            }
+            part = part + 1 == parts ? 0u : part + 1;
+        }
+        return false;
     }
 };
 
@@ -280,6 +288,39 @@ __global__ __launch_bounds__(256) void k_gather_ids(const uint32_t* __restrict__
     for (uint32_t j = (uint32_t)t & 15u; j < cnt; j += 16) out[dso + j] = ids_src[so + j];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Locality order of a pass. Reads drawn from the same locus share their colour sets, and a pass of millions of
+// reads fetches every list dozens of times — in file order those fetches are spread over the whole launch and
+// miss the L2. The colour kernels therefore take the reads of a pass sorted by the RAREST colour set among a
+// read's ids (set_rank: position of a colour set when the sets are sorted by the number of k-mers that carry
+// them; reads without ids come last): reads that share a rare set overlap on the same few unitigs. Counting
+// sort, three light kernels: keys + histogram, scan (scan_*), scatter. The histogram is left all zero by the
+// scatter, ready for the next pass. The order inside a bucket is whatever the atomics give: results go to the
+// read's own row, so nothing observable depends on it.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_order_keys(const uint32_t* __restrict__ nids, const uint64_t* __restrict__ idoff,
+                                                    const uint32_t* __restrict__ ids_pool, const uint32_t* __restrict__ set_rank,
+                                                    uint32_t num_sets, uint64_t n_reads, uint32_t* __restrict__ keys,
+                                                    uint32_t* __restrict__ hist) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t cnt = nids[r];
+    const uint64_t off = idoff[r];
+    uint32_t key = num_sets;
+    for (uint32_t i = 0; i < cnt; ++i) key = min(key, set_rank[ids_pool[off + i]]);
+    keys[r] = key;
+    atomicAdd(&hist[key], 1u);
+}
+__global__ __launch_bounds__(256) void k_order_scatter(const uint32_t* __restrict__ keys, uint64_t n_reads,
+                                                       const uint64_t* __restrict__ bucket_off, uint32_t* __restrict__ hist,
+                                                       uint32_t* __restrict__ order) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t key = keys[r];
+    const uint32_t left = atomicSub(&hist[key], 1u);  // counts down to zero
+    order[bucket_off[key] + left - 1u] = (uint32_t)r;
+}
+
 __global__ __launch_bounds__(256) void k_desc(const uint32_t* __restrict__ nids,
                                               const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ ids_src,
                                               const uint32_t* __restrict__ cnt_src, const uint64_t* __restrict__ dst_off,
@@ -437,7 +478,13 @@ template <bool PAIR>
 __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint32_t* __restrict__ nids,
                                                      const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
                                                      uint64_t n_reads, uint32_t* __restrict__ out_bitmap,
-                                                     uint32_t* __restrict__ out_count, unsigned int* tickets) {
+                                                     uint32_t* __restrict__ out_count, unsigned int* tickets,
+                                                     const uint32_t* __restrict__ order, uint32_t* __restrict__ small_out) {
+    // order != nullptr: the reads are taken in that order (k_order_*: reads that share their rarest colour set are
+    // neighbours, so the lists of a ticket are fetched once and found in the L2 by the reads behind); results land at
+    // the read's own row whatever the order.
+    // small_out != nullptr: a result of at most SMALL_RESULT colours is written as colours into the read's slot of
+    // small_out (SMALL_RESULT u32 per read) INSTEAD of its bitmap row, which is then left untouched.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t W = c.w32, W4 = W >> 2;  // W is a multiple of 4: the bitmaps move as 128-bit groups
@@ -471,9 +518,18 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
         // The colour-set ids of the next group are requested while a group is processed; its descriptors (one 32-byte gather
         // per list) are fetched at the top of the group. (Requesting the descriptors a group ahead as well was slower, in
         // registers and through an LDS stage: DESIGN.md §8.)
-        const uint64_t rl = min(t_first + (uint64_t)lane, n_reads - 1);
-        const uint32_t cnt_l = (uint32_t)lane < t_count ? nids[rl] : 0u;  // lanes past the ticket: empty reads
-        const uint64_t off_l = idoff[rl];
+        const uint64_t tl = min(t_first + (uint64_t)lane, n_reads - 1);
+        // the read behind place `lane` of the ticket (a pass has fewer than 2^32 reads); kept in LDS, not in a register:
+        // it is needed once per read, for the stores
+        uint32_t* const t_read = (uint32_t*)sc.h_score;  // (the score column of the scratch is the union kernel's)
+        uint32_t cnt_l;
+        uint64_t off_l;
+        {
+            const uint32_t rd_l = order ? order[tl] : (uint32_t)tl;
+            cnt_l = (uint32_t)lane < t_count ? nids[rd_l] : 0u;  // lanes past the ticket: empty reads
+            off_l = idoff[rd_l];
+            t_read[lane] = rd_l;
+        }
         // the group that starts with the ticket's read i: its list counts, and whether read i + 1 belongs to it
         // (t_count <= BATCH < 62: the lanes exist and read as empty past the ticket)
         auto group_at = [&](uint32_t i, uint32_t& a0, uint32_t& a1) -> bool {
@@ -498,12 +554,14 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
             uint32_t n0, n1;
             const bool npair = group_at(ri + nr, n0, n1);
             const uint32_t id2 = fetch_ids(ri + nr, n0, n1, npair);
-            const uint64_t r = t_first + ri;
             const uint64_t off = readlane_u64(off_l, ri);
-            const uint32_t second = (pair && (uint32_t)lane >= c0) ? SECOND_FLAG : 0u;  // this lane's list belongs to read r + 1
+            const uint32_t second = (pair && (uint32_t)lane >= c0) ? SECOND_FLAG : 0u;  // this lane's list belongs to the group's second read
             if (nlist == 0) {
-                uint4* bm4 = (uint4*)(out_bitmap + r * W);
-                for (uint32_t g4 = lane; g4 < W4; g4 += 64) bm4[g4] = make_uint4(0u, 0u, 0u, 0u);
+                const uint64_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_read[ri]);
+                if (!small_out) {
+                    uint4* bm4 = (uint4*)(out_bitmap + r * W);
+                    for (uint32_t g4 = lane; g4 < W4; g4 += 64) bm4[g4] = make_uint4(0u, 0u, 0u, 0u);
+                }
                 if (lane == 0) out_count[r] = 0;
             } else {
                 for (uint32_t p = 0; p < nr; ++p)
@@ -570,17 +628,51 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
                     wave_lds_sync();
                 }
                 for (uint32_t p = 0; p < nr; ++p) {
-                    uint4* bm4 = (uint4*)(out_bitmap + (r + p) * W);
+                    const uint64_t rp = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_read[ri + p]);
+                    uint4* bm4 = (uint4*)(out_bitmap + rp * W);
                     uint32_t pc = 0;
-                    for (uint32_t g4 = lane; g4 < W4; g4 += 64) {
-                        const uint4 e = EX4[p * W4 + g4];
-                        const uint4 x = make_uint4(~e.x, ~e.y, ~e.z, ~e.w);
-                        // streamed past the L2 (nontemporal): the rows are read back by another kernel, the L2 is for the lists
-                        __builtin_nontemporal_store((u32x4){x.x, x.y, x.z, x.w}, (u32x4*)&bm4[g4]);
-                        pc += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
+                    if (!small_out) {  // count and store in one pass
+                        for (uint32_t g4 = lane; g4 < W4; g4 += 64) {
+                            const uint4 e = EX4[p * W4 + g4];
+                            const uint4 x = make_uint4(~e.x, ~e.y, ~e.z, ~e.w);
+                            // streamed past the L2 (nontemporal): the rows are read back by another kernel, the L2 is for the lists
+                            __builtin_nontemporal_store((u32x4){x.x, x.y, x.z, x.w}, (u32x4*)&bm4[g4]);
+                            pc += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
+                        }
+                        pc = wave_sum_u32(pc);
+                    } else {
+                        for (uint32_t g4 = lane; g4 < W4; g4 += 64) {
+                            const uint4 e = EX4[p * W4 + g4];
+                            pc += __popc(~e.x) + __popc(~e.y) + __popc(~e.z) + __popc(~e.w);
+                        }
+                        pc = wave_sum_u32(pc);
+                        if (pc > SMALL_RESULT) {
+                            for (uint32_t g4 = lane; g4 < W4; g4 += 64) {
+                                const uint4 e = EX4[p * W4 + g4];
+                                __builtin_nontemporal_store((u32x4){~e.x, ~e.y, ~e.z, ~e.w}, (u32x4*)&bm4[g4]);
+                            }
+                        } else if (pc) {  // the colours themselves, no row
+                            uint32_t* so = small_out + rp * SMALL_RESULT;
+                            uint32_t at = 0;  // colours in the groups of earlier rounds
+                            for (uint32_t g0 = 0; g0 < W4; g0 += 64) {
+                                uint4 x = make_uint4(0u, 0u, 0u, 0u);
+                                if (g0 + lane < W4) {
+                                    const uint4 e = EX4[p * W4 + g0 + lane];
+                                    x = make_uint4(~e.x, ~e.y, ~e.z, ~e.w);
+                                }
+                                const uint32_t m = __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
+                                const uint32_t incl = wave_incl_scan_u32(m);
+                                uint32_t pos = at + incl - m;
+                                const uint32_t c0w = (g0 + (uint32_t)lane) * 128u;
+                                for (uint32_t y = x.x; y; y &= y - 1) so[pos++] = c0w + (uint32_t)__builtin_ctz(y);
+                                for (uint32_t y = x.y; y; y &= y - 1) so[pos++] = c0w + 32u + (uint32_t)__builtin_ctz(y);
+                                for (uint32_t y = x.z; y; y &= y - 1) so[pos++] = c0w + 64u + (uint32_t)__builtin_ctz(y);
+                                for (uint32_t y = x.w; y; y &= y - 1) so[pos++] = c0w + 96u + (uint32_t)__builtin_ctz(y);
+                                at += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                            }
+                        }
                     }
-                    pc = wave_sum_u32(pc);
-                    if (lane == 0) out_count[r + p] = pc;
+                    if (lane == 0) out_count[rp] = pc;
                 }
                 wave_lds_sync();
             }
@@ -1136,7 +1228,8 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
                                                   const uint64_t* __restrict__ out_off, uint64_t n_reads, uint32_t W,
                                                   uint32_t* __restrict__ colors, unsigned int* tickets,
                                                   uint32_t* __restrict__ hit_partial, const uint64_t* __restrict__ totals,
-                                                  uint64_t capacity, uint32_t block_cap) {
+                                                  uint64_t capacity, uint32_t block_cap, const uint32_t* __restrict__ small) {
+    // small != nullptr: reads with 1..SMALL_RESULT colours have them in their slot of `small` and no bitmap row
     // launched behind the scan without a host round trip: if the colours of the pass do not fit `colors`
     // (capacity in u32), do nothing — the host enlarges the buffer and launches again
     if (totals[0] > capacity) return;
@@ -1180,14 +1273,41 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
     const uint64_t rl = t_first + min((uint32_t)lane, t_count - 1);
     const uint32_t cnt_l = (uint32_t)lane < t_count ? counts[rl] : 0u;
     const uint64_t off_l = out_off[rl];
+    uint64_t lg = __ballot(cnt_l != 0u);  // the reads whose result comes as a bitmap row
+    if (small) {
+        // results of at most SMALL_RESULT colours arrive as colours (k2a_intersect): four reads per step, lane = (read, slot)
+        const bool is_small = cnt_l != 0u && cnt_l <= SMALL_RESULT;
+        const uint64_t sm = __ballot(is_small);
+        lg = __ballot(cnt_l > SMALL_RESULT);
+        if (sm) {
+            if (is_small) *lds16(k2b_stage_skew(v_wave + (mask_rank(sm) << 1))) = (uint16_t)lane;  // k-th small read of the ticket
+            wave_lds_sync();
+            const uint32_t nsm = (uint32_t)__popcll(sm);
+            for (uint32_t g = 0; g < nsm; g += 4) {
+                const uint32_t kk = g + ((uint32_t)lane >> 4), slot = (uint32_t)lane & 15u;
+                const uint32_t j = kk < nsm ? (uint32_t)*lds16(k2b_stage_skew(v_wave + (kk << 1))) : 0u;
+                const uint32_t cj = (uint32_t)__shfl((int)cnt_l, (int)j);
+                const uint64_t oj = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(off_l >> 32), (int)j) << 32) |
+                                    (uint32_t)__shfl((int)(uint32_t)off_l, (int)j);
+                if (kk < nsm && slot < cj) {
+                    const uint32_t v = __builtin_nontemporal_load(&small[(t_first + j) * SMALL_RESULT + slot]);
+                    colors[oj + slot] = v;
+                    // the colour's hit counter: round v >> 11 (low / high half of the word by its parity), entry v & 2047
+                    if (hit_partial) lds_add((v >> 12) * 8192u + ((v & 2047u) << 2), (v & 2048u) ? 0x10000u : 1u);
+                }
+            }
+            wave_lds_sync();
+        }
+    }
     uint32_t cur[3], nxt[3] = {0u, 0u, 0u};
-    fetch3(t_first, nxt);
-    for (uint32_t j = 0; j < t_count; ++j) {
+    if (lg) fetch3(t_first + (uint32_t)__builtin_ctzll(lg), nxt);
+    while (lg) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(lg);
+        lg &= lg - 1;
         const uint64_t r = t_first + j;
 #pragma unroll
         for (uint32_t q = 0; q < 3; ++q) cur[q] = nxt[q];
-        if (j + 1 < t_count && __builtin_amdgcn_readlane((int)cnt_l, j + 1) != 0) fetch3(r + 1, nxt);
-        if (__builtin_amdgcn_readlane((int)cnt_l, j) == 0) continue;
+        if (lg) fetch3(t_first + (uint32_t)__builtin_ctzll(lg), nxt);
         uint32_t* out = colors + readlane_u64(off_l, j);
         const uint32_t* bm = bitmap + r * W;
         // one round = 64 words. The first three rounds have their words in registers and contain no loads: a load would make
@@ -1463,6 +1583,21 @@ __device__ __forceinline__ uint32_t cfmt_gap_payload(uint32_t W, int lane, WordF
     return total;
 }
 
+// the same payload for a result of at most 64 colours given as colours (results without a bitmap row: SMALL_RESULT)
+template <bool WRITE, typename Emit>
+__device__ __forceinline__ uint32_t cfmt_small_payload(const uint32_t* cols, uint32_t size, int lane, Emit emit) {
+    const uint32_t c = (uint32_t)lane < size ? cols[lane] : 0u;
+    const uint32_t before = (uint32_t)__shfl_up((int)c, 1);
+    uint32_t gap = 0, len = 0;
+    if ((uint32_t)lane < size) {
+        gap = lane == 0 ? c : c - before - 1u;
+        (void)delta_code(gap, len);
+    }
+    const uint32_t incl = wave_incl_scan_u32(len);
+    if (WRITE && (uint32_t)lane < size) emit(gap, incl - len);
+    return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+}
+
 __device__ __forceinline__ uint32_t cfmt_word(const uint32_t* row, uint32_t w, uint32_t n, bool complemented) {
     uint32_t x = row[w];
     if (complemented) {
@@ -1475,7 +1610,9 @@ __device__ __forceinline__ uint32_t cfmt_word(const uint32_t* row, uint32_t w, u
 
 __global__ __launch_bounds__(256) void k_cfmt_sizes(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
                                                     uint64_t n_reads, uint32_t W, uint32_t n, uint32_t sparse_thr, uint32_t dense_thr,
-                                                    uint32_t first_id, uint32_t* __restrict__ bits) {
+                                                    uint32_t first_id, uint32_t* __restrict__ bits,
+                                                    const uint64_t* __restrict__ small_off, const uint32_t* __restrict__ small_colors) {
+    // small_off != nullptr: results of at most SMALL_RESULT colours have no bitmap row; their colours are read from the CSR
     const int lane = lane_id();
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t r = wave; r < n_reads; r += nwaves) {
@@ -1485,6 +1622,7 @@ __global__ __launch_bounds__(256) void k_cfmt_sizes(const uint32_t* __restrict__
         (void)delta_code(size, l2);
         uint32_t payload = 0;
         if (size == 0) payload = 0;
+        else if (small_off && size <= SMALL_RESULT) payload = cfmt_small_payload<false>(small_colors + small_off[r], size, lane, [](uint32_t, uint32_t) {});
         else if (size >= sparse_thr && size < dense_thr) payload = n;
         else {
             const uint32_t* row = bitmap + r * W;
@@ -1524,7 +1662,8 @@ __global__ __launch_bounds__(256) void k_cfmt_write(const uint32_t* __restrict__
                                                     uint32_t first_id, const uint32_t* __restrict__ rec_bits,
                                                     const uint32_t* __restrict__ rec_off,
                                                     const uint32_t* __restrict__ block_bits, const uint64_t* __restrict__ block_off,
-                                                    unsigned long long* __restrict__ out, uint32_t cap_words) {
+                                                    unsigned long long* __restrict__ out, uint32_t cap_words,
+                                                    const uint64_t* __restrict__ small_off, const uint32_t* __restrict__ small_colors) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
     const int lane = lane_id();
     unsigned long long* buf = (unsigned long long*)smem_c + (size_t)(threadIdx.x >> 6) * cap_words;
@@ -1558,6 +1697,12 @@ __global__ __launch_bounds__(256) void k_cfmt_write(const uint32_t* __restrict__
         const uint64_t pay = pos0 + l1 + l2;
         const uint32_t* row = bitmap + r * W;
         if (size == 0) {
+        } else if (small_off && size <= SMALL_RESULT) {  // (as in k_cfmt_sizes)
+            cfmt_small_payload<true>(small_colors + small_off[r], size, lane, [&](uint32_t gap, uint32_t at) {
+                uint32_t len;
+                const uint64_t code = delta_code(gap, len);
+                put(pay + at, code, len);
+            });
         } else if (size >= sparse_thr && size < dense_thr) {  // the n bits of the row, shifted into place
             for (uint32_t w = lane; w * 32 < n; w += 64) {
                 uint32_t x = row[w];

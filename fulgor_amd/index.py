@@ -15,7 +15,7 @@ from . import _native
 FULL_INTERSECTION = 0
 THRESHOLD_UNION = 1
 HYBRID, DIFF, META, META_DIFF = 0, 1, 2, 3  # index_t, include/util.hpp:18
-KERNELS = ("k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits", "k_desc", "k_format")
+KERNELS = ("k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits", "k_desc", "k_format", "k_order")
 
 
 def pack_reads(reads):
@@ -253,6 +253,13 @@ class Index:
         if count is None:
             count = reads.n - first
         _native.check(self._L.fgpu_run(self._h, reads._h, first, count, algo, C.c_double(threshold), result._h))
+
+    def tune(self, order_min_reads=None, small_results=None):
+        """execution knobs of the colour stage (fgpu_tune); results never depend on them"""
+        if order_min_reads is not None:
+            _native.check(self._L.fgpu_tune(self._h, 0, int(order_min_reads) if order_min_reads >= 0 else 0xFFFFFFFFFFFFFFFF))
+        if small_results is not None:
+            _native.check(self._L.fgpu_tune(self._h, 1, 1 if small_results else 0))
 
     def timing_enable(self, on=True):
         _native.check(self._L.fgpu_timing_enable(self._h, 1 if on else 0))

@@ -110,9 +110,18 @@ int fgpu_result_accumulate_hits(fgpu_index* idx, const fgpu_result* res, void* d
 int fgpu_result_algorithmic_bytes(const fgpu_result* res, uint64_t* list_bytes, uint64_t* output_bytes,
                                   uint64_t* lookup_bytes);
 
+/* Execution knobs of the colour stage; none of them changes a result.
+ *   FGPU_TUNE_ORDER_MIN_READS  passes of at least this many reads are processed in locality order (reads sorted by the rarest
+ *                              colour set among their ids, so that the lists of neighbouring reads are found in the L2);
+ *                              UINT64_MAX = never. Default 16384 (environment: FULGOR_ORDER=0, FULGOR_ORDER_MIN_READS).
+ *   FGPU_TUNE_SMALL_RESULTS    1 (default; environment FULGOR_SMALL=0): full-intersection results of at most 16 colours travel
+ *                              between the intersection and the expansion kernel as colours instead of as a bitmap row. */
+enum { FGPU_TUNE_ORDER_MIN_READS = 0, FGPU_TUNE_SMALL_RESULTS = 1 };
+int fgpu_tune(fgpu_index* idx, int knob, uint64_t value);
+
 /* per-kernel HIP-event timing on the engine's stream */
 enum { FGPU_K_LOOKUP = 0, FGPU_K_INTERSECT = 1, FGPU_K_UNION = 2, FGPU_K_SCAN = 3, FGPU_K_EXPAND = 4,
-       FGPU_K_HITS = 5, FGPU_K_DESC = 6, FGPU_K_FORMAT = 7, FGPU_K_COUNT = 8 };
+       FGPU_K_HITS = 5, FGPU_K_DESC = 6, FGPU_K_FORMAT = 7, FGPU_K_ORDER = 8, FGPU_K_COUNT = 9 };
 int fgpu_timing_enable(fgpu_index* idx, int on);
 int fgpu_timing_reset(fgpu_index* idx);
 int fgpu_timing_get(fgpu_index* idx, int kernel, double* total_ms, uint64_t* launches);
