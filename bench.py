@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--order", type=int, default=1, help="0: take the reads of a pass in file order (fgpu_tune; A/B measurements)")
     ap.add_argument("--small", type=int, default=1, help="0: a bitmap row for every result (fgpu_tune; A/B measurements)")
+    ap.add_argument("--rows", type=int, default=1, help="0: full intersection on the packed blocks, not on dense rows (fgpu_tune; A/B measurements)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,8 +115,8 @@ def main():
     n_reads = args.reads or default_reads[args.workload]
 
     ix = fulgor_amd.Index(fg, device=local_rank)
-    if not args.order or not args.small:
-        ix.tune(order_min_reads=None if args.order else -1, small_results=bool(args.small))
+    if not args.order or not args.small or not args.rows:
+        ix.tune(order_min_reads=None if args.order else -1, small_results=bool(args.small), dense_rows=bool(args.rows))
     itype = {"hybrid": 0, "diff": 1, "meta": 2, "meta-diff": 3}[args.index_type]
     if itype:
         ix.convert(itype, args.partition_size, args.cluster_size)

@@ -82,7 +82,8 @@ struct fgpu_index {
     // fgpu_tune
     uint64_t order_min_reads = env_u64("FULGOR_ORDER", 1) ? env_u64("FULGOR_ORDER_MIN_READS", 16384) : ~0ull;
     bool small_results = env_u64("FULGOR_SMALL", 1) != 0;
-    DevBuf d_table, d_bmp_rows, d_offsets, d_set_desc, d_blk_words, d_set_rank;
+    bool dense_rows = env_u64("FULGOR_DENSE_ROWS", 1) != 0;  // use the dense rows (when they were built: d_rows)
+    DevBuf d_table, d_bmp_rows, d_offsets, d_set_desc, d_blk_words, d_set_rank, d_rows;
     DevBuf d_gops, d_gset_ops_off, d_gset_ops, d_garena, d_gblk_hdr, d_gblk_words, d_gset_bytes;
     DevDict dd{};
     DevColors dc{};
@@ -253,6 +254,23 @@ void upload_index(fgpu_index* ix) {
     ix->dd = DevDict{ix->d_table.as<uint32_t>(), d.num_buckets, d.k, d.m, d.seed};
     ix->dc = DevColors{ix->d_bmp_rows.as<uint32_t>(), ix->d_offsets.as<uint64_t>(), ix->d_set_desc.as<ListDesc>(),
                        ix->d_blk_words.as<uint32_t>(), h.num_colors, h.sparse_thr, h.dense_thr, w32};
+    // Dense rows (k2r_intersect): every colour set as a plain bitmap row, built on the device from the forms above, while
+    // they fit the budget (default: a quarter of the device's memory; FULGOR_ROWS_MAX_BYTES, 0 = never) and a row fits the
+    // registers of a wave (at most 4 groups of 128 bits per lane = 32768 colours)
+    {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t budget = env_u64("FULGOR_ROWS_MAX_BYTES", total_b / 4);
+        const uint64_t need = (uint64_t)h.num_sets() * w32 * 4;
+        if (h.num_sets() && need <= budget && need + (1ull << 30) <= free_b && w32 / 4 <= 256) {
+            ix->d_rows.ensure(need + 64);
+            const size_t lds = (size_t)4 * w32 * 4;
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((h.num_sets() + 3) / 4, (uint64_t)ix->num_cus * 8);
+            hipLaunchKernelGGL(k_rows_build, dim3(grid), dim3(256), lds, s, ix->dc, (uint64_t)h.num_sets(), ix->d_rows.as<uint32_t>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+    }
 }
 
 static_assert(sizeof(GenOpDev) == sizeof(ListDesc), "host and device op layouts must match");
@@ -440,12 +458,12 @@ const uint32_t* stage_order(fgpu_index* ix, fgpu_result* res) {
     }
     uint64_t* totals = res->d_order_off.as<uint64_t>() + (ns + 2);  // scratch behind the offsets (keeps d_totals intact)
     Timed t(ix, res, FGPU_K_ORDER);
-    const uint32_t grid = (uint32_t)((n + 255) / 256);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)ix->num_cus * 8);  // (both kernels: the same slices)
     hipLaunchKernelGGL(k_order_keys, dim3(grid), dim3(256), 0, s, res->d_nids.as<uint32_t>(), res->d_idoff.as<uint64_t>(),
                        res->d_ids_pool.as<uint32_t>(), ix->d_set_rank.as<uint32_t>(), (uint32_t)ns, n, res->d_order_keys.as<uint32_t>(),
                        res->d_order_hist.as<uint32_t>());
     run_scan(ix, res, res->d_order_hist.as<uint32_t>(), ns + 1, res->d_order_off.as<uint64_t>(), totals, -1);  // (inside this bracket)
-    hipLaunchKernelGGL(k_order_scatter, dim3(grid), dim3(256), 0, s, res->d_order_keys.as<uint32_t>(), n,
+    hipLaunchKernelGGL(k_order_scatter, dim3(grid), dim3(256), 0, s, res->d_order_keys.as<uint32_t>(), (uint32_t)ns, n,
                        res->d_order_off.as<uint64_t>(), res->d_order_hist.as<uint32_t>(), res->d_order.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     return res->d_order.as<uint32_t>();
@@ -520,7 +538,19 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
                                res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, order, small_out);
             HIP_TRY(hipGetLastError());
         };
-        if (pair) launch(k2a_intersect<true>);
+        auto launch_rows = [&](auto kernel) {
+            const uint32_t grid = resident_grid(kernel, n, 4, ix->num_cus, 256, 0);
+            Timed t(ix, res, FGPU_K_INTERSECT);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, ix->d_rows.as<uint32_t>(), W, res->d_nids.as<uint32_t>(),
+                               res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), n, res->d_bitmap.as<uint32_t>(),
+                               res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, order, small_out);
+            HIP_TRY(hipGetLastError());
+        };
+        if (ix->d_rows.p && ix->dense_rows) {
+            if (W / 4 <= 64) launch_rows(k2r_intersect<1>);
+            else if (W / 4 <= 128) launch_rows(k2r_intersect<2>);
+            else launch_rows(k2r_intersect<4>);
+        } else if (pair) launch(k2a_intersect<true>);
         else launch(k2a_intersect<false>);
     } else if (algo == FGPU_THRESHOLD_UNION) {
         // score counters from the longest read of the batch: biased 8-bit up to 127 k-mers, plain 8-bit up to 255, biased
@@ -646,7 +676,7 @@ void fgpu_close(fgpu_index* ix) {
     if (!ix) return;
     if (ix->device == FGPU_HOST_ONLY) { delete ix; return; }
     (void)hipSetDevice(ix->device);
-    for (DevBuf* b : {&ix->d_table, &ix->d_bmp_rows, &ix->d_offsets, &ix->d_set_rank,
+    for (DevBuf* b : {&ix->d_table, &ix->d_bmp_rows, &ix->d_offsets, &ix->d_set_rank, &ix->d_rows,
                       &ix->d_set_desc, &ix->d_blk_words, &ix->d_gops, &ix->d_gset_ops_off, &ix->d_gset_ops,
                       &ix->d_garena, &ix->d_gblk_hdr, &ix->d_gblk_words, &ix->d_gset_bytes})
         b->release();
@@ -1039,6 +1069,7 @@ int fgpu_tune(fgpu_index* ix, int knob, uint64_t value) {
     if (!ix) return fail(-EINVAL, "null argument");
     if (knob == FGPU_TUNE_ORDER_MIN_READS) ix->order_min_reads = value;
     else if (knob == FGPU_TUNE_SMALL_RESULTS) ix->small_results = value != 0;
+    else if (knob == FGPU_TUNE_DENSE_ROWS) ix->dense_rows = value != 0;
     else return fail(-EINVAL, "unknown knob");
     return 0;
 }

@@ -298,27 +298,61 @@ __global__ __launch_bounds__(256) void k_gather_ids(const uint32_t* __restrict__
 // scatter, ready for the next pass. The order inside a bucket is whatever the atomics give: results go to the
 // read's own row, so nothing observable depends on it.
 // ---------------------------------------------------------------------------------------------
+// The most common colour sets (the ORDER_HOT highest ranks) and the bucket of the reads without ids receive thousands of
+// reads each — atomics on one address serialise — so every block counts those keys in LDS and touches their global
+// counters once. Persistent blocks, each over a contiguous slice of the reads.
+constexpr uint32_t ORDER_HOT = 1023;  // + the bucket of reads without ids = 1024 LDS bins
 __global__ __launch_bounds__(256) void k_order_keys(const uint32_t* __restrict__ nids, const uint64_t* __restrict__ idoff,
                                                     const uint32_t* __restrict__ ids_pool, const uint32_t* __restrict__ set_rank,
                                                     uint32_t num_sets, uint64_t n_reads, uint32_t* __restrict__ keys,
                                                     uint32_t* __restrict__ hist) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
-    const uint32_t cnt = nids[r];
-    const uint64_t off = idoff[r];
-    uint32_t key = num_sets;
-    for (uint32_t i = 0; i < cnt; ++i) key = min(key, set_rank[ids_pool[off + i]]);
-    keys[r] = key;
-    atomicAdd(&hist[key], 1u);
+    __shared__ uint32_t hot[ORDER_HOT + 1];
+    for (uint32_t i = threadIdx.x; i <= ORDER_HOT; i += blockDim.x) hot[i] = 0;
+    __syncthreads();
+    const uint32_t hot_lo = num_sets > ORDER_HOT ? num_sets - ORDER_HOT : 0u;  // keys hot_lo .. num_sets
+    const uint64_t per = (n_reads + gridDim.x - 1) / gridDim.x;
+    const uint64_t r0 = min(n_reads, (uint64_t)blockIdx.x * per), r1 = min(n_reads, r0 + per);
+    for (uint64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+        const uint32_t cnt = nids[r];
+        const uint64_t off = idoff[r];
+        uint32_t key = num_sets;
+        for (uint32_t i = 0; i < cnt; ++i) key = min(key, set_rank[ids_pool[off + i]]);
+        keys[r] = key;
+        if (key >= hot_lo) atomicAdd(&hot[key - hot_lo], 1u);
+        else atomicAdd(&hist[key], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= ORDER_HOT; i += blockDim.x)
+        if (hot[i] && hot_lo + i <= num_sets) atomicAdd(&hist[hot_lo + i], hot[i]);
 }
-__global__ __launch_bounds__(256) void k_order_scatter(const uint32_t* __restrict__ keys, uint64_t n_reads,
+// same grid as k_order_keys (the slices must be the same)
+__global__ __launch_bounds__(256) void k_order_scatter(const uint32_t* __restrict__ keys, uint32_t num_sets, uint64_t n_reads,
                                                        const uint64_t* __restrict__ bucket_off, uint32_t* __restrict__ hist,
                                                        uint32_t* __restrict__ order) {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
-    const uint32_t key = keys[r];
-    const uint32_t left = atomicSub(&hist[key], 1u);  // counts down to zero
-    order[bucket_off[key] + left - 1u] = (uint32_t)r;
+    __shared__ uint32_t hot_cnt[ORDER_HOT + 1], hot_base[ORDER_HOT + 1];
+    for (uint32_t i = threadIdx.x; i <= ORDER_HOT; i += blockDim.x) hot_cnt[i] = 0;
+    __syncthreads();
+    const uint32_t hot_lo = num_sets > ORDER_HOT ? num_sets - ORDER_HOT : 0u;
+    const uint64_t per = (n_reads + gridDim.x - 1) / gridDim.x;
+    const uint64_t r0 = min(n_reads, (uint64_t)blockIdx.x * per), r1 = min(n_reads, r0 + per);
+    for (uint64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+        const uint32_t key = keys[r];
+        if (key >= hot_lo) atomicAdd(&hot_cnt[key - hot_lo], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i <= ORDER_HOT; i += blockDim.x) {  // this block's places in every hot bucket
+        const uint32_t c = hot_cnt[i];
+        hot_base[i] = c ? atomicSub(&hist[hot_lo + i], c) - c : 0u;
+        hot_cnt[i] = 0;
+    }
+    __syncthreads();
+    for (uint64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+        const uint32_t key = keys[r];
+        uint32_t place;
+        if (key >= hot_lo) place = hot_base[key - hot_lo] + atomicAdd(&hot_cnt[key - hot_lo], 1u);
+        else place = atomicSub(&hist[key], 1u) - 1u;  // counts down to zero
+        order[bucket_off[key] + place] = (uint32_t)r;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_desc(const uint32_t* __restrict__ nids,
@@ -681,6 +715,154 @@ __global__ __launch_bounds__(256, 8) void k2a_intersect(DevColors c, const uint3
             c0 = n0;
             c1 = n1;
             pair = npair;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense rows: every colour set as a plain bitmap row of w32 words (16-byte aligned, zero behind colour n - 1).
+// 288 GB of HBM hold the rows of collections far beyond the benchmark's (0.85 M sets x 576 bytes = 0.49 GB), and a
+// row needs no descriptor, no block header and no decoder: its address is the colour-set id times the row size, the
+// intersection is an AND of registers. The rows are built on the device at upload from the packed blocks / bitmap
+// rows of the hybrid device form (k_rows_build), which stays the form of collections whose rows do not fit.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rows_build(DevColors c, uint64_t num_sets, uint32_t* __restrict__ rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_rb[];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t W = c.w32, W4 = W >> 2;
+    uint32_t* T = (uint32_t*)smem_rb + (size_t)wv * W;
+    uint4* T4 = (uint4*)T;
+    const uint32_t t_at = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr(T));
+    const uint32_t n = c.n, tail_word = n >> 5, tail_mask = (1u << (n & 31u)) - 1u;  // valid colours of the last word
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t id = wave; id < num_sets; id += nwaves) {
+        const ListDesc d = c.set_desc[id];
+        const int type = desc_type(d);
+        uint4* out4 = (uint4*)(rows + id * W);
+        if (type == D_ENC_BITMAP) {
+            const uint4* row = (const uint4*)(c.bmp_words + desc_body(d));
+            for (uint32_t g4 = lane; g4 < W4; g4 += 64) out4[g4] = row[g4];
+            continue;
+        }
+        for (uint32_t g4 = lane; g4 < W4; g4 += 64) T4[g4] = make_uint4(0u, 0u, 0u, 0u);
+        wave_lds_sync();
+        const uint32_t nblk = d.ncodes;
+        for (uint32_t s0 = 0; s0 < nblk; s0 += 64) {
+            BlockLane bl{0u, 0u, 0u, 0u};
+            const uint32_t sb = s0 + lane;
+            if (sb < nblk) {
+                const uint64_t hd = nblk == 1 ? d.soff : ((const uint64_t*)(c.blk_words + d.begin))[sb];
+                bl.word = (uint32_t)d.begin + blk_rel_word(hd);
+                bl.start = blk_start(hd);
+                bl.meta = blk_width(hd) | ((blk_count(hd) - 1u) << 5);
+            }
+            run_blocks(c.blk_words, bl, min(64u, nblk - s0), lane,
+                       [&](uint32_t v, uint32_t) { lds_or(lds_bit_word(t_at, v), 1u << (v & 31)); },
+                       [&](uint32_t wi, uint32_t x, uint32_t) { atomicOr(&T[wi], x); }, [](uint32_t) {});
+        }
+        wave_lds_sync();
+        for (uint32_t w = lane; w < W; w += 64) {
+            uint32_t x = T[w];
+            if (type == D_ENC_COMPLEMENT) x = ~x & (w < tail_word ? 0xFFFFFFFFu : (w == tail_word ? tail_mask : 0u));
+            rows[id * W + w] = x;
+        }
+        wave_lds_sync();
+    }
+}
+
+// K2r: full intersection over dense rows -> bitmap + cardinality (or, for small results, the colours themselves).
+// Semantics of `intersect` (ps_full_intersection.cpp:32-127): the set intersection of the given lists. One wave per read,
+// lane = 128 bits of the colour space (G groups of them for more than 8192 colours); the rows of up to UNROLL lists are in
+// flight at once, the accumulator never leaves the registers, no LDS. The reads of a pass come in locality order
+// (k_order_*), so the rows a ticket touches are mostly in the L2 of its XCD already.
+template <int G>
+__global__ __launch_bounds__(256, 8) void k2r_intersect(const uint32_t* __restrict__ rows, uint32_t W, const uint32_t* __restrict__ nids,
+                                                     const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
+                                                     uint64_t n_reads, uint32_t* __restrict__ out_bitmap,
+                                                     uint32_t* __restrict__ out_count, unsigned int* tickets,
+                                                     const uint32_t* __restrict__ order, uint32_t* __restrict__ small_out) {
+    constexpr uint32_t UNROLL = G == 1 ? 8u : (G == 2 ? 4u : 2u);
+    constexpr uint32_t BATCH = 16;
+    const int lane = lane_id();
+    const uint32_t W4 = W >> 2;
+    const WorkQueue wq{tickets, n_reads, BATCH};
+    uint64_t t_first;
+    uint32_t t_count;
+    const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu), zero = make_uint4(0u, 0u, 0u, 0u);
+    while (wq.pull(t_first, t_count)) {
+        const uint64_t tl = min(t_first + (uint64_t)lane, n_reads - 1);
+        const uint32_t rd_l = order ? order[tl] : (uint32_t)tl;  // the read behind place `lane` of the ticket
+        const uint32_t cnt_l = (uint32_t)lane < t_count ? nids[rd_l] : 0u;
+        const uint64_t off_l = idoff[rd_l];
+        auto fetch_ids = [&](uint32_t i) -> uint32_t {  // the first 64 ids of the ticket's read i, one per lane
+            const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, i);
+            return (uint32_t)lane < cn ? ids_pool[readlane_u64(off_l, i) + lane] : 0u;
+        };
+        uint32_t id_next = fetch_ids(0);
+        for (uint32_t ri = 0; ri < t_count; ++ri) {
+            const uint32_t nl = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, ri);
+            const uint32_t id_cur = id_next;
+            id_next = fetch_ids(min(ri + 1, 63u));  // (lanes past the ticket hold empty reads)
+            const uint64_t r = (uint32_t)__builtin_amdgcn_readlane((int)rd_l, ri);
+            uint4 acc[G];
+#pragma unroll
+            for (int q = 0; q < G; ++q) acc[q] = nl ? ones : zero;
+            for (uint32_t g = 0; g < nl; g += 64) {
+                uint32_t idg = id_cur;
+                if (g) idg = g + lane < nl ? ids_pool[readlane_u64(off_l, ri) + g + lane] : 0u;  // more than 64 lists: rare
+                const uint32_t m = min(64u, nl - g);
+                for (uint32_t i = 0; i < m; i += UNROLL) {
+                    uint4 x[UNROLL][G];
+#pragma unroll
+                    for (uint32_t j = 0; j < UNROLL; ++j) {
+                        if (i + j < m) {  // (wave-uniform)
+                            const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)idg, i + j);
+                            const uint4* row = (const uint4*)(rows + (uint64_t)id * W);
+#pragma unroll
+                            for (int q = 0; q < G; ++q) x[j][q] = q * 64 + (uint32_t)lane < W4 ? row[q * 64 + lane] : zero;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < G; ++q) x[j][q] = ones;
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < UNROLL; ++j)
+#pragma unroll
+                        for (int q = 0; q < G; ++q)
+                            acc[q] = make_uint4(acc[q].x & x[j][q].x, acc[q].y & x[j][q].y, acc[q].z & x[j][q].z, acc[q].w & x[j][q].w);
+                }
+            }
+            uint32_t pc = 0;
+#pragma unroll
+            for (int q = 0; q < G; ++q) pc += __popc(acc[q].x) + __popc(acc[q].y) + __popc(acc[q].z) + __popc(acc[q].w);
+            pc = wave_sum_u32(pc);
+            if (lane == 0) out_count[r] = pc;
+            if (small_out && pc <= SMALL_RESULT) {  // (wave-uniform) the colours themselves, no row
+                if (pc) {
+                    uint32_t* so = small_out + r * SMALL_RESULT;
+                    uint32_t at = 0;
+#pragma unroll
+                    for (int q = 0; q < G; ++q) {
+                        const uint4 x = acc[q];
+                        const uint32_t mq = __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
+                        const uint32_t incl = wave_incl_scan_u32(mq);
+                        uint32_t pos = at + incl - mq;
+                        const uint32_t c0w = (q * 64 + (uint32_t)lane) * 128u;
+                        for (uint32_t y = x.x; y; y &= y - 1) so[pos++] = c0w + (uint32_t)__builtin_ctz(y);
+                        for (uint32_t y = x.y; y; y &= y - 1) so[pos++] = c0w + 32u + (uint32_t)__builtin_ctz(y);
+                        for (uint32_t y = x.z; y; y &= y - 1) so[pos++] = c0w + 64u + (uint32_t)__builtin_ctz(y);
+                        for (uint32_t y = x.w; y; y &= y - 1) so[pos++] = c0w + 96u + (uint32_t)__builtin_ctz(y);
+                        at += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    }
+                }
+            } else {
+                // streamed past the L2 (nontemporal): the result rows are read back by another kernel, the L2 is for the lists
+                u32x4* bm4 = (u32x4*)(out_bitmap + r * W);
+#pragma unroll
+                for (int q = 0; q < G; ++q)
+                    if (q * 64 + (uint32_t)lane < W4)
+                        __builtin_nontemporal_store((u32x4){acc[q].x, acc[q].y, acc[q].z, acc[q].w}, &bm4[q * 64 + lane]);
+            }
         }
     }
 }
@@ -1283,17 +1465,31 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
             if (is_small) *lds16(k2b_stage_skew(v_wave + (mask_rank(sm) << 1))) = (uint16_t)lane;  // k-th small read of the ticket
             wave_lds_sync();
             const uint32_t nsm = (uint32_t)__popcll(sm);
-            for (uint32_t g = 0; g < nsm; g += 4) {
-                const uint32_t kk = g + ((uint32_t)lane >> 4), slot = (uint32_t)lane & 15u;
-                const uint32_t j = kk < nsm ? (uint32_t)*lds16(k2b_stage_skew(v_wave + (kk << 1))) : 0u;
-                const uint32_t cj = (uint32_t)__shfl((int)cnt_l, (int)j);
-                const uint64_t oj = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(off_l >> 32), (int)j) << 32) |
-                                    (uint32_t)__shfl((int)(uint32_t)off_l, (int)j);
-                if (kk < nsm && slot < cj) {
-                    const uint32_t v = __builtin_nontemporal_load(&small[(t_first + j) * SMALL_RESULT + slot]);
-                    colors[oj + slot] = v;
-                    // the colour's hit counter: round v >> 11 (low / high half of the word by its parity), entry v & 2047
-                    if (hit_partial) lds_add((v >> 12) * 8192u + ((v & 2047u) << 2), (v & 2048u) ? 0x10000u : 1u);
+            // all the loads of the ticket first (at most 32 small reads = 8 steps), then the stores: one latency per ticket
+            uint32_t v[8];
+            uint64_t dst[8];
+#pragma unroll
+            for (uint32_t g = 0; g < 8; ++g) {
+                dst[g] = ~0ull;
+                if (4 * g < nsm) {  // (wave-uniform)
+                    const uint32_t kk = 4 * g + ((uint32_t)lane >> 4), slot = (uint32_t)lane & 15u;
+                    const uint32_t j = kk < nsm ? (uint32_t)*lds16(k2b_stage_skew(v_wave + (kk << 1))) : 0u;
+                    const uint32_t cj = (uint32_t)__shfl((int)cnt_l, (int)j);
+                    const uint64_t oj = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(off_l >> 32), (int)j) << 32) |
+                                        (uint32_t)__shfl((int)(uint32_t)off_l, (int)j);
+                    if (kk < nsm && slot < cj) {
+                        v[g] = __builtin_nontemporal_load(&small[(t_first + j) * SMALL_RESULT + slot]);
+                        dst[g] = oj + slot;
+                    }
+                }
+            }
+#pragma unroll
+            for (uint32_t g = 0; g < 8; ++g) {
+                if (4 * g < nsm && dst[g] != ~0ull) {
+                    const uint32_t c = v[g];
+                    colors[dst[g]] = c;
+                    // the colour's hit counter: round c >> 11 (low / high half of the word by its parity), entry c & 2047
+                    if (hit_partial) lds_add((c >> 12) * 8192u + ((c & 2047u) << 2), (c & 2048u) ? 0x10000u : 1u);
                 }
             }
             wave_lds_sync();

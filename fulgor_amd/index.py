@@ -254,12 +254,14 @@ class Index:
             count = reads.n - first
         _native.check(self._L.fgpu_run(self._h, reads._h, first, count, algo, C.c_double(threshold), result._h))
 
-    def tune(self, order_min_reads=None, small_results=None):
+    def tune(self, order_min_reads=None, small_results=None, dense_rows=None):
         """execution knobs of the colour stage (fgpu_tune); results never depend on them"""
         if order_min_reads is not None:
             _native.check(self._L.fgpu_tune(self._h, 0, int(order_min_reads) if order_min_reads >= 0 else 0xFFFFFFFFFFFFFFFF))
         if small_results is not None:
             _native.check(self._L.fgpu_tune(self._h, 1, 1 if small_results else 0))
+        if dense_rows is not None:
+            _native.check(self._L.fgpu_tune(self._h, 2, 1 if dense_rows else 0))
 
     def timing_enable(self, on=True):
         _native.check(self._L.fgpu_timing_enable(self._h, 1 if on else 0))

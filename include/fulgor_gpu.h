@@ -115,8 +115,11 @@ int fgpu_result_algorithmic_bytes(const fgpu_result* res, uint64_t* list_bytes, 
  *                              colour set among their ids, so that the lists of neighbouring reads are found in the L2);
  *                              UINT64_MAX = never. Default 16384 (environment: FULGOR_ORDER=0, FULGOR_ORDER_MIN_READS).
  *   FGPU_TUNE_SMALL_RESULTS    1 (default; environment FULGOR_SMALL=0): full-intersection results of at most 16 colours travel
- *                              between the intersection and the expansion kernel as colours instead of as a bitmap row. */
-enum { FGPU_TUNE_ORDER_MIN_READS = 0, FGPU_TUNE_SMALL_RESULTS = 1 };
+ *                              between the intersection and the expansion kernel as colours instead of as a bitmap row.
+ *   FGPU_TUNE_DENSE_ROWS       1 (default; environment FULGOR_DENSE_ROWS=0): the full intersection of a hybrid index runs on
+ *                              dense rows (every colour set as a plain bitmap row in HBM, built at load while they fit a quarter
+ *                              of the device's memory: FULGOR_ROWS_MAX_BYTES); 0: on the packed blocks of the gap-coded lists. */
+enum { FGPU_TUNE_ORDER_MIN_READS = 0, FGPU_TUNE_SMALL_RESULTS = 1, FGPU_TUNE_DENSE_ROWS = 2 };
 int fgpu_tune(fgpu_index* idx, int knob, uint64_t value);
 
 /* per-kernel HIP-event timing on the engine's stream */

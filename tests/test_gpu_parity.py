@@ -1128,8 +1128,8 @@ def test_pooled_buffers_and_reused_stream_results(s10_gpu, s10_oracle, tmp_path)
 
 
 def test_s4546_execution_knobs_do_not_change_results(s4546):
-    """fgpu_tune: the locality order of a pass (k_order_*: reads sorted by their rarest colour set, results at the read's own
-    row) and the small-result bypass (results of at most 16 colours travel from k2a to k2b as colours, no bitmap row) are
+    """fgpu_tune: dense rows (k2r_intersect) or packed blocks (k2a_intersect), the locality order of a pass (k_order_*: reads
+    sorted by their rarest colour set, results at the read's own row) and the small-result bypass (results of at most 16 colours travel from k2a to k2b as colours, no bitmap row) are
     execution choices — offsets, colours, hit counts and all three output formats must be the same bytes in every combination,
     and equal to the oracle's"""
     import torch
@@ -1144,8 +1144,9 @@ def test_s4546_execution_knobs_do_not_change_results(s4546):
     ncol = ix.num_colors()
     outs = []
     try:
-        for order_min, small in ((-1, False), (1, False), (-1, True), (1, True)):
-            ix.tune(order_min_reads=order_min, small_results=small)
+        for order_min, small, rows in ((-1, False, False), (1, False, False), (-1, True, False), (1, True, False),
+                                       (-1, False, True), (1, True, True)):
+            ix.tune(order_min_reads=order_min, small_results=small, dense_rows=rows)
             ix.run(rd, res, fulgor_amd.FULL_INTERSECTION)
             offs, cols = res.download()
             hits = torch.zeros(ncol + 2, dtype=torch.int64, device="cuda:0")
@@ -1155,7 +1156,7 @@ def test_s4546_execution_knobs_do_not_change_results(s4546):
             ix.run(rd, res, fulgor_amd.THRESHOLD_UNION, 0.8)  # (the union kernels under the same knobs)
             outs[-1] += res.download()
     finally:
-        ix.tune(order_min_reads=16384, small_results=True)
+        ix.tune(order_min_reads=16384, small_results=True, dense_rows=True)
     sz = np.diff(outs[0][0].astype(np.int64))
     assert (sz == 0).any() and ((sz > 0) & (sz <= 16)).sum() > n // 10 and (sz > 16).sum() > n // 10
     for other in outs[1:]:
@@ -1165,8 +1166,8 @@ def test_s4546_execution_knobs_do_not_change_results(s4546):
     oo, oc = orc.full_intersection(b, o, threads=32)
     assert np.array_equal(offs, oo) and np.array_equal(cols, oc)
     assert np.array_equal(hits[:ncol], np.bincount(cols, minlength=ncol)) and hits[ncol] == n and hits[ncol + 1] == (sz > 0).sum()
-    ids, po, pc = parse_compressed(Formatter("compressed", ncol).header + outs[3][5])
+    ids, po, pc = parse_compressed(Formatter("compressed", ncol).header + outs[5][5])
     assert np.array_equal(ids, np.arange(5, 5 + n, dtype=np.uint32)) and np.array_equal(po, offs) and np.array_equal(pc, cols)
-    assert outs[3][3] == Formatter("ascii", ncol).add(5, offs, cols)
+    assert outs[5][3] == Formatter("ascii", ncol).add(5, offs, cols)
     uo, uc = orc.threshold_union(b, o, 0.8, threads=32)
-    assert np.array_equal(outs[3][6], uo) and np.array_equal(outs[3][7], uc)
+    assert np.array_equal(outs[5][6], uo) and np.array_equal(outs[5][7], uc)
