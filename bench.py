@@ -6,6 +6,9 @@ A step = one pass of the hot path (k-mer lookup -> colour-set ids -> full-inters
 timed region starts; the per-colour hit counts are all-reduced over RCCL at the end of every step.
 Weak scaling: every rank gets `--reads` reads (rank r owns global reads [r*reads, (r+1)*reads)); the
 index is replicated. Prints ONE JSON line on rank 0.
+
+`python bench.py --gpus N` outside a launcher starts its own N ranks (one per GPU); under torchrun it takes
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 """
 import argparse
 import glob
@@ -28,18 +31,223 @@ def s10_genomes():
     return g
 
 
-def prepare_workload(name, rank):
-    """returns (index path, ReadGenerator, description). Rank 0 builds missing caches; others wait."""
+def prepare_workload(name):
+    """returns (index path, ReadGenerator, description); builds missing caches"""
     import __graft_entry__ as ge
+    from fulgor_amd import synth
     from fulgor_amd.reads import ReadGenerator
+    data = os.path.join(ROOT, "data")
     if name == "s10":
         fg, _ = ge._s10_index()
         return fg, ReadGenerator(s10_genomes()), "salmonella_10 (real genomes, 10 colours, 6.9M 31-mers, 171 colour sets)"
     if name == "s4546syn":
-        from fulgor_amd import synth
-        fg, extra = synth.ensure_s4546(os.path.join(ROOT, "data"), s10_genomes())
+        dump = os.environ.get("FULGOR_S4546_DUMP")
+        if dump:  # a real `fulgor dump` of salmonella_4546 (README.md:144-160 of the reference) takes the synthetic index's place
+            return real_dump_workload(dump, data)
+        fg, extra = synth.ensure_s4546(data, s10_genomes())
         return fg, ReadGenerator(s10_genomes(), raw_sequences=extra), synth.DESCRIPTION
+    if name == "s4546core":
+        fg, extra = synth.ensure_s4546_core(data, s10_genomes())
+        return fg, ReadGenerator(s10_genomes(), raw_sequences=extra), synth.DESCRIPTION_CORE
     raise SystemExit("unknown workload %s" % name)
+
+
+def real_dump_workload(base, data):
+    """FULGOR_S4546_DUMP=<basename>: the four text files of `fulgor dump -i salmonella_4546.fur` (src/index.cpp:59-120). The
+    index is ingested once into data/<name>.v7.fgidx; the reads are drawn by the same seeded generator from the unitig
+    sequences of the dump themselves (the genomes are not part of a dump): every unitig of at least 150 bases is a source
+    sequence, so reads stay inside unitigs — state it when quoting: fewer colour sets per read than reads across junctions."""
+    import fulgor_amd
+    from fulgor_amd.reads import ReadGenerator
+    for suffix in (".metadata.txt", ".unitigs.fa", ".color_sets.txt"):
+        if not os.path.exists(base + suffix):
+            raise SystemExit("FULGOR_S4546_DUMP=%s: %s%s is missing" % (base, base, suffix))
+    fg = os.path.join(data, os.path.basename(base) + ".v7.fgidx")
+    if not os.path.exists(fg) or os.path.getmtime(fg) < os.path.getmtime(base + ".color_sets.txt"):
+        os.makedirs(data, exist_ok=True)
+        ix = fulgor_amd.Index(base, device=-1)
+        ix.save(fg + ".tmp")
+        ix.close()
+        os.replace(fg + ".tmp", fg)
+    seqs = []
+    with open(base + ".unitigs.fa", "rb") as f:
+        for line in f:
+            if not line.startswith(b">") and len(line) > 150:
+                seqs.append(line.strip())
+    if not seqs:
+        raise SystemExit("FULGOR_S4546_DUMP=%s: no unitig of at least 150 bases to draw reads from" % base)
+    src = np.frombuffer(b"N".join(seqs), dtype=np.uint8)
+    return fg, ReadGenerator((), raw_sequences=[src]), "index ingested from the dump %s (reads drawn from its unitigs of >= 150 bases)" % base
+
+
+def launch_ranks(argv, gpus):
+    """--gpus N outside a launcher: one process per GPU with the environment torchrun would give it. The first rank that
+    fails takes the others down (they would otherwise wait in a collective until the process-group timeout)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = 1
+                for q in live:
+                    q.terminate()
+    return rc
+
+
+class Workload:
+    """an index resident on this rank's GPU + this rank's reads"""
+
+    def __init__(self, name, rank, local_rank, n_reads, read_len, index_type, psize, csize, prepared=None):
+        import fulgor_amd
+        fg, gen, desc = prepared or prepare_workload(name)
+        self.ix = fulgor_amd.Index(fg, device=local_rank)
+        self.itype = {"hybrid": 0, "diff": 1, "meta": 2, "meta-diff": 3}[index_type]
+        if self.itype:
+            self.ix.convert(self.itype, psize, csize)
+            desc += "; colour sets re-encoded as %s (partitions of %d colours, clusters of %d sets)" % (index_type, psize, csize)
+        self.desc = desc
+        self.n_reads = n_reads
+        self.read_len = read_len
+        self.bases, self.offs = gen.generate(rank * n_reads, n_reads, read_len, 42)
+        self.reads = self.ix.upload_reads(self.bases, self.offs)
+        self.ncol = self.ix.num_colors()
+
+    def close(self):
+        self.reads.close()
+        self.ix.close()
+
+
+def measure(w, algo, tau, chunk, steps, warmup, streams, local_rank, world=1, dist=None, share=False):
+    """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; returns the numbers of a bench line"""
+    import fulgor_amd
+    import torch
+    ix = w.ix
+    results = [ix.new_result() for _ in range(max(1, streams))]
+    hits = torch.zeros(w.ncol + 2, dtype=torch.int64, device="cuda:%d" % local_rank)
+    chunks = [(first, min(chunk, w.n_reads - first)) for first in range(0, w.n_reads, chunk)]
+
+    def worker(k):
+        for i in range(k, len(chunks), len(results)):
+            ix.run(w.reads, results[k], algo, tau, chunks[i][0], chunks[i][1])
+            results[k].accumulate_hits(hits.data_ptr())
+
+    def step():
+        hits.zero_()
+        torch.cuda.synchronize()
+        if len(results) == 1:
+            worker(0)
+        else:  # the C ABI calls release the GIL; every result owns its HIP stream
+            import threading
+            ts = [threading.Thread(target=worker, args=(k,)) for k in range(len(results))]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+        if world > 1:  # RCCL: per-colour hit counts + {reads, mapped}
+            if share:
+                h_cpu = hits.cpu()
+                dist.all_reduce(h_cpu)
+                hits.copy_(h_cpu)
+            else:
+                dist.all_reduce(hits)
+
+    for _ in range(warmup):
+        step()
+    ix.timing_enable(True)
+    ix.timing_reset()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda:%d" % local_rank)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timing = ix.timing()
+    ix.timing_enable(False)
+    h = hits.cpu().numpy()
+    # self check of the reduction: the reads of every rank are in the job's counters
+    if int(h[w.ncol]) != world * w.n_reads:
+        raise SystemExit("hit-count reduction is wrong: %d reads counted, %d ranks x %d reads expected" % (int(h[w.ncol]), world, w.n_reads))
+
+    # algorithmic bytes (SURVEY §8d) of one step on this rank, from the resident per-read id lists / sizes
+    acct = {"lists": 0, "output": 0, "lookup": 0}
+    total_colors = 0
+    for first, cnt in chunks:
+        ix.run(w.reads, results[0], algo, tau, first, cnt)
+        a = results[0].algorithmic_bytes()
+        for k_ in acct:
+            acct[k_] += a[k_]
+        total_colors += results[0].sizes()[1]
+    for r in results:
+        r.close()
+    stage_kernel = "k2_intersect" if algo == fulgor_amd.FULL_INTERSECTION else "k3_union"
+    kbytes = {"k1_lookup": acct["lookup"], stage_kernel: acct["lists"], "k2b_expand": acct["output"]}
+    return {"elapsed": elapsed, "timing": timing, "acct": acct, "kbytes": kbytes, "stage_kernel": stage_kernel,
+            "total_colors": total_colors, "reads_job": int(h[w.ncol]), "mapped_job": int(h[w.ncol + 1]), "steps": steps,
+            "launches_per_step": len(chunks)}
+
+
+def kernel_rooflines(m, traffic):
+    """per kernel: algorithmic bytes per launch / average launch time (HIP events on the engine's stream), the fraction of the
+    8 TB/s peak, and the HBM-side traffic per launch from the committed PMC passes (or null)"""
+    out = {}
+    for k_, b in m["kbytes"].items():
+        ms, launches = m["timing"][k_]
+        if not launches:
+            continue
+        per_launch = b / m["launches_per_step"]
+        achieved = per_launch / (ms / launches * 1e-3) / 1e9
+        out[k_] = {"avg_launch_ms": round(ms / launches, 4), "algorithmic_bytes_per_launch": int(per_launch),
+                   "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5),
+                   "traffic": (traffic or {}).get(k_)}
+    return out
+
+
+def stage_numbers(m):
+    """the colour stage as SURVEY §8d defines it: lists + ids + u32 output over every kernel between the lookup and the CSR"""
+    stage = [m["stage_kernel"], "k_desc", "k_order", "scan", "k2b_expand"]
+    stage_ms = sum(m["timing"][k_][0] for k_ in stage) / m["steps"]
+    b = m["acct"]["lists"] + m["acct"]["output"]
+    return {"kernels": [k_ for k_ in stage if m["timing"][k_][1]], "bytes_per_step": b, "ms_per_step": round(stage_ms, 4),
+            "achieved": round(b / (stage_ms * 1e-3) / 1e9, 2), "frac": round(b / (stage_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+
+
+def load_traffic(workload, itype, algo_name, chunk, n_reads):
+    """HBM-side bytes per launch and kernel from the committed rocprofv3 PMC passes of this build (profiles/traffic.json, made by
+    profiles/traffic_from_pmc.py with the calibrated FETCH_SIZE factors); only quoted for the configuration the counters were
+    collected on (same workload, codec, algorithm and reads per launch), otherwise null."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if (workload == tj.get("workload", "s4546syn") and itype == 0 and tj["reads_per_launch"] == chunk and n_reads >= chunk
+                and tj.get("algo", "full-intersection") == algo_name):
+            return {k_: v["total"] for k_, v in tj["kernels"].items()}, tj["source"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
 
 
 def main():
@@ -47,7 +255,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default=os.environ.get("FULGOR_BENCH_WORKLOAD", "s4546syn"), choices=["s4546syn", "s10"])
+    ap.add_argument("--workload", default=os.environ.get("FULGOR_BENCH_WORKLOAD", "s4546syn"), choices=["s4546syn", "s4546core", "s10"])
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the BASELINE config size)")
     ap.add_argument("--algo", default="full-intersection", choices=["full-intersection", "threshold-union"])
     ap.add_argument("--tau", type=float, default=0.8)
@@ -61,12 +269,17 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="passes in flight per GPU: chunk i runs on stream i %% streams (own result buffers, own host thread)")
     ap.add_argument("--read-len", type=int, default=150, help="read length in bases (the metric is quoted on 150)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--order", type=int, default=1, help="0: take the reads of a pass in file order (fgpu_tune; A/B measurements)")
-    ap.add_argument("--small", type=int, default=1, help="0: a bitmap row for every result (fgpu_tune; A/B measurements)")
-    ap.add_argument("--rows", type=int, default=1, help="0: full intersection on the packed blocks, not on dense rows (fgpu_tune; A/B measurements)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the PCIe / command-line legs")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary workloads (threshold union, meta-diff codec, core-heavy index)")
+    ap.add_argument("--order", type=int, default=None, help="1: passes in locality order, 0: in file order (fgpu_tune; A/B measurements)")
+    ap.add_argument("--small", type=int, default=None, help="0: a bitmap row for every result (fgpu_tune; A/B measurements)")
+    ap.add_argument("--rows", type=int, default=None,
+                    help="0: full intersection on the packed blocks, not on dense rows (fgpu_tune; A/B measurements)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -76,13 +289,16 @@ def main():
     import __graft_entry__ as ge
     # Rank 0 builds the library and the index caches BEFORE any rank joins the process group; the other ranks wait for a marker
     # file, not inside a collective: a slow build (cold box, 40 s to minutes for the synthetic index) cannot run into the
-    # process-group timeout.
-    marker = os.path.join(ROOT, "data", ".bench_ready_%s_%s" % (args.workload, os.environ.get("MASTER_PORT", "0")))
+    # process-group timeout. The marker's name carries this launch (launcher pid, port, restart count), so a file that a
+    # crashed earlier run left behind is never mistaken for this run's.
+    nonce = "%s_%s_%s_%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "x"), os.getppid(), os.environ.get("MASTER_PORT", "0"),
+                             os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+    marker = os.path.join(ROOT, "data", ".bench_ready_%s_%s" % (args.workload, nonce))
     if rank == 0:
         if os.path.exists(marker):
             os.remove(marker)
         ge.build()
-        fg, gen, desc = prepare_workload(args.workload, rank)
+        prepared = prepare_workload(args.workload)
         os.makedirs(os.path.dirname(marker), exist_ok=True)
         open(marker, "w").close()
     else:
@@ -91,7 +307,7 @@ def main():
             if time.time() - t_wait > 3600:
                 raise SystemExit("rank 0 did not finish preparing the workload within an hour")
             time.sleep(0.5)
-        fg, gen, desc = prepare_workload(args.workload, rank)
+        prepared = prepare_workload(args.workload)
     import fulgor_amd  # binds libfulgor_gpu.so to torch's HIP runtime (fulgor_amd/_native.py)
     import torch
     import torch.distributed as dist
@@ -101,167 +317,119 @@ def main():
     if share:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    backend = None
     if world > 1:
         import datetime
+        backend = "gloo" if share else "nccl"
         if share:
             dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=30))
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(minutes=30))
         dist.barrier()
-        if rank == 0 and os.path.exists(marker):
-            os.remove(marker)
+    if rank == 0 and os.path.exists(marker):
+        os.remove(marker)
 
-    default_reads = {"s10": 1_000_000, "s4546syn": 10_000_000}
+    default_reads = {"s10": 1_000_000, "s4546syn": 10_000_000, "s4546core": 5_000_000}
     n_reads = args.reads or default_reads[args.workload]
-
-    ix = fulgor_amd.Index(fg, device=local_rank)
-    if not args.order or not args.small or not args.rows:
-        ix.tune(order_min_reads=None if args.order else -1, small_results=bool(args.small), dense_rows=bool(args.rows))
-    itype = {"hybrid": 0, "diff": 1, "meta": 2, "meta-diff": 3}[args.index_type]
-    if itype:
-        ix.convert(itype, args.partition_size, args.cluster_size)
-        desc += "; colour sets re-encoded as %s (partitions of %d colours, clusters of %d sets)" % (
-            args.index_type, args.partition_size, args.cluster_size)
+    w = Workload(args.workload, rank, local_rank, n_reads, args.read_len, args.index_type, args.partition_size, args.cluster_size, prepared)
+    if args.order is not None or args.small is not None or args.rows is not None:
+        w.ix.tune(order_min_reads=None if args.order is None else (16384 if args.order else -1),
+                  small_results=None if args.small is None else bool(args.small),
+                  dense_rows=None if args.rows is None else bool(args.rows))
     algo = fulgor_amd.FULL_INTERSECTION if args.algo == "full-intersection" else fulgor_amd.THRESHOLD_UNION
-    bases, offs = gen.generate(rank * n_reads, n_reads, args.read_len, 42)
-    reads = ix.upload_reads(bases, offs)
-    results = [ix.new_result() for _ in range(max(1, args.streams))]
-    res = results[0]
-    ncol = ix.num_colors()
-    hits = torch.zeros(ncol + 2, dtype=torch.int64, device="cuda:%d" % local_rank)
-    chunks = [(first, min(args.chunk, n_reads - first)) for first in range(0, n_reads, args.chunk)]
-
-    def worker(w):
-        for i in range(w, len(chunks), len(results)):
-            ix.run(reads, results[w], algo, args.tau, chunks[i][0], chunks[i][1])
-            results[w].accumulate_hits(hits.data_ptr())
-
-    def step():
-        hits.zero_()
-        torch.cuda.synchronize()
-        if len(results) == 1:
-            worker(0)
-        else:  # the C ABI calls release the GIL; every result owns its HIP stream
-            import threading
-            ts = [threading.Thread(target=worker, args=(w,)) for w in range(len(results))]
-            for t in ts:
-                t.start()
-            for t in ts:
-                t.join()
-        if world > 1:  # RCCL: per-colour hit counts + {reads, mapped}
-            if share:
-                h_cpu = hits.cpu()
-                dist.all_reduce(h_cpu)
-                hits.copy_(h_cpu)
-            else:
-                dist.all_reduce(hits)
-
-    for _ in range(args.warmup):
-        step()
-    ix.timing_enable(True)
-    ix.timing_reset()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda:%d" % local_rank)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    timing = ix.timing()
-    ix.timing_enable(False)
-    h = hits.cpu().numpy()
-    total_reads_job, mapped_job = int(h[ncol]), int(h[ncol + 1])
-
-    # algorithmic bytes of one step on this rank, from the resident per-read id lists / sizes
-    acct = {"lists": 0, "output": 0, "lookup": 0}
-    total_colors = 0
-    for first in range(0, n_reads, args.chunk):
-        cnt = min(args.chunk, n_reads - first)
-        ix.run(reads, res, algo, args.tau, first, cnt)
-        a = res.algorithmic_bytes()
-        for k_ in acct:
-            acct[k_] += a[k_]
-        total_colors += res.sizes()[1]
+    m = measure(w, algo, args.tau, args.chunk, args.steps, args.warmup, args.streams, local_rank, world, dist, share)
 
     if rank == 0:
-        stage_kernel = "k2a_intersect" if algo == fulgor_amd.FULL_INTERSECTION else "k3a_union"
-        kbytes = {"k1_lookup": acct["lookup"], stage_kernel: acct["lists"], "k2b_expand": acct["output"]}
-        cand = {k_: timing[k_] for k_ in kbytes if timing[k_][1] > 0}
-        dom = max(cand, key=lambda k_: cand[k_][0])
-        dom_ms, dom_launches = cand[dom]
-        launches_per_step = dom_launches / args.steps
-        avg_ms = dom_ms / dom_launches
-        achieved = kbytes[dom] / launches_per_step / (avg_ms * 1e-3) / 1e9
-        kernels = {k_: {"avg_ms": round(v[0] / v[1], 4), "launches": v[1]} for k_, v in timing.items() if v[1]}
-        stage_ms = sum(timing[k_][0] for k_ in (stage_kernel, "k_order", "scan", "k2b_expand")) / args.steps
-        # HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
-        # build (profiles/traffic.json, made by profiles/traffic_from_pmc.py); only quoted for the configuration the
-        # counters were collected on (same workload, codec and reads per launch), otherwise null.
-        traffic, traffic_src = None, None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if (args.workload == "s4546syn" and itype == 0 and tj["reads_per_launch"] == args.chunk and n_reads >= args.chunk
-                    and tj.get("algo", "full-intersection") == args.algo
-                    and dom in tj["kernels"]):
-                traffic, traffic_src = tj["kernels"][dom]["total"], tj["source"]
-        except (OSError, ValueError, KeyError):
-            pass
+        traffic, traffic_src = load_traffic(args.workload, w.itype, args.algo, args.chunk, n_reads)
+        per_kernel = kernel_rooflines(m, traffic)
+        dom = max(per_kernel, key=lambda k_: per_kernel[k_]["avg_launch_ms"])
+        kernels = {k_: {"avg_ms": round(v[0] / v[1], 4), "launches": v[1]} for k_, v in m["timing"].items() if v[1]}
         out = {
             "metric": "pseudoaligned reads/sec (%d bp, k=31)" % args.read_len,
-            "value": round(world * n_reads * args.steps / elapsed, 1),
+            "value": round(world * n_reads * args.steps / m["elapsed"], 1),
             "unit": "reads/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step": round(m["elapsed"] / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": "%s, %s, %d synthetic %d bp reads per GPU (seed 42), k=31, chunk %d reads/pass"
-                                   % (desc, args.algo + (" tau=%g" % args.tau if algo else ""), n_reads, args.read_len, args.chunk),
-                       "index_replicated": True, "reads_per_gpu": n_reads, "streams": len(results),
-                       "mapped_fraction": round(mapped_job / max(1, total_reads_job), 4),
-                       "avg_colours_per_read": round(total_colors / n_reads, 2)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": int(kbytes[dom] / launches_per_step),
-                         "avg_launch_ms": round(avg_ms, 4),
-                         "stage": {"kernels": [stage_kernel, "k_order", "scan", "k2b_expand"],
-                                   "bytes_per_step": acct["lists"] + acct["output"], "ms_per_step": round(stage_ms, 4),
-                                   "achieved": round((acct["lists"] + acct["output"]) / (stage_ms * 1e-3) / 1e9, 2)}},
+                                   % (w.desc, args.algo + (" tau=%g" % args.tau if algo else ""), n_reads, args.read_len, args.chunk),
+                       "index_replicated": True, "reads_per_gpu": n_reads, "streams": max(1, args.streams),
+                       "mapped_fraction": round(m["mapped_job"] / max(1, m["reads_job"]), 4),
+                       "avg_colours_per_read": round(m["total_colors"] / n_reads, 2)},
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "collective_backend": backend,
+            "roofline": dict({"bound": "hbm", "kernel": dom, "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+                             **{k_: per_kernel[dom][k_] for k_ in ("achieved", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms")},
+                             traffic_source=traffic_src, kernels=per_kernel, stage=stage_numbers(m)),
             "kernels": kernels,
         }
+        if world == 1 and not args.no_secondary and args.workload == "s4546syn" and w.itype == 0 and algo == fulgor_amd.FULL_INTERSECTION:
+            out["secondary"] = secondary(w, args, local_rank)
         if world == 1 and not args.no_cpu_baseline:
-            out["end_to_end"] = end_to_end(ix, bases, offs, algo, args.tau, min(n_reads, 1 << 20), 0)
-            out["end_to_end_compressed"] = end_to_end(ix, bases, offs, algo, args.tau, min(n_reads, 1 << 20), 2)
+            out["end_to_end"] = end_to_end(w.ix, w.bases, w.offs, algo, args.tau, min(n_reads, 1 << 20), 0)
+            out["end_to_end_compressed"] = end_to_end(w.ix, w.bases, w.offs, algo, args.tau, min(n_reads, 1 << 20), 2)
             try:
-                out["cli_end_to_end"] = cli_end_to_end(ix, bases, offs, algo, args.tau, min(n_reads, 10_000_000), args.read_len)
+                out["cli_end_to_end"] = cli_end_to_end(w.ix, w.bases, w.offs, algo, args.tau, min(n_reads, 10_000_000), args.read_len)
             except Exception as e:  # (no room for the FASTQ file, ...): the bench line must not depend on this leg
                 out["cli_end_to_end"] = {"value": None, "error": str(e)[:200]}
-            out["cpu_baseline"] = cpu_baseline(ix, bases, offs, algo, args.tau, itype, args.partition_size, args.cluster_size)
+            out["cpu_baseline"] = cpu_baseline(w.ix, w.bases, w.offs, algo, args.tau, w.itype, args.partition_size, args.cluster_size)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
+def secondary(w, args, local_rank):
+    """the other BASELINE configurations in the same driver-run line, 3 timed steps each on this GPU: configs[3] (threshold
+    union, tau = 0.8), the meta-differential codec of configs[4] (its per-GPU kernel path; the 8-GPU form is the --gpus run),
+    and the full intersection on the core-heavy profile of the synthetic index (dense results: bounds the workload risk)"""
+    import fulgor_amd
+
+    def entry(wl, m, n_reads):
+        return {"value": round(n_reads * m["steps"] / m["elapsed"], 1), "unit": "reads/s", "reads": n_reads, "steps": m["steps"],
+                "ms_per_step": round(m["elapsed"] / m["steps"] * 1e3, 3), "workload": wl.desc,
+                "avg_colours_per_read": round(m["total_colors"] / n_reads, 2),
+                "kernels": {k_: {"avg_ms": round(v[0] / v[1], 4), "launches": v[1]} for k_, v in m["timing"].items() if v[1]},
+                "roofline_kernels": kernel_rooflines(m, None), "stage": stage_numbers(m)}
+
+    out = {}
+    try:
+        m = measure(w, fulgor_amd.THRESHOLD_UNION, 0.8, args.chunk, 3, 1, 1, local_rank)
+        out["threshold_union_0.8"] = entry(w, m, w.n_reads)
+    except Exception as e:  # noqa: BLE001 — a secondary entry must not take the line down
+        out["threshold_union_0.8"] = {"value": None, "error": str(e)[:300]}
+    full, desc = w.n_reads, w.desc
+    try:
+        w.ix.convert(3, args.partition_size, args.cluster_size)
+        w.desc = desc + "; colour sets re-encoded as meta-diff (partitions of %d colours, clusters of %d sets)" % (args.partition_size, args.cluster_size)
+        w.n_reads = min(full, 5_000_000)  # (the first 5 M reads of the same resident read set)
+        m = measure(w, fulgor_amd.FULL_INTERSECTION, 0.0, args.chunk, 3, 1, 1, local_rank)
+        out["meta_diff"] = entry(w, m, w.n_reads)
+    except Exception as e:  # noqa: BLE001
+        out["meta_diff"] = {"value": None, "error": str(e)[:300]}
+    finally:
+        w.n_reads, w.desc = full, desc
+        w.ix.convert(0)
+    try:
+        wc = Workload("s4546core", 0, local_rank, 5_000_000, args.read_len, "hybrid", 0, 0)
+        m = measure(wc, fulgor_amd.FULL_INTERSECTION, 0.0, args.chunk, 3, 1, 1, local_rank)
+        out["core_heavy"] = entry(wc, m, wc.n_reads)
+        wc.close()
+    except Exception as e:  # noqa: BLE001
+        out["core_heavy"] = {"value": None, "error": str(e)[:300]}
+    return out
+
+
 def end_to_end(ix, bases, offs, algo, tau, n, fmt):
     """PCIe-inclusive rate of one bounded pass (SURVEY §8d timing protocol): host-resident reads -> H2D -> kernels ->
     records formatted on the device (0 ascii, 2 the reference's compressed format) -> D2H of the output into host
     memory. Reported beside `value`, never as it."""
-    import fulgor_amd
     b, o = bases[:int(offs[n])], offs[:n + 1]
     res = ix.new_result()
     best = None

@@ -63,7 +63,7 @@ void upload(DevBuf& b, const std::vector<T>& v, hipStream_t s) {
 
 constexpr size_t TICKET_BYTES = 3 * 8 * TICKET_STRIDE * sizeof(unsigned int);
 
-const char* KERNEL_NAMES[FGPU_K_COUNT] = {"k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits", "k_desc", "k_format", "k_order"};
+const char* KERNEL_NAMES[FGPU_K_COUNT] = {"k1_lookup", "k2_intersect", "k3_union", "scan", "k2b_expand", "k_hits", "k_desc", "k_format", "k_order"};
 
 // defaults of the fgpu_tune knobs from the environment (measurement: FULGOR_ORDER=0 takes the reads of a pass in file order,
 // FULGOR_ORDER_MIN_READS sets the smallest pass that is ordered, FULGOR_SMALL=0 writes a bitmap row for every result)
@@ -80,7 +80,7 @@ struct fgpu_index {
     hipStream_t stream = nullptr;
     int num_cus = 256;
     // fgpu_tune
-    uint64_t order_min_reads = env_u64("FULGOR_ORDER", 1) ? env_u64("FULGOR_ORDER_MIN_READS", 16384) : ~0ull;
+    uint64_t order_min_reads = env_u64("FULGOR_ORDER", 0) ? env_u64("FULGOR_ORDER_MIN_READS", 16384) : ~0ull;  // off: measured, no gain
     bool small_results = env_u64("FULGOR_SMALL", 1) != 0;
     bool dense_rows = env_u64("FULGOR_DENSE_ROWS", 1) != 0;  // use the dense rows (when they were built: d_rows)
     DevBuf d_table, d_bmp_rows, d_offsets, d_set_desc, d_blk_words, d_set_rank, d_rows;
@@ -334,7 +334,7 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     const uint32_t stride = std::max<uint32_t>(1, rd->max_kmers);  // at most one id per k-mer
     res->id_stride = stride;
     res->pool_units = units;
-    res->d_ids_pool.ensure(units * (uint64_t)stride * 4 + 16);
+    res->d_ids_pool.ensure(units * (uint64_t)stride * 4 + 64);  // (k2r_intersect reads the ids eight at a time)
     res->d_cnt_pool.ensure(units * (uint64_t)stride * 4 + 16);
     res->have_ids = true;
     uint32_t* kmer_out = nullptr;
@@ -378,7 +378,7 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     res->d_nids2.ensure(count * 4 + 16);
     res->d_npos2.ensure(count * 4 + 16);
     res->d_idoff2.ensure(count * 8 + 16);
-    res->d_ids_pool2.ensure(units * (uint64_t)stride * 4 + 16);
+    res->d_ids_pool2.ensure(units * (uint64_t)stride * 4 + 64);
     res->d_cnt_pool2.ensure(units * (uint64_t)stride * 4 + 16);
     {
         Timed t(ix, res, FGPU_K_LOOKUP);
@@ -541,7 +541,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         auto launch_rows = [&](auto kernel) {
             const uint32_t grid = resident_grid(kernel, n, 4, ix->num_cus, 256, 0);
             Timed t(ix, res, FGPU_K_INTERSECT);
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, ix->d_rows.as<uint32_t>(), W, res->d_nids.as<uint32_t>(),
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, ix->d_rows.as<u32x4>(), W, res->d_nids.as<uint32_t>(),
                                res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), n, res->d_bitmap.as<uint32_t>(),
                                res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, order, small_out);
             HIP_TRY(hipGetLastError());
@@ -1194,7 +1194,7 @@ int fgpu_intersect_ids(fgpu_index* ix, const uint32_t* ids, const uint64_t* id_o
         res->d_nids.ensure(n * 4 + 16);
         res->d_npos.ensure(n * 4 + 16);
         res->d_idoff.ensure(n * 8 + 16);
-        res->d_ids_pool.ensure(id_offs[n] * 4 + 16);
+        res->d_ids_pool.ensure(id_offs[n] * 4 + 64);
         if (n) {
             HIP_TRY(hipMemcpy(res->d_nids.p, nids.data(), n * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(res->d_idoff.p, id_offs, n * 8, hipMemcpyHostToDevice));

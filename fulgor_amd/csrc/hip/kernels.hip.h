@@ -775,63 +775,77 @@ __global__ __launch_bounds__(256) void k_rows_build(DevColors c, uint64_t num_se
 // lane = 128 bits of the colour space (G groups of them for more than 8192 colours); the rows of up to UNROLL lists are in
 // flight at once, the accumulator never leaves the registers, no LDS. The reads of a pass come in locality order
 // (k_order_*), so the rows a ticket touches are mostly in the L2 of its XCD already.
+// AND of the rows of the first K of eight colour sets into acc: K x G unconditional 16-byte loads back to back, then the ANDs —
+// no control flow between the requests, so that all of them are in flight together. The ids are scalars: a row's address is a
+// scalar base plus the lane's offset.
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef u32x8 u32x8_a4 __attribute__((aligned(4)));
+template <int K, int G>
+__device__ __forceinline__ void rows_and(const u32x4* __restrict__ rows4, uint32_t W4, const u32x8 id, const uint32_t (&lo)[G], u32x4 (&acc)[G]) {
+    u32x4 x[K][G];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const u32x4* row = rows4 + (uint64_t)id[j] * W4;
+#pragma unroll
+        for (int q = 0; q < G; ++q) x[j][q] = row[lo[q]];
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int q = 0; q < G; ++q) acc[q] &= x[j][q];
+}
+
 template <int G>
-__global__ __launch_bounds__(256, 8) void k2r_intersect(const uint32_t* __restrict__ rows, uint32_t W, const uint32_t* __restrict__ nids,
+__global__ __launch_bounds__(256, 8) void k2r_intersect(const u32x4* __restrict__ rows4, uint32_t W, const uint32_t* __restrict__ nids,
                                                      const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
                                                      uint64_t n_reads, uint32_t* __restrict__ out_bitmap,
                                                      uint32_t* __restrict__ out_count, unsigned int* tickets,
                                                      const uint32_t* __restrict__ order, uint32_t* __restrict__ small_out) {
-    constexpr uint32_t UNROLL = G == 1 ? 8u : (G == 2 ? 4u : 2u);
     constexpr uint32_t BATCH = 16;
     const int lane = lane_id();
     const uint32_t W4 = W >> 2;
     const WorkQueue wq{tickets, n_reads, BATCH};
     uint64_t t_first;
     uint32_t t_count;
-    const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu), zero = make_uint4(0u, 0u, 0u, 0u);
+    // the 128-bit group(s) of this lane; lanes past the row load its last group (and are cleared at the end)
+    uint32_t lo[G];
+#pragma unroll
+    for (int q = 0; q < G; ++q) lo[q] = min(q * 64 + (uint32_t)lane, W4 - 1);
+    // The ids of a read are fetched with SCALAR loads, eight at a time (wave-uniform address, read-only data): they arrive
+    // through the scalar cache and their own counter, so no vector-memory wait — which would also wait for the stores of the
+    // read before, one in-order counter — stands between two reads. (The eight words may reach past the read's list, into
+    // the slack behind the id pool at worst; only the first nl are used.)
+    typedef const __attribute__((address_space(4))) u32x8_a4* ids8_ptr;
     while (wq.pull(t_first, t_count)) {
         const uint64_t tl = min(t_first + (uint64_t)lane, n_reads - 1);
         const uint32_t rd_l = order ? order[tl] : (uint32_t)tl;  // the read behind place `lane` of the ticket
         const uint32_t cnt_l = (uint32_t)lane < t_count ? nids[rd_l] : 0u;
         const uint64_t off_l = idoff[rd_l];
-        auto fetch_ids = [&](uint32_t i) -> uint32_t {  // the first 64 ids of the ticket's read i, one per lane
-            const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, i);
-            return (uint32_t)lane < cn ? ids_pool[readlane_u64(off_l, i) + lane] : 0u;
-        };
-        uint32_t id_next = fetch_ids(0);
+        // (the scalars of read ri + 1 are taken out of the lanes at the end of read ri: the ticket's loads are waited for once,
+        // in front of the loop, not at the top of every read — where the wait would also cover the stores of the read before)
+        uint32_t nl = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, 0);
+        uint64_t r = (uint32_t)__builtin_amdgcn_readlane((int)rd_l, 0);
+        const uint32_t* ids = ids_pool + readlane_u64(off_l, 0);
         for (uint32_t ri = 0; ri < t_count; ++ri) {
-            const uint32_t nl = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, ri);
-            const uint32_t id_cur = id_next;
-            id_next = fetch_ids(min(ri + 1, 63u));  // (lanes past the ticket hold empty reads)
-            const uint64_t r = (uint32_t)__builtin_amdgcn_readlane((int)rd_l, ri);
-            uint4 acc[G];
+            u32x4 acc[G];
 #pragma unroll
-            for (int q = 0; q < G; ++q) acc[q] = nl ? ones : zero;
-            for (uint32_t g = 0; g < nl; g += 64) {
-                uint32_t idg = id_cur;
-                if (g) idg = g + lane < nl ? ids_pool[readlane_u64(off_l, ri) + g + lane] : 0u;  // more than 64 lists: rare
-                const uint32_t m = min(64u, nl - g);
-                for (uint32_t i = 0; i < m; i += UNROLL) {
-                    uint4 x[UNROLL][G];
-#pragma unroll
-                    for (uint32_t j = 0; j < UNROLL; ++j) {
-                        if (i + j < m) {  // (wave-uniform)
-                            const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)idg, i + j);
-                            const uint4* row = (const uint4*)(rows + (uint64_t)id * W);
-#pragma unroll
-                            for (int q = 0; q < G; ++q) x[j][q] = q * 64 + (uint32_t)lane < W4 ? row[q * 64 + lane] : zero;
-                        } else {
-#pragma unroll
-                            for (int q = 0; q < G; ++q) x[j][q] = ones;
-                        }
-                    }
-#pragma unroll
-                    for (uint32_t j = 0; j < UNROLL; ++j)
-#pragma unroll
-                        for (int q = 0; q < G; ++q)
-                            acc[q] = make_uint4(acc[q].x & x[j][q].x, acc[q].y & x[j][q].y, acc[q].z & x[j][q].z, acc[q].w & x[j][q].w);
+            for (int q = 0; q < G; ++q) acc[q] = nl && q * 64 + (uint32_t)lane < W4 ? u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu} : u32x4{0u, 0u, 0u, 0u};
+            auto round8 = [&](const uint32_t* p, uint32_t left) {  // (left wave-uniform) the rows of up to eight lists in one round
+                const u32x8 id = *(ids8_ptr)p;
+                switch (min(left, 8u)) {
+                    case 1: rows_and<1, G>(rows4, W4, id, lo, acc); break;
+                    case 2: rows_and<2, G>(rows4, W4, id, lo, acc); break;
+                    case 3: rows_and<3, G>(rows4, W4, id, lo, acc); break;
+                    case 4: rows_and<4, G>(rows4, W4, id, lo, acc); break;
+                    case 5: rows_and<5, G>(rows4, W4, id, lo, acc); break;
+                    case 6: rows_and<6, G>(rows4, W4, id, lo, acc); break;
+                    case 7: rows_and<7, G>(rows4, W4, id, lo, acc); break;
+                    default: rows_and<8, G>(rows4, W4, id, lo, acc); break;
                 }
-            }
+            };
+            if (nl) round8(ids, nl);
+            if (nl > 8)  // (a read in twenty)
+                for (uint32_t i = 8; i < nl; i += 8) round8(ids + i, nl - i);
             uint32_t pc = 0;
 #pragma unroll
             for (int q = 0; q < G; ++q) pc += __popc(acc[q].x) + __popc(acc[q].y) + __popc(acc[q].z) + __popc(acc[q].w);
@@ -843,7 +857,7 @@ __global__ __launch_bounds__(256, 8) void k2r_intersect(const uint32_t* __restri
                     uint32_t at = 0;
 #pragma unroll
                     for (int q = 0; q < G; ++q) {
-                        const uint4 x = acc[q];
+                        const u32x4 x = acc[q];
                         const uint32_t mq = __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
                         const uint32_t incl = wave_incl_scan_u32(mq);
                         uint32_t pos = at + incl - mq;
@@ -863,6 +877,10 @@ __global__ __launch_bounds__(256, 8) void k2r_intersect(const uint32_t* __restri
                     if (q * 64 + (uint32_t)lane < W4)
                         __builtin_nontemporal_store((u32x4){acc[q].x, acc[q].y, acc[q].z, acc[q].w}, &bm4[q * 64 + lane]);
             }
+            const uint32_t nx = min(ri + 1, 63u);  // (lanes past the ticket hold empty reads)
+            nl = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, nx);
+            r = (uint32_t)__builtin_amdgcn_readlane((int)rd_l, nx);
+            ids = ids_pool + readlane_u64(off_l, nx);
         }
     }
 }

@@ -17,9 +17,14 @@
 // Reads for the benchmark are drawn from the 10 real genomes and from the accessory sequence, so reads
 // cross several unitigs with nested colour sets, as real reads do.
 //
-// usage: synth_s4546 <s10_dump_base> <out.fgidx> <out_accessory.txt> [seed [core_stride [target_kmers]]]
+// usage: synth_s4546 <s10_dump_base> <out.fgidx> <out_accessory.txt> [seed [core_stride [target_kmers [profile]]]]
 //        core_stride > 1 keeps every core_stride-th salmonella_10 unitig only and target_kmers shrinks the accessory part: a small
 //        index with the same 4546 colours and list shapes, for tests that move the whole index through text files
+//        profile 1 = CORE-HEAVY (round 3: bounds the risk of the default model, whose reads have small results — median <= 10
+//        colours — while real Salmonella reads are expected to be dominated by core-genome sets of >= 3409 colours):
+//        nine salmonella_10 unitigs in ten are carried by the whole collection whatever their set over the ten genomes, a piece
+//        loses at most one small clade (<= 64 strains) with probability 0.3. More than 70 % of the mapped reads then have
+//        results of at least 3409 colours, and the dense (complemented) lists dominate the colour work.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +43,7 @@ constexpr uint32_t NW = (N + 63) / 64;
 constexpr uint32_t K = 31;
 uint64_t TARGET_KMERS = 43788757;
 uint64_t CORE_STRIDE = 1;
+int PROFILE = 0;  // 1: core-heavy
 
 uint64_t rng_state;
 inline uint64_t rnd() {
@@ -121,6 +127,7 @@ int main(int argc, char** argv) {
     rng_state = argc > 4 ? strtoull(argv[4], nullptr, 10) : 4546;
     if (argc > 5) CORE_STRIDE = std::max<uint64_t>(1, strtoull(argv[5], nullptr, 10));
     if (argc > 6) TARGET_KMERS = strtoull(argv[6], nullptr, 10);
+    if (argc > 7) PROFILE = atoi(argv[7]);
 
     // ---- phylogeny ----
     tree.reserve(2 * N);
@@ -152,6 +159,13 @@ int main(int argc, char** argv) {
     auto random_clade = [&]() {
         for (;;) {
             auto& v = by_log[rnd() % by_log.size()];
+            if (!v.empty()) return v[rnd() % v.size()];
+        }
+    };
+
+    auto random_small_clade = [&]() {  // at most 64 strains
+        for (;;) {
+            auto& v = by_log[rnd() % 7];
             if (!v.empty()) return v[rnd() % v.size()];
         }
     };
@@ -189,14 +203,15 @@ int main(int argc, char** argv) {
             for (int g = 0; g < 10; ++g)
                 if ((real_set[sid] >> g) & 1)
                     for (uint32_t i = 0; i < NW; ++i) carriers.w[i] |= node_bm[top[g]].w[i];
+            if (PROFILE == 1 && rnd() % 100 < 90) carriers = node_bm[0];  // a core locus of the whole collection
             const uint64_t nkm = seq.size() - K + 1;
             for (uint64_t s = 0; s < nkm;) {
                 uint64_t piece = std::min<uint64_t>(nkm - s, geometric(24.0));
                 Bitmap bm = carriers;
-                if (rnd() % 100 < 85) {
-                    const uint32_t drops = 1 + (uint32_t)(rnd() % 3);  // 1-3 clades lost this segment
+                if (rnd() % 100 < (PROFILE == 1 ? 30u : 85u)) {
+                    const uint32_t drops = PROFILE == 1 ? 1u : 1 + (uint32_t)(rnd() % 3);  // 1-3 clades lost this segment
                     for (uint32_t t = 0; t < drops; ++t) {
-                        const Bitmap& d = node_bm[random_clade()];
+                        const Bitmap& d = node_bm[PROFILE == 1 ? random_small_clade() : random_clade()];
                         for (uint32_t i = 0; i < NW; ++i) bm.w[i] &= ~d.w[i] | (type_strains.w[i] & carriers.w[i]);
                     }
                 }

@@ -15,7 +15,7 @@ from . import _native
 FULL_INTERSECTION = 0
 THRESHOLD_UNION = 1
 HYBRID, DIFF, META, META_DIFF = 0, 1, 2, 3  # index_t, include/util.hpp:18
-KERNELS = ("k1_lookup", "k2a_intersect", "k3a_union", "scan", "k2b_expand", "k_hits", "k_desc", "k_format", "k_order")
+KERNELS = ("k1_lookup", "k2_intersect", "k3_union", "scan", "k2b_expand", "k_hits", "k_desc", "k_format", "k_order")
 
 
 def pack_reads(reads):

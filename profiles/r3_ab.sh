@@ -7,8 +7,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "knobs or s4546_full_intersection or compressed_formatter or hit_counts or edge_batches or golden" 2>&1 | tail -5 > gpurun_out/${TAG}_pytest.txt
-for cfg in "0 0 0" "0 1 0" "1 0 0" "1 1 0" "1 1 1" "0 0 1" "0 1 1"; do
-  set -- $cfg
+for cfg in ${CFGS:-0:0:0 1:0:0 1:0:1 1:1:0 1:1:1}; do
+  set -- ${cfg//:/ }
   timeout 600 python bench.py --no-cpu-baseline --steps 5 --warmup 1 --rows $1 --order $2 --small $3 2> gpurun_out/${TAG}_r$1o$2s$3.err | tail -1 > gpurun_out/${TAG}_r$1o$2s$3.json
 done
 python - <<'PY'

@@ -9,8 +9,8 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("k1_lookup", "k2a_intersect", "k3a_union", "k2b_expand", "k_hits", "scan_block_sums", "scan_top", "scan_apply",
-              "k_account", "k_add_totals", "k2_fused"):
+    for k in ("k1_lookup", "k2a_intersect", "k2r_intersect", "k3a_union", "k3r_union", "k2b_expand", "k_hits", "scan_block_sums", "scan_top",
+              "scan_apply", "k_account", "k_add_totals", "k2_fused", "k_order_keys", "k_order_scatter", "k_rows_build", "k_generic", "k_desc"):
         if k in name:
             return k
     return name[:60]

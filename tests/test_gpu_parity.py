@@ -1156,7 +1156,7 @@ def test_s4546_execution_knobs_do_not_change_results(s4546):
             ix.run(rd, res, fulgor_amd.THRESHOLD_UNION, 0.8)  # (the union kernels under the same knobs)
             outs[-1] += res.download()
     finally:
-        ix.tune(order_min_reads=16384, small_results=True, dense_rows=True)
+        ix.tune(order_min_reads=-1, small_results=True, dense_rows=True)
     sz = np.diff(outs[0][0].astype(np.int64))
     assert (sz == 0).any() and ((sz > 0) & (sz <= 16)).sum() > n // 10 and (sz > 16).sum() > n // 10
     for other in outs[1:]:
@@ -1171,3 +1171,24 @@ def test_s4546_execution_knobs_do_not_change_results(s4546):
     assert outs[5][3] == Formatter("ascii", ncol).add(5, offs, cols)
     uo, uc = orc.threshold_union(b, o, 0.8, threads=32)
     assert np.array_equal(outs[5][6], uo) and np.array_equal(outs[5][7], uc)
+
+
+def test_bench_starts_its_own_ranks_and_checks_the_reduction(tmp_path):
+    """`python bench.py --gpus 2` outside any launcher: it starts its two ranks itself (both on the one GPU of the test box, gloo:
+    FULGOR_BENCH_SHARE_GPU=1), every rank processes its own reads, the hit vector is all-reduced and the bench asserts that the
+    reads of all ranks are in it; the line carries the rank count, the backend and a roofline entry per kernel"""
+    import json
+    import subprocess
+    env = dict(os.environ, FULGOR_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "s10", "--reads", "200000", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["collective_backend"] == "gloo" and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["steps"] == 2 and line["config"]["reads_per_gpu"] == 200000
+    ks = line["roofline"]["kernels"]
+    assert set(ks) == {"k1_lookup", "k2_intersect", "k2b_expand"}
+    assert all(0 < v["frac"] < 1 and v["avg_launch_ms"] > 0 for v in ks.values())
+    assert line["roofline"]["kernel"] in ks and line["roofline"]["frac"] == ks[line["roofline"]["kernel"]]["frac"]
