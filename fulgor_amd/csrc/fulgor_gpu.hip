@@ -335,7 +335,7 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     res->id_stride = stride;
     res->pool_units = units;
     res->d_ids_pool.ensure(units * (uint64_t)stride * 4 + 64);  // (k2r_intersect reads the ids eight at a time)
-    res->d_cnt_pool.ensure(units * (uint64_t)stride * 4 + 16);
+    res->d_cnt_pool.ensure(units * (uint64_t)stride * 4 + 64);
     res->have_ids = true;
     uint32_t* kmer_out = nullptr;
     if (res->want_kmer_ids) {
@@ -379,7 +379,7 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     res->d_npos2.ensure(count * 4 + 16);
     res->d_idoff2.ensure(count * 8 + 16);
     res->d_ids_pool2.ensure(units * (uint64_t)stride * 4 + 64);
-    res->d_cnt_pool2.ensure(units * (uint64_t)stride * 4 + 16);
+    res->d_cnt_pool2.ensure(units * (uint64_t)stride * 4 + 64);
     {
         Timed t(ix, res, FGPU_K_LOOKUP);
         const uint32_t mgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((count + 3) / 4, (uint64_t)ix->num_cus * 8));
@@ -573,7 +573,29 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
                                res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, scores_out);
             HIP_TRY(hipGetLastError());
         };
-        if (plain8) launch(k3a_union<8, false>);
+        // on dense rows: k3r_union
+        auto launch_rows = [&](auto kernel) {
+            const uint32_t grid = resident_grid(kernel, n, 4, ix->num_cus, 256, 0);
+            Timed t(ix, res, FGPU_K_UNION);
+            uint32_t* scores_out = nullptr;
+            if (res->want_scores) {
+                res->d_scores.ensure(n * (uint64_t)ix->dc.n * 4 + 16);
+                scores_out = res->d_scores.as<uint32_t>();
+            }
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, ix->d_rows.as<uint32_t>(), W, ix->dc.n, res->d_npos.as<uint32_t>(),
+                               res->d_nids.as<uint32_t>(), res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(),
+                               res->d_cnt_pool.as<uint32_t>(), tau, n, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
+                               res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, scores_out);
+            HIP_TRY(hipGetLastError());
+        };
+        if (ix->d_rows.p && ix->dense_rows) {
+            const bool sc = res->want_scores;
+            if (plain8) { if (sc) launch_rows(k3r_union<8, false, true>); else launch_rows(k3r_union<8, false>); }
+            else if (bits == 8) { if (sc) launch_rows(k3r_union<8, true, true>); else launch_rows(k3r_union<8>); }
+            else if (bits == 16) { if (sc) launch_rows(k3r_union<16, true, true>); else launch_rows(k3r_union<16>); }
+            else if (sc) launch_rows(k3r_union<32, true, true>);
+            else launch_rows(k3r_union<32>);
+        } else if (plain8) launch(k3a_union<8, false>);
         else if (bits == 8) launch(k3a_union<8>);
         else if (bits == 16) launch(k3a_union<16>);
         else launch(k3a_union<32>);

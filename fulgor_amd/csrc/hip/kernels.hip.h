@@ -1103,6 +1103,116 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 4 : 2)) void k3a
 }
 
 // ---------------------------------------------------------------------------------------------
+// K3r: threshold union over dense rows -> bitmap + cardinality. Same counters as k3a_union (biased 8/16/32-bit fields,
+// colour c -> plane c % PLANES, word c / 32, field (c % 32) / PLANES), but every colour set is its plain row
+// (k_rows_build): no descriptors, no blocks, no complemented lists — a list adds its multiplicity to the counters of its
+// members, `merge` as the reference states it (ps_threshold_union.cpp:16-40) before its complement trick. Lane = word of
+// the row (rounds of 64 words), so the PLANES counter words of a word's 32 colours belong to one lane and live in
+// its REGISTERS: no LDS at all; spreading a row word over them costs one shift, one mask and one multiply-add per plane.
+// Ids and multiplicities arrive through scalar loads (once per round), the row words of up to four lists are in flight at once.
+// ---------------------------------------------------------------------------------------------
+template <int K, int BITS>
+__device__ __forceinline__ void rows_spread(const uint32_t* __restrict__ rows, uint32_t W, const u32x4 id, const u32x4 mult, uint32_t wi,
+                                            uint32_t (&cnt)[BITS]) {
+    constexpr uint32_t ONES = BITS == 8 ? 0x01010101u : (BITS == 16 ? 0x00010001u : 1u);
+    uint32_t x[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) x[j] = rows[(uint64_t)id[j] * W + wi];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (uint32_t q = 0; q < BITS; ++q) cnt[q] += ((x[j] >> q) & ONES) * mult[j];  // (PLANES = BITS)
+}
+
+template <int BITS, bool BIASED = true, bool SCORES = false>
+__global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 6 : 4)) void k3r_union(const uint32_t* __restrict__ rows, uint32_t W, uint32_t n,
+                                                                  const uint32_t* __restrict__ npos, const uint32_t* __restrict__ nids,
+                                                                  const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
+                                                                  const uint32_t* __restrict__ cnt_pool, double tau, uint64_t n_reads,
+                                                                  uint32_t* __restrict__ out_bitmap, uint32_t* __restrict__ out_count,
+                                                                  unsigned int* tickets, uint32_t* __restrict__ scores_out) {
+    constexpr uint32_t PLANES = BITS, HALF = 1u << (BITS - 1);
+    constexpr uint32_t ONES = BITS == 8 ? 0x01010101u : (BITS == 16 ? 0x00010001u : 1u);
+    const int lane = lane_id();
+    const uint32_t Wn = (n + 31) >> 5;  // words that hold colours
+    typedef const __attribute__((address_space(4))) u32x4_a4* s4_ptr;  // scalar loads, as in k2r_intersect
+    const WorkQueue wq{tickets, n_reads, 8};
+    uint64_t t_first;
+    uint32_t t_count;
+    while (wq.pull(t_first, t_count)) {
+        const uint64_t rl = min(t_first + (uint64_t)lane, n_reads - 1);
+        const uint32_t cnt_l = (uint32_t)lane < t_count ? nids[rl] : 0u;
+        const uint64_t off_l = idoff[rl];
+        const uint32_t min_l = (uint32_t)(unsigned long long)((double)npos[rl] * tau);  // ps_threshold_union.cpp:389
+        for (uint32_t ri = 0; ri < t_count; ++ri) {
+            const uint64_t r = t_first + ri;
+            const uint32_t nl = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, ri);
+            const uint32_t min_score = (uint32_t)__builtin_amdgcn_readlane((int)min_l, ri);
+            const uint64_t off = readlane_u64(off_l, ri);
+            uint32_t* bm = out_bitmap + r * W;
+            if (nl == 0) {
+                for (uint32_t w = lane; w < W; w += 64) bm[w] = 0;
+                if (lane == 0) out_count[r] = 0;
+                if (SCORES)
+                    for (uint32_t cc = lane; cc < n; cc += 64) scores_out[r * (uint64_t)n + cc] = 0;
+                continue;
+            }
+            const uint32_t start = (BIASED ? HALF - min_score : 0u) * ONES;
+            const uint32_t thr_c = (256u - min_score) & 0xFFu;  // (unbiased counters only)
+            const uint32_t add7 = (thr_c & 0x7Fu) * 0x01010101u, top7 = (thr_c & 0x80u) ? 0xFFFFFFFFu : 0u;
+            const uint32_t all_pass = min_score == 0 ? 0xFFFFFFFFu : 0u;
+            uint32_t pc = 0;
+            // one round = 64 words of the rows, one per lane, with their PLANES counter words in this lane's registers
+            for (uint32_t w0 = 0; w0 < Wn; w0 += 64) {
+                const uint32_t w = w0 + (uint32_t)lane;
+                const uint32_t wi = min(w, W - 1);  // (lanes past the row load its last word and store nothing)
+                uint32_t cnt[PLANES];
+#pragma unroll
+                for (uint32_t q = 0; q < PLANES; ++q) cnt[q] = start;
+                for (uint32_t i = 0; i < nl; i += 4) {  // the row words of four lists in flight
+                    const u32x4 id = *(s4_ptr)(ids_pool + off + i), mu = *(s4_ptr)(cnt_pool + off + i);
+                    switch (min(nl - i, 4u)) {  // (wave-uniform)
+                        case 1: rows_spread<1, BITS>(rows, W, id, mu, wi, cnt); break;
+                        case 2: rows_spread<2, BITS>(rows, W, id, mu, wi, cnt); break;
+                        case 3: rows_spread<3, BITS>(rows, W, id, mu, wi, cnt); break;
+                        default: rows_spread<4, BITS>(rows, W, id, mu, wi, cnt); break;
+                    }
+                }
+                uint32_t m = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < PLANES; ++q) {
+                    const uint32_t x = cnt[q];
+                    if (BIASED) {
+                        m = (m >> 1) | (x & (ONES << (BITS - 1)));  // plane q ends PLANES - 1 - q = BITS - 1 - q places below its field's top bit
+                    } else {  // byte >= min_score  <=>  carry out of byte + (256 - min_score); min_score = 0 keeps every colour
+                        const uint32_t low = (x & 0x7F7F7F7Fu) + add7;
+                        const uint32_t out = (x & low) | ((x ^ low) & top7);
+                        m |= (((out | all_pass) >> 7) & ONES) << q;
+                    }
+                }
+                if (w >= (n >> 5)) m &= w == (n >> 5) ? (1u << (n & 31u)) - 1u : 0u;  // (only the last words hold colours >= n)
+                if (w < W) {
+                    bm[w] = m;
+                    pc += __popc(m);
+                    if (SCORES && w < Wn) {  // (index::kmer_matches) counter = HALF - min_score + score
+#pragma unroll
+                        for (uint32_t bit = 0; bit < 32; ++bit) {
+                            const uint32_t cc = w * 32 + bit;
+                            const uint32_t x = cnt[bit % PLANES];
+                            const uint32_t field = BITS == 32 ? x : ((x >> ((BITS & 31) * (bit / PLANES))) & ((1u << (BITS & 31)) - 1u));
+                            if (cc < n) scores_out[r * (uint64_t)n + cc] = BIASED ? field - HALF + min_score : field;
+                        }
+                    }
+                }
+            }
+            for (uint32_t w = ((Wn + 63) & ~63u) + lane; w < W; w += 64) bm[w] = 0;  // (padding words behind the last round)
+            pc = wave_sum_u32(pc);
+            if (lane == 0) out_count[r] = pc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Generic colour-set kernel for the meta, differential and meta-differential codecs.
 // Every colour set is a short list of ops (host/codecs_build.hpp); every op contributes a set of colours that
 // is XORed into the set under construction T (members of disjoint partitions, a representative, a symmetric
