@@ -76,6 +76,8 @@ def lib():
     L.fgpu_fastx_names.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.fgpu_fastx_close.argtypes = [vp]
     L.fgpu_fastx_close.restype = None
+    L.fgpu_fastx_ring.argtypes = []
+    L.fgpu_fastx_ring.restype = C.c_int
     L.fgpu_result_algorithmic_bytes.argtypes = [vp, u64p, u64p, u64p]
     L.fgpu_tune.argtypes = [vp, C.c_int, C.c_uint64]
     L.fgpu_timing_enable.argtypes = [vp, C.c_int]

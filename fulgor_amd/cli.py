@@ -26,10 +26,32 @@ def _launch_ranks(argv, gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, "-m", "fulgor_amd", "pseudoalign"] + list(argv), env=env))
+    # the first rank that fails takes the others down: they would wait in a collective until the process-group timeout
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    return 1 if rc else 0
+    live = list(procs)
+    while live:
+        time.sleep(0.1)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = 1
+                for q in live:
+                    q.terminate()
+    if rc:  # no half-written output: the parts of the ranks that got that far
+        out = None
+        for i, a in enumerate(argv):
+            if a == "-o" and i + 1 < len(argv):
+                out = argv[i + 1]
+        if out:
+            for r in range(gpus):
+                try:
+                    os.remove("%s.part%d" % (out, r))
+                except OSError:
+                    pass
+    return rc
 
 
 def pseudoalign(argv):

@@ -711,7 +711,12 @@ void fgpu_close(fgpu_index* ix) {
 int fgpu_save(const fgpu_index* ix, const char* path) {
     if (!ix || !path) return fail(-EINVAL, "null argument");
     return guarded([&] {
-        if (ends_with(path, "fur")) save_fur(ix->host, path);  // the reference's layout (fur_format.hpp: not validated on a real file)
+        if (ends_with(path, "fur")) {  // the reference's layout (fur_format.hpp: not validated on a real file)
+            fprintf(stderr, "fulgor_amd: WARNING: %s is written in the reference's section order with this engine's own k-mer dictionary "
+                            "block and unverified bit-vector layouts: the reference's `fulgor` cannot read it. Use `dump` to hand an "
+                            "index to the reference.\n", path);
+            save_fur(ix->host, path);
+        }
         else save_binary(ix->host, path);
     });
 }
@@ -1486,6 +1491,7 @@ int fgpu_fastx_names(fgpu_fastx* f, const char** names, const uint64_t** name_of
 }
 
 void fgpu_fastx_close(fgpu_fastx* f) { delete f; }
+int fgpu_fastx_ring(void) { return fgpu_fastx::RING; }
 
 // ---- export ---------------------------------------------------------------------------------------------
 int fgpu_export_sizes(const fgpu_index* ix, uint64_t* unitig_bases, uint64_t* num_unitigs, uint64_t* color_words,

@@ -48,14 +48,21 @@ struct FastxChunk {
     }
 };
 
-// kseq's record grammar over a stream of lines: next(s, n) yields the next line without its terminator
+// kseq's record grammar over a stream of lines: next(s, n) yields the next line without its terminator.
+// odd (optional): set when the lines did not read as whole records — bit 0: text between a record and the next header, bit 1: a
+// FASTQ record whose quality ends before its sequence does. A byte range of a file that was cut at true record boundaries never shows either;
+// a range cut inside a wrapped FASTQ record does.
 template <typename NextLine, typename Emit>
-void parse_fastx_records(NextLine&& next, FastxChunk& c, Emit&& emit) {
+void parse_fastx_records(NextLine&& next, FastxChunk& c, Emit&& emit, unsigned* odd = nullptr) {
     const char* s;
     size_t n;
     bool have = next(s, n);
     while (have) {
-        if (n == 0 || (s[0] != '>' && s[0] != '@')) { have = next(s, n); continue; }  // stray text before a header
+        if (n == 0 || (s[0] != '>' && s[0] != '@')) {  // stray text before a header
+            if (n && odd && c.name_offs.size() > 1) *odd |= 1u;  // (in front of the first header: skipped, as kseq does)
+            have = next(s, n);
+            continue;
+        }
         {
             size_t e = 1;
             while (e < n && s[e] != ' ' && s[e] != '\t') ++e;
@@ -72,10 +79,63 @@ void parse_fastx_records(NextLine&& next, FastxChunk& c, Emit&& emit) {
         if (have && s[0] == '+') {  // quality: as many characters as bases (may itself start with '@')
             uint64_t q = 0;
             while (q < len && (have = next(s, n))) q += n;
+            if (q < len && odd) *odd |= 2u;
             have = next(s, n);
         }
         if (!emit(c)) return;
     }
+}
+
+// What the head of a FASTA / FASTQ text says about cutting it into byte ranges. kind: the first character of the first line
+// that starts with '>' or '@' (kseq skips whatever stands in front of it), 0 if there is none. Returns false when the text
+// cannot be cut at guessed boundaries: FASTQ records that are not exactly four lines (wrapped sequence / quality lines —
+// there a quality line that begins with '@' is indistinguishable from a header), or no header at all. Such a file is
+// parsed as one stream with the full grammar, as the reference does (kseq).
+inline bool fastx_head_rangeable(const char* p, size_t n, char& kind) {
+    kind = 0;
+    size_t at = 0;
+    auto line = [&](const char*& s, size_t& len) -> bool {  // complete lines only
+        if (at >= n) return false;
+        const char* nl = (const char*)memchr(p + at, '\n', n - at);
+        if (!nl) return false;
+        s = p + at;
+        len = (size_t)(nl - s);
+        at += len + 1;
+        if (len && s[len - 1] == '\r') --len;
+        return true;
+    };
+    const char* s;
+    size_t len;
+    bool have;
+    while ((have = line(s, len)) && !(len && (s[0] == '>' || s[0] == '@'))) {}
+    if (!have) {  // no complete header line in the head: a header without a line end still tells the kind
+        if (at < n && (p[at] == '>' || p[at] == '@')) kind = p[at];
+        return kind == '>';
+    }
+    kind = s[0];
+    if (kind == '>') return true;
+    for (int rec = 0; rec < 4096; ++rec) {  // '@' header in s: sequence, '+', quality of the same length, then the next header
+        size_t ls, lq;
+        const char* t;
+        if (!line(t, ls)) return true;
+        if (ls && t[0] == '+') return false;  // (an empty sequence: leave it to the stream parser)
+        if (!line(t, lq)) return true;
+        if (!(lq && t[0] == '+')) return false;  // a second sequence line
+        if (!line(t, lq)) return true;
+        if (lq != ls) return false;
+        if (!line(s, len)) return true;
+        if (!(len && s[0] == '@')) return false;
+    }
+    return true;
+}
+inline bool fastx_file_rangeable(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::vector<char> head(1u << 20);
+    const size_t got = fread(head.data(), 1, head.size(), f);
+    fclose(f);
+    char kind;
+    return got == 0 || fastx_head_rangeable(head.data(), got, kind);
 }
 
 class FastxSource {
@@ -272,9 +332,11 @@ protected:
     virtual void consumed(uint64_t) {}          // range r has been handed out
     virtual bool lazy() const { return false; }
     void start(unsigned threads, uint64_t begin, uint64_t end) {
-        if (size_) {  // FASTA or FASTQ, by the file's first character: which line starts can open a record
-            ensure(0, 1);
-            kind_ = map_[0] == '>' || map_[0] == '@' ? map_[0] : 0;
+        if (size_) {  // FASTA or FASTQ, by the first header line: which line starts can open a record
+            const uint64_t head = std::min<uint64_t>(size_, 1u << 20);
+            ensure(0, head);
+            if (!fastx_head_rangeable(map_, head, kind_))
+                throw std::runtime_error("this FASTQ text has records that are not four lines long (wrapped lines): it cannot be cut into byte ranges");
         }
         begin_ = std::min(begin, size_);
         end_ = std::min(end, size_);
@@ -357,6 +419,7 @@ protected:
                 const uint64_t hi = r + 1 == num_ranges_ ? (end_ == size_ ? size_ : boundary(end_)) : boundary(begin_ + (r + 1) * range_);
                 ensure(lo, hi);
                 uint64_t pos = lo;
+                unsigned odd = 0;
                 c.bases.reserve((hi - lo) / 2 + 64);
                 parse_fastx_records(
                     [&](const char*& s, size_t& n) {
@@ -368,7 +431,11 @@ protected:
                         if (n && s[n - 1] == '\r') --n;
                         return true;
                     },
-                    c, [](FastxChunk&) { return true; });
+                    c, [](FastxChunk&) { return true; }, &odd);
+                // a range that starts at a record boundary and ends at one holds whole records and nothing else
+                if ((odd & 1u) || ((odd & 2u) && hi != size_))  // (a quality cut short by the end of the text is the file's business)
+                    throw std::runtime_error("the query file does not parse as whole records in byte ranges (FASTQ with wrapped lines behind "
+                                             "a four-line head?): bytes " + std::to_string(lo) + " to " + std::to_string(hi));
             } catch (std::exception& e) {
                 std::lock_guard<std::mutex> g(m_);
                 error_ = e.what();
@@ -448,7 +515,10 @@ inline uint64_t fastx_text_size(const std::string& path, bool& parts) {
     unsigned char m[2] = {0, 0};
     const size_t got = fread(m, 1, 2, f0);
     fclose(f0);
-    if (!(got == 2 && m[0] == 0x1f && m[1] == 0x8b)) return (uint64_t)st.st_size;
+    if (!(got == 2 && m[0] == 0x1f && m[1] == 0x8b)) {
+        parts = fastx_file_rangeable(path);  // (FASTQ with wrapped lines: one stream)
+        return (uint64_t)st.st_size;
+    }
     if (!is_bgzf_file(path)) { parts = false; return 0; }
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) throw std::runtime_error("cannot open " + path);
@@ -718,7 +788,11 @@ public:
                 else src_.reset(new StreamFastxSource(path));
             }
         } else {
-            src_.reset(new MappedFastxSource(path, threads, begin, end));
+            // FASTQ with wrapped lines (records that are not four lines long) offers no record boundaries to guess: one stream,
+            // kseq's full grammar, as the reference reads it
+            if (fastx_file_rangeable(path)) src_.reset(new MappedFastxSource(path, threads, begin, end));
+            else if (begin == 0 && end == ~0ULL) src_.reset(new StreamFastxSource(path));
+            else throw std::runtime_error("a FASTQ file with wrapped lines cannot be read in parts");
         }
     }
     // Bases: clear(), reserve(bytes), data(), set_size(bytes)

@@ -448,7 +448,7 @@ struct MetaDiffSec {
             for (auto& pr : lists[s]) rc.append(pr.second, msb64(std::max<uint64_t>(1, m.endpoints[pr.first].num_color_sets)) + 1);
             rco.push_back(rc.nbits);
         }
-        if (!sets.empty()) m.partition_sets_partitions.set(sets.size() - 1);
+        // (no bit behind the last group: the reference sets one only where the NEXT partition set begins, meta_differential.hpp:40-41)
         m.psp_rank.build(m.partition_sets_partitions);
         m.partition_sets = BV::from_writer(ps);
         m.relative_colors = BV::from_writer(rc);
@@ -601,6 +601,12 @@ inline void read_fur(const std::string& path, HostIndex& idx, uint32_t& psize, u
     u2c.read(in);
     r.read(in);
     if (idx.dict.unitig_off.size() != u2c.num_bits + 1) throw std::runtime_error("corrupt index file (u2c)");
+    {  // the unitig table as load_binary checks it: the dictionary builder trusts it
+        const auto& uo = idx.dict.unitig_off;
+        if (uo.empty() || uo[0] != 0 || uo.back() != idx.dict.total_bases) throw std::runtime_error("corrupt index file (unitig table)");
+        for (size_t u = 0; u + 1 < uo.size(); ++u)
+            if (uo[u + 1] < uo[u] + idx.dict.k) throw std::runtime_error("corrupt index file (unitig offsets)");
+    }
     idx.dict.unitig_csid.resize(u2c.num_bits);
     uint32_t id = 0;
     for (uint64_t u = 0; u < u2c.num_bits; ++u) { idx.dict.unitig_csid[u] = id; id += u2c.get(u); }  // index.hpp:37

@@ -2,8 +2,11 @@
 (tools/pseudoalign.cpp:12-89) with the per-read loop replaced by batched passes through the C ABI, the
 output formatters of src/ps_utils.cpp:48-136, and the multi-GPU sharding (reads are independent units:
 contiguous ranges per rank, index replicated, one all-reduce of the hit counters)."""
+import threading
+
 import numpy as np
 
+from . import _native
 from .index import FULL_INTERSECTION, THRESHOLD_UNION, pack_reads  # noqa: F401
 
 
@@ -180,13 +183,17 @@ def pseudoalign_stream(index, batches, algo=FULL_INTERSECTION, threshold=0.0, si
         return n, mapped
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
-    inflight = max(1, min(3, int(inflight)))  # the reader keeps four batches alive
+    # the reader keeps RING batches alive (fgpu_fastx_next): batch k - (RING - 1) must survive the request for batch k
+    inflight = max(1, min(_native.lib().fgpu_fastx_ring() - 1, int(inflight)))
     # the results (device buffers sized for one batch, a stream each) stay with the index: a second stream of batches through
-    # the same index finds them allocated (allocating and freeing device memory synchronises the whole device)
-    results = getattr(index, "_stream_results", None) or []
+    # the same index finds them allocated (allocating and freeing device memory synchronises the whole device). They are
+    # checked out of a pool under a lock: two streams running through one index at the same time never share a result.
+    lock = index.__dict__.setdefault("_stream_lock", threading.Lock())
+    with lock:
+        pool_ = index.__dict__.setdefault("_stream_results", [])
+        results = [pool_.pop() for _ in range(min(inflight, len(pool_)))]
     while len(results) < inflight:
         results.append(index.new_result())
-    index._stream_results = results
 
     def one_pass(slot, bases, offs, id0):
         res = results[slot]
@@ -206,16 +213,20 @@ def pseudoalign_stream(index, batches, algo=FULL_INTERSECTION, threshold=0.0, si
         if view is not None:
             sink.write(view)
 
-    with ThreadPoolExecutor(max_workers=inflight) as pool:
-        slot = 0
-        for bases, offs in batches:
-            if len(pending) == inflight:
-                retire()  # frees the slot that is taken next: slots are used round robin
-            pending.append(pool.submit(one_pass, slot, bases, offs, first_id + n))
-            slot = (slot + 1) % inflight
-            n += len(offs) - 1
-        while pending:
-            retire()
+    try:
+        with ThreadPoolExecutor(max_workers=inflight) as pool:
+            slot = 0
+            for bases, offs in batches:
+                if len(pending) == inflight:
+                    retire()  # frees the slot that is taken next: slots are used round robin
+                pending.append(pool.submit(one_pass, slot, bases, offs, first_id + n))
+                slot = (slot + 1) % inflight
+                n += len(offs) - 1
+            while pending:
+                retire()
+    finally:
+        with lock:
+            index._stream_results.extend(results)  # back to the pool
     if f is not None:
         f.finish()  # (the host formatter only supplied the file header)
     return n, mapped
@@ -244,8 +255,8 @@ def pseudoalign_sharded(open_index, query, output, algo=FULL_INTERSECTION, thres
     from .reads import FastxReader, count_reads, text_size
     size, in_parts = text_size(query)
     if world > 1 and not in_parts:
-        raise ValueError("a gzip stream cannot be read in parts: decompress the query file for a multi-GPU run, or compress it "
-                         "in blocks (bgzip)")
+        raise ValueError("the query file cannot be read in parts (a gzip stream, or FASTQ with wrapped lines): for a multi-GPU run "
+                         "decompress it or compress it in blocks (bgzip); unwrap the FASTQ records to four lines")
     begin, end = size * rank // world, size * (rank + 1) // world
     first_id = 0
     if world > 1:

@@ -167,6 +167,9 @@ int fgpu_fastx_next(fgpu_fastx* f, uint64_t max_reads, const char** bases, const
  * same lifetime as the batch */
 int fgpu_fastx_names(fgpu_fastx* f, const char** names, const uint64_t** name_offs);
 void fgpu_fastx_close(fgpu_fastx* f);
+/* batches of a reader that stay valid at a time (the ring behind fgpu_fastx_next): a worker loop may keep this many minus one
+ * passes in flight */
+int fgpu_fastx_ring(void);
 
 /* Device-side formatting of the last pass of `res` (src/ps_utils.cpp:48-135): the records of reads
  * first_read_id .. first_read_id + n - 1 in file order, ascii ("<id>\t<count>[\t<colour>...]\n") or binary (u32 id, u32

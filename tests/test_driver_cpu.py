@@ -544,3 +544,52 @@ def test_reader_under_sanitizers(tmp_path):
                 assert len(lines) == 3 and len(set(lines)) == 1
                 outs.add((tuple(args[1:]), lines[0]))
         assert len(outs) == 2  # plain and block-compressed agree, whole and in parts
+
+
+def test_wrapped_fastq_is_read_as_one_stream_and_leading_junk_does_not_change_the_kind(built, tmp_path):
+    """(1) FASTQ whose sequence and quality lines are wrapped offers no boundary a byte range could start at (a
+    quality line that begins with '@', two lines in front of one that begins with '+', looks exactly like a record): such a
+    file is recognised at open and parsed as one stream with kseq's grammar — 50000 reads of 250 bases wrapped at 60 columns
+    with uniform qualities come out as 50000 reads — and it refuses to be read in parts. (2) A FASTQ file that starts with a
+    blank line or stray text is still a FASTQ file: a quality line that begins with '>' is not a FASTA header in any part."""
+    from fulgor_amd.reads import FastxReader, count_reads, text_size
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n = 50000
+    seqs = [bytes(alpha[rng.integers(0, 4, size=250)]) for _ in range(n)]
+    p = str(tmp_path / "wrapped.fq")
+    with open(p, "wb") as f:
+        for i, s in enumerate(seqs):
+            q = bytes(rng.integers(33, 74, size=250, dtype=np.uint8))
+            f.write(b"@w%d\n" % i + b"".join(s[j:j + 60] + b"\n" for j in range(0, 250, 60)) + b"+\n" +
+                    b"".join(q[j:j + 60] + b"\n" for j in range(0, 250, 60)))
+    assert os.path.getsize(p) > 24 << 20  # several 8 MB ranges, had it been cut
+    got = []
+    rd = FastxReader(p, copy=True, batch=20000, threads=4)
+    for bases, offs in rd:
+        b = bytes(bases)
+        got += [b[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+    rd.close()
+    assert len(got) == n and got == seqs
+    assert text_size(p) == (os.path.getsize(p), False)
+    with pytest.raises(RuntimeError):
+        count_reads(p, 1000, os.path.getsize(p), 2)
+    # (2) leading junk, then strict four-line records whose quality lines all begin with '>'
+    small = [b"ACGT" * 30] * 3000
+    for junk in (b"\n", b"\xef\xbb\xbf\n", b"# produced by some tool\n\n"):
+        p2 = str(tmp_path / "junk.fq")
+        with open(p2, "wb") as f:
+            f.write(junk)
+            for i, sq in enumerate(small):
+                f.write(b"@r%d\n%s\n+\n>%s\n" % (i, sq, b"I" * (len(sq) - 1)))
+        sz = os.path.getsize(p2)
+        assert text_size(p2) == (sz, True)
+        for cut in range(200000, 200000 + 260, 13):  # cut points in every kind of line
+            parts = []
+            for a, b in ((0, cut), (cut, sz)):
+                rd = FastxReader(p2, copy=True, batch=5000, threads=2, begin=a, end=b)
+                for bases, offs in rd:
+                    bb = bytes(bases)
+                    parts += [bb[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+                rd.close()
+            assert parts == small, (junk, cut)
