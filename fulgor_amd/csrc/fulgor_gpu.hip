@@ -419,7 +419,7 @@ void run_scan(fgpu_index* ix, fgpu_result* res, const uint32_t* sizes, uint64_t 
 // round trip), so they skip this.
 void stage_descriptors(fgpu_index* ix, fgpu_result* res, uint64_t max_total_ids, int algo) {
     (void)algo;
-    if (ix->host.type == IDX_HYBRID) return;
+    if (ix->host.type == IDX_HYBRID || (ix->d_rows.p && ix->dense_rows)) return;  // (the dense rows serve every codec)
     hipStream_t s = res->stream;
     const uint64_t n = res->n;
     res->d_idcsr.ensure((n + 1) * 8 + 16);
@@ -488,7 +488,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     // for larger collections the expand kernel runs without it and k_hits counts from the bitmaps on demand
     const size_t stage_lds = (K2B_THREADS / 64) * K2B_STAGE_BYTES + 16;  // + the block's ticket counter
     const bool hits_fold = stage_lds + k2b_hist_region(W) <= 80 * 1024;  // two blocks per CU
-    if (ix->host.type != IDX_HYBRID) {
+    if (ix->host.type != IDX_HYBRID && !(ix->d_rows.p && ix->dense_rows)) {
         const bool uni = algo == FGPU_THRESHOLD_UNION;
         if (!uni && algo != FGPU_FULL_INTERSECTION) throw std::runtime_error("unknown algorithm");
         if (uni && res->max_kmers_in_batch > 32767)  // biased 16-bit score counters at most

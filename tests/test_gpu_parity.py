@@ -375,6 +375,7 @@ CODECS = [(fulgor_amd.DIFF, 10, 4), (fulgor_amd.DIFF, 10, 1), (fulgor_amd.META, 
 def test_gpu_codecs_match_golden_and_oracle(s10_fgidx, s10_dump, seeded_reads, index_type, psize, csize):
     from oracle.pyoracle import OracleIndex
     ix = fulgor_amd.Index(s10_fgidx, device=0).convert(index_type, psize, csize)
+    ix.tune(dense_rows=False)  # the codec's own kernels (k_generic), not the dense rows
     b, o = pack_reads(load_golden_reads())
     assert csr_to_lists(*ix.pseudoalign_full_intersection_batch(b, o)) == load_golden_tsv("s10_full_intersection.tsv")
     for tau in (0.8, 1.0, 0.01):
@@ -408,6 +409,7 @@ def test_s4546_codecs_equal_hybrid(s4546, index_type, psize, csize):
     want_tu = ix.pseudoalign_threshold_union_batch(b, o, 0.8)
     fg, _ = synth.ensure_s4546(DATA, S10_GENOMES)
     iy = fulgor_amd.Index(fg, device=0).convert(index_type, psize, csize)
+    iy.tune(dense_rows=False)  # the codec's own kernels (k_generic), not the dense rows
     got_fi = iy.pseudoalign_full_intersection_batch(b, o)
     got_tu = iy.pseudoalign_threshold_union_batch(b, o, 0.8)
     assert np.array_equal(got_fi[0], want_fi[0]) and np.array_equal(got_fi[1], want_fi[1])
@@ -479,6 +481,7 @@ def test_gpu_kmer_matches_on_other_codecs(s10_gpu, s10_fgidx, index_type, psize,
     mo, pos, counts = s10_gpu.kmer_matches_batch(b, o)
     ix = fulgor_amd.Index(s10_fgidx, device=0)
     ix.convert(index_type, psize, csize)
+    ix.tune(dense_rows=False)  # the codec's own kernels (k_generic), not the dense rows
     mo2, pos2, counts2 = ix.kmer_matches_batch(b, o)
     assert np.array_equal(mo, mo2) and np.array_equal(pos, pos2) and np.array_equal(counts, counts2)
 
@@ -812,6 +815,7 @@ def test_s4546_config_metadiff_12M5_reads_per_gpu_properties(s4546):
     ix, orc_h, gen = s4546
     fg, _ = synth.ensure_s4546(DATA, S10_GENOMES)
     iy = fulgor_amd.Index(fg, device=0).convert(fulgor_amd.META_DIFF, 160, 16)
+    iy.tune(dense_rows=False)  # the codec's own kernels (k_generic), not the dense rows
     N = 12_500_000
     b, o = gen.generate(3 * N, N, 150, 42)  # the slice rank 3 of the 8-GPU job owns
     nc = iy.num_colors()
@@ -969,6 +973,7 @@ def test_s4546small_codecs_equal_oracle_convert(s4546small, index_type, psize, c
     from oracle.pyoracle import OracleIndex
     _, _, gen, fg, base = s4546small
     iy = fulgor_amd.Index(fg, device=0).convert(index_type, psize, csize)
+    iy.tune(dense_rows=False)  # the codec's own kernels (k_generic), not the dense rows
     orc = OracleIndex.from_dump(base).convert(index_type, psize, csize)
     b, o = gen.generate(50000, 12000, 150, 42)
     go, gc = iy.pseudoalign_full_intersection_batch(b, o)
@@ -986,6 +991,7 @@ def test_gpu_matches_golden_at_256_colours(c256_dump, index_type, psize, csize):
     ix = fulgor_amd.Index(c256_dump, device=0)
     if index_type != fulgor_amd.HYBRID:
         ix.convert(index_type, psize, csize)
+        ix.tune(dense_rows=False)  # the codec's own kernels (k_generic), not the dense rows
     b, o = pack_reads(load_golden_reads("c256_reads.fa"))
     offs, cols = ix.pseudoalign_full_intersection_batch(b, o)
     assert csr_to_lists(offs, cols) == load_golden_tsv("c256_full_intersection.tsv")
@@ -1036,6 +1042,8 @@ def test_gpu_queries_on_an_index_loaded_from_the_fur_layout(s10_fgidx, s10_oracl
     p = str(tmp_path / ("x." + suffix))
     ix.save(p)
     iy = fulgor_amd.Index(p, device=0)
+    if index_type:
+        iy.tune(dense_rows=False)  # the codec's own kernels (k_generic), not the dense rows
     assert iy.index_type == index_type
     b, o = seeded_reads
     b, o = b[:int(o[8000])], o[:8001]
@@ -1192,3 +1200,23 @@ def test_bench_starts_its_own_ranks_and_checks_the_reduction(tmp_path):
     assert set(ks) == {"k1_lookup", "k2_intersect", "k2b_expand"}
     assert all(0 < v["frac"] < 1 and v["avg_launch_ms"] > 0 for v in ks.values())
     assert line["roofline"]["kernel"] in ks and line["roofline"]["frac"] == ks[line["roofline"]["kernel"]]["frac"]
+
+
+@pytest.mark.parametrize("index_type,psize,csize", [(fulgor_amd.DIFF, 4546, 16), (fulgor_amd.META, 160, 1), (fulgor_amd.META_DIFF, 160, 16)])
+def test_s4546_dense_rows_serve_every_codec(s4546, index_type, psize, csize):
+    """the dense rows are built from the colour sets themselves, so an index re-encoded as differential / meta / meta-differential
+    answers from them too (k2r_intersect / k3r_union) unless told otherwise: the same results as the codec's own kernels and as
+    the hybrid index"""
+    from conftest import DATA
+    from fulgor_amd import synth
+    ix, _, gen = s4546
+    fg, _ = synth.ensure_s4546(DATA, S10_GENOMES)
+    b, o = gen.generate(4242, 12000, 150, 42)
+    iy = fulgor_amd.Index(fg, device=0).convert(index_type, psize, csize)
+    want = ix.pseudoalign_full_intersection_batch(b, o), ix.pseudoalign_threshold_union_batch(b, o, 0.7)
+    for rows in (True, False):
+        iy.tune(dense_rows=rows)
+        got = iy.pseudoalign_full_intersection_batch(b, o), iy.pseudoalign_threshold_union_batch(b, o, 0.7)
+        for (wo, wc), (go, gc) in zip(want, got):
+            assert np.array_equal(wo, go) and np.array_equal(wc, gc), rows
+    iy.close()
