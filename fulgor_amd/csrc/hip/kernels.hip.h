@@ -1534,6 +1534,17 @@ __host__ __device__ __forceinline__ uint32_t k2b_hist_words(uint32_t W) {
 }
 // bytes in front of the stages (a multiple of 1088 = 1024 * 17 / 16) and the virtual address that lands there
 __host__ __device__ __forceinline__ uint32_t k2b_hist_region(uint32_t W) { return (k2b_hist_words(W) * 4 + 1087) / 1088 * 1088; }
+// Inside its group of G words (2048, or what the last round of an odd number of rounds needs) the counter of entry e lives at
+// word (e % 4) * (G / 4) + e / 4: a lane copies four consecutive entries out (one 16-byte store), in dense rows those are
+// four consecutive colours, and the four ds_add of a wave then go to consecutive words each — with the plain layout 64 lanes
+// hit 8 banks (57 % of the kernel's LDS cycles were bank conflicts on the threshold union: profiles/r3). G is a multiple of 128.
+__host__ __device__ __forceinline__ uint32_t k2b_group_words(uint32_t W, uint32_t group) {
+    const uint32_t rounds = (W + 63) / 64;
+    return ((rounds & 1u) && group == rounds / 2) ? (W - 64 * (rounds - 1)) * 32 : 2048u;
+}
+__device__ __forceinline__ uint32_t k2b_hist_addr(uint32_t group_at, uint32_t G, uint32_t e) {  // byte address; group_at = 8192 * group
+    return group_at + __umul24(e & 3u, G) + (e & ~3u);
+}
 __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
                                                   const uint64_t* __restrict__ out_off, uint64_t n_reads, uint32_t W,
                                                   uint32_t* __restrict__ colors, unsigned int* tickets,
@@ -1617,7 +1628,7 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
                     const uint32_t c = v[g];
                     colors[dst[g]] = c;
                     // the colour's hit counter: round c >> 11 (low / high half of the word by its parity), entry c & 2047
-                    if (hit_partial) lds_add((c >> 12) * 8192u + ((c & 2047u) << 2), (c & 2048u) ? 0x10000u : 1u);
+                    if (hit_partial) lds_add(k2b_hist_addr((c >> 12) * 8192u, k2b_group_words(W, c >> 12), c & 2047u), (c & 2048u) ? 0x10000u : 1u);
                 }
             }
             wave_lds_sync();
@@ -1654,7 +1665,7 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
             const uint32_t cbase = w0 * 32;
             // hit counters of this round: which half of the word, which 2048-word group
             const uint32_t hinc = (w0 & 64u) ? 0x10000u : 1u;
-            const uint32_t hoff = (w0 >> 7) * 8192u;
+            const uint32_t hoff = (w0 >> 7) * 8192u, hG = k2b_group_words(W, w0 >> 7);
             // copy-out: every lane takes 4 consecutive slots (two LDS words) and stores 4 colours at once; the last
             // total % 4 slots (all of them in a round of at most 64) go out one per lane
             const uint32_t full = total <= 64 ? 0u : total & ~3u;  // short rounds: one slot per lane, one pass
@@ -1664,17 +1675,17 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
                 const uint32_t e0 = e01 & 0xFFFFu, e1 = e01 >> 16, e2 = e23 & 0xFFFFu, e3 = e23 >> 16;
                 *(u32x4_a4*)(out + i) = u32x4{cbase + e0, cbase + e1, cbase + e2, cbase + e3};
                 if (hit_partial) {
-                    lds_add(hoff + (e0 << 2), hinc);
-                    lds_add(hoff + (e1 << 2), hinc);
-                    lds_add(hoff + (e2 << 2), hinc);
-                    lds_add(hoff + (e3 << 2), hinc);
+                    lds_add(k2b_hist_addr(hoff, hG, e0), hinc);
+                    lds_add(k2b_hist_addr(hoff, hG, e1), hinc);
+                    lds_add(k2b_hist_addr(hoff, hG, e2), hinc);
+                    lds_add(k2b_hist_addr(hoff, hG, e3), hinc);
                 }
             }
             if ((uint32_t)lane < total - full) {
                 const uint32_t i = full + lane;
                 const uint32_t e = *lds16(k2b_stage_skew(v_wave + (i << 1)));
                 out[i] = cbase + e;
-                if (hit_partial) lds_add(hoff + (e << 2), hinc);
+                if (hit_partial) lds_add(k2b_hist_addr(hoff, hG, e), hinc);
             }
             out += total;
             wave_lds_sync();
@@ -1691,7 +1702,8 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
         const uint32_t ncol = W * 32;
         for (uint32_t i = threadIdx.x; i < hist_words; i += blockDim.x) {
             const uint32_t v = hist[i];
-            const uint32_t c = (i >> 11) * 4096u + (i & 2047u);  // colour of the low half; the high half is 2048 further
+            const uint32_t q4 = k2b_group_words(W, i >> 11) >> 2, wi = i & 2047u;  // word wi of its group = entry (wi % q4) * 4 + wi / q4
+            const uint32_t c = (i >> 11) * 4096u + (wi % q4) * 4u + wi / q4;  // colour of the low half; the high half is 2048 further
             row[c] = v & 0xFFFFu;
             if (c + 2048u < ncol) row[c + 2048u] = v >> 16;
         }

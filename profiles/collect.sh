@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --no-cpu-baseline $*"
+BENCH="python $R/bench.py --no-cpu-baseline --no-secondary $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- $BENCH > $OUT/stats.log 2>&1
 pmc() { # name counters...
   local name=$1; shift
