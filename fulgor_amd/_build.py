@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "fulgor_amd")
 CSRC = os.path.join(PKG, "csrc")
 
-LIB_GPU = os.path.join(PKG, "libfulgor_gpu.so")
+LIB_GPU = os.environ.get("FULGOR_LIB_GPU") or os.path.join(PKG, "libfulgor_gpu.so")  # (FULGOR_LIB_GPU: measure another build of the library)
 LIB_TOOLS = os.path.join(PKG, "libfgtools.so")
 BIN_CCDBG = os.path.join(PKG, "ccdbg_from_fasta")
 LIB_ORACLE = os.path.join(ROOT, "oracle", "liboracle.so")
@@ -35,6 +35,8 @@ def _run(cmd):
 
 def build_gpu(force=False):
     srcs = _walk(CSRC, (".hip", ".h", ".hpp")) + [os.path.join(ROOT, "include", "fulgor_gpu.h")]
+    if os.environ.get("FULGOR_LIB_GPU"):
+        return LIB_GPU
     if force or _newer(LIB_GPU, srcs):
         _run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
               os.path.join(CSRC, "fulgor_gpu.hip"), "-o", LIB_GPU, "-lz", "-ldl"])

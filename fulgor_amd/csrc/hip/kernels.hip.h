@@ -1124,6 +1124,45 @@ __device__ __forceinline__ void rows_spread(const uint32_t* __restrict__ rows, u
         for (uint32_t q = 0; q < BITS; ++q) cnt[q] += ((x[j] >> q) & ONES) * mult[j];  // (PLANES = BITS)
 }
 
+// Threshold union of a read with few lists without any counter: whether colour c passes depends only on WHICH of the read's
+// L lists contain it, a boolean function f of L bits that is monotone (multiplicities are positive). Its truth table — 2^L
+// entries, one ballot: lane p adds up the multiplicities of the lists in pattern p and compares with min_score — is wave-uniform,
+// and f is evaluated on whole row words as a multiplexer tree over the lists (Shannon expansion, bit-sliced over the 32
+// colours of a word): a node is lo | (x_l & hi) with hi >= lo, one v_and_or; the leaves are the table's constants, so a node
+// of the first level is one of {0, x_0, ~0} = (x_0 | lo) & hi. About 3 * 2^(L-1) operations per word against 24 L + 22 for
+// the byte counters: 48 against 142 for five lists.
+constexpr uint32_t K3R_MUX_LISTS = 6;  // reads of up to this many lists take the multiplexer tree (2^L = one ballot)
+template <int LEVEL>
+__device__ __forceinline__ uint32_t mux_tree(const uint32_t (&x)[K3R_MUX_LISTS], uint64_t table, uint32_t p) {  // p: pattern of the lists above LEVEL
+    if constexpr (LEVEL == 1) {
+        const uint32_t lo = 0u - (uint32_t)((table >> (2 * p)) & 1ull), hi = 0u - (uint32_t)((table >> (2 * p + 1)) & 1ull);  // (scalars)
+        return (x[0] | lo) & hi;
+    } else {
+        const uint32_t lo = mux_tree<LEVEL - 1>(x, table, 2 * p), hi = mux_tree<LEVEL - 1>(x, table, 2 * p + 1);
+        return lo | (x[LEVEL - 1] & hi);
+    }
+}
+// the whole read: rounds of 64 row words, one per lane; returns the lane's share of the result's cardinality
+template <int L>
+__device__ __forceinline__ uint32_t mux_union_read(const uint32_t* __restrict__ rows, uint32_t W, uint32_t Wn, uint32_t n, const u32x8 id,
+                                                   uint64_t table, uint32_t* __restrict__ bm, int lane) {
+    uint32_t pc = 0;
+    for (uint32_t w0 = 0; w0 < Wn; w0 += 64) {
+        const uint32_t w = w0 + (uint32_t)lane;
+        const uint32_t wi = min(w, W - 1);  // (lanes past the row load its last word and store nothing)
+        uint32_t x[K3R_MUX_LISTS];
+#pragma unroll
+        for (int l = 0; l < L; ++l) x[l] = rows[(uint64_t)id[l] * W + wi];
+        uint32_t m = mux_tree<L>(x, table, 0u);
+        if (w >= (n >> 5)) m &= w == (n >> 5) ? (1u << (n & 31u)) - 1u : 0u;  // (only the last words hold colours >= n)
+        if (w < W) {
+            bm[w] = m;
+            pc += __popc(m);
+        }
+    }
+    return pc;
+}
+
 template <int BITS, bool BIASED = true, bool SCORES = false>
 __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 6 : 4)) void k3r_union(const uint32_t* __restrict__ rows, uint32_t W, uint32_t n,
                                                                   const uint32_t* __restrict__ npos, const uint32_t* __restrict__ nids,
@@ -1155,6 +1194,27 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 6 : 4)) void k3r
                 if (lane == 0) out_count[r] = 0;
                 if (SCORES)
                     for (uint32_t cc = lane; cc < n; cc += 64) scores_out[r * (uint64_t)n + cc] = 0;
+                continue;
+            }
+            if (!SCORES && nl <= K3R_MUX_LISTS) {  // few lists: the multiplexer tree, no counters
+                typedef const __attribute__((address_space(4))) u32x8_a4* s8_ptr;
+                const u32x8 id = *(s8_ptr)(ids_pool + off), mu = *(s8_ptr)(cnt_pool + off);
+                uint32_t score = 0;  // of the pattern `lane` of lists
+#pragma unroll
+                for (uint32_t l = 0; l < K3R_MUX_LISTS; ++l) score += (l < nl && (((uint32_t)lane >> l) & 1u)) ? mu[l] : 0u;
+                const uint64_t table = __ballot(score >= min_score);
+                uint32_t pcm = 0;
+                switch (nl) {  // (wave-uniform)
+                    case 1: pcm = mux_union_read<1>(rows, W, Wn, n, id, table, bm, lane); break;
+                    case 2: pcm = mux_union_read<2>(rows, W, Wn, n, id, table, bm, lane); break;
+                    case 3: pcm = mux_union_read<3>(rows, W, Wn, n, id, table, bm, lane); break;
+                    case 4: pcm = mux_union_read<4>(rows, W, Wn, n, id, table, bm, lane); break;
+                    case 5: pcm = mux_union_read<5>(rows, W, Wn, n, id, table, bm, lane); break;
+                    default: pcm = mux_union_read<6>(rows, W, Wn, n, id, table, bm, lane); break;
+                }
+                for (uint32_t w = ((Wn + 63) & ~63u) + lane; w < W; w += 64) bm[w] = 0;  // (padding words behind the last round)
+                pcm = wave_sum_u32(pcm);
+                if (lane == 0) out_count[r] = pcm;
                 continue;
             }
             const uint32_t start = (BIASED ? HALF - min_score : 0u) * ONES;
