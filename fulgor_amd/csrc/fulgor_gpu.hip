@@ -1080,7 +1080,9 @@ int fgpu_result_algorithmic_bytes(const fgpu_result* r, uint64_t* list_bytes, ui
             hipLaunchKernelGGL(k_account, dim3(1024), dim3(256), 0, r->stream, ix->dc, r->d_nids.as<uint32_t>(),
                                r->d_idoff.as<uint64_t>(), r->d_ids_pool.as<uint32_t>(), r->d_counts.as<uint32_t>(), r->n,
                                r->d_acct.as<unsigned long long>(),
-                               ix->host.type == IDX_HYBRID ? (const uint32_t*)nullptr : ix->d_gset_bytes.as<uint32_t>());
+                               // (a re-encoded index that answers from the dense rows is charged the hybrid lists the rows were built from,
+                               // not the longer chains of partial lists its codec would have walked)
+                               ix->host.type == IDX_HYBRID || (ix->d_rows.p && ix->dense_rows) ? (const uint32_t*)nullptr : ix->d_gset_bytes.as<uint32_t>());
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(acct, r->d_acct.p, 16, hipMemcpyDeviceToHost, r->stream));
             HIP_TRY(hipStreamSynchronize(r->stream));

@@ -106,7 +106,9 @@ int fgpu_result_accumulate_hits(fgpu_index* idx, const fgpu_result* res, void* d
 /* algorithmic bytes of the last run. Colour-intersection stage, per read:
  *   list side   = sum over its colour-set ids of ceil(list bits / 8) + 16 (two offsets) + 4 (the id)
  *   output side = 4 * |result| + 8 (CSR offset)
- * lookup stage = ceil(bases / 4) + 8 per k-mer */
+ * lookup stage = ceil(bases / 4) + 8 per k-mer
+ * (meta / differential codecs on their own kernels: the list side counts every partial list the set's ops touch; on the dense rows
+ * every codec is charged the hybrid lists, which is what the rows were built from) */
 int fgpu_result_algorithmic_bytes(const fgpu_result* res, uint64_t* list_bytes, uint64_t* output_bytes,
                                   uint64_t* lookup_bytes);
 
