@@ -542,9 +542,10 @@ def _write_wide_dump(base, rng, n=70001, k=31):
     allc = np.arange(n, dtype=np.int64)
     def pick(m):
         return np.sort(rng.choice(n, size=m, replace=False))
-    sets = [pick(50), pick(5000), pick(300), pick(30000), np.setdiff1d(allc, pick(40)), allc, np.array([n - 1]),
-            np.array([0]), np.setdiff1d(allc, pick(10000)), pick(17499), pick(17500), np.setdiff1d(allc, pick(17500)),
-            np.concatenate([np.arange(100, 400), pick(64)]), np.arange(65000, 70001)]
+    q = n // 4  # (the sparse / bitmap boundary of the hybrid encoding: 17500 at 70001 colours)
+    sets = [pick(50), pick(n // 14), pick(300), pick(3 * n // 7), np.setdiff1d(allc, pick(40)), allc, np.array([n - 1]),
+            np.array([0]), np.setdiff1d(allc, pick(n // 7)), pick(q - 1), pick(q), np.setdiff1d(allc, pick(q)),
+            np.concatenate([np.arange(100, 400), pick(64)]), np.arange(n - n // 14, n)]
     sets = [np.unique(s) for s in sets]
     unitigs = []
     for sid in range(len(sets)):
@@ -608,6 +609,54 @@ def test_gpu_more_than_65535_colours(built, tmp_path):
         assert bytes(res.format_view(code, 7)) == Formatter(fmt, 70001).add(7, go, gc)
     ids, po, pc = parse_compressed(Formatter("compressed", 70001).header + bytes(res.format_view(2, 7)))
     assert np.array_equal(ids, np.arange(7, 7 + len(reads), dtype=np.uint32)) and np.array_equal(po, go) and np.array_equal(pc, gc)
+
+
+@pytest.mark.parametrize("n", [12001, 24001])
+def test_gpu_dense_rows_of_two_and_four_groups_per_lane(built, tmp_path, n):
+    """8193 to 32768 colours: a dense row is two resp. four 128-bit groups per lane (k2r_intersect<2>, <4>; k3r_union runs more
+    rounds); intersection, union, hit counts and the compressed formatter against the oracle, and against the packed-block
+    kernels of the same index"""
+    import torch
+    from oracle.pyoracle import OracleIndex, parse_compressed
+    from fulgor_amd.driver import Formatter
+    rng = np.random.default_rng(n)
+    base = str(tmp_path / "mid")
+    unitigs, nsets = _write_wide_dump(base, rng, n=n)
+    ix = fulgor_amd.Index(base, device=0)
+    orc = OracleIndex.from_dump(base)
+    assert ix.num_colors() == n
+    reads = []
+    for _ in range(600):
+        reads.append("".join(u[s:s + 60] for u, s in ((unitigs[rng.integers(len(unitigs))], rng.integers(0, 140))
+                                                    for _ in range(rng.integers(1, 4)))))
+    reads += [u[:150] for u in unitigs]
+    b, o = pack_reads(reads)
+    oo, oc = orc.full_intersection(b, o, threads=8, self_check=True)
+    for rows in (True, False):
+        ix.tune(dense_rows=rows)
+        go, gc = ix.pseudoalign_full_intersection_batch(b, o)
+        assert np.array_equal(go, oo) and np.array_equal(gc, oc), rows
+        for tau in (0.3, 1.0):
+            go, gc = ix.pseudoalign_threshold_union_batch(b, o, tau)
+            uo, uc = orc.threshold_union(b, o, tau, threads=8)
+            assert np.array_equal(go, uo) and np.array_equal(gc, uc), (rows, tau)
+    ix.tune(dense_rows=True)
+    lists = [np.unique(rng.integers(0, nsets, size=l)).astype(np.uint32) for l in rng.integers(1, 12, size=300)]
+    ido = np.zeros(len(lists) + 1, dtype=np.uint64)
+    ido[1:] = np.cumsum([len(l) for l in lists])
+    go, gc = ix.intersect_ids_batch(np.concatenate(lists), ido)
+    io, ic = orc.intersect_ids(np.concatenate(lists), ido, threads=8)
+    assert np.array_equal(go, io) and np.array_equal(gc, ic)
+    rd, res = ix.upload_reads(b, o), ix.new_result()
+    ix.run(rd, res, fulgor_amd.FULL_INTERSECTION)
+    hits = torch.zeros(n + 2, dtype=torch.int64, device="cuda:0")
+    res.accumulate_hits(hits.data_ptr())
+    go, gc = res.download()
+    got = hits.cpu().numpy()
+    assert np.array_equal(got[:n], np.bincount(gc, minlength=n)) and got[n] == len(reads)
+    ids, po, pc = parse_compressed(Formatter("compressed", n).header + bytes(res.format_view(2, 3)))
+    assert np.array_equal(ids, np.arange(3, 3 + len(reads), dtype=np.uint32)) and np.array_equal(po, go) and np.array_equal(pc, gc)
+    assert bytes(res.format_view(0, 3)) == Formatter("ascii", n).add(3, go, gc)
 
 
 def test_preprocessed_query_file_path_equals_direct_path(s4546, tmp_path):
