@@ -202,6 +202,10 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                     }
                     wave_lds_sync();
                 }
+#if defined(FG_K1_STOP) && FG_K1_STOP == 1  // knock-out build (profiles/k1_phase_counts.sh): the kernel up to the end of phase A
+                if (lane == 0) { nids[t_first + j] = v[0] == 0x12345u; npos[t_first + j] = 0; idoff[t_first + j] = (t_first + j) * (uint64_t)stride; }
+                continue;
+#endif
                 // ---- B: runs of k-mers sharing a minimizer occurrence, queued behind the runs that wait ----
                 uint32_t pos[NA - 1];
                 uint64_t H[NA - 1];
@@ -228,6 +232,10 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                 }
                 wave_lds_sync();
             }
+#if defined(FG_K1_STOP) && FG_K1_STOP == 2  // (knock-out build: up to the end of phase B)
+            if (j < t_count && lane == 0) { nids[t_first + j] = R == 0x12345u; npos[t_first + j] = 0; idoff[t_first + j] = (t_first + j) * (uint64_t)stride; }
+            continue;
+#endif
             if (ng == 0 || (q + R <= 64u && ng < (uint32_t)GROUP)) {  // the read joins the pass in preparation
                 q += R;
                 ++ng;
@@ -446,6 +454,9 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                 if (single && lane == 0) { meta[gfirst][M_HA] = 0; meta[gfirst][M_HB] = hcount; }
                 wave_lds_sync();
                 // ---- E: sorted distinct ids with summed multiplicities, per read slot ----
+#if defined(FG_K1_STOP) && FG_K1_STOP == 3  // (knock-out build: without phase E)
+                if (lane == 0 && hcount == 0x12345u) nids[0] = hid[0];
+#else
                 uint32_t maxseg = 0;
                 for (uint32_t t = t0; t < t1; ++t) {
                     const uint32_t g = (gs + t) % (uint32_t)NSLOT;
@@ -562,6 +573,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                         }
                     }
                 }
+#endif
                 wave_lds_sync();
                 if ((uint32_t)lane >= t0 && (uint32_t)lane < t1) {
                     const uint32_t g = (gs + (uint32_t)lane) % (uint32_t)NSLOT;
