@@ -54,7 +54,7 @@ def prepare_workload(name):
 
 def real_dump_workload(base, data):
     """FULGOR_S4546_DUMP=<basename>: the four text files of `fulgor dump -i salmonella_4546.fur` (src/index.cpp:59-120). The
-    index is ingested once into data/<name>.v7.fgidx; the reads are drawn by the same seeded generator from the unitig
+    index is ingested once into data/<name>.v8.fgidx; the reads are drawn by the same seeded generator from the unitig
     sequences of the dump themselves (the genomes are not part of a dump): every unitig of at least 150 bases is a source
     sequence, so reads stay inside unitigs — state it when quoting: fewer colour sets per read than reads across junctions."""
     import fulgor_amd
@@ -62,7 +62,7 @@ def real_dump_workload(base, data):
     for suffix in (".metadata.txt", ".unitigs.fa", ".color_sets.txt"):
         if not os.path.exists(base + suffix):
             raise SystemExit("FULGOR_S4546_DUMP=%s: %s%s is missing" % (base, base, suffix))
-    fg = os.path.join(data, os.path.basename(base) + ".v7.fgidx")
+    fg = os.path.join(data, os.path.basename(base) + ".v8.fgidx")
     if not os.path.exists(fg) or os.path.getmtime(fg) < os.path.getmtime(base + ".color_sets.txt"):
         os.makedirs(data, exist_ok=True)
         ix = fulgor_amd.Index(base, device=-1)

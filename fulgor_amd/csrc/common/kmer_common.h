@@ -117,8 +117,8 @@ FG_HD uint32_t dict_tag(uint32_t lo, uint32_t hi) {
 // smin..smax: the k-mers of that strand whose leftmost smallest-order m-mer is this occurrence (a super-k-mer).
 //   w0  context, lo plane, bases 0..31
 //   w1  context, hi plane, bases 0..31
-//   w2  lo plane bases 32..42 | hi plane bases 32..42 << 11 | smin << 22 | smax << 26
-//   w3  colour-set id (31 bits; u2c folded in, index.hpp:37 of the reference) | spill << 31
+//   w2  lo plane bases 32..44 | hi plane bases 32..44 << 13 | smin << 26 | redirect flag << 31
+//   w3  colour-set id (27 bits; u2c folded in, index.hpp:37 of the reference) | smax << 27 | spill << 31
 // An empty slot has smin > smax.
 // A key whose records do not fit its home bucket next to the other keys living there (or that has more than four)
 // keeps ONE slot in the home bucket, a REDIRECT: w0 = dict_tag of the key, w1 = its first overflow bucket,
@@ -127,24 +127,28 @@ FG_HD uint32_t dict_tag(uint32_t lo, uint32_t hi) {
 // spill (bit 31 of w3 of a bucket's last slot): the query goes on with the next bucket. Set on the overflow
 // buckets of a key from the REDIRECT_DIRECT-th on (but the last), and on a hashed bucket when more than four keys
 // live there (rare), whose surplus slots then sit in the following buckets.
-// Needs 2k - m <= 43 and k - m <= 15 (k = 31, m = 19: exactly 43 bases).
+// Needs 2k - m <= 45 and k - m <= 15 (k = 31, m = 17: exactly 45 bases, 15 windows: 16 runs per 150-base read, so that four
+// reads fill a pass of the lookup kernel; round 2 had 43 bases for m = 19 and a 31-bit colour-set id).
 constexpr uint32_t REC_WORDS = 4;
 constexpr uint32_t BUCKET_RECS = 4;
 constexpr uint32_t BUCKET_WORDS = REC_WORDS * BUCKET_RECS;
-constexpr uint32_t REC_CTX_MAX = 43;
-constexpr uint32_t REC_MAX_CSID = 0x7FFFFFFFu;
+constexpr uint32_t REC_CTX_MAX = 45;
+constexpr uint32_t REC_HI_BITS = REC_CTX_MAX - 32;            // context bases held in w2, per plane
+constexpr uint32_t REC_HI_MASK = (1u << REC_HI_BITS) - 1u;
+constexpr uint32_t REC_MAX_CSID = 0x07FFFFFFu;                // (also the width of a redirect's bucket count)
 constexpr uint32_t REC_SPILL = 0x80000000u;
-constexpr uint32_t REC_W2_EMPTY = 15u << 22;  // smin = 15 > smax = 0
+constexpr uint32_t REC_W2_EMPTY = 15u << 26;  // smin = 15 > smax = 0 (w3 = 0)
 constexpr uint32_t REC_W2_REDIRECT = REC_W2_EMPTY | 0x80000000u;
 constexpr uint32_t DICT_MAX_BUCKETS = 1u << 26;  // a (source lane, bucket) pair of the lookup kernel packs into 32 bits
 constexpr uint32_t REDIRECT_DIRECT = 3;
-FG_HD uint32_t rec_w2(uint64_t ctx_lo, uint64_t ctx_hi, uint32_t smin, uint32_t smax) {
-    return (uint32_t)(ctx_lo >> 32) | ((uint32_t)(ctx_hi >> 32) << 11) | (smin << 22) | (smax << 26);
+FG_HD uint32_t rec_w2(uint64_t ctx_lo, uint64_t ctx_hi, uint32_t smin) {
+    return (uint32_t)(ctx_lo >> 32) | ((uint32_t)(ctx_hi >> 32) << REC_HI_BITS) | (smin << 26);
 }
-FG_HD uint32_t rec_smin(uint32_t w2) { return (w2 >> 22) & 15u; }
-FG_HD uint32_t rec_smax(uint32_t w2) { return (w2 >> 26) & 15u; }
-FG_HD uint64_t rec_ctx_lo(uint32_t w0, uint32_t w2) { return (uint64_t)w0 | ((uint64_t)(w2 & 0x7FFu) << 32); }
-FG_HD uint64_t rec_ctx_hi(uint32_t w1, uint32_t w2) { return (uint64_t)w1 | ((uint64_t)((w2 >> 11) & 0x7FFu) << 32); }
+FG_HD uint32_t rec_w3(uint32_t csid, uint32_t smax) { return csid | (smax << 27); }
+FG_HD uint32_t rec_smin(uint32_t w2) { return (w2 >> 26) & 15u; }
+FG_HD uint32_t rec_smax(uint32_t w3) { return (w3 >> 27) & 15u; }
+FG_HD uint64_t rec_ctx_lo(uint32_t w0, uint32_t w2) { return (uint64_t)w0 | ((uint64_t)(w2 & REC_HI_MASK) << 32); }
+FG_HD uint64_t rec_ctx_hi(uint32_t w1, uint32_t w2) { return (uint64_t)w1 | ((uint64_t)((w2 >> REC_HI_BITS) & REC_HI_MASK) << 32); }
 // ---- unitig strings ----------------------------------------------------------------------------
 // word w holds bases [32w, 32w+32): low 32 bits = lo plane, high 32 bits = hi plane.
 // extract an L-mer (L<=32) starting at base s from two consecutive words

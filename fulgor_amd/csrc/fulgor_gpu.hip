@@ -343,7 +343,7 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
         kmer_out = res->d_kmer_ids.as<uint32_t>();
     }
     if (units == 0) return;
-    const bool w13 = ix->dd.k - ix->dd.m == 12;
+    const bool w13 = ix->dd.k - ix->dd.m + 1 == K1_WFIX;  // (the window count the kernel unrolls for)
     // units of at most 128 k-mers: one window each; up to 512 k-mers (250- to 500-base reads, segments of longer reads): 2 to 4 windows
     const int halves = (int)((std::max<uint32_t>(rd->max_kmers, 1) + 127) / 128);
     {

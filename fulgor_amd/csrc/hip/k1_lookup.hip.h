@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t run_pack(uint32_t pm, uint32_t i0, uint32_t 
 }
 
 #ifndef FG_K1_TICKET
-#define FG_K1_TICKET 9  // three reads fill a pass of 64 runs (18 runs per 150-base read): tickets of 3 n reads leave no short pass behind
+#define FG_K1_TICKET 32  // a pass of 64 run lanes takes three or four 150-base reads (15.9 runs each at m = 17): long tickets leave few short passes behind (9: 7.47, 16: 7.25, 32: 7.11, 48: 7.10 ms per 10 M reads)
 #endif
 constexpr uint32_t K1_TICKET = FG_K1_TICKET;  // reads per pull from the work queue
 
@@ -58,12 +58,13 @@ __device__ unsigned long long k1_stats[16];
 // the pools: ids ascending + how many positive k-mers had each id. KMER_OUT: also the colour-set id of every k-mer
 // (0xFFFFFFFF = negative), the input of the reference's kmer_conservation / kmer_matches queries
 // (src/kmer_conservation.cpp:7-54, src/kmer_matches.cpp:7-30).
-// W13 fixes the number of m-mers per k-mer at 13 (k - m = 12, e.g. k = 31, m = 19) so that the window minima unroll.
+// WFIX fixes the number of m-mers per k-mer at K1_WFIX = 15 (k - m = 14, e.g. k = 31, m = 17) so that the window minima unroll.
 // HALVES = 1, 2, 4: units of up to 128 * HALVES k-mers.
 #ifndef FG_K1_WAVES
 #define FG_K1_WAVES 6  // waves per SIMD the register allocation aims at (measured: profiles/r2)
 #endif
-template <bool W13, int HALVES, bool KMER_OUT>
+constexpr uint32_t K1_WFIX = 15;
+template <bool WFIX, int HALVES, bool KMER_OUT>
 __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(DevDict d, const uint8_t* __restrict__ bases,
                                                                       const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
                                                                       uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
@@ -109,8 +110,8 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
     uint32_t* hres = L.hres;
     uint32_t* hsrt = L.hsrt;
     uint32_t (*meta)[M_WORDS] = L.meta;
-    const uint32_t k = d.k, m = d.m, km = k - m, W = W13 ? 13u : km + 1, CL = 2 * k - m;
-    const uint32_t span = W13 ? 8u : 1u << (31 - __builtin_clz(W));  // largest power of two <= W (W <= 16)
+    const uint32_t k = d.k, m = d.m, km = k - m, W = WFIX ? K1_WFIX : km + 1, CL = 2 * k - m;
+    const uint32_t span = WFIX ? 8u : 1u << (31 - __builtin_clz(W));  // largest power of two <= W (W <= 16)
     const uint32_t tail = W - span;
     const uint32_t maskm = low_mask32(m), maskkm = (1u << km) - 1u;
     const uint32_t clo_mask = CL >= 32 ? 0xFFFFFFFFu : (1u << CL) - 1u, chi_mask = CL > 32 ? (1u << (CL - 32)) - 1u : 0u;
@@ -366,14 +367,14 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                         for (int r = 0; r < (int)BUCKET_RECS; ++r) {
                             const uint32_t w0 = rec[r].x, w1 = rec[r].y, w2 = rec[r].z;
                             const uint32_t x0 = (T[0] ^ w0) | (T[2] ^ w1) | T[4];
-                            const uint32_t x1 = (T[1] ^ (w2 & 0x7FFu)) | (T[3] ^ ((w2 >> 11) & 0x7FFu)) | T[5];
+                            const uint32_t x1 = (T[1] ^ (w2 & REC_HI_MASK)) | (T[3] ^ ((w2 >> REC_HI_BITS) & REC_HI_MASK)) | T[5];
                             // mismatches below the core bound the windows from below, those above it from above
                             const uint32_t A = x0 & maskkm;
                             const uint32_t sl = 31u - (uint32_t)__builtin_clz((A << 1) | 1u);
                             const uint32_t B = __builtin_amdgcn_alignbit(x1, x0, k) & maskkm;
                             const uint32_t su = (uint32_t)__builtin_ctz(B | (1u << km));
                             const uint32_t lo = max(max(sl, rec_smin(w2)), runlo);
-                            const uint32_t hi = min(min(su, rec_smax(w2)), runhi);
+                            const uint32_t hi = min(min(su, rec_smax(rec[r].w)), runhi);
                             const bool hit = live && (x0 & core_mask) == 0 && lo <= hi;
                             hv[r] = rec[r].w & REC_MAX_CSID;
                             hc[r] = hit ? hi - lo + 1u : 0u;

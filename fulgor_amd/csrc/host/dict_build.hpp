@@ -46,7 +46,7 @@ inline uint32_t string_base(const std::vector<uint64_t>& strings, uint64_t pos) 
 inline void check_dict_params(uint32_t k, uint32_t m) {
     if (k < 2 || k > 31) throw std::runtime_error("k must be in [2,31]");
     if (m < 1 || m > k || k - m > 15) throw std::runtime_error("need m <= k and k - m <= 15");
-    if (2 * k - m > REC_CTX_MAX) throw std::runtime_error("need 2k - m <= 43 (the record's context)");
+    if (2 * k - m > REC_CTX_MAX) throw std::runtime_error("need 2k - m <= 45 (the record's context)");
 }
 
 // the minimizer of a record, cut out of its context
@@ -143,7 +143,7 @@ inline void build_dict_table(Dict& d) {
         for (uint64_t i = b; i < e; ++i) {
             const uint32_t* w = &d.records[(uint64_t)refs[i].rec * REC_WORDS];
             uint32_t* o = &ordered[i * REC_WORDS];
-            o[0] = w[0]; o[1] = w[1]; o[2] = w[2]; o[3] = w[3] & REC_MAX_CSID;
+            o[0] = w[0]; o[1] = w[1]; o[2] = w[2]; o[3] = w[3] & ~REC_SPILL;
         }
     });
     auto put = [&](uint32_t* dst, uint64_t at_ref) {  // the record of refs[at_ref]
@@ -264,8 +264,8 @@ inline void build_dict(Dict& d, uint32_t k, uint32_t m, const char* bases, uint6
                             auto put = [&](uint32_t a, uint32_t z) {
                                 out.push_back((uint32_t)clo);
                                 out.push_back((uint32_t)chi);
-                                out.push_back(rec_w2(clo, chi, a, z));
-                                out.push_back(unitig_csid[u]);
+                                out.push_back(rec_w2(clo, chi, a));
+                                out.push_back(rec_w3(unitig_csid[u], z));
                             };
                             if (strand == 0 || (k & 1u)) { put(s0, s1); return; }
                             // reverse strand, even k: a k-mer equal to its own reverse complement is already there
@@ -342,7 +342,7 @@ inline uint32_t dict_lookup(const Dict& d, uint32_t klo, uint32_t khi, uint32_t*
             const uint32_t* w = bw + r * REC_WORDS;
             if ((w[2] & 0x80000000u) && w[0] == tag)  // this key's redirect (or a tag collision: harmless)
                 for (uint32_t j = 0; j < std::min(w[3] & REC_MAX_CSID, REDIRECT_DIRECT); ++j) visit.push_back((uint64_t)w[1] + j);
-            if (s < rec_smin(w[2]) || s > rec_smax(w[2])) continue;
+            if (s < rec_smin(w[2]) || s > rec_smax(w[3])) continue;
             const uint32_t lo = (uint32_t)(rec_ctx_lo(w[0], w[2]) >> s) & low_mask32(k);
             const uint32_t hi = (uint32_t)(rec_ctx_hi(w[1], w[2]) >> s) & low_mask32(k);
             if (lo == klo && hi == khi) {

@@ -107,7 +107,7 @@ inline void load_dump(const std::string& base, HostIndex& idx, uint32_t m = 0, u
             csid.push_back((uint32_t)id);
         }
     }
-    if (m == 0) m = k >= 13 ? (uint32_t)k - 12 : 1;  // k=31 -> m=19
+    if (m == 0) m = k >= 15 ? (uint32_t)k - 14 : 1;  // k=31 -> m=17: 15 windows, contexts of 45 bases
     idx.type = IDX_HYBRID;
     build_dict(idx.dict, (uint32_t)k, m, bases.data(), bases.size(), off, csid, nthreads);
     if (num_kmers && idx.dict.num_kmers != num_kmers) throw std::runtime_error("num_kmers does not match metadata");
@@ -115,7 +115,7 @@ inline void load_dump(const std::string& base, HostIndex& idx, uint32_t m = 0, u
 
 // ---- own binary container ------------------------------------------------------------------------
 namespace detail {
-static const char FGIDX_MAGIC[8] = {'F', 'G', 'I', 'D', 'X', '0', '0', '7'};  // 007: self-contained 16-byte super-k-mer records of both strands in 64-byte buckets
+static const char FGIDX_MAGIC[8] = {'F', 'G', 'I', 'D', 'X', '0', '0', '8'};  // 008: records with contexts of up to 45 bases (m = 17 at k = 31), smax in w3, 27-bit colour-set ids
 template <typename T>
 void wr(std::ofstream& o, const T& v) { o.write(reinterpret_cast<const char*>(&v), sizeof(T)); }
 template <typename T>

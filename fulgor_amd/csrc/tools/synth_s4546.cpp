@@ -295,7 +295,7 @@ int main(int argc, char** argv) {
             csid.push_back(unitigs[i].set);
         }
         std::string().swap(seqs);
-        build_dict(idx.dict, K, 19, bases.data(), bases.size(), off, csid);
+        build_dict(idx.dict, K, 17, bases.data(), bases.size(), off, csid);
         const DictStats ds = dict_stats(idx.dict);
         fprintf(stderr, "dictionary: %llu k-mers, %llu super-k-mer records in %llu hashed buckets of 64 bytes (%.0f MB with %llu overflow buckets), %llu redirects, %llu spill buckets\n",
                 (unsigned long long)idx.dict.num_kmers, (unsigned long long)ds.records, (unsigned long long)ds.buckets,
