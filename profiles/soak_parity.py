@@ -62,6 +62,11 @@ print("%-46s %s" % ("k-mer conservation triples, 20000 reads", "equal" if same e
 b, o = gen.generate(200_000_000, n // 2, 150, 12)
 ref_fi = ix.pseudoalign_full_intersection_batch(b, o)
 ref_tu = ix.pseudoalign_threshold_union_batch(b, o, 0.8)
+# (round 3) the reference results above came from the dense rows (k2r_intersect / k3r_union); the packed-block kernels of the
+# hybrid index and the codec kernels must give the same
+ix.tune(dense_rows=False)
+check("hybrid on packed blocks (k2a), full intersection, %d reads" % (n // 2), ix.pseudoalign_full_intersection_batch(b, o), ref_fi)
+check("hybrid on packed blocks (k3a), threshold union 0.8", ix.pseudoalign_threshold_union_batch(b, o, 0.8), ref_tu)
 for t, name in ((3, "meta-differential"), (1, "differential"), (2, "meta")):
     ix.convert(t, 128, 16)
     check("%s, full intersection, %d reads" % (name, n // 2), ix.pseudoalign_full_intersection_batch(b, o), ref_fi)
