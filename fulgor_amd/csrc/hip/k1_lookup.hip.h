@@ -45,6 +45,7 @@ __device__ __forceinline__ uint32_t run_pack(uint32_t pm, uint32_t i0, uint32_t 
 #define FG_K1_TICKET 32  // a pass of 64 run lanes takes three or four 150-base reads (15.9 runs each at m = 17): long tickets leave few short passes behind (9: 7.47, 16: 7.25, 32: 7.11, 48: 7.10 ms per 10 M reads)
 #endif
 constexpr uint32_t K1_TICKET = FG_K1_TICKET;  // reads per pull from the work queue
+constexpr uint32_t K1_RUN_LANES = 64;  // runs a pass of several reads may hold: all lanes (leaving 2 / 4 / 7 lanes to the overflow buckets of the first batch: 7.15 / 7.19 / 7.29 ms against 7.11)
 
 #ifdef FG_K1_STATS  // instrumented build (profiles/k1_stats.py): how often every loop of the kernel runs
 __device__ unsigned long long k1_stats[16];
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
             if (j < t_count && lane == 0) { nids[t_first + j] = R == 0x12345u; npos[t_first + j] = 0; idoff[t_first + j] = (t_first + j) * (uint64_t)stride; }
             continue;
 #endif
-            if (ng == 0 || (q + R <= 64u && ng < (uint32_t)GROUP)) {  // the read joins the pass in preparation
+            if (ng == 0 || (q + R <= K1_RUN_LANES && ng < (uint32_t)GROUP)) {  // the read joins the pass in preparation
                 q += R;
                 ++ng;
                 continue;
