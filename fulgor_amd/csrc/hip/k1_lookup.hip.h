@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                                                                       uint32_t* __restrict__ cnt_pool, uint32_t stride, unsigned int* tickets,
                                                                       uint32_t* __restrict__ kmer_out) {
     constexpr int KMAX = 128 * HALVES;      // k-mers per unit
+    constexpr uint32_t TICKET = HALVES == 1 ? K1_TICKET : 9;  // longer units: one to three per pass, short tickets (and the LDS of the 512-k-mer variant is tight)
     constexpr int NB = 2 * HALVES + 1;      // 64-base groups fetched per unit
     constexpr int NA = 2 * HALVES + 1;      // rounds of 64 m-mer positions (the last one: 16 positions)
     constexpr int PW = 2 * NB + 3;          // plane words per unit: one pad word in front, two behind
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
         uint32_t hres[HCAP];             // heads sorted by (read, id): id  (long passes: total of the id within its read | FIRST, 0 for repeats)
         uint32_t hsrt[HCAP];             //                             k-mers | tags
         uint32_t meta[NSLOT][M_WORDS];
-        uint32_t offs[2 * (K1_TICKET + 1)];  // read offsets of the ticket
+        uint32_t offs[2 * (TICKET + 1)];  // read offsets of the ticket
     };
     __shared__ WaveLds s_lds[4];
     const int lane = lane_id();
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
     const uint32_t maskm = low_mask32(m), maskkm = (1u << km) - 1u;
     const uint32_t clo_mask = CL >= 32 ? 0xFFFFFFFFu : (1u << CL) - 1u, chi_mask = CL > 32 ? (1u << (CL - 32)) - 1u : 0u;
     const uint32_t core_mask = low_mask32(k) & ~maskkm;  // context bases k-m .. k-1: part of every window
-    const WorkQueue wq{tickets, n_reads, K1_TICKET};
+    const WorkQueue wq{tickets, n_reads, TICKET};
     uint64_t t_first;
     uint32_t t_count;
 
