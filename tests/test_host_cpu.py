@@ -178,14 +178,22 @@ def test_host_code_under_sanitizers(c256_dump, tmp_path):
         pytest.skip("no g++")
     from conftest import ROOT
     src = os.path.join(ROOT, "tests", "host_sanitize.cpp")
-    for tag, flags in (("asan", ["-fsanitize=address,undefined"]), ("tsan", ["-fsanitize=thread"])):
+    def one(tag, flags):
         exe = str(tmp_path / ("host_" + tag))
         r = subprocess.run(["g++", "-O1", "-g", "-std=c++17"] + flags + ["-I", os.path.join(ROOT, "fulgor_amd", "csrc"), "-I",
                             os.path.join(ROOT, "include"), src, "-o", exe, "-lz", "-ldl", "-pthread"], capture_output=True, text=True)
         if r.returncode != 0:
-            pytest.skip("sanitizer build not available: " + r.stderr[-200:])
+            return "skip", r.stderr[-200:]
         out = tmp_path / tag
         out.mkdir()
         r = subprocess.run([exe, c256_dump, str(out)], capture_output=True, text=True, timeout=900)
+        return "ran", r
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as pool:  # the two builds side by side: they are most of the CPU suite's time
+        results = list(pool.map(lambda a: one(*a), (("asan", ["-fsanitize=address,undefined"]), ("tsan", ["-fsanitize=thread"]))))
+    for kind, r in results:
+        if kind == "skip":
+            pytest.skip("sanitizer build not available: " + r)
         assert r.returncode == 0 and r.stdout.strip().endswith("host ok"), (r.stdout[-500:], r.stderr[-2000:])
         assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
