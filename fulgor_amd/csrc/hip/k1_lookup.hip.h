@@ -36,9 +36,48 @@ struct DevDict {
     uint32_t num_buckets, k, m, seed;
 };
 
-// run descriptor in the queue: minimizer position | first k-mer << 10 | k-mers << 20 | read slot << 25
-__device__ __forceinline__ uint32_t run_pack(uint32_t pm, uint32_t i0, uint32_t cnt, uint32_t g) {
-    return pm | (i0 << 10) | (cnt << 20) | (g << 25);
+// run descriptor in the queue: minimizer position within the ticket's span of bases (13 bits) | its distance from the run's
+// first k-mer << 13 (0 .. k - m) | k-mers << 17 (filled in by phase C) | read slot << 22
+constexpr uint32_t RUN_POS_BITS = 13;
+constexpr uint32_t RUN_POS_MASK = (1u << RUN_POS_BITS) - 1u;
+__device__ __forceinline__ uint32_t run_pack(uint32_t pa, uint32_t dm, uint32_t g) { return pa | (dm << RUN_POS_BITS) | (g << 22); }
+__device__ __forceinline__ uint32_t run_first_kmer(uint32_t desc) { return (desc & RUN_POS_MASK) - ((desc >> RUN_POS_BITS) & 15u); }
+
+// ---- bases -> bit planes, 16 bases per lane (one 16-byte load), no ballots ----
+// The reads of a ticket lie one behind the other in the base buffer, so a wave turns the whole span into bit planes at once:
+// bit p of a plane = base p of the span. Per dword (4 letters): bits 1 and 2 of a letter give its code (A0 C1 G2 T3 =
+// bit1 ^ bit2, bit2); the four bits of a dword are gathered with a multiplication (bit 8i + c of the source lands on bit
+// 24 + i; two dwords share one product, the second shifted by four: its bits land on 28 + i; the stray partial products fall
+// on distinct bits below 24 or leave the word), a letter is valid if, case folded, it is the letter its own code stands for
+// (v_perm as a four-entry table).
+__device__ __forceinline__ uint32_t gather_bits(uint32_t m0, uint32_t m1, uint32_t m2, uint32_t m3, uint32_t mult) {
+    const uint32_t p0 = (m0 | (m1 << 4)) * mult, p1 = (m2 | (m3 << 4)) * mult;
+    return __builtin_amdgcn_perm(p1, p0, 0x0C0C0703u);  // byte 3 of p0 | byte 3 of p1 << 8
+}
+__device__ __forceinline__ void encode16(u32x4 x, uint32_t& lo16, uint32_t& hi16, uint32_t& bad) {
+    uint32_t lm[4], hm[4];
+    bad = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t a = x[j] >> 1;
+        lm[j] = (x[j] ^ a) & 0x02020202u;  // bit 1 of every byte: bit1 ^ bit2 of the letter
+        hm[j] = x[j] & 0x04040404u;        // bit 2 of every byte
+        const uint32_t expect = __builtin_amdgcn_perm(0x47544341u, 0x47544341u, a & 0x03030303u);  // (letter >> 1) & 3: A C T G
+        bad |= (x[j] & 0xDFDFDFDFu) ^ expect;
+    }
+    lo16 = gather_bits(lm[0], lm[1], lm[2], lm[3], 0x00810204u);  // 8 i + 1 -> 24 + i
+    hi16 = gather_bits(hm[0], hm[1], hm[2], hm[3], 0x00408102u);  // 8 i + 2 -> 24 + i
+}
+// the same for the letters that are not nucleotides (the rare path): a byte of `d` that is not zero -> its bit
+__device__ __forceinline__ uint32_t invalid16(u32x4 x) {
+    uint32_t nz[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t expect = __builtin_amdgcn_perm(0x47544341u, 0x47544341u, (x[j] >> 1) & 0x03030303u);
+        const uint32_t d = (x[j] & 0xDFDFDFDFu) ^ expect;
+        nz[j] = ((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) >> 6) & 0x02020202u;  // bit 1 of every byte that is not zero
+    }
+    return gather_bits(nz[0], nz[1], nz[2], nz[3], 0x00810204u);
 }
 
 #ifndef FG_K1_TICKET
@@ -73,10 +112,11 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                                                                       uint32_t* __restrict__ cnt_pool, uint32_t stride, unsigned int* tickets,
                                                                       uint32_t* __restrict__ kmer_out) {
     constexpr int KMAX = 128 * HALVES;      // k-mers per unit
-    constexpr uint32_t TICKET = HALVES == 1 ? K1_TICKET : 9;  // longer units: one to three per pass, short tickets (and the LDS of the 512-k-mer variant is tight)
-    constexpr int NB = 2 * HALVES + 1;      // 64-base groups fetched per unit
+    constexpr uint32_t TICKET = HALVES == 1 ? K1_TICKET : (HALVES == 2 ? 6 : 1);  // longer units: one to three per pass, and the planes of a ticket's span live in LDS: short tickets
     constexpr int NA = 2 * HALVES + 1;      // rounds of 64 m-mer positions (the last one: 16 positions)
-    constexpr int PW = 2 * NB + 3;          // plane words per unit: one pad word in front, two behind
+    constexpr int SPAN_BASES = (int)TICKET * (KMAX + 30) + 16;  // the units of a ticket + what the 16-byte alignment of its first load adds
+    constexpr int NIT = (SPAN_BASES + 1023) / 1024;              // rounds of 64 lanes x 16 bases that cover the span
+    constexpr int SPW = 1 + 32 * NIT + 3;   // plane words: one pad word in front, three behind (a context reaches 14 bases past its read)
     constexpr int GROUP = HALVES == 1 ? 6 : (HALVES == 2 ? 3 : 1);  // most reads whose runs share one pass of phase C
     constexpr int NSLOT = GROUP + 1;        // read slots (a ring): the reads of a pass plus the read waiting for the next one
     constexpr int QCAP = KMAX + 64;         // the runs of a pass (at most 64, or one unit: at most one run per k-mer) + those of the next read
@@ -84,7 +124,8 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
     constexpr uint32_t POSM = (1u << ORDER_POS_BITS) - 1u;
     constexpr uint32_t FIRST = 0x80000000u;
     constexpr uint32_t PAIRS = 256;         // ring of (bucket << 6 | source lane) pairs waiting for a lane (at most 4 new ones per lane and batch)
-    enum { M_UNIT = 0, M_QA = 1, M_QB = 2, M_NIDS = 3, M_NPOS = 4, M_HA = 5, M_HB = 6, M_NK = 7, M_WORDS = 8 };
+    // M_UNIT: unit within the ticket | span position of its first base << 8; M_KEND: span position behind its last k-mer's first base
+    enum { M_UNIT = 0, M_QA = 1, M_QB = 2, M_NIDS = 3, M_NPOS = 4, M_HA = 5, M_HB = 6, M_KEND = 7, M_WORDS = 8 };
     // one block of LDS per wave, every array at a constant offset from the wave's base address (one address register
     // serves them all)
     struct WaveLds {
@@ -92,7 +133,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
             uint32_t mn[KMAX + 80];      // window minima of the m-mer orders
             uint32_t pairs[PAIRS];
         };
-        uint32_t planes[NSLOT][3][PW];   // bases of the reads in flight: lo, hi, invalid
+        uint32_t span[3][SPW];           // the bases of the ticket's units as bit planes: lo, hi, invalid (bit 32 + p = base p behind the ticket's first 16-byte boundary)
         uint32_t queue[QCAP + 1];        // run descriptors (+ one: a lane also looks at the entry behind its own)
         uint32_t hid[HCAP];              // heads: colour-set id
         uint32_t hcnt[HCAP];             //        k-mers | read slot << 16 | place of the slot in the pass << 20
@@ -122,16 +163,45 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
     uint64_t t_first;
     uint32_t t_count;
 
-    // padding of the plane buffers: invalid bases in front of and behind every read
-    for (uint32_t i = lane; i < (uint32_t)NSLOT * 3 * PW; i += 64) (&L.planes[0][0][0])[i] = (i / PW) % 3 == 2 ? 0xFFFFFFFFu : 0u;
-    wave_lds_sync();
-
     uint32_t gs = 0;  // first read slot of the current pass (ring index)
     while (wq.pull(t_first, t_count)) {
         if ((uint32_t)lane <= t_count) {
             const uint64_t x = offs[first + t_first + lane];
             L.offs[2 * lane] = (uint32_t)x;
             L.offs[2 * lane + 1] = (uint32_t)(x >> 32);
+        }
+        wave_lds_sync();
+        // ---- the bases of the ticket -> bit planes (every lane 16 bases per round; two lanes make a plane word) ----
+        const uint32_t sb_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.offs[0]) & ~15u;  // the span begins at the 16-byte boundary in front of the first unit
+        const uint32_t sb_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.offs[1]);
+        {
+            const uint64_t sb = ((uint64_t)sb_hi << 32) | sb_lo;
+            const uint64_t se = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)L.offs[2 * t_count + 1]) << 32) |
+                                (uint32_t)__builtin_amdgcn_readfirstlane((int)L.offs[2 * t_count]);
+            const uint32_t nchunks = min((uint32_t)((se - sb + 15u) >> 4), (uint32_t)NIT * 64u);  // (units are at most KMAX + 30 bases long)
+            const u32x4* src = (const u32x4*)(bases + sb);
+            u32x4 x[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const uint32_t c = 64u * it + (uint32_t)lane;
+                x[it] = src[min(c, nchunks - 1u)];  // (nchunks >= 1: a ticket holds at least one unit and offsets are monotone; an empty span reads its first 16 bytes, inside the buffer's slack)
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                uint32_t lo16, hi16, bad;
+                encode16(x[it], lo16, hi16, bad);
+                uint32_t iv16 = 0;
+                if (__any(bad != 0)) iv16 = invalid16(x[it]);  // (rare: a letter that is not a nucleotide among the 1024 of this round)
+                const uint32_t mine = lo16 | (hi16 << 16);
+                const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]: the lane's partner
+                const uint32_t iother = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)iv16, 0xB1, 0xF, 0xF, false);
+                if (!(lane & 1)) {
+                    uint32_t* W = &L.span[0][1 + 32 * it + (lane >> 1)];
+                    W[0] = __builtin_amdgcn_perm(other, mine, 0x05040100u);
+                    W[SPW] = __builtin_amdgcn_perm(other, mine, 0x07060302u);
+                    W[2 * SPW] = iv16 | (iother << 16);
+                }
+            }
         }
         wave_lds_sync();
         uint32_t q = 0, ng = 0;  // runs queued, read slots in use (wave-uniform)
@@ -143,34 +213,10 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
             uint32_t R = 0xFFFFu;
             if (j < t_count) {
                 const uint32_t o0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.offs[2 * j]);
-                const uint32_t o1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.offs[2 * j + 1]);
                 const uint32_t cur_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.offs[2 * j + 2]) - o0;  // (reads are shorter than 4 GB)
-                const uint8_t* seq = bases + (((uint64_t)o1 << 32) | o0);
-                // reads are padded by the host buffer: positions past the read end are masked below, not branched on
-                uint32_t bb[NB];
-#pragma unroll
-                for (int g = 0; g < NB; ++g) bb[g] = seq[lane + 64 * g];
-                // ---- A: planes, staged into the read's slot at once (lane 0 stores the ballot masks) ----
-                uint64_t LO[NB], HI[NB];
-                uint32_t* P = L.planes[ws][0];
-#pragma unroll
-                for (int g = 0; g < NB; ++g) {
-                    const uint32_t b = bb[g];
-                    // a letter (0x40..0x7F) whose low five bits select one of A, C, G, T; bits 1 and 2 of the letter give the code
-                    const bool ok = (uint32_t)lane + 64 * g < cur_len && (b & 0xC0u) == 0x40u && ((0x0010008Au >> (b & 31u)) & 1u);
-                    const uint64_t b1 = __ballot((b & 2u) != 0), b2 = __ballot((b & 4u) != 0);
-                    LO[g] = b1 ^ b2;  // A0 C1 G2 T3
-                    HI[g] = b2;
-                    const uint64_t nv = ~__ballot(ok);
-                    if (lane == 0) {
-                        P[1 + 2 * g] = (uint32_t)LO[g];
-                        P[2 + 2 * g] = (uint32_t)(LO[g] >> 32);
-                        P[PW + 1 + 2 * g] = (uint32_t)HI[g];
-                        P[PW + 2 + 2 * g] = (uint32_t)(HI[g] >> 32);
-                        P[2 * PW + 1 + 2 * g] = (uint32_t)nv;
-                        P[2 * PW + 2 + 2 * g] = (uint32_t)(nv >> 32);
-                    }
-                }
+                // span position of the unit's first base (bit 32 of the planes is the span's first base: one pad word in front;
+                // the difference of the low words is the difference: a span is far shorter than 4 GB)
+                const uint32_t base = o0 - sb_lo + 32u;
                 const uint32_t nk = cur_len >= k ? min(cur_len - k + 1, (uint32_t)KMAX) : 0;
                 if (KMER_OUT) {
                     for (uint32_t i = lane; i < nk; i += 64) kmer_out[(t_first + j) * (uint64_t)stride + i] = NEG;
@@ -180,14 +226,14 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                 mn[64 * (NA - 1) + 16 + lane] = 0xFFFFFFFFu;  // positions past the last round are "infinite"
                 uint32_t v[NA];
                 {
-                    // m-mer at position 64 a + lane: two words of each plane out of the read's slot, where lane 0 has just put them
-                    // (the ballot masks are scalars: cutting the window out of them costs a move per operand, a select per
-                    // plane and twice the shifts)
-                    const uint32_t* pw = P + 1 + (lane >> 5);
+                    // m-mer at position 64 a + lane of the unit: two words of each plane of the span, cut with one v_alignbit
+                    // (which takes the low five bits of its shift operand)
+                    const uint32_t at = base + (uint32_t)lane;
+                    const uint32_t* pw = L.span[0] + (at >> 5);
 #pragma unroll
                     for (int a = 0; a < NA; ++a) {
-                        const uint32_t lo = __builtin_amdgcn_alignbit(pw[2 * a + 1], pw[2 * a], lane);
-                        const uint32_t hi = __builtin_amdgcn_alignbit(pw[PW + 2 * a + 1], pw[PW + 2 * a], lane);
+                        const uint32_t lo = __builtin_amdgcn_alignbit(pw[2 * a + 1], pw[2 * a], at);
+                        const uint32_t hi = __builtin_amdgcn_alignbit(pw[SPW + 2 * a + 1], pw[SPW + 2 * a], at);
                         v[a] = (minimizer_order(lo & maskm, hi & maskm) << ORDER_POS_BITS) | (uint32_t)(64 * a + lane);
                         if (a < NA - 1 || lane < 16) mn[64 * a + lane] = v[a];
                     }
@@ -224,13 +270,13 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                 }
                 if (lane == 0) {
                     uint32_t* M = meta[ws];
-                    M[M_UNIT] = j; M[M_QA] = q; M[M_QB] = q + R; M[M_NIDS] = 0; M[M_NPOS] = 0; M[M_HA] = 0; M[M_HB] = 0; M[M_NK] = nk;
+                    M[M_UNIT] = j | (base << 8); M[M_QA] = q; M[M_QB] = q + R; M[M_NIDS] = 0; M[M_NPOS] = 0; M[M_HA] = 0; M[M_HB] = 0; M[M_KEND] = base + nk;
                 }
                 // (a run ends where the next one of the read begins, or with the read's last k-mer: phase C works its length out)
                 uint32_t before = q;
 #pragma unroll
                 for (int a = 0; a < NA - 1; ++a) {
-                    if ((H[a] >> lane) & 1ull) queue[before + mask_rank(H[a])] = run_pack(pos[a], 64 * a + lane, 0u, ws);
+                    if ((H[a] >> lane) & 1ull) queue[before + mask_rank(H[a])] = run_pack(base + pos[a], pos[a] - (uint32_t)(64 * a + lane), ws);
                     before += (uint32_t)__popcll(H[a]);
                 }
                 wave_lds_sync();
@@ -267,24 +313,22 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                     bool slot_last = false;  // the last run of its read slot
                     {
                         uint32_t desc = act ? queue[e] : 0u;
-                        const uint32_t pm = desc & POSM, g = desc >> 25;
+                        const uint32_t pa = desc & RUN_POS_MASK, g = desc >> 22;
                         // the run's k-mers: up to the next run of the same read slot, or to the read's last k-mer
                         const uint32_t behind = queue[min(e + 1u, (uint32_t)QCAP)];
                         const uint32_t slot_qb = single ? qb : meta[g][M_QB];
                         if (!single) slot_qa = meta[g][M_QA];
-                        const uint32_t i0 = (desc >> 10) & POSM;
-                        const uint32_t iend = e + 1u == slot_qb ? meta[g][M_NK] : (behind >> 10) & POSM;
-                        desc |= (iend - i0) << 20;
+                        const uint32_t iend = e + 1u == slot_qb ? meta[g][M_KEND] : run_first_kmer(behind);
+                        desc |= (iend - run_first_kmer(desc)) << 17;
                         slot_last = e + 1u == slot_qb;
-                        // base pm - km + c at field bit c (plane word 0 is padding)
-                        const uint32_t o = pm + 32u - km;
-                        const uint32_t* pl = L.planes[g][0] + (o >> 5);
-                        const uint32_t sh = o & 31u;
+                        // span base pa - km + c at field bit c
+                        const uint32_t o = pa - km;
+                        const uint32_t* pl = L.span[0] + (o >> 5);
 #pragma unroll
                         for (int p = 0; p < 3; ++p) {
-                            const uint32_t w0 = pl[p * PW], w1 = pl[p * PW + 1], w2 = pl[p * PW + 2];
-                            S[2 * p] = __builtin_amdgcn_alignbit(w1, w0, sh) & clo_mask;
-                            S[2 * p + 1] = __builtin_amdgcn_alignbit(w2, w1, sh) & chi_mask;
+                            const uint32_t w0 = pl[p * SPW], w1 = pl[p * SPW + 1], w2 = pl[p * SPW + 2];
+                            S[2 * p] = __builtin_amdgcn_alignbit(w1, w0, o) & clo_mask;
+                            S[2 * p + 1] = __builtin_amdgcn_alignbit(w2, w1, o) & chi_mask;
                         }
                         S[6] = desc;
                     }
@@ -358,11 +402,11 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                         }
                         const bool live = ovf || (firstb && act);
                         const uint32_t desc = T[6];
-                        const uint32_t pm = desc & POSM, i0 = (desc >> 10) & POSM, cnt = (desc >> 20) & 31u, g = (desc >> 25) & 7u;
+                        const uint32_t dm = (desc >> RUN_POS_BITS) & 15u, cnt = (desc >> 17) & 31u, g = (desc >> 22) & 7u;
                         // what a head carries besides its k-mers: read slot << 16 | place of the slot in this pass << 20
                         const uint32_t gtag = (g << 16) | ((g >= gs ? g - gs : g + (uint32_t)NSLOT - gs) << 20);
                         // windows of the run: window s of a record's context is k-mer i0 + s - runlo
-                        const uint32_t runlo = i0 + km - pm, runhi = runlo + cnt - 1u;
+                        const uint32_t runlo = km - dm, runhi = runlo + cnt - 1u;
                         uint32_t hv[BUCKET_RECS], hc[BUCKET_RECS];
                         uint32_t mine = 0, msum = 0, mid = 0;
 #pragma unroll
@@ -384,8 +428,9 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                             msum += hc[r];
                             mid = hit ? hv[r] : mid;
                             if (KMER_OUT && hit) {
-                                const uint64_t row = (t_first + meta[g][M_UNIT]) * (uint64_t)stride;
-                                for (uint32_t s = lo; s <= hi; ++s) kmer_out[row + s + pm - km] = hv[r];
+                                const uint32_t mu = meta[g][M_UNIT];
+                                const uint64_t row = (t_first + (mu & 0xFFu)) * (uint64_t)stride + ((desc & RUN_POS_MASK) - (mu >> 8));  // + window - (k - m) = k-mer of the unit
+                                for (uint32_t s = lo; s <= hi; ++s) kmer_out[row + s - km] = hv[r];
                             }
                         }
 #ifdef FG_K1_STATS
@@ -517,7 +562,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                     const uint32_t idx = (uint32_t)__popcll(below >> rs);
                     if (start) {
                         const uint32_t g = (sw >> 16) & 7u;
-                        const uint64_t rbase = (t_first + meta[g][M_UNIT]) * (uint64_t)stride;
+                        const uint64_t rbase = (t_first + (meta[g][M_UNIT] & 0xFFu)) * (uint64_t)stride;
                         ids_pool[rbase + idx] = sv;
                         cnt_pool[rbase + idx] = cs_run - cs + own;
                         if (rstart) {
@@ -568,7 +613,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                         for (uint32_t i = hmain; i < hcount; ++i)
                             rank += ((hres[i] & FIRST) != 0 && ((hcnt[i] >> 16) & 7u) == gsel && hid[i] < vv) ? 1u : 0u;
                         if (res & FIRST) {
-                            const uint64_t rbase = (t_first + meta[gsel][M_UNIT]) * (uint64_t)stride;
+                            const uint64_t rbase = (t_first + (meta[gsel][M_UNIT] & 0xFFu)) * (uint64_t)stride;
                             ids_pool[rbase + rank] = vv;
                             cnt_pool[rbase + rank] = res & ~FIRST;
                             atomicAdd(&meta[gsel][M_NIDS], 1u);
@@ -580,7 +625,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                 wave_lds_sync();
                 if ((uint32_t)lane >= t0 && (uint32_t)lane < t1) {
                     const uint32_t g = (gs + (uint32_t)lane) % (uint32_t)NSLOT;
-                    const uint64_t r = t_first + meta[g][M_UNIT];
+                    const uint64_t r = t_first + (meta[g][M_UNIT] & 0xFFu);
                     nids[r] = meta[g][M_NIDS];
                     npos[r] = meta[g][M_NPOS];
                     idoff[r] = r * (uint64_t)stride;
