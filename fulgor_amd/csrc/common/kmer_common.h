@@ -98,14 +98,6 @@ FG_HD uint32_t dict_hash(uint32_t lo, uint32_t hi, uint32_t seed) {
     x ^= x >> 13;
     return x;
 }
-// second, independent hash of the key: tells a key's redirect slot from those of its bucket neighbours
-FG_HD uint32_t dict_tag(uint32_t lo, uint32_t hi) {
-    uint32_t x = lo * 0x27D4EB2Fu ^ hi * 0x165667B1u;
-    x ^= x >> 15;
-    x *= 0x2C1B3C6Du;
-    x ^= x >> 12;
-    return x;
-}
 
 // ---- 16-byte super-k-mer record, four per 64-byte bucket ------------------------------------------
 // The dictionary is ONE table of 64-byte buckets: a hashed region addressed by the minimizer and, behind it, an
@@ -120,13 +112,13 @@ FG_HD uint32_t dict_tag(uint32_t lo, uint32_t hi) {
 //   w2  lo plane bases 32..44 | hi plane bases 32..44 << 13 | smin << 26 | redirect flag << 31
 //   w3  colour-set id (27 bits; u2c folded in, index.hpp:37 of the reference) | smax << 27 | spill << 31
 // An empty slot has smin > smax.
-// A key whose records do not fit its home bucket next to the other keys living there (or that has more than four)
-// keeps ONE slot in the home bucket, a REDIRECT: w0 = dict_tag of the key, w1 = its first overflow bucket,
-// w2 = empty | redirect flag, w3 = number of overflow buckets. Its records fill consecutive overflow buckets; the
-// query reads the first REDIRECT_DIRECT of them at once.
+// When the records of the keys living in a bucket do not all fit, the bucket's LAST slot is a REDIRECT: w1 = first
+// overflow bucket, w2 = empty | redirect flag, w3 = number of overflow buckets; the keys that did not fit (whole keys)
+// share those consecutive overflow buckets, and every query that meets the redirect reads the first REDIRECT_DIRECT
+// of them at once (a record is verified by its context: records of other keys simply do not match).
 // spill (bit 31 of w3 of a bucket's last slot): the query goes on with the next bucket. Set on the overflow
-// buckets of a key from the REDIRECT_DIRECT-th on (but the last), and on a hashed bucket when more than four keys
-// live there (rare), whose surplus slots then sit in the following buckets.
+// buckets of a run from the REDIRECT_DIRECT-th on (but the last), and on a hashed bucket when more than four keys
+// live there (rare), whose surplus keys then sit in the following buckets.
 // Needs 2k - m <= 45 and k - m <= 15 (k = 31, m = 17: exactly 45 bases, 15 windows: 16 runs per 150-base read, so that four
 // reads fill a pass of the lookup kernel; round 2 had 43 bases for m = 19 and a 31-bit colour-set id).
 constexpr uint32_t REC_WORDS = 4;

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
     const uint32_t tail = W - span;
     const uint32_t maskm = low_mask32(m), maskkm = (1u << km) - 1u;
     const uint32_t clo_mask = CL >= 32 ? 0xFFFFFFFFu : (1u << CL) - 1u, chi_mask = CL > 32 ? (1u << (CL - 32)) - 1u : 0u;
-    const uint32_t core_mask = low_mask32(k) & ~maskkm;  // context bases k-m .. k-1: part of every window
+    const uint32_t maskk = low_mask32(k);
     const WorkQueue wq{tickets, n_reads, TICKET};
     uint64_t t_first;
     uint32_t t_count;
@@ -307,8 +307,10 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                     K1_STAT(2, 1);
                     const uint32_t e = c0 + lane;
                     const bool act = (uint32_t)lane < qn;
-                    // per-run state: the CL read bases around the minimizer (three planes, two words each), S[6] = descriptor
-                    uint32_t S[7];
+                    // per-run state: the CL read bases around the minimizer — S[0..2] bases 0..31 of the planes lo, hi, invalid; S[3] bases
+                    // 32.. of lo and hi side by side, as a record's w2 holds them; S[4] those of the invalid plane; S[5] = descriptor
+                    constexpr int NS = 6;
+                    uint32_t S[NS];
                     uint32_t slot_qa = 0;
                     bool slot_last = false;  // the last run of its read slot
                     {
@@ -324,17 +326,19 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                         // span base pa - km + c at field bit c
                         const uint32_t o = pa - km;
                         const uint32_t* pl = L.span[0] + (o >> 5);
+                        uint32_t up[3];
 #pragma unroll
                         for (int p = 0; p < 3; ++p) {
                             const uint32_t w0 = pl[p * SPW], w1 = pl[p * SPW + 1], w2 = pl[p * SPW + 2];
-                            S[2 * p] = __builtin_amdgcn_alignbit(w1, w0, o) & clo_mask;
-                            S[2 * p + 1] = __builtin_amdgcn_alignbit(w2, w1, o) & chi_mask;
+                            S[p] = __builtin_amdgcn_alignbit(w1, w0, o) & clo_mask;
+                            up[p] = __builtin_amdgcn_alignbit(w2, w1, o) & chi_mask;
                         }
-                        S[6] = desc;
+                        S[3] = up[0] | (up[1] << REC_HI_BITS);
+                        S[4] = up[2];
+                        S[5] = desc;
                     }
                     // the minimizer itself: field bits km .. k-1 (k <= 31: inside the low word)
-                    const uint32_t mlo = (S[0] >> km) & maskm, mhi = (S[2] >> km) & maskm;
-                    const uint32_t tag = dict_tag(mlo, mhi);
+                    const uint32_t mlo = (S[0] >> km) & maskm, mhi = (S[1] >> km) & maskm;
                     const uint32_t home = mulhi32(dict_hash(mlo, mhi, d.seed), d.num_buckets);
                     u32x4 rec[BUCKET_RECS];
                     {
@@ -346,15 +350,12 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                     // Buckets still to be looked at go through the ring `pairs` as (bucket << 6 | lane that owns the run): the overflow
                     // bucket behind this key's redirect slot, the next bucket behind a spill flag. found(...) is run on freshly loaded buckets.
                     uint32_t ptail = 0, phead = 0;  // ring counters (wave-uniform)
-                    auto found = [&](bool loaded, uint32_t bucket, uint32_t src, uint32_t mytag) {
-                        uint32_t target = 0, nbov = 0;  // this key's redirect: first overflow bucket, how many to read at once
-#pragma unroll
-                        for (int r = 0; r < (int)BUCKET_RECS; ++r) {
-                            const bool hit = loaded && (rec[r].z & 0x80000000u) != 0 && rec[r].x == mytag;
-                            target = hit ? rec[r].y : target;
-                            nbov = hit ? min(rec[r].w & REC_MAX_CSID, REDIRECT_DIRECT) : nbov;
-                        }
-                        const bool spill = loaded && (rec[BUCKET_RECS - 1].w & REC_SPILL) != 0;
+                    auto found = [&](bool loaded, uint32_t bucket, uint32_t src) {
+                        // the bucket's redirect (its last slot): first overflow bucket, how many to read at once
+                        const u32x4 last = rec[BUCKET_RECS - 1];
+                        const uint32_t target = last.y;
+                        const uint32_t nbov = loaded && (int32_t)last.z < 0 ? min(last.w & REC_MAX_CSID, REDIRECT_DIRECT) : 0u;
+                        const bool spill = loaded && (int32_t)last.w < 0;
                         const uint64_t ms = __ballot(spill);
                         if (__any(nbov != 0) || ms) {
 #pragma unroll
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                             wave_lds_sync();
                         }
                     };
-                    found(act, home, (uint32_t)lane, tag);
+                    found(act, home, (uint32_t)lane);
 
                     bool firstb = true;  // first batch: the run lanes look at their home bucket, free lanes take pairs
                     for (;;) {
@@ -378,8 +379,8 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                         const uint32_t taken = min(waiting, 64u - base);
                         K1_STAT(3, 1); K1_STAT(5, taken);
                         const bool ovf = (uint32_t)lane >= base && (uint32_t)lane - base < taken;
-                        uint32_t T[7];
-                        uint32_t bucket = home, src = (uint32_t)lane, ttag = tag;
+                        uint32_t T[NS];
+                        uint32_t bucket = home, src = (uint32_t)lane;
                         if (taken) {
                             if (ovf) {
                                 const uint32_t pr = pairs[(phead + (uint32_t)lane - base) % PAIRS];
@@ -387,43 +388,46 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                                 bucket = pr >> 6;
                             }
 #pragma unroll
-                            for (int i = 0; i < 7; ++i) T[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)S[i]);
-                            ttag = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)tag);
+                            for (int i = 0; i < NS; ++i) T[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)S[i]);
                             if (ovf) {
                                 const u32x4* bp = (const u32x4*)(d.table + (size_t)bucket * BUCKET_WORDS);
 #pragma unroll
                                 for (int r = 0; r < (int)BUCKET_RECS; ++r) rec[r] = bp[r];
                             }
                             phead += taken;
-                            found(ovf, bucket, src, ttag);
+                            found(ovf, bucket, src);
                         } else {
 #pragma unroll
-                            for (int i = 0; i < 7; ++i) T[i] = S[i];
+                            for (int i = 0; i < NS; ++i) T[i] = S[i];
                         }
                         const bool live = ovf || (firstb && act);
-                        const uint32_t desc = T[6];
+                        const uint32_t desc = T[NS - 1];
                         const uint32_t dm = (desc >> RUN_POS_BITS) & 15u, cnt = (desc >> 17) & 31u, g = (desc >> 22) & 7u;
                         // what a head carries besides its k-mers: read slot << 16 | place of the slot in this pass << 20
                         const uint32_t gtag = (g << 16) | ((g >= gs ? g - gs : g + (uint32_t)NSLOT - gs) << 20);
                         // windows of the run: window s of a record's context is k-mer i0 + s - runlo
-                        const uint32_t runlo = km - dm, runhi = runlo + cnt - 1u;
+                        // (a lane without work: an empty range)
+                        const uint32_t runlo = live ? km - dm : 31u, runhi = live ? km - dm + cnt - 1u : 0u;
                         uint32_t hv[BUCKET_RECS], hc[BUCKET_RECS];
                         uint32_t mine = 0, msum = 0, mid = 0;
 #pragma unroll
                         for (int r = 0; r < (int)BUCKET_RECS; ++r) {
                             const uint32_t w0 = rec[r].x, w1 = rec[r].y, w2 = rec[r].z;
-                            const uint32_t x0 = (T[0] ^ w0) | (T[2] ^ w1) | T[4];
-                            const uint32_t x1 = (T[1] ^ (w2 & REC_HI_MASK)) | (T[3] ^ ((w2 >> REC_HI_BITS) & REC_HI_MASK)) | T[5];
-                            // mismatches below the core bound the windows from below, those above it from above
-                            const uint32_t A = x0 & maskkm;
+                            const uint32_t x0 = (T[0] ^ w0) | (T[1] ^ w1) | T[2];
+                            // bases 32..: the two planes lie side by side in w2 as in T[3]; only bits 0 .. k - m - 2 of x1 are looked at
+                            const uint32_t v1 = T[3] ^ w2;
+                            const uint32_t x1 = v1 | (v1 >> REC_HI_BITS) | T[4];
+                            // Mismatches below the core bound the windows from below, those above it from above; a mismatch inside the
+                            // core (context bases k - m .. k - 1, part of every window) puts the lower bound above every window.
+                            const uint32_t A = x0 & maskk;
                             const uint32_t sl = 31u - (uint32_t)__builtin_clz((A << 1) | 1u);
                             const uint32_t B = __builtin_amdgcn_alignbit(x1, x0, k) & maskkm;
                             const uint32_t su = (uint32_t)__builtin_ctz(B | (1u << km));
                             const uint32_t lo = max(max(sl, rec_smin(w2)), runlo);
                             const uint32_t hi = min(min(su, rec_smax(rec[r].w)), runhi);
-                            const bool hit = live && (x0 & core_mask) == 0 && lo <= hi;
                             hv[r] = rec[r].w & REC_MAX_CSID;
-                            hc[r] = hit ? hi - lo + 1u : 0u;
+                            hc[r] = (uint32_t)max((int32_t)(hi - lo) + 1, 0);
+                            const bool hit = hc[r] != 0;
                             mine += hit;
                             msum += hc[r];
                             mid = hit ? hv[r] : mid;
@@ -512,65 +516,45 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                 }
                 K1_STAT(7, maxseg);
                 if (hcount <= 64u) {
-                    // One pass of up to 64 heads. Every head finds its place among the heads of its read by counting those that sort
-                    // before it (smaller id, or the same id further left), in its own slot's stretch and among the few heads that came
-                    // out of overflow buckets; scattered to that place, equal ids are neighbours and the rest is lane-local.
+                    // One pass of up to 64 heads. The place of an id in its read's sorted list is the number of heads of the read with a
+                    // SMALLER id (counted over the read's own stretch of heads and the few heads that came out of overflow buckets):
+                    // heads with the same id get the same place, where an LDS add sums their k-mers; the places that were hit,
+                    // counted from the read's first place, are the output entries.
                     const bool hact = (uint32_t)lane < hcount;
                     const uint32_t vv = hact ? hid[lane] : 0u, hw = hact ? hcnt[lane] : (gfirst << 16);
                     const uint32_t gsel = (hw >> 16) & 7u, tsel = hw >> 20;
-                    const uint32_t ha = meta[gsel][M_HA], hb = meta[gsel][M_HB];
-                    // (id, place) pairs compare as one 64-bit number; ha + maxseg <= 128 <= HCAP: no clamp, what lies past hb is not counted
-                    const uint64_t key = ((uint64_t)vv << 32) | (uint32_t)lane;
+                    const uint32_t ha = meta[gsel][M_HA], seglen = meta[gsel][M_HB] - ha;
+                    hsrt[lane] = 0u;  // k-mers per place
                     uint32_t rank = 0;
-                    for (uint32_t t = 0; t < maxseg; ++t) {
-                        const uint32_t i = ha + t;
-                        const uint32_t vi = hid[i];
-                        rank += ((uint32_t)(i < hb) & (uint32_t)((((uint64_t)vi << 32) | i) < key));
+                    for (uint32_t t = 0; t < maxseg; ++t) {  // (ha + maxseg <= 128 <= HCAP: no clamp, what lies past the stretch is not counted)
+                        const uint32_t vi = hid[ha + t];
+                        rank += (uint32_t)(t < seglen) & (uint32_t)(vi < vv);
                     }
                     uint32_t before = 0;  // heads from overflow buckets that belong to earlier reads of the pass
                     for (uint32_t i = hmain; i < hcount; ++i) {
                         const uint32_t vi = hid[i], ti = hcnt[i] >> 20;
-                        rank += (ti == tsel && (vi < vv || (vi == vv && i < (uint32_t)lane))) ? 1u : 0u;
+                        rank += (uint32_t)(ti == tsel) & (uint32_t)(vi < vv);
                         before += ti < tsel ? 1u : 0u;
                     }
-                    if (hact) {
-                        const uint32_t p = ha + before + rank;
+                    if (hact) {  // (LDS operations of a wave execute in order: every lane has read hcnt before any lane overwrites it)
+                        const uint32_t ss = ha + before, p = ss + rank;
+                        atomicAdd(&hsrt[p], hw & 0xFFFFu);
                         hres[p] = vv;
-                        hsrt[p] = hw;
+                        hcnt[p] = gsel | (ss << 3);  // the same from every head of the read
                     }
                     wave_lds_sync();
-                    // lane = sorted place: runs of equal ids within a read -> one output entry with the sum of their k-mers
-                    const uint32_t sv = hact ? hres[lane] : 0u, sw = hact ? hsrt[lane] : 0xFFFFFFFFu;
-                    const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)sv, 0x138, 0xF, 0xF, false);  // wave_shr:1
-                    const uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)sw, 0x138, 0xF, 0xF, false);
-                    const bool rstart = hact && (lane == 0 || (pw >> 20) != (sw >> 20));
-                    const bool start = hact && (rstart || pv != sv);
-                    const uint64_t tailm = hcount == 64u ? 0ull : ~0ull << hcount;  // lanes past the heads end every run
-                    const uint64_t St = __ballot(start) | tailm, Rt = __ballot(rstart) | tailm;
-                    const uint32_t cs = wave_incl_scan_u32(hact ? sw & 0xFFFFu : 0u);
-                    // last lane of my run / of my read: the lane before the next start (64-bit masks shifted by lane + 1)
-                    const uint64_t sa = lane == 63 ? 1ull : St >> (lane + 1), ra = lane == 63 ? 1ull : Rt >> (lane + 1);
-                    const uint32_t run_last = (uint32_t)lane + (sa ? (uint32_t)__builtin_ctzll(sa) : 63u - (uint32_t)lane);
-                    const uint32_t read_last = (uint32_t)lane + (ra ? (uint32_t)__builtin_ctzll(ra) : 63u - (uint32_t)lane);
-                    const uint32_t cs_run = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(run_last << 2), (int)cs);
-                    const uint32_t cs_read = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(read_last << 2), (int)cs);
-                    const uint32_t own = hact ? sw & 0xFFFFu : 0u;
-                    // place of my run in the read's output: starts between the read's first lane and mine. For a read-start lane that is 0.
-                    const uint64_t below = St & ((1ull << lane) - 1ull);
-                    const uint64_t rbelow = Rt & ((2ull << lane) - 1ull);  // (a read start at or below me exists for every head)
-                    const uint32_t rs = 63u - (uint32_t)__builtin_clzll(rbelow | 1ull);
-                    const uint32_t idx = (uint32_t)__popcll(below >> rs);
-                    if (start) {
-                        const uint32_t g = (sw >> 16) & 7u;
-                        const uint64_t rbase = (t_first + (meta[g][M_UNIT] & 0xFFu)) * (uint64_t)stride;
-                        ids_pool[rbase + idx] = sv;
-                        cnt_pool[rbase + idx] = cs_run - cs + own;
-                        if (rstart) {
-                            const uint64_t mine = (St & ~tailm) >> lane;  // starts from my lane on
-                            const uint32_t span_ = read_last - (uint32_t)lane + 1u;
-                            meta[g][M_NIDS] = (uint32_t)__popcll(span_ >= 64u ? mine : mine & ((1ull << span_) - 1ull));
-                            meta[g][M_NPOS] = cs_read - cs + own;
-                        }
+                    // lane = place
+                    const uint32_t sum = hsrt[lane], sid = hres[lane], stag = hcnt[lane];
+                    const bool nz = sum != 0;
+                    const uint32_t below = mask_rank(__ballot(nz));  // places hit below mine
+                    const uint32_t below_ss = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((stag >> 3) << 2), (int)below);
+                    if (nz) {
+                        const uint32_t g = stag & 7u;
+                        const uint64_t at = (t_first + (meta[g][M_UNIT] & 0xFFu)) * (uint64_t)stride + (below - below_ss);
+                        ids_pool[at] = sid;
+                        cnt_pool[at] = sum;
+                        atomicAdd(&meta[g][M_NIDS], 1u);
+                        atomicAdd(&meta[g][M_NPOS], sum);
                     }
                 } else {
                     // pass 1: total of the head's id within its read; FIRST = no earlier head of the read has that id. A head is

@@ -62,9 +62,10 @@ inline uint64_t record_key(const uint32_t* w, uint32_t k, uint32_t m) {
 }
 
 // Places the records into the bucket table. Hashed region: a sweep over the buckets in order; the keys living
-// in a bucket (those hashed to it, plus slots carried over from a bucket with more than four keys) each get
-// one slot at least, a key with several records all of them while the bucket has room (keys with fewer records
-// first), a REDIRECT to the overflow region otherwise. ~0.6 records per bucket on average.
+// in a bucket (those hashed to it, plus keys carried over from a bucket with more than four keys) keep all their
+// records there while the bucket has room (keys with fewer records first). If they do not all fit, the bucket's LAST
+// slot becomes its REDIRECT and the keys that are left share one run of consecutive buckets in the overflow region
+// (a record is verified by its context, so records of several keys may lie side by side). ~0.6 records per bucket on average.
 inline void build_dict_table(Dict& d) {
     const uint64_t nrec = d.num_records();
     if (nrec >= (1ULL << 31)) throw std::runtime_error("too many super-k-mer records");
@@ -166,32 +167,37 @@ inline void build_dict_table(Dict& d) {
             carry.assign(items.begin() + BUCKET_RECS, items.end());
             items.resize(BUCKET_RECS);
         }
-        // every key one slot; then whole keys while they fit, fewest records first
+        // whole keys while they fit, fewest records first; with a redirect the bucket has one slot less
         std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.count < y.count; });
-        uint32_t left = BUCKET_RECS - (uint32_t)items.size(), slot = 0;
-        for (const Item& it : items) {
-            if (it.count - 1 <= left && it.count <= BUCKET_RECS) {
-                for (uint64_t j = 0; j < it.count; ++j) put(bw + (slot++) * REC_WORDS, it.first + j);
-                left -= (uint32_t)(it.count - 1);
-            } else {
-                const uint64_t nb = (it.count + BUCKET_RECS - 1) / BUCKET_RECS;
-                const uint64_t ob = nb_hashed + overflow.size() / BUCKET_WORDS;
-                if (ob + nb >= DICT_MAX_BUCKETS) throw std::runtime_error("dictionary table exceeds 2^26 buckets");
-                const size_t o0 = overflow.size();
-                overflow.resize(o0 + nb * BUCKET_WORDS, 0);
-                for (uint64_t j = 0; j < nb * BUCKET_RECS; ++j) {
-                    uint32_t* dst = &overflow[o0 + j * REC_WORDS];
-                    if (j < it.count) put(dst, it.first + j);
-                    else dst[2] = REC_W2_EMPTY;
-                }
-                // the query reads the first REDIRECT_DIRECT buckets at once; further ones hang on spill flags
-                for (uint64_t j = REDIRECT_DIRECT - 1; j + 1 < nb; ++j) overflow[o0 + j * BUCKET_WORDS + (BUCKET_RECS - 1) * REC_WORDS + 3] |= REC_SPILL;
-                uint32_t* dst = bw + (slot++) * REC_WORDS;
-                dst[0] = dict_tag((uint32_t)refs[it.first].key, (uint32_t)(refs[it.first].key >> 32));
-                dst[1] = (uint32_t)ob;
-                dst[2] = REC_W2_REDIRECT;
-                dst[3] = (uint32_t)nb;
-            }
+        uint64_t total = 0;
+        for (const Item& it : items) total += it.count;
+        const uint32_t room = total <= BUCKET_RECS ? BUCKET_RECS : BUCKET_RECS - 1;
+        uint32_t slot = 0;
+        size_t kept = 0;
+        while (kept < items.size() && slot + items[kept].count <= room) {
+            for (uint64_t j = 0; j < items[kept].count; ++j) put(bw + (slot++) * REC_WORDS, items[kept].first + j);
+            ++kept;
+        }
+        if (kept < items.size()) {
+            uint64_t moved = 0;
+            for (size_t i = kept; i < items.size(); ++i) moved += items[i].count;
+            const uint64_t nb = (moved + BUCKET_RECS - 1) / BUCKET_RECS;
+            const uint64_t ob = nb_hashed + overflow.size() / BUCKET_WORDS;
+            if (ob + nb >= DICT_MAX_BUCKETS) throw std::runtime_error("dictionary table exceeds 2^26 buckets");
+            if (nb > REC_MAX_CSID) throw std::runtime_error("dictionary table: overflow run too long");
+            const size_t o0 = overflow.size();
+            overflow.resize(o0 + nb * BUCKET_WORDS, 0);
+            uint64_t j = 0;
+            for (size_t i = kept; i < items.size(); ++i)
+                for (uint64_t r = 0; r < items[i].count; ++r, ++j) put(&overflow[o0 + j * REC_WORDS], items[i].first + r);
+            for (; j < nb * BUCKET_RECS; ++j) overflow[o0 + j * REC_WORDS + 2] = REC_W2_EMPTY;
+            // the query reads the first REDIRECT_DIRECT buckets at once; further ones hang on spill flags
+            for (uint64_t b2 = REDIRECT_DIRECT - 1; b2 + 1 < nb; ++b2) overflow[o0 + b2 * BUCKET_WORDS + (BUCKET_RECS - 1) * REC_WORDS + 3] |= REC_SPILL;
+            uint32_t* dst = bw + (BUCKET_RECS - 1) * REC_WORDS;
+            dst[0] = 0;
+            dst[1] = (uint32_t)ob;
+            dst[2] = REC_W2_REDIRECT;
+            dst[3] = (uint32_t)nb;
         }
         if (!carry.empty()) bw[(BUCKET_RECS - 1) * REC_WORDS + 3] |= REC_SPILL;
     }
@@ -333,14 +339,13 @@ inline uint32_t dict_lookup(const Dict& d, uint32_t klo, uint32_t khi, uint32_t*
     const uint32_t pm = best & ((1u << ORDER_POS_BITS) - 1u);
     const uint32_t mlo = (klo >> pm) & low_mask32(m), mhi = (khi >> pm) & low_mask32(m);
     uint32_t found = 0;
-    const uint32_t tag = dict_tag(mlo, mhi);
     const uint32_t s = km - pm;  // window of this k-mer in a record's context
     std::vector<uint64_t> visit(1, mulhi32(dict_hash(mlo, mhi, d.seed), d.num_buckets));
     for (size_t v = 0; v < visit.size(); ++v) {
         const uint32_t* bw = &d.table[visit[v] * BUCKET_WORDS];
         for (uint32_t r = 0; r < BUCKET_RECS; ++r) {
             const uint32_t* w = bw + r * REC_WORDS;
-            if ((w[2] & 0x80000000u) && w[0] == tag)  // this key's redirect (or a tag collision: harmless)
+            if (r == BUCKET_RECS - 1 && (w[2] & 0x80000000u))  // the bucket's redirect
                 for (uint32_t j = 0; j < std::min(w[3] & REC_MAX_CSID, REDIRECT_DIRECT); ++j) visit.push_back((uint64_t)w[1] + j);
             if (s < rec_smin(w[2]) || s > rec_smax(w[3])) continue;
             const uint32_t lo = (uint32_t)(rec_ctx_lo(w[0], w[2]) >> s) & low_mask32(k);
