@@ -52,17 +52,20 @@ def prepare_workload(name):
     raise SystemExit("unknown workload %s" % name)
 
 
+REAL_DUMP_PREFIX = "REAL DUMP: index ingested from the `fulgor dump` files "
+
+
 def real_dump_workload(base, data):
     """FULGOR_S4546_DUMP=<basename>: the four text files of `fulgor dump -i salmonella_4546.fur` (src/index.cpp:59-120). The
-    index is ingested once into data/<name>.v8.fgidx; the reads are drawn by the same seeded generator from the unitig
+    index is ingested once into data/<name>.v9.fgidx; the reads are drawn by the same seeded generator from the unitig
     sequences of the dump themselves (the genomes are not part of a dump): every unitig of at least 150 bases is a source
     sequence, so reads stay inside unitigs — state it when quoting: fewer colour sets per read than reads across junctions."""
     import fulgor_amd
     from fulgor_amd.reads import ReadGenerator
-    for suffix in (".metadata.txt", ".unitigs.fa", ".color_sets.txt"):
+    for suffix in (".metadata.txt", ".unitigs.fa", ".color_sets.txt", ".filenames.txt"):  # the four files `fulgor dump` writes
         if not os.path.exists(base + suffix):
             raise SystemExit("FULGOR_S4546_DUMP=%s: %s%s is missing" % (base, base, suffix))
-    fg = os.path.join(data, os.path.basename(base) + ".v8.fgidx")
+    fg = os.path.join(data, os.path.basename(base) + ".v9.fgidx")
     if not os.path.exists(fg) or os.path.getmtime(fg) < os.path.getmtime(base + ".color_sets.txt"):
         os.makedirs(data, exist_ok=True)
         ix = fulgor_amd.Index(base, device=-1)
@@ -77,7 +80,7 @@ def real_dump_workload(base, data):
     if not seqs:
         raise SystemExit("FULGOR_S4546_DUMP=%s: no unitig of at least 150 bases to draw reads from" % base)
     src = np.frombuffer(b"N".join(seqs), dtype=np.uint8)
-    return fg, ReadGenerator((), raw_sequences=[src]), "index ingested from the dump %s (reads drawn from its unitigs of >= 150 bases)" % base
+    return fg, ReadGenerator((), raw_sequences=[src]), REAL_DUMP_PREFIX + "%s (reads drawn from its unitigs of >= 150 bases)" % os.path.basename(base)
 
 
 def launch_ranks(argv, gpus):
@@ -331,6 +334,10 @@ def main():
 
     default_reads = {"s10": 1_000_000, "s4546syn": 10_000_000, "s4546core": 5_000_000}
     n_reads = args.reads or default_reads[args.workload]
+    free_b, total_b = torch.cuda.mem_get_info(local_rank)
+    print("[bench] rank %d/%d on cuda:%d %s, %.1f of %.1f GB free, %d reads of %d bases" % (
+        rank, world, local_rank, torch.cuda.get_device_name(local_rank), free_b / 1e9, total_b / 1e9, n_reads, args.read_len),
+        file=sys.stderr, flush=True)
     w = Workload(args.workload, rank, local_rank, n_reads, args.read_len, args.index_type, args.partition_size, args.cluster_size, prepared)
     if args.order is not None or args.small is not None or args.rows is not None:
         w.ix.tune(order_min_reads=None if args.order is None else (16384 if args.order else -1),
@@ -356,7 +363,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32",
-            "data": "synthetic",
+            # (the reads are synthetic either way; "real-dump" = the index came from a `fulgor dump` of a real collection)
+            "data": "real-dump" if w.desc.startswith(REAL_DUMP_PREFIX) else "synthetic",
             "config": {"workload": "%s, %s, %d synthetic %d bp reads per GPU (seed 42), k=31, chunk %d reads/pass"
                                    % (w.desc, args.algo + (" tau=%g" % args.tau if algo else ""), n_reads, args.read_len, args.chunk),
                        "index_replicated": True, "reads_per_gpu": n_reads, "streams": max(1, args.streams),
@@ -405,6 +413,20 @@ def secondary(w, args, local_rank):
     except Exception as e:  # noqa: BLE001 — a secondary entry must not take the line down
         out["threshold_union_0.8"] = {"value": None, "error": str(e)[:300]}
     full, desc = w.n_reads, w.desc
+    # the hybrid lists on their own kernels (k2a_intersect / k3a_union over the packed blocks of the gap-coded lists): what a
+    # collection runs whose dense rows do not fit the device
+    try:
+        w.n_reads = min(full, 5_000_000)
+        w.ix.tune(dense_rows=False)
+        m = measure(w, fulgor_amd.FULL_INTERSECTION, 0.0, args.chunk, 3, 1, 1, local_rank)
+        out["hybrid_packed_blocks"] = {"full_intersection": entry(w, m, w.n_reads)}
+        m = measure(w, fulgor_amd.THRESHOLD_UNION, 0.8, args.chunk, 3, 1, 1, local_rank)
+        out["hybrid_packed_blocks"]["threshold_union_0.8"] = entry(w, m, w.n_reads)
+    except Exception as e:  # noqa: BLE001
+        out.setdefault("hybrid_packed_blocks", {})["error"] = str(e)[:300]
+    finally:
+        w.n_reads = full
+        w.ix.tune(dense_rows=True if args.rows is None else bool(args.rows))
     try:
         w.ix.convert(3, args.partition_size, args.cluster_size)
         w.desc = desc + "; colour sets re-encoded as meta-diff (partitions of %d colours, clusters of %d sets)" % (args.partition_size, args.cluster_size)

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                     for (int a = 0; a < NA; ++a) {
                         const uint32_t lo = __builtin_amdgcn_alignbit(pw[2 * a + 1], pw[2 * a], at);
                         const uint32_t hi = __builtin_amdgcn_alignbit(pw[SPW + 2 * a + 1], pw[SPW + 2 * a], at);
-                        v[a] = (minimizer_order(lo & maskm, hi & maskm) << ORDER_POS_BITS) | (uint32_t)(64 * a + lane);
+                        v[a] = (minimizer_order(lo, hi & maskm, m) << ORDER_POS_BITS) | (uint32_t)(64 * a + lane);
                         if (a < NA - 1 || lane < 16) mn[64 * a + lane] = v[a];
                     }
                 }

@@ -1605,6 +1605,10 @@ __host__ __device__ __forceinline__ uint32_t k2b_group_words(uint32_t W, uint32_
 __device__ __forceinline__ uint32_t k2b_hist_addr(uint32_t group_at, uint32_t G, uint32_t e) {  // byte address; group_at = 8192 * group
     return group_at + __umul24(e & 3u, G) + (e & ~3u);
 }
+#ifndef FG_K2B_KO  // knock-out builds (profiles/k2b_knockout.sh): 1 = no hit-counter adds, 2 = no stage scatter stores; results are wrong, times and LDS counters are the point
+#define FG_K2B_KO 0
+#endif
+#define K2B_HIST_ADD(a, v) do { if (FG_K2B_KO != 1) lds_add((a), (v)); } while (0)
 __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
                                                   const uint64_t* __restrict__ out_off, uint64_t n_reads, uint32_t W,
                                                   uint32_t* __restrict__ colors, unsigned int* tickets,
@@ -1688,7 +1692,7 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
                     const uint32_t c = v[g];
                     colors[dst[g]] = c;
                     // the colour's hit counter: round c >> 11 (low / high half of the word by its parity), entry c & 2047
-                    if (hit_partial) lds_add(k2b_hist_addr((c >> 12) * 8192u, k2b_group_words(W, c >> 12), c & 2047u), (c & 2048u) ? 0x10000u : 1u);
+                    if (hit_partial) K2B_HIST_ADD(k2b_hist_addr((c >> 12) * 8192u, k2b_group_words(W, c >> 12), c & 2047u), (c & 2048u) ? 0x10000u : 1u);
                 }
             }
             wave_lds_sync();
@@ -1717,7 +1721,7 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
             uint32_t va = v_wave + ((incl - pc) << 1);
             const uint32_t rel = (uint32_t)lane * 32;
             while (x) {
-                *lds16(k2b_stage_skew(va)) = (uint16_t)(rel | (uint32_t)__builtin_ctz(x));
+                if (FG_K2B_KO != 2) *lds16(k2b_stage_skew(va)) = (uint16_t)(rel | (uint32_t)__builtin_ctz(x));
                 va += 2;
                 x &= x - 1;
             }
@@ -1733,19 +1737,23 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
                 const lds_u32* sp = lds32(k2b_stage_skew(v_wave + (i << 1)));
                 const uint32_t e01 = sp[0], e23 = sp[1];
                 const uint32_t e0 = e01 & 0xFFFFu, e1 = e01 >> 16, e2 = e23 & 0xFFFFu, e3 = e23 >> 16;
+#ifdef FG_K2B_NT
+                __builtin_nontemporal_store(u32x4{cbase + e0, cbase + e1, cbase + e2, cbase + e3}, (u32x4_a4*)(out + i));
+#else
                 *(u32x4_a4*)(out + i) = u32x4{cbase + e0, cbase + e1, cbase + e2, cbase + e3};
+#endif
                 if (hit_partial) {
-                    lds_add(k2b_hist_addr(hoff, hG, e0), hinc);
-                    lds_add(k2b_hist_addr(hoff, hG, e1), hinc);
-                    lds_add(k2b_hist_addr(hoff, hG, e2), hinc);
-                    lds_add(k2b_hist_addr(hoff, hG, e3), hinc);
+                    K2B_HIST_ADD(k2b_hist_addr(hoff, hG, e0), hinc);
+                    K2B_HIST_ADD(k2b_hist_addr(hoff, hG, e1), hinc);
+                    K2B_HIST_ADD(k2b_hist_addr(hoff, hG, e2), hinc);
+                    K2B_HIST_ADD(k2b_hist_addr(hoff, hG, e3), hinc);
                 }
             }
             if ((uint32_t)lane < total - full) {
                 const uint32_t i = full + lane;
                 const uint32_t e = *lds16(k2b_stage_skew(v_wave + (i << 1)));
                 out[i] = cbase + e;
-                if (hit_partial) lds_add(k2b_hist_addr(hoff, hG, e), hinc);
+                if (hit_partial) K2B_HIST_ADD(k2b_hist_addr(hoff, hG, e), hinc);
             }
             out += total;
             wave_lds_sync();

@@ -255,7 +255,7 @@ inline void build_dict(Dict& d, uint32_t k, uint32_t m, const char* bases, uint6
                         for (int64_t i = 0; i < len; ++i) {
                             lo = (lo >> 1) | ((uint32_t)(code[i] & 1u) << (m - 1));
                             hi = (hi >> 1) | ((uint32_t)(code[i] >> 1) << (m - 1));
-                            if (i + 1 >= (int64_t)m) ord[i + 1 - m] = minimizer_order(lo & low_mask32(m), hi & low_mask32(m));
+                            if (i + 1 >= (int64_t)m) ord[i + 1 - m] = minimizer_order(lo & low_mask32(m), hi & low_mask32(m), m);
                         }
                         auto emit = [&](int64_t p, int64_t sa, int64_t sb) {  // k-mers sa..sb of the strand share the minimizer occurrence p
                             uint64_t clo = 0, chi = 0;  // context base c = strand base p - km + c
@@ -334,7 +334,7 @@ inline uint32_t dict_lookup(const Dict& d, uint32_t klo, uint32_t khi, uint32_t*
     uint32_t best = 0xFFFFFFFFu;
     for (uint32_t j = 0; j <= km; ++j) {
         const uint32_t lo = (klo >> j) & low_mask32(m), hi = (khi >> j) & low_mask32(m);
-        best = std::min(best, (minimizer_order(lo, hi) << ORDER_POS_BITS) | j);
+        best = std::min(best, (minimizer_order(lo, hi, m) << ORDER_POS_BITS) | j);
     }
     const uint32_t pm = best & ((1u << ORDER_POS_BITS) - 1u);
     const uint32_t mlo = (klo >> pm) & low_mask32(m), mhi = (khi >> pm) & low_mask32(m);

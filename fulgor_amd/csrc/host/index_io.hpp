@@ -115,7 +115,7 @@ inline void load_dump(const std::string& base, HostIndex& idx, uint32_t m = 0, u
 
 // ---- own binary container ------------------------------------------------------------------------
 namespace detail {
-static const char FGIDX_MAGIC[8] = {'F', 'G', 'I', 'D', 'X', '0', '0', '8'};  // 008: records with contexts of up to 45 bases (m = 17 at k = 31), smax in w3, 27-bit colour-set ids
+static const char FGIDX_MAGIC[8] = {'F', 'G', 'I', 'D', 'X', '0', '0', '9'};  // 009: minimizer order of round 4 (the records are cut by it); 008: contexts of up to 45 bases (m = 17 at k = 31), smax in w3, 27-bit colour-set ids
 template <typename T>
 void wr(std::ofstream& o, const T& v) { o.write(reinterpret_cast<const char*>(&v), sizeof(T)); }
 template <typename T>
@@ -187,7 +187,10 @@ inline void load_binary(const std::string& path, HostIndex& idx) {
     if (!i.is_open()) throw std::runtime_error("cannot open index file");
     char magic[8];
     i.read(magic, 8);
-    if (!i || std::memcmp(magic, FGIDX_MAGIC, 8) != 0) throw std::runtime_error("not an .fgidx file (bad magic/version)");
+    if (i && std::memcmp(magic, FGIDX_MAGIC, 5) == 0 && std::memcmp(magic, FGIDX_MAGIC, 8) != 0)
+        throw std::runtime_error("this .fgidx file has container version " + std::string(magic + 5, 3) + ", this build reads " + std::string(FGIDX_MAGIC + 5, 3) +
+                                 ": rebuild the index from its dump files (the super-k-mer records depend on the build's minimizer order)");
+    if (!i || std::memcmp(magic, FGIDX_MAGIC, 8) != 0) throw std::runtime_error("not an .fgidx file (bad magic)");
     int32_t type;
     rd(i, type);
     idx.type = type;

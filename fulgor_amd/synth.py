@@ -28,7 +28,7 @@ def build_tool():
 
 def ensure_s4546(data_dir, s10_genomes):
     """returns (path of the .fgidx, [accessory sequence as uint8 array]); generates them if missing"""
-    fg = os.path.join(data_dir, "s4546syn.v8.fgidx")
+    fg = os.path.join(data_dir, "s4546syn.v9.fgidx")
     acc = os.path.join(data_dir, "s4546syn.accessory.txt")
     if not (os.path.exists(fg) and os.path.exists(acc)):
         os.makedirs(data_dir, exist_ok=True)
@@ -46,7 +46,7 @@ def ensure_s4546(data_dir, s10_genomes):
 def ensure_s4546_small(data_dir, s10_genomes):
     """a small index with the same 4546 colours and list shapes (every 24th salmonella_10 unitig, 2.2 M k-mers): for tests
     that move the whole index through the reference's text dump. Returns (path of the .fgidx, [accessory sequence])."""
-    fg = os.path.join(data_dir, "s4546small.v8.fgidx")
+    fg = os.path.join(data_dir, "s4546small.v9.fgidx")
     acc = os.path.join(data_dir, "s4546small.accessory.txt")
     if not (os.path.exists(fg) and os.path.exists(acc)):
         os.makedirs(data_dir, exist_ok=True)
@@ -68,7 +68,7 @@ DESCRIPTION_CORE = ("SYNTHETIC salmonella_4546-shaped index, CORE-HEAVY profile 
 
 def ensure_s4546_core(data_dir, s10_genomes):
     """the core-heavy profile of the same generator (synth_s4546.cpp, profile 1). Returns (path of the .fgidx, [accessory])."""
-    fg = os.path.join(data_dir, "s4546core.v8.fgidx")
+    fg = os.path.join(data_dir, "s4546core.v9.fgidx")
     acc = os.path.join(data_dir, "s4546core.accessory.txt")
     if not (os.path.exists(fg) and os.path.exists(acc)):
         os.makedirs(data_dir, exist_ok=True)

@@ -42,7 +42,7 @@ def s10_dump(built):
 @pytest.fixture(scope="session")
 def s10_fgidx(built, s10_dump):
     import fulgor_amd
-    p = os.path.join(DATA, "s10.v8.fgidx")
+    p = os.path.join(DATA, "s10.v9.fgidx")
     if not os.path.exists(p):
         ix = fulgor_amd.Index(s10_dump, device=-1)
         ix.save(p)

@@ -593,3 +593,43 @@ def test_wrapped_fastq_is_read_as_one_stream_and_leading_junk_does_not_change_th
                     parts += [bb[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
                 rd.close()
             assert parts == small, (junk, cut)
+
+
+def test_bench_real_dump_hook_ingests_a_dump_and_labels_the_line(built, tmp_path, monkeypatch):
+    """FULGOR_S4546_DUMP (bench.py): the four text files of a `fulgor dump` (src/index.cpp:59-120) take the synthetic index's
+    place. Here the dump is the 4546-colour test index written by fgpu_dump: all four files are required, the index is ingested
+    into the data directory given, reads are drawn from its unitigs, and the description says what the data is."""
+    import fulgor_amd
+    from conftest import DATA, S10_GENOMES
+    from fulgor_amd import synth
+    import bench
+    fg, _ = synth.ensure_s4546_small(DATA, S10_GENOMES)
+    base = os.path.join(DATA, "s4546small_dump")
+    if not os.path.exists(base + ".unitigs.fa"):
+        ix = fulgor_amd.Index(fg, device=-1)
+        ix.dump(base)
+        ix.close()
+    # a private copy (links) so that one file can go missing
+    mine = str(tmp_path / "salmonella_4546")
+    for suffix in (".metadata.txt", ".unitigs.fa", ".color_sets.txt", ".filenames.txt"):
+        os.symlink(base + suffix, mine + suffix)
+    data = str(tmp_path / "data")
+    got_fg, gen, desc = bench.real_dump_workload(mine, data)
+    assert got_fg == os.path.join(data, "salmonella_4546.v9.fgidx") and os.path.exists(got_fg)
+    assert desc.startswith(bench.REAL_DUMP_PREFIX) and "salmonella_4546" in desc and str(tmp_path) not in desc
+    ix = fulgor_amd.Index(got_fg, device=-1)
+    assert ix.num_colors() == 4546 and ix.k() == 31
+    ix.close()
+    b, o = gen.generate(0, 500, 150, 42)
+    assert len(o) == 501 and int(o[-1]) == 500 * 150 and set(np.unique(b).tolist()) <= set(b"ACGT")
+    b2, _ = gen.generate(0, 500, 150, 42)
+    assert np.array_equal(b, b2)  # seeded
+    # the environment variable routes the default workload there
+    monkeypatch.setenv("FULGOR_S4546_DUMP", mine)
+    mtime = os.path.getmtime(got_fg)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))  # (prepare_workload puts its caches under ROOT/data)
+    fg2, _, desc2 = bench.prepare_workload("s4546syn")
+    assert fg2 == got_fg and desc2 == desc and os.path.getmtime(got_fg) == mtime  # ingested once
+    os.remove(mine + ".filenames.txt")
+    with pytest.raises(SystemExit, match="filenames.txt is missing"):
+        bench.real_dump_workload(mine, data)

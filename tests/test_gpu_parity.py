@@ -1,6 +1,7 @@
 """GPU suite: the HIP path, called through the C ABI, against (1) the committed golden vectors of the
 independent k-mer oracle, (2) the oracle (CPU restatement of the reference) on seeded reads, bit-exact,
 (3) size-independent properties at BASELINE config size (1M reads on salmonella_10)."""
+import contextlib
 import os
 import sys
 
@@ -13,17 +14,39 @@ from fulgor_amd import pack_reads
 
 pytestmark = pytest.mark.gpu
 
+# The colour stage has two executions (fgpu_tune, FGPU_TUNE_DENSE_ROWS): the dense rows (k2r_intersect / k3r_union, the default
+# while the rows fit the device) and the packed blocks of the gap-coded lists (k2a_intersect / k3a_union: what decodes the
+# reference's lists, and what a collection runs whose rows do not fit). Tests that take `colour_stage` run under both.
+COLOUR_STAGES = [pytest.param(True, id="dense-rows"), pytest.param(False, id="packed-blocks")]
 
-def test_gpu_full_intersection_matches_golden(s10_gpu):
+
+@pytest.fixture(params=COLOUR_STAGES)
+def colour_stage(request):
+    return request.param
+
+
+@contextlib.contextmanager
+def stage(ix, dense_rows):
+    """the index with the colour stage set to dense rows / packed blocks (the session's indexes go back to the default)"""
+    ix.tune(dense_rows=dense_rows)
+    try:
+        yield ix
+    finally:
+        ix.tune(dense_rows=True)
+
+
+def test_gpu_full_intersection_matches_golden(s10_gpu, colour_stage):
     b, o = pack_reads(load_golden_reads())
-    offs, cols = s10_gpu.pseudoalign_full_intersection_batch(b, o)
+    with stage(s10_gpu, colour_stage):
+        offs, cols = s10_gpu.pseudoalign_full_intersection_batch(b, o)
     assert csr_to_lists(offs, cols) == load_golden_tsv("s10_full_intersection.tsv")
 
 
 @pytest.mark.parametrize("tau", [0.8, 1.0, 0.01])
-def test_gpu_threshold_union_matches_golden(s10_gpu, tau):
+def test_gpu_threshold_union_matches_golden(s10_gpu, tau, colour_stage):
     b, o = pack_reads(load_golden_reads())
-    offs, cols = s10_gpu.pseudoalign_threshold_union_batch(b, o, tau)
+    with stage(s10_gpu, colour_stage):
+        offs, cols = s10_gpu.pseudoalign_threshold_union_batch(b, o, tau)
     assert csr_to_lists(offs, cols) == load_golden_tsv("s10_threshold_union_%s.tsv" % tau)
 
 
@@ -41,38 +64,41 @@ def test_gpu_fetch_color_set_ids_equals_oracle(s10_gpu, s10_oracle, seeded_reads
     assert np.array_equal(go, oo) and np.array_equal(gi, oi)
 
 
-def test_gpu_full_intersection_equals_oracle(s10_gpu, s10_oracle, seeded_reads):
+def test_gpu_full_intersection_equals_oracle(s10_gpu, s10_oracle, seeded_reads, colour_stage):
     b, o = seeded_reads
-    go, gc = s10_gpu.pseudoalign_full_intersection_batch(b, o)
+    with stage(s10_gpu, colour_stage):
+        go, gc = s10_gpu.pseudoalign_full_intersection_batch(b, o)
     oo, oc = s10_oracle.full_intersection(b, o)
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
 
 
 @pytest.mark.parametrize("tau", [0.8, 0.5, 1.0])
-def test_gpu_threshold_union_equals_oracle(s10_gpu, s10_oracle, seeded_reads, tau):
+def test_gpu_threshold_union_equals_oracle(s10_gpu, s10_oracle, seeded_reads, tau, colour_stage):
     b, o = seeded_reads
-    go, gc = s10_gpu.pseudoalign_threshold_union_batch(b, o, tau)
+    with stage(s10_gpu, colour_stage):
+        go, gc = s10_gpu.pseudoalign_threshold_union_batch(b, o, tau)
     oo, oc = s10_oracle.threshold_union(b, o, tau)
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
 
 
-def test_gpu_intersect_ids_equals_oracle(s10_gpu, s10_oracle, seeded_reads):
+def test_gpu_intersect_ids_equals_oracle(s10_gpu, s10_oracle, seeded_reads, colour_stage):
     b, o = seeded_reads
     ido, ids = s10_oracle.fetch_color_set_ids(b, o)
-    go, gc = s10_gpu.intersect_ids_batch(ids, ido)
-    oo, oc = s10_oracle.intersect_ids(ids, ido)
-    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
     # random id lists (not produced by any read): every hybrid encoding mixed, up to 40 lists
     rng = np.random.default_rng(3)
     ns = s10_gpu.num_color_sets()
     lens = rng.integers(0, 40, size=3000)
     lists = [np.unique(rng.integers(0, ns, size=l)).astype(np.uint32) for l in lens]
-    ido = np.zeros(len(lists) + 1, dtype=np.uint64)
-    ido[1:] = np.cumsum([len(l) for l in lists])
-    ids = np.concatenate(lists) if lists else np.zeros(0, dtype=np.uint32)
-    go, gc = s10_gpu.intersect_ids_batch(ids, ido)
-    oo, oc = s10_oracle.intersect_ids(ids, ido, self_check=True)
+    ido2 = np.zeros(len(lists) + 1, dtype=np.uint64)
+    ido2[1:] = np.cumsum([len(l) for l in lists])
+    ids2 = np.concatenate(lists) if lists else np.zeros(0, dtype=np.uint32)
+    with stage(s10_gpu, colour_stage):
+        go, gc = s10_gpu.intersect_ids_batch(ids, ido)
+        go2, gc2 = s10_gpu.intersect_ids_batch(ids2, ido2)
+    oo, oc = s10_oracle.intersect_ids(ids, ido)
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+    oo, oc = s10_oracle.intersect_ids(ids2, ido2, self_check=True)
+    assert np.array_equal(go2, oo) and np.array_equal(gc2, oc)
 
 
 def test_gpu_per_read_members(s10_gpu, s10_oracle):
@@ -100,7 +126,7 @@ def test_gpu_edge_batches(s10_gpu):
 
 
 @pytest.mark.parametrize("windows", [2, 3, 4])
-def test_gpu_reads_up_to_512_kmers(s10_gpu, s10_oracle, windows):
+def test_gpu_reads_up_to_512_kmers(s10_gpu, s10_oracle, windows, colour_stage):
     """batches whose longest read has 129..512 k-mers (250- to 500-base reads) run the 2-, 3- and 4-window variants of the
     short-read lookup kernel: every length around the window boundaries, invalid bases in several windows, substitutions."""
     from oracle.kmer_oracle import read_fasta
@@ -126,9 +152,10 @@ def test_gpu_reads_up_to_512_kmers(s10_gpu, s10_oracle, windows):
             r = bytearray(bytes(r).lower())
         reads.append(bytes(r))
     b, o = pack_reads(reads)
-    for got, want in ((s10_gpu.pseudoalign_full_intersection_batch(b, o), s10_oracle.full_intersection(b, o)),
-                      (s10_gpu.pseudoalign_threshold_union_batch(b, o, 0.8), s10_oracle.threshold_union(b, o, 0.8)),
-                      (s10_gpu.fetch_color_set_ids_batch(b, o), s10_oracle.fetch_color_set_ids(b, o))):
+    with stage(s10_gpu, colour_stage):
+        got3 = (s10_gpu.pseudoalign_full_intersection_batch(b, o), s10_gpu.pseudoalign_threshold_union_batch(b, o, 0.8),
+                s10_gpu.fetch_color_set_ids_batch(b, o))
+    for got, want in zip(got3, (s10_oracle.full_intersection(b, o), s10_oracle.threshold_union(b, o, 0.8), s10_oracle.fetch_color_set_ids(b, o))):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     # per-k-mer ids keep their order across the two windows
     from fulgor_amd.index import conservation_triples
@@ -139,7 +166,7 @@ def test_gpu_reads_up_to_512_kmers(s10_gpu, s10_oracle, windows):
         assert conservation_triples(ids) == s10_oracle.kmer_conservation(r)
 
 
-def test_gpu_threshold_union_reads_of_128_to_255_kmers(s10_gpu, s10_oracle):
+def test_gpu_threshold_union_reads_of_128_to_255_kmers(s10_gpu, s10_oracle, colour_stage):
     """batches whose longest read has 128..255 k-mers (e.g. 250-base reads) keep 8-bit score counters, unbiased, and
     compare them with the threshold byte-wise: thresholds on both sides of 128, zero, and equal to the score; chimeric reads
     (many colour sets, complemented lists included); the scores themselves through kmer_matches."""
@@ -165,7 +192,9 @@ def test_gpu_threshold_union_reads_of_128_to_255_kmers(s10_gpu, s10_oracle):
     reads += [srcs[0][1000:1100], srcs[1][5000:5031], b""]  # shorter reads in the same batch
     b, o = pack_reads(reads)
     for tau in (0.001, 0.3, 0.5, 0.55, 0.8, 1.0):
-        got, want = s10_gpu.pseudoalign_threshold_union_batch(b, o, tau), s10_oracle.threshold_union(b, o, tau)
+        with stage(s10_gpu, colour_stage):
+            got = s10_gpu.pseudoalign_threshold_union_batch(b, o, tau)
+        want = s10_oracle.threshold_union(b, o, tau)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), tau
     mo, pos, counts = s10_gpu.kmer_matches_batch(b, o)
     for j in range(0, len(reads), 7):
@@ -266,10 +295,11 @@ def s4546(built):
     return ix, orc, gen
 
 
-def test_s4546_full_intersection_equals_oracle(s4546):
+def test_s4546_full_intersection_equals_oracle(s4546, colour_stage):
     ix, orc, gen = s4546
     b, o = gen.generate(0, 30000, 150, 42)
-    go, gc = ix.pseudoalign_full_intersection_batch(b, o)
+    with stage(ix, colour_stage):
+        go, gc = ix.pseudoalign_full_intersection_batch(b, o)
     oo, oc = orc.full_intersection(b, o, threads=32)
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
     orc.full_intersection(b[:150 * 500], o[:501], threads=8, self_check=True)  # restatement vs check_intersection
@@ -279,31 +309,34 @@ def test_s4546_full_intersection_equals_oracle(s4546):
 
 
 @pytest.mark.parametrize("tau", [0.8, 0.3, 1.0])
-def test_s4546_threshold_union_equals_oracle(s4546, tau):
+def test_s4546_threshold_union_equals_oracle(s4546, tau, colour_stage):
     ix, orc, gen = s4546
     b, o = gen.generate(100000, 20000, 150, 42)
-    go, gc = ix.pseudoalign_threshold_union_batch(b, o, tau)
+    with stage(ix, colour_stage):
+        go, gc = ix.pseudoalign_threshold_union_batch(b, o, tau)
     oo, oc = orc.threshold_union(b, o, tau, threads=32)
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
     orc.threshold_union(b[:150 * 300], o[:301], tau, threads=8, self_check=True)
 
 
 @pytest.mark.parametrize("read_len", [250, 300, 500])
-def test_s4546_longer_reads_equal_oracle(s4546, read_len):
+def test_s4546_longer_reads_equal_oracle(s4546, read_len, colour_stage):
     """4546 colours, reads of 220 / 270 / 470 k-mers: the windowed lookup kernel (2, 3, 4 windows) and the threshold union's
     plain 8-bit (250) and 16-bit (300, 500) counters against the oracle"""
     ix, orc, gen = s4546
     b, o = gen.generate(300000, 6000, read_len, 42)
-    go, gc = ix.pseudoalign_full_intersection_batch(b, o)
+    with stage(ix, colour_stage):
+        go, gc = ix.pseudoalign_full_intersection_batch(b, o)
     oo, oc = orc.full_intersection(b, o, threads=32)
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
     for tau in (0.8, 0.3):
-        go, gc = ix.pseudoalign_threshold_union_batch(b, o, tau)
+        with stage(ix, colour_stage):
+            go, gc = ix.pseudoalign_threshold_union_batch(b, o, tau)
         oo, oc = orc.threshold_union(b, o, tau, threads=32)
         assert np.array_equal(go, oo) and np.array_equal(gc, oc), tau
 
 
-def test_s4546_random_id_lists(s4546):
+def test_s4546_random_id_lists(s4546, colour_stage):
     """intersections of arbitrary colour-set ids: many sparse lists, > 64 lists per read, all encodings"""
     ix, orc, _ = s4546
     rng = np.random.default_rng(11)
@@ -313,7 +346,8 @@ def test_s4546_random_id_lists(s4546):
     ido = np.zeros(len(lists) + 1, dtype=np.uint64)
     ido[1:] = np.cumsum([len(l) for l in lists])
     ids = np.concatenate(lists)
-    go, gc = ix.intersect_ids_batch(ids, ido)
+    with stage(ix, colour_stage):
+        go, gc = ix.intersect_ids_batch(ids, ido)
     oo, oc = orc.intersect_ids(ids, ido, threads=32, self_check=True)
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
 
@@ -514,7 +548,7 @@ def _fuzz_reads(gen, rng, n):
 
 
 @pytest.mark.parametrize("which", ["s10", "s4546"])
-def test_fuzz_dirty_ragged_reads(which, s10_gpu, s10_oracle, s4546, built):
+def test_fuzz_dirty_ragged_reads(which, s10_gpu, s10_oracle, s4546, built, colour_stage):
     from fulgor_amd.reads import ReadGenerator
     rng = np.random.default_rng(2026)
     if which == "s10":
@@ -524,15 +558,12 @@ def test_fuzz_dirty_ragged_reads(which, s10_gpu, s10_oracle, s4546, built):
     for rep in range(3):
         reads = _fuzz_reads(gen, rng, 6000)
         b, o = pack_reads(reads)
-        for got, want in ((ix.fetch_color_set_ids_batch(b, o), orc.fetch_color_set_ids(b, o, threads=32)),
-                          (ix.pseudoalign_full_intersection_batch(b, o), orc.full_intersection(b, o, threads=32)),
-                          (ix.pseudoalign_threshold_union_batch(b, o, float(rng.choice([0.3, 0.8, 1.0]))), None)):
-            if want is None:
-                continue
+        tau = float(rng.choice([0.25, 0.3, 0.8, 1.0]))
+        with stage(ix, colour_stage):
+            got3 = (ix.fetch_color_set_ids_batch(b, o), ix.pseudoalign_full_intersection_batch(b, o), ix.pseudoalign_threshold_union_batch(b, o, tau))
+        want3 = (orc.fetch_color_set_ids(b, o, threads=32), orc.full_intersection(b, o, threads=32), orc.threshold_union(b, o, tau, threads=32))
+        for got, want in zip(got3, want3):
             assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
-        tau = float(rng.choice([0.25, 0.8, 1.0]))
-        got, want = ix.pseudoalign_threshold_union_batch(b, o, tau), orc.threshold_union(b, o, tau, threads=32)
-        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
 
 
 def _write_wide_dump(base, rng, n=70001, k=31):
@@ -1034,13 +1065,13 @@ def test_s4546small_codecs_equal_oracle_convert(s4546small, index_type, psize, c
 
 
 @pytest.mark.parametrize("index_type,psize,csize", [(fulgor_amd.HYBRID, 0, 0), (fulgor_amd.DIFF, 16, 4), (fulgor_amd.META, 48, 8), (fulgor_amd.META_DIFF, 48, 8)])
-def test_gpu_matches_golden_at_256_colours(c256_dump, index_type, psize, csize):
+def test_gpu_matches_golden_at_256_colours(c256_dump, index_type, psize, csize, colour_stage):
     """golden vectors ABOVE 64 colours: computed by the independent k-mer oracle straight from the 256 seeded genomes
     (tests/golden/make_golden_c256.py); nothing of the restatement is involved"""
     ix = fulgor_amd.Index(c256_dump, device=0)
     if index_type != fulgor_amd.HYBRID:
         ix.convert(index_type, psize, csize)
-        ix.tune(dense_rows=False)  # the codec's own kernels (k_generic), not the dense rows
+    ix.tune(dense_rows=colour_stage)  # False: the codec's own kernels (k2a / k3a on the hybrid lists, k_generic on the others)
     b, o = pack_reads(load_golden_reads("c256_reads.fa"))
     offs, cols = ix.pseudoalign_full_intersection_batch(b, o)
     assert csr_to_lists(offs, cols) == load_golden_tsv("c256_full_intersection.tsv")

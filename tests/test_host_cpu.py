@@ -128,6 +128,10 @@ def test_bad_container_is_rejected(tmp_path):
     p.write_bytes(b"NOTANIDX" + b"\0" * 64)
     with pytest.raises(RuntimeError, match="magic"):
         fulgor_amd.Index(str(p), device=-1)
+    # a container of an earlier build says so and tells what to do
+    p.write_bytes(b"FGIDX008" + b"\0" * 64)
+    with pytest.raises(RuntimeError, match="container version 008.*rebuild the index"):
+        fulgor_amd.Index(str(p), device=-1)
 
 
 def test_readgen_is_sliceable_and_seeded(built):
