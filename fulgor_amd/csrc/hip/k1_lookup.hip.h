@@ -239,17 +239,31 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                     }
                 }
                 wave_lds_sync();
+                if (WFIX) {
+                    // 15 m-mers per window: minima of four neighbours first, then four of those cover the window ([i, i + 4), [i + 4, i + 8),
+                    // [i + 8, i + 12), [i + 11, i + 15)): two rounds through LDS (doubling by 1, 2, 4 and the tail took four)
+                    uint32_t n1[NA], n2[NA], n3[NA];
 #pragma unroll
-                for (uint32_t st = 1; st < span; st <<= 1) {  // in place: every lane reads before any lane writes
-                    uint32_t nb_[NA];
+                    for (int a = 0; a < NA; ++a) { n1[a] = mn[64 * a + lane + 1]; n2[a] = mn[64 * a + lane + 2]; n3[a] = mn[64 * a + lane + 3]; }
 #pragma unroll
-                    for (int a = 0; a < NA; ++a) nb_[a] = mn[64 * a + lane + st];
-#pragma unroll
-                    for (int a = 0; a < NA; ++a) {
-                        v[a] = min(v[a], nb_[a]);
+                    for (int a = 0; a < NA; ++a) {  // in place: every lane has read before any lane writes
+                        v[a] = min(min(v[a], n1[a]), min(n2[a], n3[a]));
                         if (a < NA - 1 || lane < 16) mn[64 * a + lane] = v[a];
                     }
                     wave_lds_sync();
+                } else {
+#pragma unroll
+                    for (uint32_t st = 1; st < span; st <<= 1) {  // in place: every lane reads before any lane writes
+                        uint32_t nb_[NA];
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) nb_[a] = mn[64 * a + lane + st];
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) {
+                            v[a] = min(v[a], nb_[a]);
+                            if (a < NA - 1 || lane < 16) mn[64 * a + lane] = v[a];
+                        }
+                        wave_lds_sync();
+                    }
                 }
 #if defined(FG_K1_STOP) && FG_K1_STOP == 1  // knock-out build (profiles/k1_phase_counts.sh): the kernel up to the end of phase A
                 if (lane == 0) { nids[t_first + j] = v[0] == 0x12345u; npos[t_first + j] = 0; idoff[t_first + j] = (t_first + j) * (uint64_t)stride; }
@@ -262,7 +276,8 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
 #pragma unroll
                 for (int a = 0; a < NA - 1; ++a) {
                     // [i, i + span) and [i + W - span, i + W) cover the window
-                    pos[a] = min(v[a], mn[64 * a + lane + tail]) & POSM;
+                    if (WFIX) pos[a] = min(min(v[a], mn[64 * a + lane + 4]), min(mn[64 * a + lane + 8], mn[64 * a + lane + 11])) & POSM;
+                    else pos[a] = min(v[a], mn[64 * a + lane + tail]) & POSM;
                     const uint32_t carry = a ? (uint32_t)__builtin_amdgcn_readlane((int)pos[a ? a - 1 : 0], 63) : 0xFFFFFFFFu;
                     const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)pos[a], 0x138, 0xF, 0xF, false);  // wave_shr:1
                     H[a] = __ballot((uint32_t)(64 * a + lane) < nk && pos[a] != prev);

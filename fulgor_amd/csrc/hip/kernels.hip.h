@@ -1142,18 +1142,36 @@ __device__ __forceinline__ uint32_t mux_tree(const uint32_t (&x)[K3R_MUX_LISTS],
         return lo | (x[LEVEL - 1] & hi);
     }
 }
-// the whole read: rounds of 64 row words, one per lane; returns the lane's share of the result's cardinality
+// The whole read: rounds of 64 row words, one per lane; returns the lane's share of the result's cardinality. `id` = the L lists
+// that go through the tree; the lists in `mand` (a mask over the lanes, whose `id_l` is the lane's list) must contain every
+// result colour: their rows are ANDed in (two in flight).
 template <int L>
-__device__ __forceinline__ uint32_t mux_union_read(const uint32_t* __restrict__ rows, uint32_t W, uint32_t Wn, uint32_t n, const u32x8 id,
-                                                   uint64_t table, uint32_t* __restrict__ bm, int lane) {
+__device__ __forceinline__ uint32_t mux_union_read(const uint32_t* __restrict__ rows, uint32_t W, uint32_t Wn, uint32_t n, const uint32_t (&id)[K3R_MUX_LISTS],
+                                                   uint64_t table, uint64_t mand, uint32_t id_l, uint32_t* __restrict__ bm, int lane) {
     uint32_t pc = 0;
+    // the first two mandatory lists travel with the lists of the tree (one wait per round); further ones are rare
+    uint64_t rest = mand;
+    const bool m0 = rest != 0;
+    const uint32_t i0 = m0 ? (uint32_t)__builtin_amdgcn_readlane((int)id_l, (int)__builtin_ctzll(rest)) : 0u;
+    rest &= rest - 1;
+    const bool m1 = rest != 0;
+    const uint32_t i1 = m1 ? (uint32_t)__builtin_amdgcn_readlane((int)id_l, (int)__builtin_ctzll(rest)) : 0u;
+    rest &= rest - 1;
     for (uint32_t w0 = 0; w0 < Wn; w0 += 64) {
         const uint32_t w = w0 + (uint32_t)lane;
         const uint32_t wi = min(w, W - 1);  // (lanes past the row load its last word and store nothing)
         uint32_t x[K3R_MUX_LISTS];
 #pragma unroll
         for (int l = 0; l < L; ++l) x[l] = rows[(uint64_t)id[l] * W + wi];
-        uint32_t m = mux_tree<L>(x, table, 0u);
+        uint32_t y0 = 0xFFFFFFFFu, y1 = 0xFFFFFFFFu;
+        if (m0) y0 = rows[(uint64_t)i0 * W + wi];  // (wave-uniform)
+        if (m1) y1 = rows[(uint64_t)i1 * W + wi];
+        uint32_t m;
+        if constexpr (L == 0) m = 0u - (uint32_t)(table & 1ull);
+        else m = mux_tree<L>(x, table, 0u);
+        m &= y0 & y1;
+        for (uint64_t mm = rest; mm; mm &= mm - 1)  // (wave-uniform)
+            m &= rows[(uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)id_l, (int)__builtin_ctzll(mm)) * W + wi];
         if (w >= (n >> 5)) m &= w == (n >> 5) ? (1u << (n & 31u)) - 1u : 0u;  // (only the last words hold colours >= n)
         if (w < W) {
             bm[w] = m;
@@ -1182,11 +1200,13 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 6 : 4)) void k3r
         const uint64_t rl = min(t_first + (uint64_t)lane, n_reads - 1);
         const uint32_t cnt_l = (uint32_t)lane < t_count ? nids[rl] : 0u;
         const uint64_t off_l = idoff[rl];
-        const uint32_t min_l = (uint32_t)(unsigned long long)((double)npos[rl] * tau);  // ps_threshold_union.cpp:389
+        const uint32_t np_l = npos[rl];
+        const uint32_t min_l = (uint32_t)(unsigned long long)((double)np_l * tau);  // ps_threshold_union.cpp:389
         for (uint32_t ri = 0; ri < t_count; ++ri) {
             const uint64_t r = t_first + ri;
             const uint32_t nl = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, ri);
             const uint32_t min_score = (uint32_t)__builtin_amdgcn_readlane((int)min_l, ri);
+            const uint32_t positive = (uint32_t)__builtin_amdgcn_readlane((int)np_l, ri);
             const uint64_t off = readlane_u64(off_l, ri);
             uint32_t* bm = out_bitmap + r * W;
             if (nl == 0) {
@@ -1196,26 +1216,46 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 6 : 4)) void k3r
                     for (uint32_t cc = lane; cc < n; cc += 64) scores_out[r * (uint64_t)n + cc] = 0;
                 continue;
             }
-            if (!SCORES && nl <= K3R_MUX_LISTS) {  // few lists: the multiplexer tree, no counters
-                typedef const __attribute__((address_space(4))) u32x8_a4* s8_ptr;
-                const u32x8 id = *(s8_ptr)(ids_pool + off), mu = *(s8_ptr)(cnt_pool + off);
-                uint32_t score = 0;  // of the pattern `lane` of lists
+            // A colour that is not in list l scores at most P - m_l: a list with m_l > P - min_score is MANDATORY, every result colour
+            // is in it (one AND per row word). What the others contribute is a monotone boolean function of which of them contain the
+            // colour: with at most six of them, the multiplexer tree; no counters.
+            if (!SCORES && nl <= 64u) {
+                const bool has = (uint32_t)lane < nl;
+                const uint32_t id_l = has ? ids_pool[off + lane] : 0u, mu_l = has ? cnt_pool[off + lane] : 0u;
+                const uint32_t slack = positive - min_score;
+                const uint64_t FREE = __ballot(has && mu_l <= slack), MAND = __ballot(has && mu_l > slack);
+                const uint32_t nfree = (uint32_t)__popcll(FREE);
+                if (nfree <= K3R_MUX_LISTS) {
+                    uint32_t idf[K3R_MUX_LISTS], muf[K3R_MUX_LISTS];
+                    uint64_t ff = FREE;
+                    uint32_t free_total = 0;
 #pragma unroll
-                for (uint32_t l = 0; l < K3R_MUX_LISTS; ++l) score += (l < nl && (((uint32_t)lane >> l) & 1u)) ? mu[l] : 0u;
-                const uint64_t table = __ballot(score >= min_score);
-                uint32_t pcm = 0;
-                switch (nl) {  // (wave-uniform)
-                    case 1: pcm = mux_union_read<1>(rows, W, Wn, n, id, table, bm, lane); break;
-                    case 2: pcm = mux_union_read<2>(rows, W, Wn, n, id, table, bm, lane); break;
-                    case 3: pcm = mux_union_read<3>(rows, W, Wn, n, id, table, bm, lane); break;
-                    case 4: pcm = mux_union_read<4>(rows, W, Wn, n, id, table, bm, lane); break;
-                    case 5: pcm = mux_union_read<5>(rows, W, Wn, n, id, table, bm, lane); break;
-                    default: pcm = mux_union_read<6>(rows, W, Wn, n, id, table, bm, lane); break;
+                    for (uint32_t j = 0; j < K3R_MUX_LISTS; ++j) {
+                        const uint32_t a = ff ? (uint32_t)__builtin_ctzll(ff) : 0u;
+                        idf[j] = ff ? (uint32_t)__builtin_amdgcn_readlane((int)id_l, a) : 0u;
+                        muf[j] = ff ? (uint32_t)__builtin_amdgcn_readlane((int)mu_l, a) : 0u;
+                        free_total += muf[j];
+                        ff &= ff - 1;
+                    }
+                    uint32_t score = positive - free_total;  // the mandatory lists + pattern `lane` of the others
+#pragma unroll
+                    for (uint32_t j = 0; j < K3R_MUX_LISTS; ++j) score += (((uint32_t)lane >> j) & 1u) ? muf[j] : 0u;
+                    const uint64_t table = __ballot(score >= min_score);
+                    uint32_t pcm = 0;
+                    switch (nfree) {  // (wave-uniform)
+                        case 0: pcm = mux_union_read<0>(rows, W, Wn, n, idf, table, MAND, id_l, bm, lane); break;
+                        case 1: pcm = mux_union_read<1>(rows, W, Wn, n, idf, table, MAND, id_l, bm, lane); break;
+                        case 2: pcm = mux_union_read<2>(rows, W, Wn, n, idf, table, MAND, id_l, bm, lane); break;
+                        case 3: pcm = mux_union_read<3>(rows, W, Wn, n, idf, table, MAND, id_l, bm, lane); break;
+                        case 4: pcm = mux_union_read<4>(rows, W, Wn, n, idf, table, MAND, id_l, bm, lane); break;
+                        case 5: pcm = mux_union_read<5>(rows, W, Wn, n, idf, table, MAND, id_l, bm, lane); break;
+                        default: pcm = mux_union_read<6>(rows, W, Wn, n, idf, table, MAND, id_l, bm, lane); break;
+                    }
+                    for (uint32_t w = ((Wn + 63) & ~63u) + lane; w < W; w += 64) bm[w] = 0;  // (padding words behind the last round)
+                    pcm = wave_sum_u32(pcm);
+                    if (lane == 0) out_count[r] = pcm;
+                    continue;
                 }
-                for (uint32_t w = ((Wn + 63) & ~63u) + lane; w < W; w += 64) bm[w] = 0;  // (padding words behind the last round)
-                pcm = wave_sum_u32(pcm);
-                if (lane == 0) out_count[r] = pcm;
-                continue;
             }
             const uint32_t start = (BIASED ? HALF - min_score : 0u) * ONES;
             const uint32_t thr_c = (256u - min_score) & 0xFFu;  // (unbiased counters only)

@@ -1,0 +1,33 @@
+"""Threshold union, which lists are MANDATORY: a colour that misses list l scores at most P - m_l, so a list with
+m_l > P - min_score must contain every result colour. How many lists of a read are left once those are taken out?
+(decides whether the multiplexer tree of k3r_union can serve reads of more than 6 lists). python profiles/k3r_mandatory_stats.py [reads] [tau]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench, fulgor_amd
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+tau = float(sys.argv[2]) if len(sys.argv) > 2 else 0.8
+fg, gen, desc = bench.prepare_workload("s4546syn")
+ix = fulgor_amd.Index(fg, device=0)
+b, o = gen.generate(0, n, 150, 42)
+ko, ki = ix.kmer_color_set_ids_batch(b, o)
+ko = ko.astype(np.int64)
+nl_all, free_all, P_all = [], [], []
+for r in range(n):
+    ids = ki[ko[r]:ko[r + 1]]
+    ids = ids[ids != 0xFFFFFFFF]
+    if len(ids) == 0:
+        nl_all.append(0); free_all.append(0); P_all.append(0); continue
+    _, m = np.unique(ids, return_counts=True)
+    P = int(m.sum()); ms = int(P * tau); slack = P - ms
+    nl_all.append(len(m)); free_all.append(int((m <= slack).sum())); P_all.append(P)
+nl, fr = np.array(nl_all), np.array(free_all)
+print("workload:", desc)
+print("reads %d tau %.2f; lists per read mean %.2f; reads with > 6 lists %.1f%%" % (n, tau, nl.mean(), 100 * (nl > 6).mean()))
+big = nl > 6
+print("of those: lists mean %.2f, not mandatory mean %.2f; with <= 6 not mandatory %.1f%%, <= 5: %.1f%%, <= 4: %.1f%%" % (
+    nl[big].mean(), fr[big].mean(), 100 * (fr[big] <= 6).mean(), 100 * (fr[big] <= 5).mean(), 100 * (fr[big] <= 4).mean()))
+print("all reads with lists: not mandatory mean %.2f; histogram of not-mandatory lists:" % fr[nl > 0].mean(),
+      " ".join("%d:%.1f%%" % (i, 100.0 * c / (nl > 0).sum()) for i, c in enumerate(np.bincount(fr[nl > 0])) if c))
+print("histogram of lists:", " ".join("%d:%.1f%%" % (i, 100.0 * c / (nl > 0).sum()) for i, c in enumerate(np.bincount(nl[nl > 0])) if c))

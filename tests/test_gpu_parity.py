@@ -25,6 +25,16 @@ def colour_stage(request):
     return request.param
 
 
+_ORACLE_MEMO = {}
+
+
+def oracle_once(key, fn):
+    """the oracle's answer does not depend on how the GPU executes: computed once per test and inputs, shared by the two stages"""
+    if key not in _ORACLE_MEMO:
+        _ORACLE_MEMO[key] = fn()
+    return _ORACLE_MEMO[key]
+
+
 @contextlib.contextmanager
 def stage(ix, dense_rows):
     """the index with the colour stage set to dense rows / packed blocks (the session's indexes go back to the default)"""
@@ -68,7 +78,7 @@ def test_gpu_full_intersection_equals_oracle(s10_gpu, s10_oracle, seeded_reads, 
     b, o = seeded_reads
     with stage(s10_gpu, colour_stage):
         go, gc = s10_gpu.pseudoalign_full_intersection_batch(b, o)
-    oo, oc = s10_oracle.full_intersection(b, o)
+    oo, oc = oracle_once("s10_fi", lambda: s10_oracle.full_intersection(b, o))
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
 
 
@@ -77,7 +87,7 @@ def test_gpu_threshold_union_equals_oracle(s10_gpu, s10_oracle, seeded_reads, ta
     b, o = seeded_reads
     with stage(s10_gpu, colour_stage):
         go, gc = s10_gpu.pseudoalign_threshold_union_batch(b, o, tau)
-    oo, oc = s10_oracle.threshold_union(b, o, tau)
+    oo, oc = oracle_once(("s10_tu", tau), lambda: s10_oracle.threshold_union(b, o, tau))
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
 
 
@@ -95,9 +105,9 @@ def test_gpu_intersect_ids_equals_oracle(s10_gpu, s10_oracle, seeded_reads, colo
     with stage(s10_gpu, colour_stage):
         go, gc = s10_gpu.intersect_ids_batch(ids, ido)
         go2, gc2 = s10_gpu.intersect_ids_batch(ids2, ido2)
-    oo, oc = s10_oracle.intersect_ids(ids, ido)
+    oo, oc = oracle_once("s10_ids", lambda: s10_oracle.intersect_ids(ids, ido))
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
-    oo, oc = s10_oracle.intersect_ids(ids2, ido2, self_check=True)
+    oo, oc = oracle_once("s10_ids2", lambda: s10_oracle.intersect_ids(ids2, ido2, self_check=True))
     assert np.array_equal(go2, oo) and np.array_equal(gc2, oc)
 
 
@@ -155,7 +165,8 @@ def test_gpu_reads_up_to_512_kmers(s10_gpu, s10_oracle, windows, colour_stage):
     with stage(s10_gpu, colour_stage):
         got3 = (s10_gpu.pseudoalign_full_intersection_batch(b, o), s10_gpu.pseudoalign_threshold_union_batch(b, o, 0.8),
                 s10_gpu.fetch_color_set_ids_batch(b, o))
-    for got, want in zip(got3, (s10_oracle.full_intersection(b, o), s10_oracle.threshold_union(b, o, 0.8), s10_oracle.fetch_color_set_ids(b, o))):
+    want3 = oracle_once(("s10_512", windows), lambda: (s10_oracle.full_intersection(b, o), s10_oracle.threshold_union(b, o, 0.8), s10_oracle.fetch_color_set_ids(b, o)))
+    for got, want in zip(got3, want3):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     # per-k-mer ids keep their order across the two windows
     from fulgor_amd.index import conservation_triples
@@ -194,7 +205,7 @@ def test_gpu_threshold_union_reads_of_128_to_255_kmers(s10_gpu, s10_oracle, colo
     for tau in (0.001, 0.3, 0.5, 0.55, 0.8, 1.0):
         with stage(s10_gpu, colour_stage):
             got = s10_gpu.pseudoalign_threshold_union_batch(b, o, tau)
-        want = s10_oracle.threshold_union(b, o, tau)
+        want = oracle_once(("s10_255", tau), lambda: s10_oracle.threshold_union(b, o, tau))
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), tau
     mo, pos, counts = s10_gpu.kmer_matches_batch(b, o)
     for j in range(0, len(reads), 7):
@@ -300,11 +311,12 @@ def test_s4546_full_intersection_equals_oracle(s4546, colour_stage):
     b, o = gen.generate(0, 30000, 150, 42)
     with stage(ix, colour_stage):
         go, gc = ix.pseudoalign_full_intersection_batch(b, o)
-    oo, oc = orc.full_intersection(b, o, threads=32)
+    oo, oc = oracle_once("s4546_fi", lambda: orc.full_intersection(b, o, threads=32))
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
-    orc.full_intersection(b[:150 * 500], o[:501], threads=8, self_check=True)  # restatement vs check_intersection
+    if colour_stage:
+        orc.full_intersection(b[:150 * 500], o[:501], threads=8, self_check=True)  # restatement vs check_intersection
     i1, d1 = ix.fetch_color_set_ids_batch(b, o)
-    i2, d2 = orc.fetch_color_set_ids(b, o, threads=32)
+    i2, d2 = oracle_once("s4546_ids", lambda: orc.fetch_color_set_ids(b, o, threads=32))
     assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
 
 
@@ -314,9 +326,10 @@ def test_s4546_threshold_union_equals_oracle(s4546, tau, colour_stage):
     b, o = gen.generate(100000, 20000, 150, 42)
     with stage(ix, colour_stage):
         go, gc = ix.pseudoalign_threshold_union_batch(b, o, tau)
-    oo, oc = orc.threshold_union(b, o, tau, threads=32)
+    oo, oc = oracle_once(("s4546_tu", tau), lambda: orc.threshold_union(b, o, tau, threads=32))
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
-    orc.threshold_union(b[:150 * 300], o[:301], tau, threads=8, self_check=True)
+    if colour_stage:
+        orc.threshold_union(b[:150 * 300], o[:301], tau, threads=8, self_check=True)
 
 
 @pytest.mark.parametrize("read_len", [250, 300, 500])
@@ -327,12 +340,12 @@ def test_s4546_longer_reads_equal_oracle(s4546, read_len, colour_stage):
     b, o = gen.generate(300000, 6000, read_len, 42)
     with stage(ix, colour_stage):
         go, gc = ix.pseudoalign_full_intersection_batch(b, o)
-    oo, oc = orc.full_intersection(b, o, threads=32)
+    oo, oc = oracle_once(("s4546_long_fi", read_len), lambda: orc.full_intersection(b, o, threads=32))
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
     for tau in (0.8, 0.3):
         with stage(ix, colour_stage):
             go, gc = ix.pseudoalign_threshold_union_batch(b, o, tau)
-        oo, oc = orc.threshold_union(b, o, tau, threads=32)
+        oo, oc = oracle_once(("s4546_long_tu", read_len, tau), lambda: orc.threshold_union(b, o, tau, threads=32))
         assert np.array_equal(go, oo) and np.array_equal(gc, oc), tau
 
 
@@ -348,7 +361,7 @@ def test_s4546_random_id_lists(s4546, colour_stage):
     ids = np.concatenate(lists)
     with stage(ix, colour_stage):
         go, gc = ix.intersect_ids_batch(ids, ido)
-    oo, oc = orc.intersect_ids(ids, ido, threads=32, self_check=True)
+    oo, oc = oracle_once("s4546_random_ids", lambda: orc.intersect_ids(ids, ido, threads=32, self_check=True))
     assert np.array_equal(go, oo) and np.array_equal(gc, oc)
 
 
@@ -561,7 +574,8 @@ def test_fuzz_dirty_ragged_reads(which, s10_gpu, s10_oracle, s4546, built, colou
         tau = float(rng.choice([0.25, 0.3, 0.8, 1.0]))
         with stage(ix, colour_stage):
             got3 = (ix.fetch_color_set_ids_batch(b, o), ix.pseudoalign_full_intersection_batch(b, o), ix.pseudoalign_threshold_union_batch(b, o, tau))
-        want3 = (orc.fetch_color_set_ids(b, o, threads=32), orc.full_intersection(b, o, threads=32), orc.threshold_union(b, o, tau, threads=32))
+        want3 = oracle_once(("fuzz", which, rep), lambda: (orc.fetch_color_set_ids(b, o, threads=32), orc.full_intersection(b, o, threads=32),
+                                                          orc.threshold_union(b, o, tau, threads=32)))
         for got, want in zip(got3, want3):
             assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
 
@@ -1300,3 +1314,40 @@ def test_s4546_dense_rows_serve_every_codec(s4546, index_type, psize, csize):
         for (wo, wc), (go, gc) in zip(want, got):
             assert np.array_equal(wo, go) and np.array_equal(wc, gc), rows
     iy.close()
+
+
+def test_bench_two_ranks_on_the_synthetic_4546_colour_index():
+    """first contact of the multi-GPU bench (the driver's 8-GPU run) as far as one GPU can show it: `bench.py --gpus 2` on the
+    BASELINE workload itself — rank 0 builds the synthetic 4546-colour index (tens of seconds on a cold box) while rank 1 waits
+    for the marker file, both open it, every rank announces its device on stderr, the hit vector is all-reduced and checked"""
+    import json
+    import subprocess
+    env = dict(os.environ, FULGOR_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "FULGOR_S4546_DUMP"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "s4546syn", "--reads", "200000", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["collective_backend"] == "gloo" and line["scaling"] == "weak"
+    assert line["data"] == "synthetic" and "SYNTHETIC" in line["config"]["workload"] and line["config"]["reads_per_gpu"] == 200000
+    assert line["value"] > 0 and 0 < line["roofline"]["frac"] < 1
+    for rank in (0, 1):
+        assert "[bench] rank %d/2 on cuda:0" % rank in r.stderr
+
+
+def test_bench_on_a_real_dump_says_so(s4546small):
+    """FULGOR_S4546_DUMP: the bench line of an index ingested from `fulgor dump` files carries "data": "real-dump" and the dump's
+    name (here the dump is the small 4546-colour test index written by fgpu_dump)"""
+    import json
+    import subprocess
+    _, _, _, _, base = s4546small
+    env = dict(os.environ, FULGOR_S4546_DUMP=base)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "20000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-secondary"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["data"] == "real-dump" and os.path.basename(base) in line["config"]["workload"] and "REAL DUMP" in line["config"]["workload"]
+    assert line["config"]["reads_per_gpu"] == 20000 and line["value"] > 0 and line["config"]["mapped_fraction"] > 0.8
