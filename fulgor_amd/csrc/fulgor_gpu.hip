@@ -454,8 +454,8 @@ const uint32_t* stage_order(fgpu_index* ix, fgpu_result* res) {
     if (res->order_hist_sets < ns + 1) {  // (the scatter leaves the histogram all zero)
         res->d_order_hist.ensure((ns + 1) * 4 + 16);
         HIP_TRY(hipMemsetAsync(res->d_order_hist.p, 0, (ns + 1) * 4, s));
-        res->order_hist_sets = ns + 1;
     }
+    res->order_hist_sets = 0;  // dirty from k_order_keys on; known zero again once the scatter has been queued (a failure in between leaves it dirty: cleared on the next pass)
     uint64_t* totals = res->d_order_off.as<uint64_t>() + (ns + 2);  // scratch behind the offsets (keeps d_totals intact)
     Timed t(ix, res, FGPU_K_ORDER);
     const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)ix->num_cus * 8);  // (both kernels: the same slices)
@@ -466,6 +466,7 @@ const uint32_t* stage_order(fgpu_index* ix, fgpu_result* res) {
     hipLaunchKernelGGL(k_order_scatter, dim3(grid), dim3(256), 0, s, res->d_order_keys.as<uint32_t>(), (uint32_t)ns, n,
                        res->d_order_off.as<uint64_t>(), res->d_order_hist.as<uint32_t>(), res->d_order.as<uint32_t>());
     HIP_TRY(hipGetLastError());
+    res->order_hist_sets = ns + 1;
     return res->d_order.as<uint32_t>();
 }
 

@@ -796,7 +796,8 @@ __device__ __forceinline__ void rows_and(const u32x4* __restrict__ rows4, uint32
 }
 
 template <int G>
-__global__ __launch_bounds__(256, 8) void k2r_intersect(const u32x4* __restrict__ rows4, uint32_t W, const uint32_t* __restrict__ nids,
+__global__ __launch_bounds__(256, G == 1 ? 8 : (G == 2 ? 6 : 4)) void k2r_intersect(  // (G groups per lane: 8 waves per SIMD would spill from two groups on)
+const u32x4* __restrict__ rows4, uint32_t W, const uint32_t* __restrict__ nids,
                                                      const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
                                                      uint64_t n_reads, uint32_t* __restrict__ out_bitmap,
                                                      uint32_t* __restrict__ out_count, unsigned int* tickets,
@@ -1645,7 +1646,7 @@ __host__ __device__ __forceinline__ uint32_t k2b_group_words(uint32_t W, uint32_
 __device__ __forceinline__ uint32_t k2b_hist_addr(uint32_t group_at, uint32_t G, uint32_t e) {  // byte address; group_at = 8192 * group
     return group_at + __umul24(e & 3u, G) + (e & ~3u);
 }
-#ifndef FG_K2B_KO  // knock-out builds (profiles/k2b_knockout.sh): 1 = no hit-counter adds, 2 = no stage scatter stores; results are wrong, times and LDS counters are the point
+#ifndef FG_K2B_KO  // knock-out builds (profiles/k2b_knockout.sh): 1 = no hit-counter adds, 2 = no stage scatter stores, 3 = no colour stores of the bitmap rows; results are wrong, times and LDS counters are the point
 #define FG_K2B_KO 0
 #endif
 #define K2B_HIST_ADD(a, v) do { if (FG_K2B_KO != 1) lds_add((a), (v)); } while (0)
@@ -1777,11 +1778,7 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
                 const lds_u32* sp = lds32(k2b_stage_skew(v_wave + (i << 1)));
                 const uint32_t e01 = sp[0], e23 = sp[1];
                 const uint32_t e0 = e01 & 0xFFFFu, e1 = e01 >> 16, e2 = e23 & 0xFFFFu, e3 = e23 >> 16;
-#ifdef FG_K2B_NT
-                __builtin_nontemporal_store(u32x4{cbase + e0, cbase + e1, cbase + e2, cbase + e3}, (u32x4_a4*)(out + i));
-#else
-                *(u32x4_a4*)(out + i) = u32x4{cbase + e0, cbase + e1, cbase + e2, cbase + e3};
-#endif
+                if (FG_K2B_KO != 3 || e0 == 0x12345u) *(u32x4_a4*)(out + i) = u32x4{cbase + e0, cbase + e1, cbase + e2, cbase + e3};
                 if (hit_partial) {
                     K2B_HIST_ADD(k2b_hist_addr(hoff, hG, e0), hinc);
                     K2B_HIST_ADD(k2b_hist_addr(hoff, hG, e1), hinc);
@@ -1792,7 +1789,7 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
             if ((uint32_t)lane < total - full) {
                 const uint32_t i = full + lane;
                 const uint32_t e = *lds16(k2b_stage_skew(v_wave + (i << 1)));
-                out[i] = cbase + e;
+                if (FG_K2B_KO != 3 || e == 0x12345u) out[i] = cbase + e;
                 if (hit_partial) K2B_HIST_ADD(k2b_hist_addr(hoff, hG, e), hinc);
             }
             out += total;

@@ -780,7 +780,14 @@ public:
         threads_ = threads;
         if (is_gzip_file(path)) {
             if (is_bgzf_file(path)) {
-                src_.reset(new BgzfFastxSource(path, threads, begin, end));
+                // (a block-compressed FASTQ with wrapped lines cannot be cut into ranges: read whole, it falls back to the one-stream
+                // reader, which takes block-compressed files as any gzip reader does; parts of it stay an error)
+                try {
+                    src_.reset(new BgzfFastxSource(path, threads, begin, end));
+                } catch (const std::runtime_error& e) {
+                    if (begin != 0 || end != ~0ULL || std::string(e.what()).find("wrapped lines") == std::string::npos) throw;
+                    src_.reset(new StreamFastxSource(path));
+                }
             } else {
                 if (begin != 0 || end != ~0ULL) throw std::runtime_error("a gzip stream cannot be read in parts (a block-compressed one, as bgzip writes it, can)");
                 FastxSource* whole = getenv("FULGOR_GZIP_STREAM") ? nullptr : InflatedFastxSource::try_open(path, threads);

@@ -574,6 +574,28 @@ def test_wrapped_fastq_is_read_as_one_stream_and_leading_junk_does_not_change_th
     assert text_size(p) == (os.path.getsize(p), False)
     with pytest.raises(RuntimeError):
         count_reads(p, 1000, os.path.getsize(p), 2)
+    # the same text block-compressed (bgzip layout): read whole it falls back to the one-stream reader; parts stay an error
+    import struct, zlib
+    raw = open(p, "rb").read()[:6 << 20]
+    raw = raw[:raw.rfind(b"\n@w") + 1]
+    nb = raw.count(b"\n@w") + 1
+    pz = str(tmp_path / "wrapped.fq.gz")
+    with open(pz, "wb") as f:
+        for at in list(range(0, len(raw), 60000)) + [len(raw)]:
+            blk = raw[at:at + 60000]
+            co = zlib.compressobj(1, zlib.DEFLATED, -15)
+            cd = co.compress(blk) + co.flush()
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cd) + 25) + cd +
+                    struct.pack("<II", zlib.crc32(blk) & 0xFFFFFFFF, len(blk)))
+    gotz = []
+    rd = FastxReader(pz, copy=True, batch=20000, threads=4)
+    for bases, offs in rd:
+        b = bytes(bases)
+        gotz += [b[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+    rd.close()
+    assert len(gotz) == nb and gotz == seqs[:nb]
+    with pytest.raises(RuntimeError):
+        count_reads(pz, 1000, 3 << 20, 2)
     # (2) leading junk, then strict four-line records whose quality lines all begin with '>'
     small = [b"ACGT" * 30] * 3000
     for junk in (b"\n", b"\xef\xbb\xbf\n", b"# produced by some tool\n\n"):
