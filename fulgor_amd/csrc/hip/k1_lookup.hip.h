@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
         uint32_t queue[QCAP + 1];        // run descriptors (+ one: a lane also looks at the entry behind its own)
         uint32_t hid[HCAP];              // heads: colour-set id
         uint32_t hcnt[HCAP];             //        k-mers | read slot << 16 | place of the slot in the pass << 20
-        uint32_t hres[HCAP];             // heads sorted by (read, id): id  (long passes: total of the id within its read | FIRST, 0 for repeats)
-        uint32_t hsrt[HCAP];             //                             k-mers | tags
+        uint32_t hres[HCAP];             // passes of at most 64 heads: id per place; longer passes: total of the head's id within its read | FIRST, 0 for repeats
+        uint32_t hsrt[64];               // (passes of at most 64 heads) k-mers per place
         uint32_t meta[NSLOT][M_WORDS];
         uint32_t offs[2 * (TICKET + 1)];  // read offsets of the ticket
     };
@@ -208,9 +208,12 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
         // Reads are taken one by one: phases A and B put the runs of read j behind the queued ones; if they do not fit the
         // 64 lanes of a pass any more (or the ticket is over: j = t_count), the queued reads go through phases C and E first
         // and the new runs move to the front of the queue.
-        for (uint32_t j = 0; j <= t_count; ++j) {
+        for (uint32_t j = 0; j <= t_count;) {
             const uint32_t ws = (gs + ng) % (uint32_t)NSLOT;  // slot of read j
             uint32_t R = 0xFFFFu;
+            // Adversarial input (a homopolymer has one run per k-mer): the queue holds a unit's runs behind the waiting ones only up
+            // to QCAP. If they do not fit, the waiting units go through phases C and E first and this unit takes its turn again.
+            bool retry = false;
             if (j < t_count) {
                 const uint32_t o0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.offs[2 * j]);
                 const uint32_t cur_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.offs[2 * j + 2]) - o0;  // (reads are shorter than 4 GB)
@@ -267,6 +270,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                 }
 #if defined(FG_K1_STOP) && FG_K1_STOP == 1  // knock-out build (profiles/k1_phase_counts.sh): the kernel up to the end of phase A
                 if (lane == 0) { nids[t_first + j] = v[0] == 0x12345u; npos[t_first + j] = 0; idoff[t_first + j] = (t_first + j) * (uint64_t)stride; }
+                ++j;
                 continue;
 #endif
                 // ---- B: runs of k-mers sharing a minimizer occurrence, queued behind the runs that wait ----
@@ -283,26 +287,33 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                     H[a] = __ballot((uint32_t)(64 * a + lane) < nk && pos[a] != prev);
                     R += (uint32_t)__popcll(H[a]);
                 }
-                if (lane == 0) {
-                    uint32_t* M = meta[ws];
-                    M[M_UNIT] = j | (base << 8); M[M_QA] = q; M[M_QB] = q + R; M[M_NIDS] = 0; M[M_NPOS] = 0; M[M_HA] = 0; M[M_HB] = 0; M[M_KEND] = base + nk;
-                }
-                // (a run ends where the next one of the read begins, or with the read's last k-mer: phase C works its length out)
-                uint32_t before = q;
+                retry = ng > 0 && q + R > (uint32_t)QCAP;
+                if (retry) {
+                    R = 0xFFFFu;  // (nothing joins: the pass in preparation is processed as it is)
+                } else {
+                    if (lane == 0) {
+                        uint32_t* M = meta[ws];
+                        M[M_UNIT] = j | (base << 8); M[M_QA] = q; M[M_QB] = q + R; M[M_NIDS] = 0; M[M_NPOS] = 0; M[M_HA] = 0; M[M_HB] = 0; M[M_KEND] = base + nk;
+                    }
+                    // (a run ends where the next one of the read begins, or with the read's last k-mer: phase C works its length out)
+                    uint32_t before = q;
 #pragma unroll
-                for (int a = 0; a < NA - 1; ++a) {
-                    if ((H[a] >> lane) & 1ull) queue[before + mask_rank(H[a])] = run_pack(base + pos[a], pos[a] - (uint32_t)(64 * a + lane), ws);
-                    before += (uint32_t)__popcll(H[a]);
+                    for (int a = 0; a < NA - 1; ++a) {
+                        if ((H[a] >> lane) & 1ull) queue[before + mask_rank(H[a])] = run_pack(base + pos[a], pos[a] - (uint32_t)(64 * a + lane), ws);
+                        before += (uint32_t)__popcll(H[a]);
+                    }
+                    wave_lds_sync();
                 }
-                wave_lds_sync();
             }
 #if defined(FG_K1_STOP) && FG_K1_STOP == 2  // (knock-out build: up to the end of phase B)
             if (j < t_count && lane == 0) { nids[t_first + j] = R == 0x12345u; npos[t_first + j] = 0; idoff[t_first + j] = (t_first + j) * (uint64_t)stride; }
+            ++j;
             continue;
 #endif
             if (ng == 0 || (q + R <= K1_RUN_LANES && ng < (uint32_t)GROUP)) {  // the read joins the pass in preparation
                 q += R;
                 ++ng;
+                ++j;
                 continue;
             }
 
@@ -635,6 +646,11 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                 ++t1;
             }
             gs = (gs + ng) % (uint32_t)NSLOT;  // = ws: the slot of read j
+            if (retry) {  // phases A and B of the same unit again, in front of an empty queue
+                q = 0;
+                ng = 0;
+                continue;
+            }
             if (j < t_count) {  // the runs of read j move to the front of the queue
                 for (uint32_t c = 0; c < R; c += 64) {
                     const uint32_t x = c + lane < R ? queue[q + c + lane] : 0u;
@@ -645,6 +661,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                 q = R;
                 ng = 1;
             }
+            ++j;
         }
     }
 }

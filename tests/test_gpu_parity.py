@@ -1351,3 +1351,56 @@ def test_bench_on_a_real_dump_says_so(s4546small):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["data"] == "real-dump" and os.path.basename(base) in line["config"]["workload"] and "REAL DUMP" in line["config"]["workload"]
     assert line["config"]["reads_per_gpu"] == 20000 and line["value"] > 0 and line["config"]["mapped_fraction"] > 0.8
+
+
+def test_gpu_reads_with_one_run_per_kmer(built, tmp_path):
+    """a homopolymer read has as many minimizer runs as k-mers (all m-mers tie, the leftmost wins): consecutive such reads fill the
+    lookup kernel's run queue beyond what waits in it, and here they MATCH (the index holds the k-mer A^31), so the heads of the
+    pass in front are written while their runs wait. Mixed with ordinary reads, in one ticket and across tickets, 150 and 158 bases."""
+    from oracle.pyoracle import OracleIndex
+    rng = np.random.default_rng(31)
+    k, n = 31, 12
+    unitigs = [(0, "A" * k), (1, ("AC" * 16)[:k])]
+    for sid in range(2, 8):
+        unitigs.append((sid, "".join("ACGT"[c] for c in rng.integers(0, 4, size=220))))
+    sets = [np.array([0, 3, 7]), np.array([1, 2]), np.arange(n), np.array([5]), np.arange(0, n, 2), np.arange(3, 9), np.array([0, 11]), np.arange(1, n)]
+    base = str(tmp_path / "runs")
+    with open(base + ".metadata.txt", "w") as f:
+        f.write("k=%d\nnum_kmers=%d\nnum_colors=%d\nnum_unitigs=%d\nnum_color_sets=%d\n" %
+                (k, sum(len(u) - k + 1 for _, u in unitigs), n, len(unitigs), len(sets)))
+    with open(base + ".filenames.txt", "w") as f:
+        f.write("".join("g%d.fa\n" % i for i in range(n)))
+    with open(base + ".unitigs.fa", "w") as f:
+        for sid, seq in unitigs:
+            f.write("> color_set_id=%d\n%s\n" % (sid, seq))
+    with open(base + ".color_sets.txt", "w") as f:
+        for s_ in sets:
+            f.write("size=%d %s\n" % (len(s_), " ".join(map(str, s_))))
+    ix = fulgor_amd.Index(base, device=0)
+    orc = OracleIndex.from_dump(base)
+    long_u = [u for _, u in unitigs[2:]]
+    reads = []
+    for i in range(4000):
+        kind = i % 8
+        if kind in (0, 1, 2):
+            reads.append("A" * (150 if i % 3 else 158))
+        elif kind == 3:
+            reads.append("T" * 150)
+        elif kind == 4:
+            reads.append(("AC" * 80)[:150])
+        elif kind == 5:
+            u = long_u[int(rng.integers(len(long_u)))]
+            reads.append(u[int(rng.integers(0, 60)):][:150])
+        elif kind == 6:
+            reads.append("A" * 70 + long_u[0][:80])
+        else:
+            reads.append("C" * 150)
+    reads = [r.encode() for r in reads]
+    b, o = pack_reads(reads)
+    for got, want in ((ix.fetch_color_set_ids_batch(b, o), orc.fetch_color_set_ids(b, o, threads=8)),
+                      (ix.pseudoalign_full_intersection_batch(b, o), orc.full_intersection(b, o, threads=8)),
+                      (ix.pseudoalign_threshold_union_batch(b, o, 0.7), orc.threshold_union(b, o, 0.7, threads=8))):
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    sizes = np.diff(ix.pseudoalign_full_intersection_batch(b, o)[0].astype(np.int64))
+    assert sizes[0] == 3 and sizes[3] == 3 and sizes[4] == 2 and sizes[7] == 0  # A^150, T^150 -> {0, 3, 7}; (AC)^75 -> {1, 2}; C^150 -> nothing
+    ix.close()
