@@ -5,26 +5,29 @@
 // sshash::streaming_query::lookup_advanced behind them (call sites ps_full_intersection.cpp:341-352).
 //
 // The reference extends the previous hit along the unitig and looks a k-mer up from scratch only when that
-// fails. The SIMT counterpart of that idea works on whole minimizer runs instead of single k-mers:
-//   A  bases -> 2-bit planes by ballot; order of every m-mer; window minima by doubling: every k-mer knows the
-//      position of its minimizer (leftmost smallest m-mer).
+// fails. The SIMT counterpart of that idea works on whole minimizer runs instead of single k-mers. A wave pulls a TICKET of
+// consecutive units (reads; 32 of them for reads of up to 128 k-mers) and goes through
+//   T  the bases of the whole ticket — the units lie one behind the other in the base buffer — become bit planes in LDS at once:
+//      16 bases per lane and 16-byte load, the two code bits of four letters gathered with one multiplication (encode16); no
+//      ballots, one global-memory wait per ticket instead of one per read.
+//   A  per unit: order of every m-mer (a three-instruction multiplicative hash, cut out of the planes with one v_alignbit per
+//      plane), window minima in two rounds through LDS: every k-mer knows the position of its minimizer (leftmost smallest m-mer).
 //   B  consecutive k-mers with the same minimizer occurrence form a RUN (a super-k-mer of the read, 1..k-m+1
-//      k-mers, 18 per 150-base read on average). Runs are compacted into a queue, one entry each; the runs of
-//      several reads share the queue so that the next phase fills its 64 lanes.
-//   C  lane = run: hash of the canonical minimizer -> ONE 64-byte bucket of four self-contained records
-//      (common/kmer_common.h). The 2k-m read bases around the minimizer are compared with a record's context in
-//      one XOR; the k-mers of the run that match are those whose window is free of mismatches, an INTERVAL of
-//      window positions given by the highest mismatch below and the lowest mismatch above the core bases
+//      k-mers, 15.9 per 150-base read at m = 17). Runs are compacted into a queue, one entry each; the runs of
+//      several units share the queue so that the next phase fills its 64 lanes (3.4 reads per pass).
+//   C  lane = run: hash of the minimizer (as read: the dictionary holds both strands) -> ONE 64-byte bucket of four
+//      self-contained records (common/kmer_common.h). The 2k-m read bases around the minimizer are compared with a record's
+//      context in one XOR per plane; the k-mers of the run that match are those whose window is free of mismatches, an INTERVAL
+//      of window positions given by the highest mismatch below and the lowest mismatch above the core bases
 //      k-m..k-1. So a run costs one line fetch and a handful of integer operations per record whatever its number
-//      of k-mers, positive or negative; a non-ACGT base or the end of the read is just a mismatch. The dictionary
-//      holds both strands of every unitig, so the read is compared as it is: no canonical forms, no reverse
-//      complements, no strand cases.
-//      The few keys whose records live in the overflow region (a redirect slot in the home bucket) do not make the
-//      wave loop: their (run, overflow bucket) pairs are handed to the lanes the queue left free, which borrow the
-//      run's registers with ds_bpermute and go through the same comparison in the same pass.
+//      of k-mers, positive or negative; a non-ACGT base or the end of the read is just a mismatch: no canonical forms, no
+//      reverse complements, no strand cases.
+//      A bucket whose keys do not fit keeps a redirect in its last slot: the (run, overflow bucket) pairs behind it are handed to
+//      the lanes the queue left free, which borrow the run's registers with ds_bpermute and go through the same comparison in
+//      the same pass.
 //   E  every matching (run, record) pair is a "head" (colour-set id, number of k-mers), neighbouring runs with the
-//      same id are folded into one; the heads of a read are reduced to sorted distinct ids with summed
-//      multiplicities, several reads per pass.
+//      same id are folded into one; the place of an id in its read's sorted list is the number of heads of the read with a
+//      smaller id, heads with the same id meet at the same place, where an LDS add sums their k-mers; several reads per pass.
 // The kernel has no slow path; what would need one (strands, k-mers equal to their reverse complement) is settled by
 // the dictionary builder (host/dict_build.hpp).
 #pragma once

@@ -773,8 +773,8 @@ __global__ __launch_bounds__(256) void k_rows_build(DevColors c, uint64_t num_se
 // K2r: full intersection over dense rows -> bitmap + cardinality (or, for small results, the colours themselves).
 // Semantics of `intersect` (ps_full_intersection.cpp:32-127): the set intersection of the given lists. One wave per read,
 // lane = 128 bits of the colour space (G groups of them for more than 8192 colours); the rows of up to UNROLL lists are in
-// flight at once, the accumulator never leaves the registers, no LDS. The reads of a pass come in locality order
-// (k_order_*), so the rows a ticket touches are mostly in the L2 of its XCD already.
+// flight at once, the accumulator never leaves the registers, no LDS. Reads come in file order (the locality order of a pass,
+// k_order_*, is off by default: it cut the fetched bytes and bought no time).
 // AND of the rows of the first K of eight colour sets into acc: K x G unconditional 16-byte loads back to back, then the ANDs —
 // no control flow between the requests, so that all of them are in flight together. The ids are scalars: a row's address is a
 // scalar base plus the lane's offset.
