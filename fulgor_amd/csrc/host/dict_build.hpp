@@ -13,6 +13,7 @@
 // reverse complement (even k only) is kept on the unitig's strand only, so that it is found once.
 #pragma once
 #include <atomic>
+#include <cstdlib>
 #include <algorithm>
 #include <stdexcept>
 #include <thread>
@@ -69,7 +70,10 @@ inline uint64_t record_key(const uint32_t* w, uint32_t k, uint32_t m) {
 inline void build_dict_table(Dict& d) {
     const uint64_t nrec = d.num_records();
     if (nrec >= (1ULL << 31)) throw std::runtime_error("too many super-k-mer records");
-    d.num_buckets = (uint32_t)std::max<uint64_t>(16, nrec + nrec / 2 + nrec / 8);
+    // 1.625 buckets per record (0.6 records per bucket); FULGOR_DICT_BUCKET_FACTOR overrides it (measurements: the table is rebuilt at every open)
+    double factor = 1.625;
+    if (const char* e = getenv("FULGOR_DICT_BUCKET_FACTOR")) { const double v = atof(e); if (v >= 1.0 && v <= 16.0) factor = v; }
+    d.num_buckets = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>((uint64_t)((double)nrec * factor), DICT_MAX_BUCKETS - DICT_TAIL_BUCKETS - nrec / 4 - 4096));
     const uint64_t nb_hashed = (uint64_t)d.num_buckets + DICT_TAIL_BUCKETS;
     struct Ref { uint32_t home; uint32_t rec; uint64_t key; };
     // The table is rebuilt from the records whenever an index is opened: the sort of the records by (home bucket, key) is
