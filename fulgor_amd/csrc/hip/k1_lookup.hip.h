@@ -143,7 +143,6 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
         uint32_t hres[HCAP];             // passes of at most 64 heads: id per place; longer passes: total of the head's id within its read | FIRST, 0 for repeats
         uint32_t hsrt[64];               // (passes of at most 64 heads) k-mers per place
         uint32_t meta[NSLOT][M_WORDS];
-        uint32_t offs[2 * (TICKET + 1)];  // read offsets of the ticket
     };
     __shared__ WaveLds s_lds[4];
     const int lane = lane_id();
@@ -168,19 +167,21 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
 
     uint32_t gs = 0;  // first read slot of the current pass (ring index)
     while (wq.pull(t_first, t_count)) {
-        if ((uint32_t)lane <= t_count) {
-            const uint64_t x = offs[first + t_first + lane];
-            L.offs[2 * lane] = (uint32_t)x;
-            L.offs[2 * lane + 1] = (uint32_t)(x >> 32);
+        // the ticket's unit offsets stay in the lanes (lane i: offset of unit i; the low words are enough inside a ticket): a unit's
+        // offset is one v_readlane away, not an LDS round trip
+        uint32_t off_lo, off_hi;
+        {
+            const uint64_t x = offs[first + t_first + min((uint32_t)lane, t_count)];
+            off_lo = (uint32_t)x;
+            off_hi = (uint32_t)(x >> 32);
         }
-        wave_lds_sync();
         // ---- the bases of the ticket -> bit planes (every lane 16 bases per round; two lanes make a plane word) ----
-        const uint32_t sb_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.offs[0]) & ~15u;  // the span begins at the 16-byte boundary in front of the first unit
-        const uint32_t sb_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.offs[1]);
+        const uint32_t sb_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)off_lo) & ~15u;  // the span begins at the 16-byte boundary in front of the first unit
+        const uint32_t sb_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)off_hi);
         {
             const uint64_t sb = ((uint64_t)sb_hi << 32) | sb_lo;
-            const uint64_t se = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)L.offs[2 * t_count + 1]) << 32) |
-                                (uint32_t)__builtin_amdgcn_readfirstlane((int)L.offs[2 * t_count]);
+            const uint64_t se = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)off_hi, (int)t_count) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)off_lo, (int)t_count);
             const uint32_t nchunks = min((uint32_t)((se - sb + 15u) >> 4), (uint32_t)NIT * 64u);  // (units are at most KMAX + 30 bases long)
             const u32x4* src = (const u32x4*)(bases + sb);
             u32x4 x[NIT];
@@ -218,8 +219,8 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
             // to QCAP. If they do not fit, the waiting units go through phases C and E first and this unit takes its turn again.
             bool retry = false;
             if (j < t_count) {
-                const uint32_t o0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.offs[2 * j]);
-                const uint32_t cur_len = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.offs[2 * j + 2]) - o0;  // (reads are shorter than 4 GB)
+                const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)off_lo, (int)j);
+                const uint32_t cur_len = (uint32_t)__builtin_amdgcn_readlane((int)off_lo, (int)j + 1) - o0;  // (reads are shorter than 4 GB)
                 // span position of the unit's first base (bit 32 of the planes is the span's first base: one pad word in front;
                 // the difference of the low words is the difference: a span is far shorter than 4 GB)
                 const uint32_t base = o0 - sb_lo + 32u;
