@@ -75,6 +75,21 @@ def c256_dump(built):
 
 
 @pytest.fixture(scope="session")
+def s4546small_dump(built):
+    """the small synthetic 4546-colour index (seeded, rebuilt identically everywhere) as the reference's dump files, written by
+    fgpu_dump on a host-only handle; returns (path of the .fgidx, basename of the dump)"""
+    import fulgor_amd
+    from fulgor_amd import synth
+    fg, _ = synth.ensure_s4546_small(DATA, S10_GENOMES)
+    base = os.path.join(DATA, "s4546small_dump")
+    if not os.path.exists(base + ".unitigs.fa"):
+        ix = fulgor_amd.Index(fg, device=-1)
+        ix.dump(base)
+        ix.close()
+    return fg, base
+
+
+@pytest.fixture(scope="session")
 def c256_oracle(built, c256_dump):
     from oracle.pyoracle import OracleIndex
     return OracleIndex.from_dump(c256_dump)
@@ -86,8 +101,9 @@ def load_golden_reads(name="s10_reads.fa"):
 
 
 def load_golden_tsv(name):
+    import gzip
     out = []
-    with open(os.path.join(GOLDEN, name)) as f:
+    with (gzip.open if name.endswith(".gz") else open)(os.path.join(GOLDEN, name), "rt") as f:
         for line in f:
             t = line.rstrip("\n").split("\t")
             assert int(t[0]) == len(out)

@@ -1404,3 +1404,19 @@ def test_gpu_reads_with_one_run_per_kmer(built, tmp_path):
     sizes = np.diff(ix.pseudoalign_full_intersection_batch(b, o)[0].astype(np.int64))
     assert sizes[0] == 3 and sizes[3] == 3 and sizes[4] == 2 and sizes[7] == 0  # A^150, T^150 -> {0, 3, 7}; (AC)^75 -> {1, 2}; C^150 -> nothing
     ix.close()
+
+
+@pytest.mark.parametrize("index_type,psize,csize", [(fulgor_amd.HYBRID, 0, 0), (fulgor_amd.DIFF, 4546, 16), (fulgor_amd.META, 160, 1), (fulgor_amd.META_DIFF, 160, 16)])
+def test_gpu_matches_golden_at_4546_colours(s4546small, colour_stage, index_type, psize, csize):
+    """golden vectors AT 4546 COLOURS from the dump-level first-principles oracle (oracle/dump_oracle.py: python sets over the
+    dump text, nothing of the restatement): lookup, both algorithms, every codec, on the dense rows and on the codec's own kernels"""
+    ix, _, _, fg, _ = s4546small
+    if index_type != fulgor_amd.HYBRID:
+        ix = fulgor_amd.Index(fg, device=0).convert(index_type, psize, csize)
+    b, o = pack_reads(load_golden_reads("s4546small_reads.fa"))
+    with stage(ix, colour_stage):
+        fi = ix.pseudoalign_full_intersection_batch(b, o)
+        tu = {tau: ix.pseudoalign_threshold_union_batch(b, o, tau) for tau in (0.8, 0.3)}
+    assert csr_to_lists(*fi) == load_golden_tsv("s4546small_full_intersection.tsv.gz")
+    for tau in (0.8, 0.3):
+        assert csr_to_lists(*tu[tau]) == load_golden_tsv("s4546small_threshold_union_%s.tsv.gz" % tau)

@@ -97,3 +97,21 @@ def test_oracle_matches_golden_at_256_colours(c256_dump, index_type, psize, csiz
     for tau in (0.8, 0.3):
         offs, cols = orc.threshold_union(b, o, tau, threads=4, self_check=index_type == 0)
         assert csr_to_lists(offs, cols) == load_golden_tsv("c256_threshold_union_%s.tsv" % tau)
+
+
+@pytest.mark.parametrize("index_type,psize,csize", [(0, 0, 0), (1, 4546, 16), (2, 160, 1), (3, 160, 16)])
+def test_oracle_matches_golden_at_4546_colours(s4546small_dump, index_type, psize, csize):
+    """golden vectors AT 4546 COLOURS, computed by oracle/dump_oracle.py straight from the dump text (colour set of a k-mer = colour
+    set of its unitig; python sets and numpy, nothing of the restatement): the restatement — built from the same dump files, with
+    its own encoder, cursors, `intersect` and `merge` — must reproduce them (tests/golden/make_golden_s4546small.py)"""
+    from oracle.pyoracle import OracleIndex
+    _, base = s4546small_dump
+    orc = OracleIndex.from_dump(base)
+    if index_type:
+        orc.convert(index_type, psize, csize)  # the restated differential / meta / meta-differential cursors and merges
+    b, o = pack_reads(load_golden_reads("s4546small_reads.fa"))
+    offs, cols = orc.full_intersection(b, o, threads=8)
+    assert csr_to_lists(offs, cols) == load_golden_tsv("s4546small_full_intersection.tsv.gz")
+    for tau in (0.8, 0.3):
+        offs, cols = orc.threshold_union(b, o, tau, threads=8)
+        assert csr_to_lists(offs, cols) == load_golden_tsv("s4546small_threshold_union_%s.tsv.gz" % tau)
