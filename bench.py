@@ -135,12 +135,12 @@ class Workload:
         self.ix.close()
 
 
-def measure(w, algo, tau, chunk, steps, warmup, streams, local_rank, world=1, dist=None, share=False):
+def measure(w, algo, tau, chunk, steps, warmup, streams, local_rank, world=1, dist=None, share=False, pipeline=False):
     """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; returns the numbers of a bench line"""
     import fulgor_amd
     import torch
     ix = w.ix
-    results = [ix.new_result() for _ in range(max(1, streams))]
+    results = [ix.new_result() for _ in range(2 if pipeline else max(1, streams))]
     hits = torch.zeros(w.ncol + 2, dtype=torch.int64, device="cuda:%d" % local_rank)
     chunks = [(first, min(chunk, w.n_reads - first)) for first in range(0, w.n_reads, chunk)]
 
@@ -148,6 +148,38 @@ def measure(w, algo, tau, chunk, steps, warmup, streams, local_rank, world=1, di
         for i in range(k, len(chunks), len(results)):
             ix.run(w.reads, results[k], algo, tau, chunks[i][0], chunks[i][1])
             results[k].accumulate_hits(hits.data_ptr())
+
+    def reduce_hits():
+        if world > 1:  # RCCL: per-colour hit counts + {reads, mapped}
+            if share:
+                h_cpu = hits.cpu()
+                dist.all_reduce(h_cpu)
+                hits.copy_(h_cpu)
+            else:
+                dist.all_reduce(hits)
+
+    def run_steps(k):
+        """k steps. pipeline: the passes of all k steps form one sequence, the lookup of pass t + 1 is queued before the colour
+        stage of pass t is waited for (two results in flight; with FULGOR_CU_SPLIT on disjoint parts of the device)"""
+        if not pipeline:
+            for _ in range(k):
+                step()
+            return
+        seq = [(s_, i) for s_ in range(k) for i in range(len(chunks))]
+        torch.cuda.synchronize()
+        if seq:
+            ix.run_lookup(w.reads, results[0], chunks[0][0], chunks[0][1])
+        for t, (s_, i) in enumerate(seq):
+            if t + 1 < len(seq):
+                nf, nc = chunks[seq[t + 1][1]]
+                ix.run_lookup(w.reads, results[(t + 1) & 1], nf, nc)
+            ix.run_colours(results[t & 1], algo, tau)
+            if i == 0:
+                hits.zero_()
+                torch.cuda.current_stream().synchronize()
+            results[t & 1].accumulate_hits(hits.data_ptr())
+            if i == len(chunks) - 1:
+                reduce_hits()
 
     def step():
         hits.zero_()
@@ -169,8 +201,7 @@ def measure(w, algo, tau, chunk, steps, warmup, streams, local_rank, world=1, di
             else:
                 dist.all_reduce(hits)
 
-    for _ in range(warmup):
-        step()
+    run_steps(warmup)
     ix.timing_enable(True)
     ix.timing_reset()
     torch.cuda.synchronize()
@@ -178,8 +209,7 @@ def measure(w, algo, tau, chunk, steps, warmup, streams, local_rank, world=1, di
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    run_steps(steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -271,6 +301,9 @@ def main():
     ap.add_argument("--cluster-size", type=int, default=16)
     ap.add_argument("--streams", type=int, default=1,
                     help="passes in flight per GPU: chunk i runs on stream i %% streams (own result buffers, own host thread)")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="1: two results in flight, the lookup of pass t + 1 queued before the colour stage of pass t is waited for "
+                         "(fgpu_run_lookup / fgpu_run_colours; FULGOR_CU_SPLIT=<n> puts the two on disjoint CUs)")
     ap.add_argument("--read-len", type=int, default=150, help="read length in bases (the metric is quoted on 150)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the PCIe / command-line legs")
     ap.add_argument("--no-secondary", action="store_true",
@@ -344,7 +377,7 @@ def main():
                   small_results=None if args.small is None else bool(args.small),
                   dense_rows=None if args.rows is None else bool(args.rows))
     algo = fulgor_amd.FULL_INTERSECTION if args.algo == "full-intersection" else fulgor_amd.THRESHOLD_UNION
-    m = measure(w, algo, args.tau, args.chunk, args.steps, args.warmup, args.streams, local_rank, world, dist, share)
+    m = measure(w, algo, args.tau, args.chunk, args.steps, args.warmup, args.streams, local_rank, world, dist, share, pipeline=bool(args.pipeline))
 
     if rank == 0:
         traffic, traffic_src = load_traffic(args.workload, w.itype, args.algo, args.chunk, n_reads)

@@ -63,6 +63,8 @@ def lib():
     L.fgpu_result_free.argtypes = [vp]
     L.fgpu_result_free.restype = None
     L.fgpu_run.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_double, vp]
+    L.fgpu_run_lookup.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp]
+    L.fgpu_run_colours.argtypes = [vp, C.c_int, C.c_double, vp]
     L.fgpu_result_sizes.argtypes = [vp, u64p, u64p, u64p]
     L.fgpu_result_download.argtypes = [vp, vp, vp]
     L.fgpu_result_accumulate_hits.argtypes = [vp, vp, vp]

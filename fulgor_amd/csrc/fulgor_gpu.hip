@@ -133,7 +133,7 @@ struct Timed {
     std::vector<fgpu_index::Pending>* sink;
     hipEvent_t a = nullptr, b = nullptr;
     bool on = false;  // (kernel < 0: a launch inside another bracket)
-    Timed(fgpu_index* i, fgpu_result* r, int k);
+    Timed(fgpu_index* i, fgpu_result* r, int k, bool lookup = false);
     ~Timed() {
         if (on) { (void)hipEventRecord(b, stream); sink->push_back({kernel, a, b}); }
     }
@@ -159,6 +159,11 @@ constexpr uint32_t SEG_KMERS = 512;  // what the 4-window lookup kernel takes as
 struct fgpu_result {
     fgpu_index* ix = nullptr;
     hipStream_t stream = nullptr;                 // every result owns a stream: passes on different results overlap
+    // CU partition (FULGOR_CU_SPLIT, fgpu_run_lookup / fgpu_run_colours): the lookup kernel of a pass runs on its own stream, bound to
+    // one part of the CUs, the colour kernels on `stream`, bound to the others; ev_lookup orders the two. Without a partition both
+    // are the same stream.
+    hipStream_t stream_lookup = nullptr;
+    hipEvent_t ev_lookup = nullptr;
     std::vector<fgpu_index::Pending> pending;     // timing events recorded on that stream
     DevBuf d_nids, d_npos, d_idoff, d_ids_pool, d_cnt_pool, d_cursor, d_bitmap, d_counts, d_offsets, d_block_sums,
         d_block_mapped, d_totals, d_colors, d_acct, d_partial, d_tickets, d_idcsr, d_desc, d_kmer_ids, d_scores;
@@ -182,7 +187,7 @@ struct fgpu_result {
     bool have_ids = false;
 };
 
-Timed::Timed(fgpu_index* i, fgpu_result* r, int k) : ix(i), kernel(k), stream(r->stream), sink(&r->pending) {
+Timed::Timed(fgpu_index* i, fgpu_result* r, int k, bool lookup) : ix(i), kernel(k), stream(lookup ? r->stream_lookup : r->stream), sink(&r->pending) {
     on = ix->timing && k >= 0;
     if (on) { a = ix->get_event(); b = ix->get_event(); HIP_TRY(hipEventRecord(a, stream)); }
 }
@@ -316,8 +321,8 @@ uint32_t resident_grid(K kernel, uint64_t units, uint32_t per_block, int num_cus
     return (uint32_t)std::max<uint64_t>(1, std::min(need, cap));
 }
 
-void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t count, fgpu_result* res) {
-    hipStream_t s = res->stream;
+void stage_lookup_on(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t count, fgpu_result* res) {
+    hipStream_t s = res->stream_lookup;
     res->total_kmers = rd->cum_kmers[first + count] - rd->cum_kmers[first];
     res->total_bases = rd->h_offs[first + count] - rd->h_offs[first];
     // units = reads, or segments when the batch holds reads longer than SEG_KMERS k-mers
@@ -349,7 +354,7 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     {
         auto launch_short = [&](auto kernel) {
             const uint32_t grid = resident_grid(kernel, units, 4, ix->num_cus, 256, 0);
-            Timed t(ix, res, FGPU_K_LOOKUP);
+            Timed t(ix, res, FGPU_K_LOOKUP, true);
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, ix->dd, rd->d_bases.as<uint8_t>(),
                                seg ? rd->d_seg_offs.as<uint64_t>() : rd->d_offs.as<uint64_t>(), seg ? u_first : first, units,
                                res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(), res->d_idoff.as<uint64_t>(),
@@ -381,7 +386,7 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     res->d_ids_pool2.ensure(units * (uint64_t)stride * 4 + 64);
     res->d_cnt_pool2.ensure(units * (uint64_t)stride * 4 + 64);
     {
-        Timed t(ix, res, FGPU_K_LOOKUP);
+        Timed t(ix, res, FGPU_K_LOOKUP, true);
         const uint32_t mgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((count + 3) / 4, (uint64_t)ix->num_cus * 8));
         hipLaunchKernelGGL(k_merge_segments, dim3(mgrid), dim3(256), 0, s, res->d_nids.as<uint32_t>(), res->d_npos.as<uint32_t>(),
                            res->d_ids_pool.as<uint32_t>(), res->d_cnt_pool.as<uint32_t>(), stride, rd->d_seg_first.as<uint64_t>(),
@@ -394,6 +399,15 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
     std::swap(res->d_idoff, res->d_idoff2);
     std::swap(res->d_ids_pool, res->d_ids_pool2);
     std::swap(res->d_cnt_pool, res->d_cnt_pool2);
+}
+
+// the lookup of a pass, queued on the result's lookup stream; what follows on the result's main stream waits for it
+void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t count, fgpu_result* res) {
+    stage_lookup_on(ix, rd, first, count, res);
+    if (res->stream_lookup != res->stream) {
+        HIP_TRY(hipEventRecord(res->ev_lookup, res->stream_lookup));
+        HIP_TRY(hipStreamWaitEvent(res->stream, res->ev_lookup, 0));
+    }
 }
 
 // exclusive scan of n u32 sizes into n+1 u64 offsets; totals -> d_totals {sum, #nonzero}
@@ -886,7 +900,27 @@ int fgpu_result_create(fgpu_index* ix, fgpu_result** out) {
     int rc = guarded([&] {
         HIP_TRY(hipSetDevice(ix->device));
         HIP_TRY(hipHostMalloc((void**)&r->h_totals, 32));
-        HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+        // FULGOR_CU_SPLIT=<n>: CUs [0, n) of the device's CU mask serve the lookup streams, the others the colour streams (a pass's
+        // lookup then overlaps another pass's colour stage without the two kernels sharing a CU: fgpu_run_lookup / fgpu_run_colours).
+        // FULGOR_CU_RANGE=<lo>:<hi> binds both to CUs [lo, hi) (scaling measurements).
+        const uint64_t split = env_u64("FULGOR_CU_SPLIT", 0);
+        const char* range = getenv("FULGOR_CU_RANGE");
+        auto masked = [&](hipStream_t* st, uint32_t lo, uint32_t hi) {
+            std::vector<uint32_t> mask((ix->num_cus + 31) / 32, 0u);
+            for (uint32_t c = lo; c < hi && c < (uint32_t)ix->num_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
+            HIP_TRY(hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()));
+        };
+        if (split > 0 && split < (uint64_t)ix->num_cus) {
+            masked(&r->stream_lookup, 0, (uint32_t)split);
+            masked(&r->stream, (uint32_t)split, (uint32_t)ix->num_cus);
+            HIP_TRY(hipEventCreateWithFlags(&r->ev_lookup, hipEventDisableTiming));
+        } else if (range && strchr(range, ':')) {
+            masked(&r->stream, (uint32_t)atoi(range), (uint32_t)atoi(strchr(range, ':') + 1));
+            r->stream_lookup = r->stream;
+        } else {
+            HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+            r->stream_lookup = r->stream;
+        }
         r->d_totals.ensure(32);
     });
     if (rc) { delete r; return rc; }
@@ -904,6 +938,8 @@ void fgpu_result_free(fgpu_result* r) {
         b->release();
     if (r->h_totals) (void)hipHostFree(r->h_totals);
     if (r->h_fmt) (void)hipHostFree(r->h_fmt);
+    if (r->stream_lookup && r->stream_lookup != r->stream) (void)hipStreamDestroy(r->stream_lookup);
+    if (r->ev_lookup) (void)hipEventDestroy(r->ev_lookup);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     for (auto& p : r->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     delete r;
@@ -917,6 +953,27 @@ int fgpu_run(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t coun
     return guarded([&] {
         HIP_TRY(hipSetDevice(ix->device));
         stage_lookup(ix, rd, first, count, res);
+        stage_descriptors(ix, res, res->total_kmers, algo);
+        stage_colors(ix, algo, tau, res);
+    });
+}
+
+int fgpu_run_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t count, fgpu_result* res) {
+    if (!ix || !rd || !res) return fail(-EINVAL, "null argument");
+    if (first > rd->n || count > rd->n - first) return fail(-EINVAL, "read range out of bounds");
+    return guarded([&] {
+        HIP_TRY(hipSetDevice(ix->device));
+        stage_lookup(ix, rd, first, count, res);  // queued, not waited for
+    });
+}
+
+int fgpu_run_colours(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
+    if (!ix || !res) return fail(-EINVAL, "null argument");
+    if (!res->have_ids) return fail(-EINVAL, "fgpu_run_colours: no lookup has been run on this result");
+    if (algo == FGPU_THRESHOLD_UNION && !(tau > 0.0 && tau <= 1.0))
+        return fail(-EINVAL, "threshold must be a float in (0.0,1.0]");  // tools/pseudoalign.cpp:275-278
+    return guarded([&] {
+        HIP_TRY(hipSetDevice(ix->device));
         stage_descriptors(ix, res, res->total_kmers, algo);
         stage_colors(ix, algo, tau, res);
     });

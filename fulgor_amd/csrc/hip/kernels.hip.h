@@ -1646,10 +1646,16 @@ __host__ __device__ __forceinline__ uint32_t k2b_group_words(uint32_t W, uint32_
 __device__ __forceinline__ uint32_t k2b_hist_addr(uint32_t group_at, uint32_t G, uint32_t e) {  // byte address; group_at = 8192 * group
     return group_at + __umul24(e & 3u, G) + (e & ~3u);
 }
+#ifndef FG_K2B_COPY_STEPS
+#define FG_K2B_COPY_STEPS 2
+#endif
+constexpr uint32_t K2B_COPY_STEPS = FG_K2B_COPY_STEPS;  // copy-out steps whose stage reads are in flight together (1 / 2 / 4: 6.04 / 5.97 / 5.81 ms on one box; 4 needs 70 VGPRs without the small-result rewrite)
 #ifndef FG_K2B_KO  // knock-out builds (profiles/k2b_knockout.sh): 1 = no hit-counter adds, 2 = no stage scatter stores, 3 = no colour stores of the bitmap rows; results are wrong, times and LDS counters are the point
 #define FG_K2B_KO 0
 #endif
 #define K2B_HIST_ADD(a, v) do { if (FG_K2B_KO != 1) lds_add((a), (v)); } while (0)
+// (no waves-per-SIMD hint: with __launch_bounds__(K2B_THREADS, 8) the compiler schedules for registers and the same source runs at 6.8 instead
+// of 6.1 ms; without it the kernel happens to need 64 VGPRs and no scratch: 8 waves per SIMD)
 __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
                                                   const uint64_t* __restrict__ out_off, uint64_t n_reads, uint32_t W,
                                                   uint32_t* __restrict__ colors, unsigned int* tickets,
@@ -1697,50 +1703,56 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
     };
     while (may_pull() && wq.pull(t_first, t_count)) {
     const uint64_t rl = t_first + min((uint32_t)lane, t_count - 1);
-    const uint32_t cnt_l = (uint32_t)lane < t_count ? counts[rl] : 0u;
-    const uint64_t off_l = out_off[rl];
-    uint64_t lg = __ballot(cnt_l != 0u);  // the reads whose result comes as a bitmap row
+    const uint32_t cnt_raw = counts[rl];  // (both loads unconditional and in one block: one latency, not two)
+    const uint64_t off_raw = out_off[rl];
+    const uint32_t cnt_l = (uint32_t)lane < t_count ? cnt_raw : 0u;
+    // a ticket is one contiguous piece of the CSR: read j of it begins at P0 + (colours of the ticket's reads in front of it)
+    const uint64_t P0 = readlane_u64(off_raw, 0);
+    const uint32_t excl_l = wave_incl_scan_u32(cnt_l) - cnt_l;
+    uint64_t lg = __ballot(cnt_l != 0u), sm = 0;  // the reads whose result comes as a bitmap row; as colours
+    bool is_small = false;
     if (small) {
-        // results of at most SMALL_RESULT colours arrive as colours (k2a_intersect): four reads per step, lane = (read, slot)
-        const bool is_small = cnt_l != 0u && cnt_l <= SMALL_RESULT;
-        const uint64_t sm = __ballot(is_small);
+        is_small = cnt_l != 0u && cnt_l <= SMALL_RESULT;
+        sm = __ballot(is_small);
         lg = __ballot(cnt_l > SMALL_RESULT);
-        if (sm) {
-            if (is_small) *lds16(k2b_stage_skew(v_wave + (mask_rank(sm) << 1))) = (uint16_t)lane;  // k-th small read of the ticket
-            wave_lds_sync();
-            const uint32_t nsm = (uint32_t)__popcll(sm);
-            // all the loads of the ticket first (at most 32 small reads = 8 steps), then the stores: one latency per ticket
-            uint32_t v[8];
-            uint64_t dst[8];
-#pragma unroll
-            for (uint32_t g = 0; g < 8; ++g) {
-                dst[g] = ~0ull;
-                if (4 * g < nsm) {  // (wave-uniform)
-                    const uint32_t kk = 4 * g + ((uint32_t)lane >> 4), slot = (uint32_t)lane & 15u;
-                    const uint32_t j = kk < nsm ? (uint32_t)*lds16(k2b_stage_skew(v_wave + (kk << 1))) : 0u;
-                    const uint32_t cj = (uint32_t)__shfl((int)cnt_l, (int)j);
-                    const uint64_t oj = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(off_l >> 32), (int)j) << 32) |
-                                        (uint32_t)__shfl((int)(uint32_t)off_l, (int)j);
-                    if (kk < nsm && slot < cj) {
-                        v[g] = __builtin_nontemporal_load(&small[(t_first + j) * SMALL_RESULT + slot]);
-                        dst[g] = oj + slot;
-                    }
-                }
-            }
-#pragma unroll
-            for (uint32_t g = 0; g < 8; ++g) {
-                if (4 * g < nsm && dst[g] != ~0ull) {
-                    const uint32_t c = v[g];
-                    colors[dst[g]] = c;
-                    // the colour's hit counter: round c >> 11 (low / high half of the word by its parity), entry c & 2047
-                    if (hit_partial) K2B_HIST_ADD(k2b_hist_addr((c >> 12) * 8192u, k2b_group_words(W, c >> 12), c & 2047u), (c & 2048u) ? 0x10000u : 1u);
-                }
-            }
-            wave_lds_sync();
-        }
     }
     uint32_t cur[3], nxt[3] = {0u, 0u, 0u};
-    if (lg) fetch3(t_first + (uint32_t)__builtin_ctzll(lg), nxt);
+    if (lg) fetch3(t_first + (uint32_t)__builtin_ctzll(lg), nxt);  // (in flight across the small results)
+    if (sm) {
+        // Results of at most SMALL_RESULT colours arrive as colours (k2r_intersect / k2a_intersect): lane = (read, slot), four reads per
+        // step. The k-th small read of the ticket leaves two words in LDS {colours | read << 5, offset in the ticket}; then ALL the loads of
+        // the ticket (at most 32 small reads = 8 steps; unconditional, in one block: a step past the last small read loads the
+        // last one's slot again), ONE wait, and the stores behind it: a wait between two stores would be a wait for the store.
+        if (is_small) {
+            lds_u32* e = lds32(k2b_stage_skew(v_wave + (mask_rank(sm) << 3)));
+            e[0] = cnt_l | ((uint32_t)lane << 5);
+            e[1] = excl_l;
+        }
+        wave_lds_sync();
+        const uint32_t nsm = (uint32_t)__popcll(sm), slot = (uint32_t)lane & 15u;
+        uint32_t info[8], at[8], v[8];
+#pragma unroll
+        for (uint32_t g = 0; g < 8; ++g) {
+            const lds_u32* e = lds32(k2b_stage_skew(v_wave + (min(4 * g + ((uint32_t)lane >> 4), nsm - 1) << 3)));
+            info[g] = e[0];
+            at[g] = e[1];
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (uint32_t g = 0; g < 8; ++g) v[g] = __builtin_nontemporal_load(&small[(t_first + (info[g] >> 5)) * SMALL_RESULT + slot]);
+        // (the values pass through the statement: the compiler waits for the loads here and knows of no load behind it)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]));
+#pragma unroll
+        for (uint32_t g = 0; g < 8; ++g) {
+            if (4 * g + ((uint32_t)lane >> 4) < nsm && slot < (info[g] & 31u)) {
+                const uint32_t c = v[g];
+                colors[P0 + at[g] + slot] = c;
+                // the colour's hit counter: round c >> 11 (low / high half of the word by its parity), entry c & 2047
+                if (hit_partial) K2B_HIST_ADD(k2b_hist_addr((c >> 12) * 8192u, k2b_group_words(W, c >> 12), c & 2047u), (c & 2048u) ? 0x10000u : 1u);
+            }
+        }
+        wave_lds_sync();
+    }
     while (lg) {
         const uint32_t j = (uint32_t)__builtin_ctzll(lg);
         lg &= lg - 1;
@@ -1748,7 +1760,7 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
 #pragma unroll
         for (uint32_t q = 0; q < 3; ++q) cur[q] = nxt[q];
         if (lg) fetch3(t_first + (uint32_t)__builtin_ctzll(lg), nxt);
-        uint32_t* out = colors + readlane_u64(off_l, j);
+        uint32_t* out = colors + P0 + (uint32_t)__builtin_amdgcn_readlane((int)excl_l, (int)j);
         const uint32_t* bm = bitmap + r * W;
         // one round = 64 words. The first three rounds have their words in registers and contain no loads: a load would make
         // the wave wait for ALL its outstanding memory operations (one in-order counter), i.e. for the stores of the round
@@ -1774,16 +1786,37 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
             // copy-out: every lane takes 4 consecutive slots (two LDS words) and stores 4 colours at once; the last
             // total % 4 slots (all of them in a round of at most 64) go out one per lane
             const uint32_t full = total <= 64 ? 0u : total & ~3u;  // short rounds: one slot per lane, one pass
-            for (uint32_t i = (uint32_t)lane * 4; i < full; i += 256) {
-                const lds_u32* sp = lds32(k2b_stage_skew(v_wave + (i << 1)));
-                const uint32_t e01 = sp[0], e23 = sp[1];
-                const uint32_t e0 = e01 & 0xFFFFu, e1 = e01 >> 16, e2 = e23 & 0xFFFFu, e3 = e23 >> 16;
-                if (FG_K2B_KO != 3 || e0 == 0x12345u) *(u32x4_a4*)(out + i) = u32x4{cbase + e0, cbase + e1, cbase + e2, cbase + e3};
+            // (K2B_COPY_STEPS steps of 256 slots at a time: their stage reads are requested together, one LDS latency per group, and the
+            // counter adds — which the next stage read would wait for as well — come behind all of them)
+            for (uint32_t i0 = (uint32_t)lane * 4; i0 < full; i0 += 256 * K2B_COPY_STEPS) {
+                uint32_t e01[K2B_COPY_STEPS], e23[K2B_COPY_STEPS];
+#pragma unroll
+                for (uint32_t u = 0; u < K2B_COPY_STEPS; ++u) {
+                    const uint32_t i = i0 + 256 * u;
+                    const lds_u32* sp = lds32(k2b_stage_skew(v_wave + (min(i, 2044u) << 1)));  // (unconditional: a step past `full` reads what it does not use)
+                    e01[u] = sp[0];
+                    e23[u] = sp[1];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < K2B_COPY_STEPS; ++u) {
+                    const uint32_t i = i0 + 256 * u;
+                    if (i < full) {
+                        const uint32_t e0 = e01[u] & 0xFFFFu, e1 = e01[u] >> 16, e2 = e23[u] & 0xFFFFu, e3 = e23[u] >> 16;
+                        if (FG_K2B_KO != 3 || e0 == 0x12345u) *(u32x4_a4*)(out + i) = u32x4{cbase + e0, cbase + e1, cbase + e2, cbase + e3};
+                    }
+                }
                 if (hit_partial) {
-                    K2B_HIST_ADD(k2b_hist_addr(hoff, hG, e0), hinc);
-                    K2B_HIST_ADD(k2b_hist_addr(hoff, hG, e1), hinc);
-                    K2B_HIST_ADD(k2b_hist_addr(hoff, hG, e2), hinc);
-                    K2B_HIST_ADD(k2b_hist_addr(hoff, hG, e3), hinc);
+#pragma unroll
+                    for (uint32_t u = 0; u < K2B_COPY_STEPS; ++u) {
+                        const uint32_t i = i0 + 256 * u;
+                        if (i < full) {
+                            const uint32_t e0 = e01[u] & 0xFFFFu, e1 = e01[u] >> 16, e2 = e23[u] & 0xFFFFu, e3 = e23[u] >> 16;
+                            K2B_HIST_ADD(k2b_hist_addr(hoff, hG, e0), hinc);
+                            K2B_HIST_ADD(k2b_hist_addr(hoff, hG, e1), hinc);
+                            K2B_HIST_ADD(k2b_hist_addr(hoff, hG, e2), hinc);
+                            K2B_HIST_ADD(k2b_hist_addr(hoff, hG, e3), hinc);
+                        }
+                    }
                 }
             }
             if ((uint32_t)lane < total - full) {

@@ -254,6 +254,16 @@ class Index:
             count = reads.n - first
         _native.check(self._L.fgpu_run(self._h, reads._h, first, count, algo, C.c_double(threshold), result._h))
 
+    def run_lookup(self, reads, result, first=0, count=None):
+        """first half of run(): queues the lookup of the reads on the result's lookup stream and returns at once"""
+        if count is None:
+            count = reads.n - first
+        _native.check(self._L.fgpu_run_lookup(self._h, reads._h, first, count, result._h))
+
+    def run_colours(self, result, algo=FULL_INTERSECTION, threshold=0.0):
+        """second half of run(): the colour stage over the ids the result holds; returns when its kernels have completed"""
+        _native.check(self._L.fgpu_run_colours(self._h, algo, C.c_double(threshold), result._h))
+
     def tune(self, order_min_reads=None, small_results=None, dense_rows=None):
         """execution knobs of the colour stage (fgpu_tune); results never depend on them"""
         if order_min_reads is not None:

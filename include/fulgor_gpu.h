@@ -97,6 +97,14 @@ void fgpu_result_free(fgpu_result* res);
  * previous contents of `res`. Returns after the kernels have completed. */
 int fgpu_run(fgpu_index* idx, const fgpu_reads* reads, uint64_t first, uint64_t count, int algo, double tau,
              fgpu_result* res);
+/* The same pass in its two halves, for a worker loop that keeps two results in flight (pseudoalign_worker's loop over batches,
+ * tools/pseudoalign.cpp:22-51, one batch ahead): fgpu_run_lookup queues fetch_color_set_ids for the reads (k-mers -> colour-set ids)
+ * and returns at once; fgpu_run_colours runs the colour stage on the ids the result holds and returns after its kernels have
+ * completed. fgpu_run_lookup(batch i + 1, result B) followed by fgpu_run_colours(result A of batch i) lets the lookup of one
+ * batch run beside the colour stage of the batch before it; with FULGOR_CU_SPLIT=<n> in the environment when the results are
+ * created the two run on disjoint parts of the device (the lookup kernels on CUs [0, n), the colour kernels on the others). */
+int fgpu_run_lookup(fgpu_index* idx, const fgpu_reads* reads, uint64_t first, uint64_t count, fgpu_result* res);
+int fgpu_run_colours(fgpu_index* idx, int algo, double tau, fgpu_result* res);
 /* ps_options counters (src/ps_utils.cpp:417-448): reads processed / reads with a non-empty result */
 int fgpu_result_sizes(const fgpu_result* res, uint64_t* num_reads, uint64_t* total_colors, uint64_t* num_mapped);
 int fgpu_result_download(const fgpu_result* res, uint64_t* offsets /* n+1 */, uint32_t* colors /* total */);

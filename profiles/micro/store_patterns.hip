@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(256) void k_tickets(uint32_t* __restrict__ out, con
     }
 }
 
+static hipStream_t g_stream = nullptr;  // (argv[1] = n: a stream bound to the first n CUs of the CU mask)
 template <class F>
 void timeit(const char* name, double bytes, F launch) {
     hipEvent_t e0, e1;
@@ -95,9 +97,9 @@ void timeit(const char* name, double bytes, F launch) {
     hipDeviceSynchronize();
     float best = 1e30f;
     for (int r = 0; r < 5; ++r) {
-        hipEventRecord(e0);
+        hipEventRecord(e0, g_stream);
         launch();
-        hipEventRecord(e1);
+        hipEventRecord(e1, g_stream);
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
@@ -106,7 +108,14 @@ void timeit(const char* name, double bytes, F launch) {
     printf("%-64s %8.3f ms  %7.1f GB/s\n", name, best, bytes / best * 1e-6);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) {
+        const int n = atoi(argv[1]);
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = 0; c < n && c < 256; ++c) mask[c >> 5] |= 1u << (c & 31);
+        if (hipExtStreamCreateWithCUMask(&g_stream, 8, mask) != hipSuccess) { printf("no CU mask\n"); return 1; }
+        printf("stream bound to %d CUs\n", n);
+    }
     const size_t bytes = 8ull << 30;
     uint32_t* a;
     hipMalloc(&a, bytes + 4096);
@@ -114,8 +123,8 @@ int main() {
     const size_t n16 = bytes / 16;
     for (int blocks : {2048, 8192}) {
         printf("grid %d x 256\n", blocks);
-        timeit("block-contiguous fill, 16 B stores", bytes, [&] { k_fill<<<blocks, 256>>>(a, n16, 7); });
-        timeit("the same, shifted by 4 bytes", bytes, [&] { k_fill<<<blocks, 256>>>(a + 1, n16, 7); });
+        timeit("block-contiguous fill, 16 B stores", bytes, [&] { k_fill<<<blocks, 256, 0, g_stream>>>(a, n16, 7); });
+        timeit("the same, shifted by 4 bytes", bytes, [&] { k_fill<<<blocks, 256, 0, g_stream>>>(a + 1, n16, 7); });
     }
     // runs of `len` u32 (+- a third, seeded) whose starts are multiples of `align` u32 (1 = any u32: the CSR of the results;
     // the gap behind a run is never written)
@@ -140,13 +149,13 @@ int main() {
             char name[128];
             for (int blocks : {4096}) {
                 snprintf(name, sizeof name, "runs of ~%u u32 at multiples of %u u32, 16 B stores from the start", len, align);
-                timeit(name, wb, [&] { k_runs<0><<<blocks, 256>>>(a, d_off, nruns, 7); });
+                timeit(name, wb, [&] { k_runs<0><<<blocks, 256, 0, g_stream>>>(a, d_off, nruns, 7); });
                 if (len > 100) {
                     snprintf(name, sizeof name, "runs of ~%u u32 at multiples of %u u32, line-aligned wave stores", len, align);
-                    timeit(name, wb, [&] { k_runs<3><<<blocks, 256>>>(a, d_off, nruns, 7); });
+                    timeit(name, wb, [&] { k_runs<3><<<blocks, 256, 0, g_stream>>>(a, d_off, nruns, 7); });
                 }
                 snprintf(name, sizeof name, "runs of ~%u u32 at multiples of %u u32, 4 B stores", len, align);
-                timeit(name, wb, [&] { k_runs<2><<<blocks, 256>>>(a, d_off, nruns, 7); });
+                timeit(name, wb, [&] { k_runs<2><<<blocks, 256, 0, g_stream>>>(a, d_off, nruns, 7); });
             }
             hipFree(d_off);
         }
@@ -173,9 +182,9 @@ int main() {
         for (int blocks : {2048, 4096}) {
             char name[128];
             snprintf(name, sizeof name, "tickets of 32 reads (bench sizes), run by run (grid %d)", blocks);
-            timeit(name, wb, [&] { k_tickets<false><<<blocks, 256>>>(a, d_off, nruns, 7); });
+            timeit(name, wb, [&] { k_tickets<false><<<blocks, 256, 0, g_stream>>>(a, d_off, nruns, 7); });
             snprintf(name, sizeof name, "tickets of 32 reads (bench sizes), one stream of whole lines (grid %d)", blocks);
-            timeit(name, wb, [&] { k_tickets<true><<<blocks, 256>>>(a, d_off, nruns, 7); });
+            timeit(name, wb, [&] { k_tickets<true><<<blocks, 256, 0, g_stream>>>(a, d_off, nruns, 7); });
         }
     }
     return 0;

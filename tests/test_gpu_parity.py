@@ -1020,6 +1020,51 @@ print("ok")
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("cu_split", ["", "96"])
+def test_gpu_lookup_and_colour_stage_as_two_calls(s10_fgidx, cu_split):
+    """fgpu_run_lookup + fgpu_run_colours (a worker loop that keeps the lookup of the next batch in flight beside the colour stage
+    of the current one: two results, alternating) give what fgpu_run gives, batch by batch — on one stream, and with
+    FULGOR_CU_SPLIT (lookup kernels and colour kernels on disjoint sets of CUs, ordered by an event; read when a result is
+    created, hence the subprocess)."""
+    import subprocess
+    code = r'''
+import glob, os, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+import fulgor_amd
+from fulgor_amd.reads import ReadGenerator
+g = sorted(glob.glob(os.path.join(%r, "tests", "data", "salmonella_10", "*.fasta.gz")))
+b, o = ReadGenerator(g).generate(3, 50000, 150, 5)
+ix = fulgor_amd.Index(%r, device=0)
+reads = ix.upload_reads(b, o)
+ref, two = ix.new_result(), [ix.new_result(), ix.new_result()]
+n = ix.num_colors()
+chunks = [(0, 20000), (20000, 17000), (37000, 13000)]
+for algo, tau in ((fulgor_amd.FULL_INTERSECTION, 0.0), (fulgor_amd.THRESHOLD_UNION, 0.7)):
+    want = []
+    for first, cnt in chunks:
+        ix.run(reads, ref, algo, tau, first, cnt)
+        h = torch.zeros(n + 2, dtype=torch.int64, device="cuda:0")
+        ref.accumulate_hits(h.data_ptr())
+        want.append(ref.download() + (h.cpu().numpy(),))
+    ix.run_lookup(reads, two[0], chunks[0][0], chunks[0][1])
+    for t in range(len(chunks)):
+        if t + 1 < len(chunks):
+            ix.run_lookup(reads, two[(t + 1) & 1], chunks[t + 1][0], chunks[t + 1][1])  # in flight beside the colour stage below
+        ix.run_colours(two[t & 1], algo, tau)
+        h = torch.zeros(n + 2, dtype=torch.int64, device="cuda:0")
+        two[t & 1].accumulate_hits(h.data_ptr())
+        got = two[t & 1].download() + (h.cpu().numpy(),)
+        assert all(np.array_equal(a, c) for a, c in zip(want[t], got)), "pass %%d differs" %% t
+print("ok")
+''' % (ROOT, ROOT, s10_fgidx)
+    env = dict(os.environ)
+    if cu_split:
+        env["FULGOR_CU_SPLIT"] = cu_split
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
 # ---- round 2: parity evidence without shared inputs ---------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def s4546small(built):
