@@ -102,7 +102,9 @@ int fgpu_run(fgpu_index* idx, const fgpu_reads* reads, uint64_t first, uint64_t 
  * and returns at once; fgpu_run_colours runs the colour stage on the ids the result holds and returns after its kernels have
  * completed. fgpu_run_lookup(batch i + 1, result B) followed by fgpu_run_colours(result A of batch i) lets the lookup of one
  * batch run beside the colour stage of the batch before it; with FULGOR_CU_SPLIT=<n> in the environment when the results are
- * created the two run on disjoint parts of the device (the lookup kernels on CUs [0, n), the colour kernels on the others). */
+ * created the two run on disjoint parts of the device (the lookup kernels on CUs [0, n), the colour kernels on the others; a measurement
+ * knob: every kernel of the pass scales with the CUs it gets). The reads and the result must stay alive until
+ * fgpu_run_colours (or any other call that waits for the result's stream) has returned. */
 int fgpu_run_lookup(fgpu_index* idx, const fgpu_reads* reads, uint64_t first, uint64_t count, fgpu_result* res);
 int fgpu_run_colours(fgpu_index* idx, int algo, double tau, fgpu_result* res);
 /* ps_options counters (src/ps_utils.cpp:417-448): reads processed / reads with a non-empty result */

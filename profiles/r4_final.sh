@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, final build: rocprofv3 stats + PMC (FI and TU, 10 M reads per launch), the default bench line (with its secondary
+# round 4, final build (tags r4a: first session, r4b: second session): rocprofv3 stats + PMC (FI and TU, 10 M reads per launch), the default bench line (with its secondary
 # workloads, PCIe legs and CPU baseline), salmonella_10, bench.py under torchrun with two ranks on the one GPU, the per-phase
 # instruction counts of the lookup kernel, the result-size histogram of the workload, and the soak against the oracle.
 # usage: bash profiles/r4_final.sh <tag>     (knock-out variants: profiles/build_variant.sh k1stop{1,2,3} -DFG_K1_STOP={1,2,3})
