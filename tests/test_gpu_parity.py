@@ -1398,6 +1398,28 @@ def test_bench_on_a_real_dump_says_so(s4546small):
     assert line["config"]["reads_per_gpu"] == 20000 and line["value"] > 0 and line["config"]["mapped_fraction"] > 0.8
 
 
+def test_bench_pipelined_passes_count_every_read():
+    """`bench.py --pipeline 1`: the passes of all steps as one sequence, the lookup of pass t + 1 queued before the colour stage of pass t
+    is waited for (fgpu_run_lookup / fgpu_run_colours on two results). The line must account for the same reads, mapped reads and
+    colours as the plain loop over the same passes."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    lines = []
+    for pipe in ("0", "1"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "s10", "--reads", "150000", "--chunk", "40000", "--steps", "2",
+                            "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--pipeline", pipe], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    a, b = lines
+    assert a["config"]["reads_per_gpu"] == b["config"]["reads_per_gpu"] == 150000 and b["value"] > 0 and b["steps"] == 2
+    assert a["config"]["mapped_fraction"] == b["config"]["mapped_fraction"] and a["config"]["avg_colours_per_read"] == b["config"]["avg_colours_per_read"]
+    assert b["kernels"]["k1_lookup"]["launches"] == a["kernels"]["k1_lookup"]["launches"] == 8  # four passes per step
+
+
 def test_gpu_reads_with_one_run_per_kmer(built, tmp_path):
     """a homopolymer read has as many minimizer runs as k-mers (all m-mers tie, the leftmost wins): consecutive such reads fill the
     lookup kernel's run queue beyond what waits in it, and here they MATCH (the index holds the k-mer A^31), so the heads of the
