@@ -61,11 +61,17 @@ __global__ __launch_bounds__(256) void k_runs(uint32_t* __restrict__ out, const 
 // run on its own, 16-byte stores from its first u32 (what the kernel does); STREAM = true: the ticket's runs as one stream in whole
 // 128-byte lines (a run's last partial line waits for the head of the next run), partial lines only at the two ends of the ticket.
 // (off[] = plain CSR here: run r = [off[r], off[r + 1]).)
-template <bool STREAM>
+// FAR: the tickets of neighbouring waves (one CU) lie 1/1024 of the buffer apart instead of side by side (address translation:
+// the waves of a CU then write to as many pages as there are waves)
+template <bool STREAM, bool FAR = false>
 __global__ __launch_bounds__(256) void k_tickets(uint32_t* __restrict__ out, const uint64_t* __restrict__ off, size_t nruns, uint32_t v) {
     const int lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    for (size_t t = wave * 32; t < nruns; t += nwaves * 32) {
+    const size_t ntick = (nruns + 31) / 32, per = (ntick + 1023) / 1024;
+    for (size_t t0 = wave; t0 < (FAR ? per * 1024 : ntick); t0 += nwaves) {
+        const size_t tk = FAR ? (t0 % 1024) * per + t0 / 1024 : t0;
+        if (tk >= ntick) continue;
+        const size_t t = tk * 32;
         const size_t t1 = t + 32 < nruns ? t + 32 : nruns;
         if (STREAM) {
             const uint64_t b = off[t], e = off[t1];
@@ -185,6 +191,8 @@ int main(int argc, char** argv) {
             timeit(name, wb, [&] { k_tickets<false><<<blocks, 256, 0, g_stream>>>(a, d_off, nruns, 7); });
             snprintf(name, sizeof name, "tickets of 32 reads (bench sizes), one stream of whole lines (grid %d)", blocks);
             timeit(name, wb, [&] { k_tickets<true><<<blocks, 256, 0, g_stream>>>(a, d_off, nruns, 7); });
+            snprintf(name, sizeof name, "tickets of 32 reads, run by run, neighbouring waves far apart (grid %d)", blocks);
+            timeit(name, wb, [&] { k_tickets<false, true><<<blocks, 256, 0, g_stream>>>(a, d_off, nruns, 7); });
         }
     }
     return 0;
