@@ -147,6 +147,7 @@ def measure(w, algo, tau, chunk, steps, warmup, streams, local_rank, world=1, di
     def worker(k):
         for i in range(k, len(chunks), len(results)):
             ix.run(w.reads, results[k], algo, tau, chunks[i][0], chunks[i][1])
+            results[k].expand()  # the metric is quoted on passes that end in u32 colour lists (the command line's compressed format skips this)
             results[k].accumulate_hits(hits.data_ptr())
 
     def reduce_hits():
@@ -174,6 +175,7 @@ def measure(w, algo, tau, chunk, steps, warmup, streams, local_rank, world=1, di
                 nf, nc = chunks[seq[t + 1][1]]
                 ix.run_lookup(w.reads, results[(t + 1) & 1], nf, nc)
             ix.run_colours(results[t & 1], algo, tau)
+            results[t & 1].expand()
             if i == 0:
                 hits.zero_()
                 torch.cuda.current_stream().synchronize()
@@ -398,8 +400,10 @@ def main():
             "dtype": "u32",
             # (the reads are synthetic either way; "real-dump" = the index came from a `fulgor dump` of a real collection)
             "data": "real-dump" if w.desc.startswith(REAL_DUMP_PREFIX) else "synthetic",
-            "config": {"workload": "%s, %s, %d synthetic %d bp reads per GPU (seed 42), k=31, chunk %d reads/pass"
+            "config": {"workload": "%s, %s, %d synthetic %d bp reads per GPU (seed 42), k=31, chunk %d reads/pass; every pass ends in the "
+                                   "u32 colour lists in HBM (fgpu_run + fgpu_result_expand) and the per-colour hit counts"
                                    % (w.desc, args.algo + (" tau=%g" % args.tau if algo else ""), n_reads, args.read_len, args.chunk),
+                       "pipeline": int(bool(args.pipeline)), "cu_split": os.environ.get("FULGOR_CU_SPLIT") or os.environ.get("FULGOR_CU_RANGE") or None,
                        "index_replicated": True, "reads_per_gpu": n_reads, "streams": max(1, args.streams),
                        "mapped_fraction": round(m["mapped_job"] / max(1, m["reads_job"]), 4),
                        "avg_colours_per_read": round(m["total_colors"] / n_reads, 2)},

@@ -65,6 +65,7 @@ def lib():
     L.fgpu_run.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_double, vp]
     L.fgpu_run_lookup.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp]
     L.fgpu_run_colours.argtypes = [vp, C.c_int, C.c_double, vp]
+    L.fgpu_result_expand.argtypes = [vp]
     L.fgpu_result_sizes.argtypes = [vp, u64p, u64p, u64p]
     L.fgpu_result_download.argtypes = [vp, vp, vp]
     L.fgpu_result_accumulate_hits.argtypes = [vp, vp, vp]
@@ -74,12 +75,16 @@ def lib():
     L.fgpu_fastx_open_part.argtypes = [C.c_char_p, C.c_uint, C.c_uint64, C.c_uint64, C.POINTER(vp)]
     L.fgpu_fastx_count.argtypes = [C.c_char_p, C.c_uint, C.c_uint64, C.c_uint64, u64p]
     L.fgpu_fastx_text_size.argtypes = [C.c_char_p, u64p, C.POINTER(C.c_int)]
+    L.fgpu_fastx_count_part.argtypes = [vp, u64p]
     L.fgpu_fastx_next.argtypes = [vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp), u64p]
     L.fgpu_fastx_names.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.fgpu_fastx_close.argtypes = [vp]
     L.fgpu_fastx_close.restype = None
     L.fgpu_fastx_ring.argtypes = []
     L.fgpu_fastx_ring.restype = C.c_int
+    L.fgpu_pseudoalign_stream.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_int, C.c_uint64, C.c_uint,
+                                          u64p, u64p]
+    L.fgpu_last_stream_report.argtypes = [C.POINTER(vp)]
     L.fgpu_result_algorithmic_bytes.argtypes = [vp, u64p, u64p, u64p]
     L.fgpu_tune.argtypes = [vp, C.c_int, C.c_uint64]
     L.fgpu_timing_enable.argtypes = [vp, C.c_int]

@@ -63,7 +63,7 @@ void upload(DevBuf& b, const std::vector<T>& v, hipStream_t s) {
 
 constexpr size_t TICKET_BYTES = 3 * 8 * TICKET_STRIDE * sizeof(unsigned int);
 
-const char* KERNEL_NAMES[FGPU_K_COUNT] = {"k1_lookup", "k2_intersect", "k3_union", "scan", "k2b_expand", "k_hits", "k_desc", "k_format", "k_order"};
+const char* KERNEL_NAMES[FGPU_K_COUNT] = {"k1_lookup", "k2_intersect", "k3_union", "scan", "k2b_expand", "k_hits", "k_desc", "k_format", "k_order", "h2d", "d2h"};
 
 // defaults of the fgpu_tune knobs from the environment (measurement: FULGOR_ORDER=0 takes the reads of a pass in file order,
 // FULGOR_ORDER_MIN_READS sets the smallest pass that is ordered, FULGOR_SMALL=0 writes a bitmap row for every result)
@@ -143,8 +143,17 @@ struct fgpu_reads {
     fgpu_index* ix = nullptr;
     DevBuf d_bases, d_offs;
     uint64_t n = 0;
+    // lengths: every read of the batch `uni_len` bases long (the common case: offsets and k-mer prefix sums are products, nothing is
+    // kept per read), or the two vectors
+    bool uniform = false;
+    uint64_t uni_len = 0, uni_nk = 0;
     std::vector<uint64_t> cum_kmers;  // prefix sums of max(0, len-k+1)
     std::vector<uint64_t> h_offs;
+    // (a batch of the streaming worker loop keeps neither: it is only ever processed whole, and knows its two totals)
+    bool whole_only = false;
+    uint64_t whole_kmers = 0, whole_bases = 0;
+    uint64_t kmers_before(uint64_t i) const { return whole_only ? (i == n ? whole_kmers : 0) : uniform ? i * uni_nk : cum_kmers[i]; }
+    uint64_t bases_before(uint64_t i) const { return whole_only ? (i == n ? whole_bases : 0) : uniform ? i * uni_len : h_offs[i]; }
     uint32_t max_kmers = 0;
     uint64_t max_total_kmers = 0;  // longest read, in k-mers (not capped by segmentation)
     // reads with more than SEG_KMERS k-mers are cut into overlapping segments (k-1 shared bases), copied one after
@@ -153,6 +162,10 @@ struct fgpu_reads {
     bool has_long = false;
     std::vector<uint64_t> seg_first, seg_start, seg_end;
     DevBuf d_seg_offs, d_seg_first;
+    // the last lookup every result queued on these reads (fgpu_run_lookup returns with the kernel in flight): fgpu_reads_free waits
+    // for them before the buffers go back to the pool
+    mutable std::mutex use_mu;
+    mutable std::vector<std::pair<const fgpu_result*, hipEvent_t>> uses;
 };
 constexpr uint32_t SEG_KMERS = 512;  // what the 4-window lookup kernel takes as one unit
 
@@ -183,6 +196,10 @@ struct fgpu_result {
     char* h_fmt = nullptr;                     // pinned host copy of the formatted records (recycled)
     size_t h_fmt_cap = 0;
     bool hits_folded = true;  // false: too many colours for the expand kernel's LDS histogram; k_hits counts from the bitmaps
+    // The u32 colour lists (CSR: d_offsets + d_colors) are materialised on demand (stage_expand): a pass leaves the result rows, the
+    // small-result slots, the sizes and the CSR offsets; fgpu_result_expand, fgpu_result_download, the ascii / binary formatters and
+    // the host-buffer calls run k2b_expand, the compressed formatter and the counters work from the rows
+    bool csr_valid = false;
     uint32_t max_kmers_in_batch = 0xFFFFFFFFu;  // bound on #positive k-mers of any read (unknown for id-only calls)
     bool have_ids = false;
 };
@@ -323,8 +340,9 @@ uint32_t resident_grid(K kernel, uint64_t units, uint32_t per_block, int num_cus
 
 void stage_lookup_on(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t count, fgpu_result* res) {
     hipStream_t s = res->stream_lookup;
-    res->total_kmers = rd->cum_kmers[first + count] - rd->cum_kmers[first];
-    res->total_bases = rd->h_offs[first + count] - rd->h_offs[first];
+    if (rd->whole_only && (first != 0 || count != rd->n)) throw std::runtime_error("internal error: a streamed batch is processed whole");
+    res->total_kmers = rd->kmers_before(first + count) - rd->kmers_before(first);
+    res->total_bases = rd->bases_before(first + count) - rd->bases_before(first);
     // units = reads, or segments when the batch holds reads longer than SEG_KMERS k-mers
     const bool seg = rd->has_long;
     const uint64_t u_first = seg ? rd->seg_first[first] : first;
@@ -404,6 +422,16 @@ void stage_lookup_on(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint6
 // the lookup of a pass, queued on the result's lookup stream; what follows on the result's main stream waits for it
 void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t count, fgpu_result* res) {
     stage_lookup_on(ix, rd, first, count, res);
+    {   // the reads are in use until this point of the stream (fgpu_reads_free waits for it)
+        std::lock_guard<std::mutex> g(rd->use_mu);
+        hipEvent_t ev = nullptr;
+        for (auto& u : rd->uses) if (u.first == res) ev = u.second;
+        if (!ev) {
+            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            rd->uses.emplace_back(res, ev);
+        }
+        HIP_TRY(hipEventRecord(ev, res->stream_lookup));
+    }
     if (res->stream_lookup != res->stream) {
         HIP_TRY(hipEventRecord(res->ev_lookup, res->stream_lookup));
         HIP_TRY(hipStreamWaitEvent(res->stream, res->ev_lookup, 0));
@@ -494,6 +522,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     res->total = res->mapped = 0;
     res->hit_rows = 0;
     res->small_mode = false;
+    res->csr_valid = false;
     if (n == 0) {
         HIP_TRY(hipMemsetAsync(res->d_offsets.p, 0, 8, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -619,10 +648,27 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     }
     run_scan(ix, res, res->d_counts.as<uint32_t>(), n, res->d_offsets.as<uint64_t>());
     HIP_TRY(hipMemcpyAsync(res->h_totals, res->d_totals.p, 16, hipMemcpyDeviceToHost, s));
-    // The expand kernel is launched right behind the scan, without waiting for the totals: it checks on the device
-    // that the colours fit the buffer it was given and does nothing otherwise; only then (first passes, growing
-    // results) the buffer is enlarged and the launch repeated. One host round trip per pass instead of two.
     res->hits_folded = hits_fold;
+    HIP_TRY(hipStreamSynchronize(s));
+    res->total = res->h_totals[0];
+    res->mapped = res->h_totals[1];
+    if (ix->timing) ix->collect_timing(res->pending);
+}
+
+// The u32 colour lists of the last pass (k2b_expand: result rows / small-result slots -> CSR colours), for the consumers that
+// read them: fgpu_result_expand, fgpu_result_download, the ascii / binary formatters, the host-buffer calls. The compressed
+// formatter (src/ps_utils.cpp:168-237 works from the colours of a read one by one; here from its row) and the counters do not.
+// The per-colour hit histogram of the pass rides along while it fits the kernel's LDS.
+void stage_expand(fgpu_index* ix, fgpu_result* res) {
+    if (res->csr_valid) return;
+    hipStream_t s = res->stream;
+    const uint64_t n = res->n;
+    const uint32_t W = ix->dc.w32;
+    res->hit_rows = 0;
+    if (n == 0 || res->total == 0) { res->d_colors.ensure(16); res->csr_valid = true; return; }
+    // the per-colour hit histogram rides along in the expand kernel's LDS while it fits (16-bit counters, about W * 64 bytes);
+    // for larger collections the expand kernel runs without it and k_hits counts from the bitmaps on demand
+    const size_t stage_lds = (K2B_THREADS / 64) * K2B_STAGE_BYTES + 16;  // + the block's ticket counter
     const size_t lds = res->hits_folded ? stage_lds + k2b_hist_region(W) : stage_lds;
     // 16-bit hit counters: a block takes tickets for at most block_cap reads (k2b_expand), and the grid is large enough for
     // the caps of the blocks of every ticket partition to exceed its reads by a quarter
@@ -635,8 +681,9 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     const uint32_t grid = std::max<uint32_t>(resident_grid(k2b_expand, n, K2B_THREADS / 64, ix->num_cus, K2B_THREADS, lds),
                                              res->hits_folded ? cap_grid : 1u);
     if (res->hits_folded) res->d_partial.ensure((size_t)grid * W * 32 * 4);
-    res->d_colors.ensure(16);
-    auto expand = [&] {
+    if (res->total > res->d_colors.cap / 4) res->d_colors.ensure(res->total * 4 + res->total + 16);  // 25 % headroom: later passes of the same size fit
+    HIP_TRY(hipMemsetAsync(res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE, 0, 8 * TICKET_STRIDE * sizeof(unsigned int), s));
+    {
         Timed t(ix, res, FGPU_K_EXPAND);
         hipLaunchKernelGGL(k2b_expand, dim3(grid), dim3(K2B_THREADS), lds, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
                            res->d_offsets.as<uint64_t>(), n, W, res->d_colors.as<uint32_t>(),
@@ -645,18 +692,10 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
                            (uint64_t)(res->d_colors.cap / 4), block_cap,
                            res->small_mode ? res->d_small.as<uint32_t>() : (const uint32_t*)nullptr);
         HIP_TRY(hipGetLastError());
-    };
-    expand();
-    HIP_TRY(hipStreamSynchronize(s));
-    res->total = res->h_totals[0];
-    res->mapped = res->h_totals[1];
-    if (res->total > res->d_colors.cap / 4) {
-        res->d_colors.ensure(res->total * 4 + res->total + 16);  // 25 % headroom: later passes of the same size fit
-        HIP_TRY(hipMemsetAsync(res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE, 0, 8 * TICKET_STRIDE * sizeof(unsigned int), s));
-        expand();
     }
-    if (res->total && res->hits_folded) res->hit_rows = grid;
+    if (res->hits_folded) res->hit_rows = grid;
     HIP_TRY(hipStreamSynchronize(s));
+    res->csr_valid = true;
     if (ix->timing) ix->collect_timing(res->pending);
 }
 
@@ -673,6 +712,8 @@ int guarded(F f) {
 }
 
 }  // namespace
+
+void fgpu_stream_cache_release(fgpu_index* ix);  // stream_pipeline.hip.h
 
 extern "C" {
 
@@ -713,6 +754,7 @@ void fgpu_close(fgpu_index* ix) {
     if (!ix) return;
     if (ix->device == FGPU_HOST_ONLY) { delete ix; return; }
     (void)hipSetDevice(ix->device);
+    fgpu_stream_cache_release(ix);  // the results the streaming worker loop keeps with the index
     for (DevBuf* b : {&ix->d_table, &ix->d_bmp_rows, &ix->d_offsets, &ix->d_set_rank, &ix->d_rows,
                       &ix->d_set_desc, &ix->d_blk_words, &ix->d_gops, &ix->d_gset_ops_off, &ix->d_gset_ops,
                       &ix->d_garena, &ix->d_gblk_hdr, &ix->d_gblk_words, &ix->d_gset_bytes})
@@ -805,17 +847,34 @@ int fgpu_reads_upload(fgpu_index* ix, const char* bases, const uint64_t* offs, u
         rd = new fgpu_reads();
         rd->ix = ix;
         rd->n = n;
-        rd->h_offs.assign(offs, offs + n + 1);
-        rd->cum_kmers.assign(n + 1, 0);
         const uint32_t k = ix->host.dict.k;
-        for (uint64_t i = 0; i < n; ++i) {
-            if (offs[i + 1] < offs[i]) throw std::runtime_error("read offsets are not monotone");
-            uint64_t len = offs[i + 1] - offs[i];
-            uint64_t nk = len >= k ? len - k + 1 : 0;
-            if (nk > SEG_KMERS) rd->has_long = true;
-            rd->max_total_kmers = std::max(rd->max_total_kmers, nk);
-            rd->max_kmers = std::max<uint32_t>(rd->max_kmers, (uint32_t)std::min<uint64_t>(nk, SEG_KMERS));
-            rd->cum_kmers[i + 1] = rd->cum_kmers[i] + nk;
+        // all reads of one length (one pass of differences, no per-read state kept)? Otherwise the prefix sums per read.
+        {
+            const uint64_t len0 = n ? offs[1] - offs[0] : 0;
+            uint64_t differ = 0;
+            for (uint64_t i = 0; i < n; ++i) differ |= (offs[i + 1] - offs[i]) ^ len0;
+            if (n && !differ && offs[0] == 0) {
+                rd->uniform = true;
+                rd->uni_len = len0;
+                rd->uni_nk = len0 >= k ? len0 - k + 1 : 0;
+                rd->max_total_kmers = rd->uni_nk;
+                rd->max_kmers = (uint32_t)std::min<uint64_t>(rd->uni_nk, SEG_KMERS);
+                rd->has_long = rd->uni_nk > SEG_KMERS;
+            }
+        }
+        if (!rd->uniform || rd->has_long) {
+            rd->uniform = false;
+            rd->h_offs.assign(offs, offs + n + 1);
+            rd->cum_kmers.assign(n + 1, 0);
+            for (uint64_t i = 0; i < n; ++i) {
+                if (offs[i + 1] < offs[i]) throw std::runtime_error("read offsets are not monotone");
+                uint64_t len = offs[i + 1] - offs[i];
+                uint64_t nk = len >= k ? len - k + 1 : 0;
+                if (nk > SEG_KMERS) rd->has_long = true;
+                rd->max_total_kmers = std::max(rd->max_total_kmers, nk);
+                rd->max_kmers = std::max<uint32_t>(rd->max_kmers, (uint32_t)std::min<uint64_t>(nk, SEG_KMERS));
+                rd->cum_kmers[i + 1] = rd->cum_kmers[i] + nk;
+            }
         }
         const uint64_t nb = offs[n];
         if (rd->has_long) {
@@ -877,7 +936,12 @@ int fgpu_reads_upload(fgpu_index* ix, const char* bases, const uint64_t* offs, u
 void fgpu_reads_free(fgpu_reads* rd) {
     if (!rd) return;
     (void)hipSetDevice(rd->ix->device);
-    if (!rd->has_long && rd->d_bases.p && rd->d_offs.p) {  // back to the pool (the kernels that read them have completed: every pass ends with a stream synchronise)
+    for (auto& u : rd->uses) {  // lookups still in flight on these buffers (fgpu_run_lookup returns at once)
+        (void)hipEventSynchronize(u.second);
+        (void)hipEventDestroy(u.second);
+    }
+    rd->uses.clear();
+    if (!rd->has_long && rd->d_bases.p && rd->d_offs.p) {  // back to the pool (the kernels that read them have completed)
         std::lock_guard<std::mutex> g(rd->ix->reads_mu);
         if (rd->ix->reads_pool.size() < fgpu_index::READS_POOL_MAX) {
             rd->ix->reads_pool.emplace_back(rd->d_bases, rd->d_offs);
@@ -979,6 +1043,14 @@ int fgpu_run_colours(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     });
 }
 
+int fgpu_result_expand(fgpu_result* res) {
+    if (!res) return fail(-EINVAL, "null argument");
+    return guarded([&] {
+        HIP_TRY(hipSetDevice(res->ix->device));
+        stage_expand(res->ix, res);
+    });
+}
+
 int fgpu_result_sizes(const fgpu_result* r, uint64_t* num_reads, uint64_t* total_colors, uint64_t* num_mapped) {
     if (!r) return fail(-EINVAL, "null argument");
     if (num_reads) *num_reads = r->n;
@@ -991,6 +1063,7 @@ int fgpu_result_download(const fgpu_result* r, uint64_t* offsets, uint32_t* colo
     if (!r || !offsets) return fail(-EINVAL, "null argument");
     return guarded([&] {
         HIP_TRY(hipSetDevice(r->ix->device));
+        if (colors) stage_expand(r->ix, const_cast<fgpu_result*>(r));
         HIP_TRY(hipMemcpy(offsets, r->d_offsets.p, (r->n + 1) * 8, hipMemcpyDeviceToHost));
         if (r->total && colors) HIP_TRY(hipMemcpy(colors, r->d_colors.p, r->total * 4, hipMemcpyDeviceToHost));
     });
@@ -1007,6 +1080,7 @@ int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_rea
         const uint64_t n = res->n;
         uint64_t bytes = 0;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 3) / 4, (uint64_t)ix->num_cus * 16);
+        if (format != FGPU_FMT_COMPRESSED) stage_expand(ix, res);  // ascii and binary records are made of the u32 colour lists
         if (n && format == FGPU_FMT_COMPRESSED) {
             // from the result bitmaps: bits per record -> offsets inside blocks of CFMT_BLOCK_READS records -> block offsets
             const uint32_t W = ix->dc.w32, nc = ix->dc.n;
@@ -1023,8 +1097,7 @@ int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_rea
             {
                 Timed t(ix, res, FGPU_K_FORMAT);
                 hipLaunchKernelGGL(k_cfmt_sizes, dim3(grid), dim3(256), 0, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
-                                   n, W, nc, sthr, dthr, first_read_id, bits, res->small_mode ? res->d_offsets.as<uint64_t>() : (const uint64_t*)nullptr,
-                                   res->d_colors.as<uint32_t>());
+                                   n, W, nc, sthr, dthr, first_read_id, bits, res->small_mode ? res->d_small.as<uint32_t>() : (const uint32_t*)nullptr);
                 hipLaunchKernelGGL(k_cfmt_blocks, dim3((uint32_t)nb), dim3(CFMT_BLOCK_READS), 0, s, bits, n, rec_off, block_bits,
                                    block_bytes);
             }
@@ -1042,7 +1115,7 @@ int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_rea
             hipLaunchKernelGGL(k_cfmt_write, dim3(grid), dim3(256), (size_t)4 * cap_words * 8, s, res->d_bitmap.as<uint32_t>(),
                                res->d_counts.as<uint32_t>(), n, W, nc, sthr, dthr, first_read_id, bits, rec_off, block_bits, block_off,
                                res->d_fmt_out.as<unsigned long long>(), cap_words,
-                               res->small_mode ? res->d_offsets.as<uint64_t>() : (const uint64_t*)nullptr, res->d_colors.as<uint32_t>());
+                               res->small_mode ? res->d_small.as<uint32_t>() : (const uint32_t*)nullptr);
             HIP_TRY(hipGetLastError());
         } else if (n && format == FGPU_FMT_BINARY) {
             bytes = 8 * n + 4 * res->total;
@@ -1079,7 +1152,10 @@ int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_rea
             HIP_TRY(hipHostMalloc((void**)&res->h_fmt, want, hipHostMallocDefault));
             res->h_fmt_cap = want;
         }
-        if (bytes) HIP_TRY(hipMemcpyAsync(res->h_fmt, res->d_fmt_out.p, bytes, hipMemcpyDeviceToHost, s));
+        if (bytes) {
+            Timed t(ix, res, FGPU_K_D2H);
+            HIP_TRY(hipMemcpyAsync(res->h_fmt, res->d_fmt_out.p, bytes, hipMemcpyDeviceToHost, s));
+        }
         HIP_TRY(hipStreamSynchronize(s));
         if (ix->timing) ix->collect_timing(res->pending);
         *out = res->h_fmt ? res->h_fmt : "";
@@ -1106,11 +1182,17 @@ int fgpu_result_accumulate_hits(fgpu_index* ix, const fgpu_result* r, void* devi
             const uint32_t W = ix->dc.w32;
             Timed t(ix, const_cast<fgpu_result*>(r), FGPU_K_HITS);
             fgpu_result* rw = const_cast<fgpu_result*>(r);
-            if (r->total && !r->hits_folded) {  // large collections: count from the result bitmaps now
+            if (r->total && (!r->hits_folded || !r->csr_valid)) {
+                // no histogram from the expand kernel (large collections, or the colour lists of this pass were never asked
+                // for): count from the result rows now, and from the slots of the results that travel as colours
                 const uint32_t rows = (uint32_t)std::min<uint64_t>(256, (r->n + 63) / 64);
                 rw->d_partial.ensure((size_t)rows * W * 32 * 4);
-                hipLaunchKernelGGL(k_hits, dim3(rows), dim3(256), 0, r->stream, r->d_bitmap.as<uint32_t>(), r->n, W,
-                                   rw->d_partial.as<uint32_t>());
+                const uint32_t* small = r->small_mode ? r->d_small.as<uint32_t>() : (const uint32_t*)nullptr;
+                hipLaunchKernelGGL(k_hits, dim3(rows), dim3(256), 0, r->stream, r->d_bitmap.as<uint32_t>(), r->d_counts.as<uint32_t>(), r->n, W,
+                                   rw->d_partial.as<uint32_t>(), small);
+                if (small)
+                    hipLaunchKernelGGL(k_hits_small, dim3((uint32_t)std::min<uint64_t>((r->n * SMALL_RESULT + 255) / 256, (uint64_t)ix->num_cus * 16)),
+                                       dim3(256), 0, r->stream, r->d_counts.as<uint32_t>(), small, r->n, (unsigned long long*)device_u64_hits);
                 rw->hit_rows = rows;
             }
             // one row of per-colour counts per block (of the expand kernel or of k_hits): sum the rows into the totals
@@ -1189,7 +1271,7 @@ static int run_host(fgpu_index* ix, const char* bases, const uint64_t* offs, uin
     int rc = fgpu_reads_upload(ix, bases, offs, n, &rd);
     if (!rc) rc = fgpu_result_create(ix, &res);
     if (!rc) rc = fgpu_run(ix, rd, 0, n, algo, tau, res);
-    if (!rc) {
+    if (!rc) {  // (fgpu_result_download materialises the colour lists)
         uint64_t* o = (uint64_t*)malloc((n + 1) * 8);
         uint32_t* c = (uint32_t*)malloc(std::max<uint64_t>(1, res->total) * 4);
         if (!o || !c) { free(o); free(c); rc = fail(-ENOMEM, "out of host memory"); }
@@ -1292,6 +1374,7 @@ int fgpu_intersect_ids(fgpu_index* ix, const uint32_t* ids, const uint64_t* id_o
         res->have_ids = false;
         stage_descriptors(ix, res, id_offs[n], FGPU_FULL_INTERSECTION);
         stage_colors(ix, FGPU_FULL_INTERSECTION, 0.0, res);
+        stage_expand(ix, res);
         uint64_t* o = (uint64_t*)malloc((n + 1) * 8);
         uint32_t* c = (uint32_t*)malloc(std::max<uint64_t>(1, res->total) * 4);
         if (!o || !c) { free(o); free(c); throw std::bad_alloc(); }
@@ -1327,9 +1410,9 @@ int fgpu_kmer_color_set_ids(fgpu_index* ix, const char* bases, const uint64_t* o
         std::vector<uint32_t> raw(units * stride);
         if (units) HIP_TRY(hipMemcpy(raw.data(), res->d_kmer_ids.p, units * stride * 4, hipMemcpyDeviceToHost));
         uint64_t* o = (uint64_t*)malloc((n + 1) * 8);
-        uint32_t* v = (uint32_t*)malloc(std::max<uint64_t>(1, rd->cum_kmers[n]) * 4);
+        uint32_t* v = (uint32_t*)malloc(std::max<uint64_t>(1, rd->kmers_before(n)) * 4);
         if (!o || !v) { free(o); free(v); throw std::bad_alloc(); }
-        for (uint64_t r = 0; r <= n; ++r) o[r] = rd->cum_kmers[r];
+        for (uint64_t r = 0; r <= n; ++r) o[r] = rd->kmers_before(r);
         for (uint64_t r = 0; r < n; ++r) {
             // segments of a long read hold consecutive, non-overlapping k-mer ranges
             const uint64_t u0 = rd->has_long ? rd->seg_first[r] : r, u1 = rd->has_long ? rd->seg_first[r + 1] : r + 1;
@@ -1426,74 +1509,29 @@ int fgpu_formatter_finish(fgpu_formatter* f, char** out, uint64_t* out_len) {
 
 // ---- query reader -------------------------------------------------------------------------------------------
 namespace {
-// grow-only byte buffer in pinned host memory (H2D copies out of it run at PCIe speed and overlap with kernels); plain
-// memory when there is no HIP device (host-only tools, CPU tests)
-// Pinning and unpinning 100 MB costs tens of milliseconds each (a reader has four such buffers: 63 ms of its close()), so
-// released pinned buffers wait in a process-wide pool for the next reader; what is still pooled at exit goes with the process.
-struct PinnedPool {
-    std::mutex mu;
-    std::vector<std::pair<char*, size_t>> free_list;
-    static constexpr size_t MAX = 8;
-    static PinnedPool& get() { static PinnedPool* p = new PinnedPool(); return *p; }  // (never destroyed: no calls into HIP at exit)
-};
-struct PinnedBytes {
-    char* p = nullptr;
-    size_t n = 0, cap = 0;
-    bool pinned = false;
-    ~PinnedBytes() { release(); }
-    void release() {
-        if (p && pinned) {
-            PinnedPool& pool = PinnedPool::get();
-            std::lock_guard<std::mutex> g(pool.mu);
-            if (pool.free_list.size() < PinnedPool::MAX) { pool.free_list.emplace_back(p, cap); p = nullptr; }
-        }
-        if (p) { if (pinned) (void)hipHostFree(p); else free(p); }
-        p = nullptr;
-        n = cap = 0;
-    }
-    void clear() { n = 0; }
-    size_t size() const { return n; }
-    char* data() { return p; }
-    void reserve(size_t want) {
-        want += 1024;  // slack: the lookup kernel over-reads padded reads
-        if (want <= cap) return;
-        want += want / 4 + 4096;
-        char* q = nullptr;
-        {
-            PinnedPool& pool = PinnedPool::get();
-            std::lock_guard<std::mutex> g(pool.mu);
-            size_t best = pool.free_list.size();
-            for (size_t i = 0; i < pool.free_list.size(); ++i)
-                if (pool.free_list[i].second >= want && (best == pool.free_list.size() || pool.free_list[i].second < pool.free_list[best].second)) best = i;
-            if (best < pool.free_list.size()) {
-                q = pool.free_list[best].first;
-                want = pool.free_list[best].second;
-                pool.free_list.erase(pool.free_list.begin() + best);
-            }
-        }
-        bool pin = q != nullptr || (hipHostMalloc((void**)&q, want, hipHostMallocDefault) == hipSuccess && q);
-        if (!pin) {
+// the reader's buffers (fg::HostVec, fg::SlabPool) in pinned host memory: H2D copies out of them run at PCIe speed and overlap
+// with kernels; plain memory when there is no HIP device (host-only tools, CPU tests)
+void install_pinned_allocator() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        HostAllocHooks& h = host_alloc_hooks();
+        h.alloc = [](size_t bytes, bool* pinned) -> void* {
+            void* p = nullptr;
+            if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) { *pinned = true; return p; }
             (void)hipGetLastError();
-            q = (char*)malloc(want);
-            if (!q) throw std::bad_alloc();
-        }
-        if (n) memcpy(q, p, n);
-        const size_t keep = n;
-        release();
-        p = q;
-        n = keep;
-        cap = want;
-        pinned = pin;
-    }
-    void set_size(size_t len) { n = len; }
-};
+            *pinned = false;
+            return nullptr;  // (the pool falls back to malloc)
+        };
+        h.release = [](void* p, bool) { (void)hipHostFree(p); };
+    });
+}
 }  // namespace
 
 struct fgpu_fastx {
     static constexpr int RING = 4;  // batches alive at a time: a worker loop keeps several passes in flight
     FastxReader reader;
-    PinnedBytes bases[RING];
-    std::vector<uint64_t> offs[RING];
+    HostVec<char> bases[RING];
+    HostVec<uint64_t> offs[RING];
     std::vector<char> names;
     std::vector<uint64_t> name_offs{0};
     int cur = RING - 1;
@@ -1505,7 +1543,12 @@ int fgpu_fastx_open(const char* path, fgpu_fastx** out) { return fgpu_fastx_open
 int fgpu_fastx_open_part(const char* path, unsigned threads, uint64_t begin, uint64_t end, fgpu_fastx** out) {
     if (!path || !out) return fail(-EINVAL, "null argument");
     *out = nullptr;
-    return guarded([&] { *out = new fgpu_fastx(path, threads, begin, end); });
+    return guarded([&] {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) install_pinned_allocator();
+        else (void)hipGetLastError();
+        *out = new fgpu_fastx(path, threads, begin, end);
+    });
 }
 
 int fgpu_fastx_text_size(const char* path, uint64_t* size, int* can_be_read_in_parts) {
@@ -1526,15 +1569,23 @@ int fgpu_fastx_count(const char* path, unsigned threads, uint64_t begin, uint64_
     });
 }
 
+int fgpu_fastx_count_part(fgpu_fastx* f, uint64_t* num_reads) {
+    if (!f || !num_reads) return fail(-EINVAL, "null argument");
+    return guarded([&] {
+        if (!f->reader.count_records(*num_reads))
+            throw std::runtime_error("this query file has to be read to be counted (a gzip stream, or FASTQ with wrapped lines)");
+    });
+}
+
 int fgpu_fastx_next(fgpu_fastx* f, uint64_t max_reads, const char** bases, const uint64_t** offs, uint64_t* n) {
     if (!f || !bases || !offs || !n) return fail(-EINVAL, "null argument");
     if (max_reads == 0) return fail(-EINVAL, "max_reads must be positive");
     return guarded([&] {
         f->cur = (f->cur + 1) % fgpu_fastx::RING;
-        PinnedBytes& b = f->bases[f->cur];
+        HostVec<char>& b = f->bases[f->cur];
         f->reader.next(max_reads, b, f->offs[f->cur]);
         *n = f->offs[f->cur].size() - 1;
-        b.reserve(b.size());
+        b.reserve(b.size() + 1);
         *bases = b.data();
         *offs = f->offs[f->cur].data();
     });
@@ -1634,3 +1685,5 @@ int fgpu_dump(const fgpu_index* ix, const char* basename) {
 }
 
 }  // extern "C"
+
+#include "stream_pipeline.hip.h"

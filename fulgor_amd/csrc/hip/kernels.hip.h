@@ -1853,28 +1853,41 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
 // Stage 1: each block sums its slice of reads into partial[block][W*32] (thread = one 32-colour word,
 // 32 register counters, 4 reads in flight). Stage 2: column sums of the partials into the u64 totals.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_hits(const uint32_t* __restrict__ bitmap, uint64_t n_reads, uint32_t W, uint32_t* __restrict__ partial) {
+__global__ void k_hits(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts, uint64_t n_reads, uint32_t W,
+                       uint32_t* __restrict__ partial, const uint32_t* __restrict__ small) {
+    // small != nullptr: results of at most SMALL_RESULT colours (the empty ones included) left no row behind: k_hits_small counts those
     const uint64_t per_block = (n_reads + gridDim.x - 1) / gridDim.x;
     const uint64_t r0 = (uint64_t)blockIdx.x * per_block, r1 = min(n_reads, r0 + per_block);
+    const uint32_t floor_ = small ? SMALL_RESULT : 0u;  // a row exists when the result has more colours than this
     for (uint32_t w = threadIdx.x; w < W; w += blockDim.x) {
         uint32_t acc[32];
 #pragma unroll
         for (int b = 0; b < 32; ++b) acc[b] = 0;
         uint64_t r = r0;
         for (; r + 4 <= r1; r += 4) {
-            const uint32_t x0 = bitmap[r * W + w], x1 = bitmap[(r + 1) * W + w], x2 = bitmap[(r + 2) * W + w],
-                           x3 = bitmap[(r + 3) * W + w];
+            const uint32_t x0 = counts[r] > floor_ ? bitmap[r * W + w] : 0u, x1 = counts[r + 1] > floor_ ? bitmap[(r + 1) * W + w] : 0u,
+                           x2 = counts[r + 2] > floor_ ? bitmap[(r + 2) * W + w] : 0u, x3 = counts[r + 3] > floor_ ? bitmap[(r + 3) * W + w] : 0u;
 #pragma unroll
             for (int b = 0; b < 32; ++b) acc[b] += ((x0 >> b) & 1u) + ((x1 >> b) & 1u) + ((x2 >> b) & 1u) + ((x3 >> b) & 1u);
         }
         for (; r < r1; ++r) {
-            const uint32_t x = bitmap[r * W + w];
+            const uint32_t x = counts[r] > floor_ ? bitmap[r * W + w] : 0u;
 #pragma unroll
             for (int b = 0; b < 32; ++b) acc[b] += (x >> b) & 1u;
         }
         uint32_t* dst = partial + ((uint64_t)blockIdx.x * W + w) * 32;
 #pragma unroll
         for (int b = 0; b < 32; ++b) dst[b] = acc[b];
+    }
+}
+
+// the results that travel as colours (1..SMALL_RESULT of them in the read's slot): thread = (read, slot), one atomic per colour
+__global__ __launch_bounds__(256) void k_hits_small(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ small, uint64_t n_reads,
+                                                    unsigned long long* __restrict__ hits) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_reads * SMALL_RESULT; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / SMALL_RESULT;
+        const uint32_t slot = (uint32_t)(i % SMALL_RESULT), cnt = counts[r];
+        if (cnt <= SMALL_RESULT && slot < cnt) atomicAdd(&hits[small[i]], 1ull);
     }
 }
 
@@ -2085,8 +2098,9 @@ __device__ __forceinline__ uint32_t cfmt_word(const uint32_t* row, uint32_t w, u
 __global__ __launch_bounds__(256) void k_cfmt_sizes(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
                                                     uint64_t n_reads, uint32_t W, uint32_t n, uint32_t sparse_thr, uint32_t dense_thr,
                                                     uint32_t first_id, uint32_t* __restrict__ bits,
-                                                    const uint64_t* __restrict__ small_off, const uint32_t* __restrict__ small_colors) {
-    // small_off != nullptr: results of at most SMALL_RESULT colours have no bitmap row; their colours are read from the CSR
+                                                    const uint32_t* __restrict__ small) {
+    // small != nullptr: results of at most SMALL_RESULT colours have no bitmap row; their colours are in their slot of `small`
+    // (the u32 colour lists of the pass are not needed: k2b_expand runs only for consumers of the CSR)
     const int lane = lane_id();
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t r = wave; r < n_reads; r += nwaves) {
@@ -2096,7 +2110,7 @@ __global__ __launch_bounds__(256) void k_cfmt_sizes(const uint32_t* __restrict__
         (void)delta_code(size, l2);
         uint32_t payload = 0;
         if (size == 0) payload = 0;
-        else if (small_off && size <= SMALL_RESULT) payload = cfmt_small_payload<false>(small_colors + small_off[r], size, lane, [](uint32_t, uint32_t) {});
+        else if (small && size <= SMALL_RESULT) payload = cfmt_small_payload<false>(small + r * SMALL_RESULT, size, lane, [](uint32_t, uint32_t) {});
         else if (size >= sparse_thr && size < dense_thr) payload = n;
         else {
             const uint32_t* row = bitmap + r * W;
@@ -2137,7 +2151,7 @@ __global__ __launch_bounds__(256) void k_cfmt_write(const uint32_t* __restrict__
                                                     const uint32_t* __restrict__ rec_off,
                                                     const uint32_t* __restrict__ block_bits, const uint64_t* __restrict__ block_off,
                                                     unsigned long long* __restrict__ out, uint32_t cap_words,
-                                                    const uint64_t* __restrict__ small_off, const uint32_t* __restrict__ small_colors) {
+                                                    const uint32_t* __restrict__ small) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
     const int lane = lane_id();
     unsigned long long* buf = (unsigned long long*)smem_c + (size_t)(threadIdx.x >> 6) * cap_words;
@@ -2171,8 +2185,8 @@ __global__ __launch_bounds__(256) void k_cfmt_write(const uint32_t* __restrict__
         const uint64_t pay = pos0 + l1 + l2;
         const uint32_t* row = bitmap + r * W;
         if (size == 0) {
-        } else if (small_off && size <= SMALL_RESULT) {  // (as in k_cfmt_sizes)
-            cfmt_small_payload<true>(small_colors + small_off[r], size, lane, [&](uint32_t gap, uint32_t at) {
+        } else if (small && size <= SMALL_RESULT) {  // (as in k_cfmt_sizes)
+            cfmt_small_payload<true>(small + r * SMALL_RESULT, size, lane, [&](uint32_t gap, uint32_t at) {
                 uint32_t len;
                 const uint64_t code = delta_code(gap, len);
                 put(pay + at, code, len);
@@ -2204,6 +2218,26 @@ __global__ __launch_bounds__(256) void k_cfmt_write(const uint32_t* __restrict__
             }
             wave_lds_sync();
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A batch of the streaming worker loop is uploaded range by range as the reader's threads parsed it: the offsets of a range
+// count from the range's first base. This adds the position of the range inside the batch (up to REBASE_RANGES ranges per launch).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t REBASE_RANGES = 64;
+struct RebaseTable {
+    uint64_t first_read[REBASE_RANGES + 1];  // reads [first_read[c], first_read[c + 1]) belong to range c
+    uint64_t base[REBASE_RANGES];            // position of the range's first base in the batch
+    uint32_t count;
+};
+__global__ __launch_bounds__(256) void k_offs_rebase(uint64_t* __restrict__ offs, RebaseTable t) {
+    // offs[r + 1] = end of read r
+    const uint64_t r0 = t.first_read[0], r1 = t.first_read[t.count];
+    for (uint64_t r = r0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < r1; r += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t c = 0;
+        while (c + 1 < t.count && r >= t.first_read[c + 1]) ++c;
+        offs[r + 1] += t.base[c];
     }
 }
 

@@ -20,7 +20,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -34,17 +36,172 @@
 
 namespace fg {
 
+// ---- host buffers of the reader: pinned when the engine is there --------------------------------------------------------
+// Parsed reads are written ONCE, by the thread that parses them, into the buffer the GPU's copy engine reads from (H2D copies out
+// of pinned host memory run at PCIe speed and asynchronously; out of pageable memory the runtime stages them through a bounce
+// buffer). The engine installs the allocator (hipHostMalloc) when it opens an index on a device; host-only tools, the CPU tests
+// and the sanitizer builds keep malloc. Pinning costs tens of microseconds per megabyte, so released buffers wait in a
+// process-wide pool for the next chunk, reader or run; what is still pooled at exit goes with the process.
+struct HostAllocHooks {
+    void* (*alloc)(size_t bytes, bool* pinned) = nullptr;  // nullptr: malloc
+    void (*release)(void* p, bool pinned) = nullptr;
+};
+inline HostAllocHooks& host_alloc_hooks() { static HostAllocHooks h; return h; }
+
+class SlabPool {
+public:
+    static SlabPool& get() { static SlabPool* p = new SlabPool(); return *p; }  // (never destroyed: no calls into HIP at exit)
+    // a buffer of at least `want` bytes: the smallest pooled one that fits (and is not wastefully large), else a new one
+    void* take(size_t want, size_t& got, bool& pinned) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            size_t best = free_.size();
+            for (size_t i = 0; i < free_.size(); ++i)
+                if (free_[i].bytes >= want && free_[i].bytes <= 4 * want + (1u << 20) && (best == free_.size() || free_[i].bytes < free_[best].bytes)) best = i;
+            if (best < free_.size()) {
+                const Slab sl = free_[best];
+                free_[best] = free_.back();
+                free_.pop_back();
+                held_ -= sl.bytes;
+                got = sl.bytes;
+                pinned = sl.pinned;
+                return sl.p;
+            }
+        }
+        const HostAllocHooks& h = host_alloc_hooks();
+        void* p = nullptr;
+        pinned = false;
+        if (h.alloc) p = h.alloc(want, &pinned);
+        if (!p) { p = malloc(want); pinned = false; }
+        if (!p) throw std::bad_alloc();
+        got = want;
+        return p;
+    }
+    void give(void* p, size_t bytes, bool pinned) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (held_ + bytes <= MAX_BYTES && free_.size() < MAX_SLABS) {
+                free_.push_back(Slab{p, bytes, pinned});
+                held_ += bytes;
+                return;
+            }
+        }
+        const HostAllocHooks& h = host_alloc_hooks();
+        if (pinned && h.release) h.release(p, true); else free(p);
+    }
+
+private:
+    struct Slab { void* p; size_t bytes; bool pinned; };
+    static constexpr size_t MAX_BYTES = (size_t)3 << 30, MAX_SLABS = 1024;
+    std::mutex mu_;
+    std::vector<Slab> free_;
+    size_t held_ = 0;
+};
+
+// grow-only array of PODs in a pooled (pinned) buffer; move-only
+template <typename T>
+class HostVec {
+public:
+    HostVec() {}
+    HostVec(HostVec&& o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_), bytes_(o.bytes_), pinned_(o.pinned_) { o.p_ = nullptr; o.n_ = o.cap_ = o.bytes_ = 0; }
+    HostVec& operator=(HostVec&& o) noexcept {
+        if (this != &o) {
+            release();
+            p_ = o.p_; n_ = o.n_; cap_ = o.cap_; bytes_ = o.bytes_; pinned_ = o.pinned_;
+            o.p_ = nullptr; o.n_ = o.cap_ = o.bytes_ = 0;
+        }
+        return *this;
+    }
+    HostVec(const HostVec&) = delete;
+    HostVec& operator=(const HostVec&) = delete;
+    ~HostVec() { release(); }
+    void release() {
+        if (p_) SlabPool::get().give(p_, bytes_, pinned_);
+        p_ = nullptr;
+        n_ = cap_ = bytes_ = 0;
+    }
+    T* data() { return p_; }
+    const T* data() const { return p_; }
+    size_t size() const { return n_; }
+    size_t capacity() const { return cap_; }
+    bool pinned() const { return pinned_; }
+    void clear() { n_ = 0; }
+    void set_size(size_t n) { n_ = n; }  // (n <= capacity)
+    T& operator[](size_t i) { return p_[i]; }
+    const T& operator[](size_t i) const { return p_[i]; }
+    T& back() { return p_[n_ - 1]; }
+    void reserve(size_t want) {
+        if (want <= cap_) return;
+        const size_t ask = std::max(want + want / 4, (size_t)(1u << 16) / sizeof(T));
+        size_t got = 0;
+        bool pin = false;
+        T* q = (T*)SlabPool::get().take(ask * sizeof(T) + 1024, got, pin);  // + slack: the lookup kernel's over-read of padded reads is copied along
+        if (n_) memcpy(q, p_, n_ * sizeof(T));
+        const size_t keep = n_;
+        release();
+        p_ = q;
+        n_ = keep;
+        bytes_ = got;
+        cap_ = (got - 1024) / sizeof(T);
+        pinned_ = pin;
+    }
+    void push_back(const T& v) {
+        if (n_ == cap_) reserve(n_ + 1);
+        p_[n_++] = v;
+    }
+    void append(const T* s, size_t n) {
+        if (n_ + n > cap_) reserve(n_ + n);
+        memcpy(p_ + n_, s, n * sizeof(T));
+        n_ += n;
+    }
+    void resize(size_t n) {  // (new elements are not initialised)
+        reserve(n);
+        n_ = n;
+    }
+    void assign(size_t n, const T& v) {
+        reserve(n);
+        for (size_t i = 0; i < n; ++i) p_[i] = v;
+        n_ = n;
+    }
+
+private:
+    T* p_ = nullptr;
+    size_t n_ = 0, cap_ = 0, bytes_ = 0;
+    bool pinned_ = false;
+};
+
 struct FastxChunk {
-    std::vector<char> bases;
-    std::vector<uint64_t> offs{0};
-    std::vector<char> names;  // record names (header up to the first blank, as kseq's name), concatenated
+    HostVec<char> bases;
+    HostVec<uint64_t> offs;   // offs[0] = 0: positions inside `bases`
+    std::vector<char> names;  // record names (header up to the first blank, as kseq's name), concatenated; kept only when asked for
     std::vector<uint64_t> name_offs{0};
+    uint64_t max_len = 0;     // longest read of the chunk
+    bool want_names = true;
+    FastxChunk() { offs.assign(1, 0); }
+    FastxChunk(FastxChunk&&) = default;
+    FastxChunk& operator=(FastxChunk&&) = default;
     uint64_t reads() const { return offs.size() - 1; }
+    // the parser's sink
+    bool any() const { return reads() > 0; }
+    void on_name(const char* s, size_t n) {
+        if (!want_names) return;
+        size_t e = 0;
+        while (e < n && s[e] != ' ' && s[e] != '\t') ++e;
+        names.insert(names.end(), s, s + e);
+        name_offs.push_back(names.size());
+    }
+    void on_seq(const char* s, size_t n) { bases.append(s, n); }
+    void on_record(uint64_t len) {
+        offs.push_back(bases.size());
+        if (len > max_len) max_len = len;
+    }
     void clear() {
         bases.clear();
         offs.assign(1, 0);
         names.clear();
         name_offs.assign(1, 0);
+        max_len = 0;
     }
 };
 
@@ -52,30 +209,29 @@ struct FastxChunk {
 // odd (optional): set when the lines did not read as whole records — bit 0: text between a record and the next header, bit 1: a
 // FASTQ record whose quality ends before its sequence does. A byte range of a file that was cut at true record boundaries never shows either;
 // a range cut inside a wrapped FASTQ record does.
-template <typename NextLine, typename Emit>
-void parse_fastx_records(NextLine&& next, FastxChunk& c, Emit&& emit, unsigned* odd = nullptr) {
+// Sink: any() (a record has been seen), on_name(s, n) (the header line without its first character), on_seq(s, n),
+// on_record(len). FastxChunk collects the reads; CountSink only counts them (the same grammar, nothing copied).
+template <typename NextLine, typename Sink, typename Emit>
+void parse_fastx_records(NextLine&& next, Sink& c, Emit&& emit, unsigned* odd = nullptr) {
     const char* s;
     size_t n;
     bool have = next(s, n);
+    bool any = c.any();
     while (have) {
         if (n == 0 || (s[0] != '>' && s[0] != '@')) {  // stray text before a header
-            if (n && odd && c.name_offs.size() > 1) *odd |= 1u;  // (in front of the first header: skipped, as kseq does)
+            if (n && odd && any) *odd |= 1u;  // (in front of the first header: skipped, as kseq does)
             have = next(s, n);
             continue;
         }
-        {
-            size_t e = 1;
-            while (e < n && s[e] != ' ' && s[e] != '\t') ++e;
-            c.names.insert(c.names.end(), s + 1, s + e);
-            c.name_offs.push_back(c.names.size());
-        }
+        any = true;
+        c.on_name(s + 1, n - 1);
         // sequence lines up to the next header or the '+' separator
         uint64_t len = 0;
         while ((have = next(s, n)) && !(n && (s[0] == '>' || s[0] == '@' || s[0] == '+'))) {
-            c.bases.insert(c.bases.end(), s, s + n);
+            c.on_seq(s, n);
             len += n;
         }
-        c.offs.push_back(c.bases.size());
+        c.on_record(len);
         if (have && s[0] == '+') {  // quality: as many characters as bases (may itself start with '@')
             uint64_t q = 0;
             while (q < len && (have = next(s, n))) q += n;
@@ -85,6 +241,14 @@ void parse_fastx_records(NextLine&& next, FastxChunk& c, Emit&& emit, unsigned* 
         if (!emit(c)) return;
     }
 }
+
+struct CountSink {
+    uint64_t n = 0;
+    bool any() const { return n > 0; }
+    void on_name(const char*, size_t) {}
+    void on_seq(const char*, size_t) {}
+    void on_record(uint64_t) { ++n; }
+};
 
 // What the head of a FASTA / FASTQ text says about cutting it into byte ranges. kind: the first character of the first line
 // that starts with '>' or '@' (kseq skips whatever stands in front of it), 0 if there is none. Returns false when the text
@@ -143,7 +307,24 @@ public:
     virtual ~FastxSource() {}
     virtual bool pop(FastxChunk& c) = 0;  // next chunk in file order; false at end of file
     virtual void recycle(FastxChunk&& c) = 0;
+    // number of records of the whole source by a walk over the record grammar that copies nothing, without consuming the
+    // source; false: this source cannot (a stream has to be read to be counted)
+    virtual bool count_records(unsigned, uint64_t&) { return false; }
+    // record names are collected unless nobody will ask for them (the pseudoalignment loop never does)
+    void set_want_names(bool on) { want_names_.store(on); }
+    // what the parser threads spent (summed over the threads): nanoseconds parsing ranges, nanoseconds waiting because the
+    // consumer was `window` ranges behind, text bytes and ranges parsed
+    struct Stats { uint64_t parse_ns = 0, wait_ns = 0, bytes = 0, ranges = 0; unsigned threads = 0; };
+    Stats stats() const { return Stats{parse_ns_.load(), wait_ns_.load(), bytes_.load(), ranges_.load(), nthreads_}; }
+
+protected:
+    std::atomic<bool> want_names_{true};
+    std::atomic<uint64_t> parse_ns_{0}, wait_ns_{0}, bytes_{0}, ranges_{0};
+    unsigned nthreads_ = 1;
 };
+inline uint64_t fastx_now_ns() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // ---- gzip (or anything zlib reads): one background thread ---------------------------------------------------------
 class StreamFastxSource : public FastxSource {
@@ -220,6 +401,7 @@ private:
     void produce() {
         try {
             FastxChunk c;
+            c.want_names = want_names_.load();
             parse_fastx_records([this](const char*& s, size_t& n) { return line(s, n); }, c, [this](FastxChunk& ch) {
                 if (ch.reads() == chunk_reads_) push(ch);
                 std::lock_guard<std::mutex> g(m_);
@@ -250,6 +432,7 @@ private:
             c = std::move(pool_.back());
             pool_.pop_back();
         }
+        c.want_names = want_names_.load();
     }
 
     gzFile f_ = nullptr;
@@ -342,6 +525,7 @@ protected:
         end_ = std::min(end, size_);
         num_ranges_ = begin_ < end_ ? (end_ - begin_ + range_ - 1) / range_ : 0;
         window_ = 2 * std::max(1u, threads) + 2;
+        nthreads_ = std::max(1u, threads);
         for (unsigned t = 0; t < std::max(1u, threads) && t < num_ranges_; ++t) workers_.emplace_back([this] { work(); });
     }
     void shutdown() {
@@ -403,10 +587,62 @@ protected:
         }
     }
 
+    // records that start in range r: bytes [lo, hi), both ends at record boundaries, made available
+    void range_bounds(uint64_t r, uint64_t& lo, uint64_t& hi) {
+        lo = boundary(begin_ + r * range_);
+        hi = r + 1 == num_ranges_ ? (end_ == size_ ? size_ : boundary(end_)) : boundary(begin_ + (r + 1) * range_);
+        ensure(lo, hi);
+    }
+
+public:
+    bool count_records(unsigned threads, uint64_t& total) override {
+        std::atomic<uint64_t> next{0}, sum{0};
+        std::mutex em;
+        std::string err;
+        auto body = [&] {
+            for (;;) {
+                const uint64_t r = next++;
+                if (r >= num_ranges_) return;
+                try {
+                    uint64_t lo, hi;
+                    range_bounds(r, lo, hi);
+                    uint64_t pos = lo;
+                    CountSink cs;
+                    parse_fastx_records(
+                        [&](const char*& s, size_t& n) {
+                            if (pos >= hi) return false;
+                            const char* nl = (const char*)memchr(map_ + pos, '\n', hi - pos);
+                            s = map_ + pos;
+                            n = nl ? (size_t)(nl - s) : (size_t)(hi - pos);
+                            pos += n + 1;
+                            if (n && s[n - 1] == '\r') --n;
+                            return true;
+                        },
+                        cs, [](CountSink&) { return true; });
+                    sum += cs.n;
+                } catch (std::exception& e) {
+                    std::lock_guard<std::mutex> g(em);
+                    err = e.what();
+                    return;
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        const unsigned nt = (unsigned)std::min<uint64_t>(std::max(1u, threads), std::max<uint64_t>(1, num_ranges_));
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(body);
+        body();
+        for (auto& t : th) t.join();
+        if (!err.empty()) throw std::runtime_error(err);
+        total = sum.load();
+        return true;
+    }
+
+protected:
     void work() {
         for (;;) {
             uint64_t r;
             FastxChunk c;
+            const uint64_t t_wait = fastx_now_ns();
             {
                 std::unique_lock<std::mutex> g(m_);
                 cv_space_.wait(g, [this] { return stop_ || next_in_ >= num_ranges_ || next_in_ < next_out_ + window_; });
@@ -414,13 +650,16 @@ protected:
                 r = next_in_++;
                 if (!pool_.empty()) { c = std::move(pool_.back()); pool_.pop_back(); }
             }
+            const uint64_t t_parse = fastx_now_ns();
+            wait_ns_ += t_parse - t_wait;
             try {
-                const uint64_t lo = boundary(begin_ + r * range_);
-                const uint64_t hi = r + 1 == num_ranges_ ? (end_ == size_ ? size_ : boundary(end_)) : boundary(begin_ + (r + 1) * range_);
-                ensure(lo, hi);
+                uint64_t lo, hi;
+                range_bounds(r, lo, hi);
                 uint64_t pos = lo;
                 unsigned odd = 0;
-                c.bases.reserve((hi - lo) / 2 + 64);
+                c.want_names = want_names_.load();
+                c.bases.reserve(kind_ == '@' ? (hi - lo) / 2 + 64 : hi - lo);  // (a FASTQ record spends as many bytes on qualities as on bases)
+                c.offs.reserve((hi - lo) / 256 + 16);
                 parse_fastx_records(
                     [&](const char*& s, size_t& n) {
                         if (pos >= hi) return false;
@@ -436,10 +675,13 @@ protected:
                 if ((odd & 1u) || ((odd & 2u) && hi != size_))  // (a quality cut short by the end of the text is the file's business)
                     throw std::runtime_error("the query file does not parse as whole records in byte ranges (FASTQ with wrapped lines behind "
                                              "a four-line head?): bytes " + std::to_string(lo) + " to " + std::to_string(hi));
+                bytes_ += hi - lo;
             } catch (std::exception& e) {
                 std::lock_guard<std::mutex> g(m_);
                 error_ = e.what();
             }
+            parse_ns_ += fastx_now_ns() - t_parse;
+            ranges_ += 1;
             {
                 std::lock_guard<std::mutex> g(m_);
                 done_[r] = std::move(c);
@@ -776,14 +1018,15 @@ inline bool is_gzip_file(const std::string& path) {
 class FastxReader {
 public:
     explicit FastxReader(const std::string& path, unsigned threads = 0, uint64_t begin = 0, uint64_t end = ~0ULL) {
-        if (threads == 0) threads = std::min(32u, std::max(1u, std::thread::hardware_concurrency() / 2));
+        if (threads == 0) threads = default_threads();
         threads_ = threads;
+        const uint64_t range_bytes = default_range_bytes();
         if (is_gzip_file(path)) {
             if (is_bgzf_file(path)) {
                 // (a block-compressed FASTQ with wrapped lines cannot be cut into ranges: read whole, it falls back to the one-stream
                 // reader, which takes block-compressed files as any gzip reader does; parts of it stay an error)
                 try {
-                    src_.reset(new BgzfFastxSource(path, threads, begin, end));
+                    src_.reset(new BgzfFastxSource(path, threads, begin, end, range_bytes));
                 } catch (const std::runtime_error& e) {
                     if (begin != 0 || end != ~0ULL || std::string(e.what()).find("wrapped lines") == std::string::npos) throw;
                     src_.reset(new StreamFastxSource(path));
@@ -797,14 +1040,42 @@ public:
         } else {
             // FASTQ with wrapped lines (records that are not four lines long) offers no record boundaries to guess: one stream,
             // kseq's full grammar, as the reference reads it
-            if (fastx_file_rangeable(path)) src_.reset(new MappedFastxSource(path, threads, begin, end));
+            if (fastx_file_rangeable(path)) src_.reset(new MappedFastxSource(path, threads, begin, end, range_bytes));
             else if (begin == 0 && end == ~0ULL) src_.reset(new StreamFastxSource(path));
             else throw std::runtime_error("a FASTQ file with wrapped lines cannot be read in parts");
         }
     }
-    // Bases: clear(), reserve(bytes), data(), set_size(bytes)
-    template <typename Bases>
-    bool next(uint64_t max_reads, Bases& bases, std::vector<uint64_t>& offs) {
+    // parser threads when the caller names none: half of the host's hardware threads, at most 32 (FULGOR_READER_THREADS overrides);
+    // the multi-GPU driver divides them among the ranks of a host
+    static unsigned default_threads() {
+        if (const char* e = getenv("FULGOR_READER_THREADS")) { const long v = atol(e); if (v > 0) return (unsigned)std::min<long>(v, 1024); }
+        return std::min(32u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    }
+    // bytes of text per parsed range (= per chunk handed to the worker loop; FULGOR_READER_RANGE_KB overrides)
+    static uint64_t default_range_bytes() {
+        if (const char* e = getenv("FULGOR_READER_RANGE_KB")) { const long v = atol(e); if (v >= 4) return (uint64_t)v << 10; }
+        return 8u << 20;
+    }
+    // Chunk-level access for a worker loop that uploads the parsed ranges as they are (no second copy on the host): the next
+    // non-empty chunk in file order, false at the end. Not to be mixed with next() on the same reader.
+    bool pop_chunk(FastxChunk& c) {
+        while (src_->pop(c)) {
+            if (c.reads()) return true;
+            src_->recycle(std::move(c));
+            c = FastxChunk();
+        }
+        return false;
+    }
+    void recycle_chunk(FastxChunk&& c) { src_->recycle(std::move(c)); }
+    FastxSource::Stats stats() const { return src_->stats(); }
+    // records of this reader's part, counted by a walk over the record grammar (nothing copied, nothing consumed); false for a
+    // source that has to be read to be counted (ordinary gzip, FASTQ with wrapped lines)
+    bool count_records(uint64_t& n) { return src_->count_records(threads_, n); }
+    void set_want_names(bool on) { src_->set_want_names(on); }
+    unsigned threads() const { return threads_; }
+    // Bases: clear(), reserve(bytes), data(), set_size(bytes); Offs: resize(n), data(), operator[]
+    template <typename Bases, typename Offs>
+    bool next(uint64_t max_reads, Bases& bases, Offs& offs) {
         // the chunks of the previous batch go back to the source; a partly used one stays in front
         for (size_t i = 0; i + (cur_partial_ ? 1 : 0) < held_.size(); ++i) src_->recycle(std::move(held_[i]));
         if (cur_partial_) {

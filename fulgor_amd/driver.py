@@ -240,49 +240,83 @@ def rank_env():
     return rank, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", str(rank)))
 
 
+def reader_threads_per_rank(io_threads, world):
+    """parser threads of one rank: what the caller named, else half of the host's hardware threads divided among the ranks that
+    share the host (at most 32 per rank, at least 2)"""
+    if io_threads:
+        return int(io_threads)
+    import os
+    hw = os.cpu_count() or 2
+    return max(2, min(32, hw // (2 * max(1, world))))
+
+
+def _place_part(part, output, offset):
+    """copy the file `part` into `output` at byte `offset` (every rank places its own part: the joins run side by side)"""
+    import os
+    with open(part, "rb") as src, open(output, "r+b") as dst:
+        size = os.fstat(src.fileno()).st_size
+        done = 0
+        while done < size:
+            try:
+                k = os.copy_file_range(src.fileno(), dst.fileno(), min(size - done, 1 << 30), done, offset + done)
+            except (OSError, AttributeError):
+                k = 0
+            if k <= 0:  # (file systems without copy_file_range: through user space)
+                buf = os.pread(src.fileno(), min(size - done, 64 << 20), done)
+                os.pwrite(dst.fileno(), buf, offset + done)
+                k = len(buf)
+            done += k
+    os.remove(part)
+
+
 def pseudoalign_sharded(open_index, query, output, algo=FULL_INTERSECTION, threshold=0.0, fmt="ascii", rank=0, world=1,
                         io_threads=0, device_for_reduce=None, batch=1 << 19):
     """One rank of a multi-GPU `pseudoalign`. Reads are independent units (tools/pseudoalign.cpp:22-51 keeps no state across
-    reads but two counters): rank r parses and processes the records that start in the r-th of `world` byte ranges of the
-    (plain) query file, numbers them in file order (the ranks exchange the record counts of their parts), writes
-    <output>.part<r>, and the two counters are all-reduced (RCCL when the tensor lives on a GPU, gloo on the CPU). Rank 0 then
-    concatenates the parts in rank order = read-id order. open_index() opens this rank's replica of the index.
+    reads but two counters): rank r opens the r-th of `world` byte ranges of the (plain or block-compressed) query file ONCE,
+    counts its records by a walk over the record boundaries that copies nothing (fgpu_fastx_count_part), the ranks exchange
+    the counts (read ids are file order), and every rank streams its part through the native worker loop
+    (fgpu_pseudoalign_stream). Rank 0 writes straight into the output file, the others into <output>.part<r>; the sizes are
+    exchanged and every rank places its own part (the joins run side by side); the two counters are all-reduced (RCCL when
+    the tensor lives on a GPU, gloo on the CPU). open_index() opens this rank's replica of the index.
     returns (num_reads, num_mapped_reads) of the whole job."""
     import os
-    import shutil
-    import torch
-    import torch.distributed as dist
-    from .reads import FastxReader, count_reads, text_size
-    size, in_parts = text_size(query)
-    if world > 1 and not in_parts:
-        raise ValueError("the query file cannot be read in parts (a gzip stream, or FASTQ with wrapped lines): for a multi-GPU run "
-                         "decompress it or compress it in blocks (bgzip); unwrap the FASTQ records to four lines")
-    begin, end = size * rank // world, size * (rank + 1) // world
+    from .reads import FastxReader, text_size
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        size, in_parts = text_size(query)
+        if not in_parts:
+            raise ValueError("the query file cannot be read in parts (a gzip stream, or FASTQ with wrapped lines): for a multi-GPU run "
+                             "decompress it or compress it in blocks (bgzip); unwrap the FASTQ records to four lines")
+        begin, end = size * rank // world, size * (rank + 1) // world
+    else:
+        begin, end = 0, (1 << 64) - 1
+    batches = FastxReader(query, batch=batch, copy=False, threads=reader_threads_per_rank(io_threads, world), begin=begin, end=end)
     first_id = 0
     if world > 1:
-        mine = torch.tensor([count_reads(query, begin, end, io_threads)], dtype=torch.int64, device=device_for_reduce)
+        mine = torch.tensor([batches.count()], dtype=torch.int64, device=device_for_reduce)
         counts = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(counts, mine)
         first_id = int(sum(int(c.item()) for c in counts[:rank]))
     index = open_index()
-    batches = FastxReader(query, batch=batch, copy=False, threads=io_threads, begin=begin, end=end if world > 1 else (1 << 64) - 1)
-    part = output if world == 1 else "%s.part%d" % (output, rank)
+    part = output if rank == 0 else "%s.part%d" % (output, rank)
     with open(part, "wb") as out:
-        n, mapped = pseudoalign_stream(index, batches, algo, threshold, sink=out, fmt=fmt, first_id=first_id,
-                                       write_header=rank == 0)
+        if hasattr(index, "pseudoalign_stream"):  # the engine: the native worker loop
+            out.flush()
+            n, mapped = index.pseudoalign_stream(batches, out.fileno(), algo, threshold, FORMATS[fmt], first_id, rank == 0, batch)
+        else:  # (an index that is not the engine's: the CPU tests of this sharding logic)
+            n, mapped = pseudoalign_stream(index, batches, algo, threshold, sink=out, fmt=fmt, first_id=first_id,
+                                           write_header=rank == 0)
     batches.close()
     if world > 1:
         t = torch.tensor([n, mapped], dtype=torch.int64, device=device_for_reduce)
         dist.all_reduce(t)
         n, mapped = int(t[0].item()), int(t[1].item())
-        dist.barrier()
-        if rank == 0:
-            with open(output, "wb") as out:
-                for r in range(world):
-                    p = "%s.part%d" % (output, r)
-                    with open(p, "rb") as src:
-                        shutil.copyfileobj(src, out, 64 << 20)
-                    os.remove(p)
+        mine = torch.tensor([os.path.getsize(part)], dtype=torch.int64, device=device_for_reduce)
+        sizes = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(sizes, mine)  # (every part is complete when this returns)
+        if rank > 0:
+            _place_part(part, output, int(sum(int(x.item()) for x in sizes[:rank])))
         dist.barrier()
     return n, mapped
 

@@ -15,7 +15,7 @@ from . import _native
 FULL_INTERSECTION = 0
 THRESHOLD_UNION = 1
 HYBRID, DIFF, META, META_DIFF = 0, 1, 2, 3  # index_t, include/util.hpp:18
-KERNELS = ("k1_lookup", "k2_intersect", "k3_union", "scan", "k2b_expand", "k_hits", "k_desc", "k_format", "k_order")
+KERNELS = ("k1_lookup", "k2_intersect", "k3_union", "scan", "k2b_expand", "k_hits", "k_desc", "k_format", "k_order", "h2d", "d2h")
 
 
 def pack_reads(reads):
@@ -87,6 +87,11 @@ class Result:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         _native.check(self._L.fgpu_result_sizes(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value  # reads, total colours, mapped reads
+
+    def expand(self):
+        """materialise the u32 colour lists (CSR) of the last pass on the device now (k2b_expand); download(), ascii and binary
+        formatting do it on demand, the compressed format and the counters never need them"""
+        _native.check(self._L.fgpu_result_expand(self._h))
 
     def download(self):
         n, total, _ = self.sizes()
@@ -263,6 +268,26 @@ class Index:
     def run_colours(self, result, algo=FULL_INTERSECTION, threshold=0.0):
         """second half of run(): the colour stage over the ids the result holds; returns when its kernels have completed"""
         _native.check(self._L.fgpu_run_colours(self._h, algo, C.c_double(threshold), result._h))
+
+    def pseudoalign_stream(self, reader, out_fd, algo=FULL_INTERSECTION, threshold=0.0, fmt=0, first_read_id=0, write_header=True,
+                           batch=0, workers=0):
+        """the native worker loop (fgpu_pseudoalign_stream; pseudoalign_orchestrator of tools/pseudoalign.cpp:53-89): every record
+        of `reader` (reads.FastxReader, consumed) -> records in format `fmt` on the file descriptor out_fd, in file order.
+        returns (num_reads, num_mapped_reads)"""
+        n, m = C.c_uint64(), C.c_uint64()
+        _native.check(self._L.fgpu_pseudoalign_stream(self._h, reader._h, int(out_fd), int(algo), C.c_double(threshold), int(fmt),
+                                                      int(first_read_id), 1 if write_header else 0, int(batch), int(workers),
+                                                      C.byref(n), C.byref(m)))
+        return n.value, m.value
+
+    def last_stream_report(self):
+        """timeline of the last pseudoalign_stream of this process (text)"""
+        p = C.c_void_p()
+        _native.check(self._L.fgpu_last_stream_report(C.byref(p)))
+        try:
+            return C.string_at(p.value).decode()
+        finally:
+            self._L.fgpu_free(p)
 
     def tune(self, order_min_reads=None, small_results=None, dense_rows=None):
         """execution knobs of the colour stage (fgpu_tune); results never depend on them"""

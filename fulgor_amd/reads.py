@@ -146,6 +146,13 @@ class FastxReader:
         bases = np.frombuffer((C.c_ubyte * max(total, 1)).from_address(pb.value), dtype=np.uint8)[:total]
         return bases, offs
 
+    def count(self):
+        """records of this reader's part, counted without consuming it (fgpu_fastx_count_part: a walk over the record grammar on
+        the reader's threads, nothing copied)"""
+        n = self._C.c_uint64()
+        self._N.check(self._L.fgpu_fastx_count_part(self._h, self._C.byref(n)))
+        return n.value
+
     def names(self):
         """names of the records of the batch returned last (header up to the first blank), as a list of str"""
         C = self._C

@@ -94,7 +94,10 @@ void fgpu_reads_free(fgpu_reads* reads);
 int fgpu_result_create(fgpu_index* idx, fgpu_result** out);
 void fgpu_result_free(fgpu_result* res);
 /* one pass of the hot path over reads [first, first+count) of an uploaded batch; results replace the
- * previous contents of `res`. Returns after the kernels have completed. */
+ * previous contents of `res`. Returns after the kernels have completed. A pass leaves every result as a row of colour bits (or, up
+ * to 16 colours, as the colours) plus its size: what the counters and the compressed formatter need (src/ps_utils.cpp:168-237).
+ * The u32 colour lists — the `colors` vector of tools/pseudoalign.cpp:27-36 — are materialised when a consumer asks for them:
+ * fgpu_result_expand, fgpu_result_download, ascii / binary formatting and the host-buffer calls above. */
 int fgpu_run(fgpu_index* idx, const fgpu_reads* reads, uint64_t first, uint64_t count, int algo, double tau,
              fgpu_result* res);
 /* The same pass in its two halves, for a worker loop that keeps two results in flight (pseudoalign_worker's loop over batches,
@@ -104,9 +107,13 @@ int fgpu_run(fgpu_index* idx, const fgpu_reads* reads, uint64_t first, uint64_t 
  * batch run beside the colour stage of the batch before it; with FULGOR_CU_SPLIT=<n> in the environment when the results are
  * created the two run on disjoint parts of the device (the lookup kernels on CUs [0, n), the colour kernels on the others; a measurement
  * knob: every kernel of the pass scales with the CUs it gets). The reads and the result must stay alive until
- * fgpu_run_colours (or any other call that waits for the result's stream) has returned. */
+ * fgpu_run_colours (or any other call that waits for the result's stream) has returned (fgpu_reads_free itself waits for the
+ * lookups queued on the reads). */
 int fgpu_run_lookup(fgpu_index* idx, const fgpu_reads* reads, uint64_t first, uint64_t count, fgpu_result* res);
 int fgpu_run_colours(fgpu_index* idx, int algo, double tau, fgpu_result* res);
+/* materialises the CSR colour lists of the last pass on the device now (idempotent; the per-colour hit histogram of the pass is
+ * taken along). bench.py calls it inside the timed region: the metric is quoted on passes that end in u32 colour lists. */
+int fgpu_result_expand(fgpu_result* res);
 /* ps_options counters (src/ps_utils.cpp:417-448): reads processed / reads with a non-empty result */
 int fgpu_result_sizes(const fgpu_result* res, uint64_t* num_reads, uint64_t* total_colors, uint64_t* num_mapped);
 int fgpu_result_download(const fgpu_result* res, uint64_t* offsets /* n+1 */, uint32_t* colors /* total */);
@@ -136,9 +143,10 @@ int fgpu_result_algorithmic_bytes(const fgpu_result* res, uint64_t* list_bytes, 
 enum { FGPU_TUNE_ORDER_MIN_READS = 0, FGPU_TUNE_SMALL_RESULTS = 1, FGPU_TUNE_DENSE_ROWS = 2 };
 int fgpu_tune(fgpu_index* idx, int knob, uint64_t value);
 
-/* per-kernel HIP-event timing on the engine's stream */
+/* per-kernel HIP-event timing on the engine's stream (FGPU_K_H2D / FGPU_K_D2H: the copies of the streaming worker loop and of
+ * the device-side formatters, bracketed the same way) */
 enum { FGPU_K_LOOKUP = 0, FGPU_K_INTERSECT = 1, FGPU_K_UNION = 2, FGPU_K_SCAN = 3, FGPU_K_EXPAND = 4,
-       FGPU_K_HITS = 5, FGPU_K_DESC = 6, FGPU_K_FORMAT = 7, FGPU_K_ORDER = 8, FGPU_K_COUNT = 9 };
+       FGPU_K_HITS = 5, FGPU_K_DESC = 6, FGPU_K_FORMAT = 7, FGPU_K_ORDER = 8, FGPU_K_H2D = 9, FGPU_K_D2H = 10, FGPU_K_COUNT = 11 };
 int fgpu_timing_enable(fgpu_index* idx, int on);
 int fgpu_timing_reset(fgpu_index* idx);
 int fgpu_timing_get(fgpu_index* idx, int kernel, double* total_ms, uint64_t* launches);
@@ -174,6 +182,10 @@ int fgpu_fastx_open(const char* path, fgpu_fastx** out);
 int fgpu_fastx_open_part(const char* path, unsigned threads, uint64_t begin, uint64_t end, fgpu_fastx** out);
 int fgpu_fastx_text_size(const char* path, uint64_t* size, int* can_be_read_in_parts);
 int fgpu_fastx_count(const char* path, unsigned threads, uint64_t begin, uint64_t end, uint64_t* num_reads);
+/* number of records of an open reader's part, by a walk over the record grammar on the reader's threads that copies nothing and
+ * does not consume the reader: the ranks of a multi-GPU run open their part ONCE, count it, exchange the counts (read ids are
+ * file order) and then stream it. Fails for a source that has to be read to be counted (ordinary gzip, wrapped FASTQ). */
+int fgpu_fastx_count_part(fgpu_fastx* f, uint64_t* num_reads);
 int fgpu_fastx_next(fgpu_fastx* f, uint64_t max_reads, const char** bases, const uint64_t** offs, uint64_t* n);
 /* names of the records of the last batch (kseq's name: the header up to the first blank), concatenated + (n + 1) offsets;
  * same lifetime as the batch */
@@ -182,6 +194,22 @@ void fgpu_fastx_close(fgpu_fastx* f);
 /* batches of a reader that stay valid at a time (the ring behind fgpu_fastx_next): a worker loop may keep this many minus one
  * passes in flight */
 int fgpu_fastx_ring(void);
+
+/* pseudoalign_orchestrator + pseudoalign_worker (tools/pseudoalign.cpp:12-89) for one query file (or one part of it): every
+ * record of the open reader `query` is pseudoaligned (algo / tau as in fgpu_run) and its result written to the file descriptor
+ * out_fd in `format` (FGPU_FMT_*), records in file order, read ids counting from first_read_id (src/ps_utils.cpp:276,286: read id =
+ * position in the file); write_header != 0 puts the compressed format's 8-byte file header in front. out_fd < 0: nothing is
+ * formatted or written (counters only). Returns when everything is written. The loop keeps `workers` batches of at most
+ * batch_reads reads in flight (0 = defaults: 4 and 2^19): the reader's threads parse byte ranges of the file into pinned
+ * memory, each range goes to the device as it lies, lookup -> colour stage -> device-side formatter -> copy out run per batch on
+ * the batch's own stream, so that the copy in of one batch, the kernels of another and the copy out of a third overlap. The u32
+ * colour lists are not built for the compressed format. num_reads / num_mapped: the two counters of ps_options
+ * (src/ps_utils.cpp:417-448). The reader is consumed; it must not be used with fgpu_fastx_next at the same time. */
+int fgpu_pseudoalign_stream(fgpu_index* idx, fgpu_fastx* query, int out_fd, int algo, double tau, int format, uint64_t first_read_id,
+                            int write_header, uint64_t batch_reads, unsigned workers, uint64_t* num_reads, uint64_t* num_mapped);
+/* timeline of the last fgpu_pseudoalign_stream of this process as text (per batch: when it was acquired from the parser, queued,
+ * through the colour stage, formatted and copied out, written), plus what the parser threads spent; malloc'd: fgpu_free */
+int fgpu_last_stream_report(char** out);
 
 /* Device-side formatting of the last pass of `res` (src/ps_utils.cpp:48-135): the records of reads
  * first_read_id .. first_read_id + n - 1 in file order, ascii ("<id>\t<count>[\t<colour>...]\n") or binary (u32 id, u32

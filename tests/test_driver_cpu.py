@@ -410,10 +410,22 @@ class Index:
     def upload_reads(self, b, o): return Reads(b, o)
     def run(self, reads, res, algo, tau): res.o, res.c = self.orc.full_intersection(reads.b, reads.o, threads=2)
 
+# every rank opens its part of the query file ONCE (one parse; the record count comes from a boundary walk on the same handle)
+from fulgor_amd import _native
+L = _native.lib()
+opens, real_open, real_count = [], L.fgpu_fastx_open_part, L.fgpu_fastx_count
+def counting_open(*a):
+    opens.append(a[0])
+    return real_open(*a)
+def no_second_parse(*a):
+    raise AssertionError("fgpu_fastx_count parses the part a second time")
+L.fgpu_fastx_open_part, L.fgpu_fastx_count = counting_open, no_second_parse
+
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 n, mapped = driver.pseudoalign_sharded(lambda: Index(os.path.join(sys.argv[1], "data", "s10")), sys.argv[2], sys.argv[3],
                                        rank=rank, world=world, io_threads=2, batch=300)
+assert len(opens) == 1, opens
 if rank == 0:
     open(sys.argv[3] + ".counters", "w").write("%d %d" % (n, mapped))
 dist.destroy_process_group()

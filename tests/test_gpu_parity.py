@@ -291,6 +291,47 @@ def test_gpu_hit_counts(s10_gpu, seeded_reads):
     assert got[n] == 2 * 50000 and got[n + 1] == 2 * int((np.diff(go.astype(np.int64)) > 0).sum())
 
 
+@pytest.mark.parametrize("algo,tau", [(fulgor_amd.FULL_INTERSECTION, 0.0), (fulgor_amd.THRESHOLD_UNION, 0.8)])
+def test_colour_lists_are_materialised_only_on_demand(s4546small, colour_stage, algo, tau):
+    """round-4 review, item 2: a pass leaves rows / small-result slots / sizes; the compressed records, the two counters and the
+    per-colour hit vector come from those and the expansion kernel never runs; download (or expand) runs it once, and the hit
+    vector counted from the rows equals the one the expansion kernel's histogram gives. 4546 colours: results of at most 16
+    colours travel as colours, not as rows (both paths of the formatter and of the hit counter)."""
+    import torch
+    from fulgor_amd.driver import Formatter, hit_vector
+    from oracle.pyoracle import parse_compressed
+    ix, _, gen, _, _ = s4546small
+    b, o = gen.generate(500, 30000, 150, 9)
+    n, nr = ix.num_colors(), len(o) - 1
+    with stage(ix, colour_stage):
+        rd, res, res2 = ix.upload_reads(b, o), ix.new_result(), ix.new_result()
+        ix.timing_enable(True)
+        ix.timing_reset()
+        ix.run(rd, res, algo, tau)
+        _, total, mapped = res.sizes()
+        rec = bytes(res.format_view(2, 11))
+        lazy = torch.zeros(n + 2, dtype=torch.int64, device="cuda:0")
+        res.accumulate_hits(lazy.data_ptr())
+        assert ix.timing()["k2b_expand"][1] == 0, "the expansion kernel ran although nobody asked for the colour lists"
+        go, gc = res.download()
+        assert ix.timing()["k2b_expand"][1] == 1
+        go2, gc2 = res.download()  # (materialised once)
+        assert ix.timing()["k2b_expand"][1] == 1 and np.array_equal(gc, gc2)
+        ix.run(rd, res2, algo, tau)
+        res2.expand()
+        folded = torch.zeros(n + 2, dtype=torch.int64, device="cuda:0")
+        res2.accumulate_hits(folded.data_ptr())
+        ix.timing_enable(False)
+    assert total == len(gc) and mapped == int((np.diff(go.astype(np.int64)) > 0).sum())
+    ids, po, pc = parse_compressed(Formatter("compressed", n).header + rec)
+    assert np.array_equal(ids, np.arange(11, 11 + nr, dtype=np.uint32)) and np.array_equal(po, go) and np.array_equal(pc, gc)
+    want = hit_vector(go, gc, n)
+    assert np.array_equal(lazy.cpu().numpy(), want) and np.array_equal(folded.cpu().numpy(), want)
+    sizes = np.diff(go.astype(np.int64))
+    if algo == fulgor_amd.FULL_INTERSECTION:
+        assert ((sizes > 0) & (sizes <= 16)).sum() > 100 and (sizes > 16).sum() > 100  # both kinds of result occur
+
+
 # ---- synthetic salmonella_4546-shaped index (n = 4546: sparse, bitmap and complement lists of real size) ----
 @pytest.fixture(scope="module")
 def s4546(built):
@@ -1007,6 +1048,7 @@ res = ix.new_result()
 n = ix.num_colors()
 for algo, tau in ((fulgor_amd.FULL_INTERSECTION, 0.0), (fulgor_amd.THRESHOLD_UNION, 0.5)):
     ix.run(reads, res, algo, tau)
+    res.expand()  # (the histogram under test is the one the expand kernel keeps; without the lists asked for, k_hits counts from the rows)
     hits = torch.zeros(n + 2, dtype=torch.int64, device="cuda:0")
     res.accumulate_hits(hits.data_ptr())
     go, gc = res.download()
