@@ -134,6 +134,7 @@ struct Timed {
     hipEvent_t a = nullptr, b = nullptr;
     bool on = false;  // (kernel < 0: a launch inside another bracket)
     Timed(fgpu_index* i, fgpu_result* r, int k, bool lookup = false);
+    Timed(fgpu_index* i, fgpu_result* r, int k, hipStream_t on_stream);
     ~Timed() {
         if (on) { (void)hipEventRecord(b, stream); sink->push_back({kernel, a, b}); }
     }
@@ -177,6 +178,11 @@ struct fgpu_result {
     // are the same stream.
     hipStream_t stream_lookup = nullptr;
     hipEvent_t ev_lookup = nullptr;
+    // Copies between pinned host memory and the device go through streams that never run a kernel: behind a kernel on the same
+    // stream the runtime performs a copy with a shader (__amd_rocclr_copyBuffer, seen in the kernel trace), which queues for the CUs
+    // that the lookup and formatter kernels of the other batches occupy; on a kernel-free stream it goes to a copy engine and
+    // runs beside them (profiles/micro/pcie_rates.hip: 80 MB up or down in 1.5 ms beside a kernel that holds every wave slot).
+    hipStream_t stream_in = nullptr, stream_out = nullptr;
     std::vector<fgpu_index::Pending> pending;     // timing events recorded on that stream
     DevBuf d_nids, d_npos, d_idoff, d_ids_pool, d_cnt_pool, d_cursor, d_bitmap, d_counts, d_offsets, d_block_sums,
         d_block_mapped, d_totals, d_colors, d_acct, d_partial, d_tickets, d_idcsr, d_desc, d_kmer_ids, d_scores;
@@ -204,7 +210,8 @@ struct fgpu_result {
     bool have_ids = false;
 };
 
-Timed::Timed(fgpu_index* i, fgpu_result* r, int k, bool lookup) : ix(i), kernel(k), stream(lookup ? r->stream_lookup : r->stream), sink(&r->pending) {
+Timed::Timed(fgpu_index* i, fgpu_result* r, int k, bool lookup) : Timed(i, r, k, lookup ? r->stream_lookup : r->stream) {}
+Timed::Timed(fgpu_index* i, fgpu_result* r, int k, hipStream_t on_stream) : ix(i), kernel(k), stream(on_stream), sink(&r->pending) {
     on = ix->timing && k >= 0;
     if (on) { a = ix->get_event(); b = ix->get_event(); HIP_TRY(hipEventRecord(a, stream)); }
 }
@@ -986,6 +993,8 @@ int fgpu_result_create(fgpu_index* ix, fgpu_result** out) {
             r->stream_lookup = r->stream;
         }
         r->d_totals.ensure(32);
+        HIP_TRY(hipStreamCreateWithFlags(&r->stream_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&r->stream_out, hipStreamNonBlocking));
     });
     if (rc) { delete r; return rc; }
     *out = r;
@@ -1003,6 +1012,8 @@ void fgpu_result_free(fgpu_result* r) {
     if (r->h_totals) (void)hipHostFree(r->h_totals);
     if (r->h_fmt) (void)hipHostFree(r->h_fmt);
     if (r->stream_lookup && r->stream_lookup != r->stream) (void)hipStreamDestroy(r->stream_lookup);
+    if (r->stream_in) (void)hipStreamDestroy(r->stream_in);
+    if (r->stream_out) (void)hipStreamDestroy(r->stream_out);
     if (r->ev_lookup) (void)hipEventDestroy(r->ev_lookup);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     for (auto& p : r->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -1152,11 +1163,14 @@ int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_rea
             HIP_TRY(hipHostMalloc((void**)&res->h_fmt, want, hipHostMallocDefault));
             res->h_fmt_cap = want;
         }
+        HIP_TRY(hipStreamSynchronize(s));  // the records are complete; their copy out runs on the kernel-free stream (a copy engine)
         if (bytes) {
-            Timed t(ix, res, FGPU_K_D2H);
-            HIP_TRY(hipMemcpyAsync(res->h_fmt, res->d_fmt_out.p, bytes, hipMemcpyDeviceToHost, s));
+            {
+                Timed t(ix, res, FGPU_K_D2H, res->stream_out);
+                HIP_TRY(hipMemcpyAsync(res->h_fmt, res->d_fmt_out.p, bytes, hipMemcpyDeviceToHost, res->stream_out));
+            }
+            HIP_TRY(hipStreamSynchronize(res->stream_out));
         }
-        HIP_TRY(hipStreamSynchronize(s));
         if (ix->timing) ix->collect_timing(res->pending);
         *out = res->h_fmt ? res->h_fmt : "";
         *out_len = bytes;

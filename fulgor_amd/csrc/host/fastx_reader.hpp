@@ -24,6 +24,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -456,6 +457,8 @@ public:
     MappedFastxSource(const std::string& path, unsigned threads, uint64_t begin = 0, uint64_t end = ~0ULL,
                       uint64_t range_bytes = 8u << 20)
         : range_(range_bytes) {
+        const uint64_t t_0 = fastx_now_ns();
+        struct Trace { uint64_t t0; ~Trace() { if (getenv("FULGOR_TRACE_READER")) fprintf(stderr, "[reader] MappedFastxSource constructed in %.2f ms\n", (fastx_now_ns() - t0) / 1e6); } } trace{t_0};
         fd_ = open(path.c_str(), O_RDONLY);
         if (fd_ < 0) throw std::runtime_error("cannot open " + path);
         struct stat st;
@@ -489,7 +492,7 @@ public:
         done_.erase(next_out_);
         const uint64_t r = next_out_++;
         g.unlock();
-        cv_space_.notify_all();
+        cv_space_.notify_one();  // one range left the window: one parser thread may take the next (waking all of them for one slot costs 70 us per pop on a 64-thread pool)
         consumed(r);
         return true;
     }
@@ -526,7 +529,9 @@ protected:
         num_ranges_ = begin_ < end_ ? (end_ - begin_ + range_ - 1) / range_ : 0;
         window_ = 2 * std::max(1u, threads) + 2;
         nthreads_ = std::max(1u, threads);
+        const uint64_t t_th = fastx_now_ns();
         for (unsigned t = 0; t < std::max(1u, threads) && t < num_ranges_; ++t) workers_.emplace_back([this] { work(); });
+        if (getenv("FULGOR_TRACE_READER")) fprintf(stderr, "[reader] %zu parser threads started in %.2f ms\n", workers_.size(), (fastx_now_ns() - t_th) / 1e6);
     }
     void shutdown() {
         {
@@ -1018,6 +1023,8 @@ inline bool is_gzip_file(const std::string& path) {
 class FastxReader {
 public:
     explicit FastxReader(const std::string& path, unsigned threads = 0, uint64_t begin = 0, uint64_t end = ~0ULL) {
+        const uint64_t t_0 = fastx_now_ns();
+        struct Trace { uint64_t t0; ~Trace() { if (getenv("FULGOR_TRACE_READER")) fprintf(stderr, "[reader] FastxReader constructed in %.2f ms\n", (fastx_now_ns() - t0) / 1e6); } } trace{t_0};
         if (threads == 0) threads = default_threads();
         threads_ = threads;
         const uint64_t range_bytes = default_range_bytes();

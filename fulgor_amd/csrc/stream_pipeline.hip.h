@@ -29,7 +29,7 @@ struct StreamBatch {
 
 struct StreamBatchLog {
     uint64_t seq, reads, bases, out_bytes;
-    uint64_t t_begin, t_acquired, t_issued, t_colours, t_formatted, t_turn, t_written;  // ns since the start of the run
+    uint64_t t_begin, t_acquired, t_copied, t_issued, t_colours, t_formatted, t_turn, t_written;  // ns since the start of the run
 };
 
 // what a worker keeps between runs (device buffers sized for one batch, a result = a stream): allocating and freeing device
@@ -134,12 +134,24 @@ void stream_one_batch(StreamRun& run, StreamWorkerState& w, StreamBatch& b, Stre
         if (fgpu_reads_upload(ix, bases.data(), offs.data(), b.reads, &uploaded)) throw std::runtime_error(fgpu_last_error());
         reads = uploaded;
     } else {
-        hipStream_t s = res->stream_lookup;
+        hipStream_t s = res->stream_lookup, sin = res->stream_in;
         w.d_bases.ensure(b.bases + 1024);  // the lookup kernel reads up to 576 bases past a unit's start unconditionally
         w.d_offs.ensure((b.reads + 1) * 8);
-        {
-            Timed t(ix, res, FGPU_K_H2D, true);
-            HIP_TRY(hipMemsetAsync(w.d_offs.p, 0, 8, s));
+        {   // every chunk as it lies, on the kernel-free copy stream (a copy engine: beside the kernels of the other batches)
+            Timed t(ix, res, FGPU_K_H2D, sin);
+            uint64_t at = 0, r = 0;
+            for (const FastxChunk& c : b.chunks) {
+                if (c.bases.size()) HIP_TRY(hipMemcpyAsync(w.d_bases.as<char>() + at, c.bases.data(), c.bases.size(), hipMemcpyHostToDevice, sin));
+                // (the first chunk brings offs[0] = 0 along)
+                if (r == 0) HIP_TRY(hipMemcpyAsync(w.d_offs.as<uint64_t>(), c.offs.data(), (c.reads() + 1) * 8, hipMemcpyHostToDevice, sin));
+                else HIP_TRY(hipMemcpyAsync(w.d_offs.as<uint64_t>() + r + 1, c.offs.data() + 1, c.reads() * 8, hipMemcpyHostToDevice, sin));
+                at += c.bases.size();
+                r += c.reads();
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(sin));
+        lg.t_copied = now_ns() - run.t0;
+        {   // offsets of a chunk count from the chunk's first base: add its position in the batch
             uint64_t at = 0, r = 0;
             RebaseTable tab;
             tab.count = 0;
@@ -151,8 +163,6 @@ void stream_one_batch(StreamRun& run, StreamWorkerState& w, StreamBatch& b, Stre
                 tab.count = 0;
             };
             for (const FastxChunk& c : b.chunks) {
-                if (c.bases.size()) HIP_TRY(hipMemcpyAsync(w.d_bases.as<char>() + at, c.bases.data(), c.bases.size(), hipMemcpyHostToDevice, s));
-                HIP_TRY(hipMemcpyAsync(w.d_offs.as<uint64_t>() + r + 1, c.offs.data() + 1, c.reads() * 8, hipMemcpyHostToDevice, s));
                 tab.first_read[tab.count] = r;
                 tab.base[tab.count] = at;
                 ++tab.count;
@@ -342,9 +352,9 @@ int fgpu_pseudoalign_stream(fgpu_index* ix, fgpu_fastx* query, int out_fd, int a
           << " parser threads, " << t_end / 1e6 << " ms, " << run.out_bytes.load() << " output bytes\n";
         o << "parser: " << st.bytes << " text bytes in " << st.ranges << " ranges; per thread " << st.parse_ns / 1e6 / std::max(1u, st.threads)
           << " ms parsing, " << st.wait_ns / 1e6 / std::max(1u, st.threads) << " ms waiting for the workers\n";
-        o << "# seq reads bases out_bytes | ms since start: begin acquired issued colours formatted turn written\n";
+        o << "# seq reads bases out_bytes | ms since start: begin acquired copied-in issued colours formatted+copied-out turn written\n";
         for (const StreamBatchLog& l : run.log)
-            o << l.seq << " " << l.reads << " " << l.bases << " " << l.out_bytes << " | " << l.t_begin / 1e6 << " " << l.t_acquired / 1e6 << " "
+            o << l.seq << " " << l.reads << " " << l.bases << " " << l.out_bytes << " | " << l.t_begin / 1e6 << " " << l.t_acquired / 1e6 << " " << l.t_copied / 1e6 << " "
               << l.t_issued / 1e6 << " " << l.t_colours / 1e6 << " " << l.t_formatted / 1e6 << " " << l.t_turn / 1e6 << " " << l.t_written / 1e6 << "\n";
         std::lock_guard<std::mutex> g(g_report_mu);
         g_stream_report = o.str();

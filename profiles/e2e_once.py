@@ -1,0 +1,40 @@
+"""one streamed run of the command-line path on an n-read FASTQ file on tmpfs (for rocprofv3): python profiles/e2e_once.py [n] [threads] [workers] [batch] [runs]"""
+import glob, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import fulgor_amd
+from fulgor_amd import synth
+from fulgor_amd.reads import FastxReader, ReadGenerator
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+threads, workers, batch, runs = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((2, 32), (3, 4), (4, 1 << 19), (5, 3)))
+g = sorted(glob.glob(os.path.join(ROOT, "tests", "data", "salmonella_10", "*.fasta.gz")))
+fg, extra = synth.ensure_s4546(os.path.join(ROOT, "data"), g)
+b, o = ReadGenerator(g, raw_sequences=extra).generate(0, n, 150, 42)
+path = "/dev/shm/e2e_once_%d.fq" % os.getpid()
+rec = np.empty((n, 316), dtype=np.uint8)
+ids = np.arange(n, dtype=np.int64)
+rec[:, 0], rec[:, 1], rec[:, 11] = ord("@"), ord("r"), ord("\n")
+for d in range(9):
+    rec[:, 2 + d] = ord("0") + (ids // 10 ** (8 - d)) % 10
+rec[:, 12:162] = np.asarray(b).reshape(n, 150)
+rec[:, 162:165] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+rec[:, 165:-1] = ord("I")
+rec[:, -1] = ord("\n")
+rec.tofile(path)
+del rec, b, o
+try:
+    ix = fulgor_amd.Index(fg, device=0)
+    for r in range(runs):
+        time.sleep(0.3)  # (the mapping of the run before is torn down in the background)
+        t0 = time.perf_counter()
+        rd = FastxReader(path, copy=False, threads=threads)
+        fd = os.open("/dev/null", os.O_WRONLY)
+        got, mapped = ix.pseudoalign_stream(rd, fd, 0, 0.0, 2, 0, True, batch, workers)
+        os.close(fd)
+        rd.close()
+        dt = time.perf_counter() - t0
+        print("run %d: %d reads in %.1f ms = %.1f M reads/s" % (r, got, dt * 1e3, got / dt / 1e6))
+    print(ix.last_stream_report())
+finally:
+    os.remove(path)
