@@ -540,18 +540,23 @@ def cli_end_to_end(ix, bases, offs, algo, tau, n, read_len):
         size = os.path.getsize(path)
         del rec
         best = None
-        for _ in range(2):  # the second run finds warm buffers
+        runs = []
+        for _ in range(3):  # the first run pins the host buffers and sizes the device buffers; the later ones find them
             t0 = time.perf_counter()
             got, mapped = driver.pseudoalign_sharded(lambda: ix, path, "/dev/null", algo, tau, "compressed")
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
+            runs.append(time.perf_counter() - t0)
+        best = min(runs)
         assert got == n
+        report = ix.last_stream_report().splitlines()[:2]
     finally:
         if os.path.exists(path):
             os.remove(path)
     return {"value": round(n / best, 1), "unit": "reads/s", "reads": int(n), "fastq_bytes": int(size),
-            "includes": "FASTQ file on tmpfs -> parse (parallel, native) -> pinned batches -> H2D -> kernels -> compressed records "
-                        "built on the device -> D2H -> /dev/null; index already resident"}
+            "runs_ms": [round(t * 1e3, 1) for t in runs], "first_run_value": round(n / runs[0], 1), "last_run": report,
+            "includes": "FASTQ file on tmpfs -> byte ranges read and parsed by the reader's threads into pinned chunks -> H2D of every chunk "
+                        "(copy engine) -> lookup, intersection (no u32 colour lists), compressed records built on the device -> D2H (copy "
+                        "engine) -> /dev/null, batches of 2^19 reads on 4 streams (fgpu_pseudoalign_stream); index already resident; best of "
+                        "three runs in one process (the first pins the host buffers)"}
 
 
 def cpu_baseline(ix, bases, offs, algo, tau, itype=0, psize=160, csize=16):

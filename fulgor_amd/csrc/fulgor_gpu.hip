@@ -206,6 +206,9 @@ struct fgpu_result {
     // small-result slots, the sizes and the CSR offsets; fgpu_result_expand, fgpu_result_download, the ascii / binary formatters and
     // the host-buffer calls run k2b_expand, the compressed formatter and the counters work from the rows
     bool csr_valid = false;
+    // a worker loop that knows its largest batch says so: the buffers are sized for it at their first use instead of growing batch by
+    // batch (growing a device buffer synchronises the device; growing the pinned output buffer stalls the copies in flight)
+    uint64_t reserve_reads = 0;
     uint32_t max_kmers_in_batch = 0xFFFFFFFFu;  // bound on #positive k-mers of any read (unknown for id-only calls)
     bool have_ids = false;
 };
@@ -356,16 +359,17 @@ void stage_lookup_on(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint6
     const uint64_t units = seg ? rd->seg_first[first + count] - u_first : count;
     res->n = count;
     res->max_kmers_in_batch = (uint32_t)std::min<uint64_t>(rd->max_total_kmers, 0xFFFFFFFFull);
-    res->d_nids.ensure(units * 4 + 16);
-    res->d_npos.ensure(units * 4 + 16);
-    res->d_idoff.ensure(units * 8 + 16);
+    const uint64_t cap_units = std::max(units, seg ? (uint64_t)0 : res->reserve_reads);
+    res->d_nids.ensure(cap_units * 4 + 16);
+    res->d_npos.ensure(cap_units * 4 + 16);
+    res->d_idoff.ensure(cap_units * 8 + 16);
     res->d_tickets.ensure(TICKET_BYTES);  // 8 padded work counters for each persistent launch of a pass
     HIP_TRY(hipMemsetAsync(res->d_tickets.p, 0, TICKET_BYTES, s));
     const uint32_t stride = std::max<uint32_t>(1, rd->max_kmers);  // at most one id per k-mer
     res->id_stride = stride;
     res->pool_units = units;
-    res->d_ids_pool.ensure(units * (uint64_t)stride * 4 + 64);  // (k2r_intersect reads the ids eight at a time)
-    res->d_cnt_pool.ensure(units * (uint64_t)stride * 4 + 64);
+    res->d_ids_pool.ensure(cap_units * (uint64_t)stride * 4 + 64);  // (k2r_intersect reads the ids eight at a time)
+    res->d_cnt_pool.ensure(cap_units * (uint64_t)stride * 4 + 64);
     res->have_ids = true;
     uint32_t* kmer_out = nullptr;
     if (res->want_kmer_ids) {
@@ -449,9 +453,9 @@ void stage_lookup(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint64_t
 void run_scan(fgpu_index* ix, fgpu_result* res, const uint32_t* sizes, uint64_t n, uint64_t* offsets, uint64_t* totals = nullptr,
               int timed_as = FGPU_K_SCAN) {
     hipStream_t s = res->stream;
-    const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-    res->d_block_sums.ensure(std::max<uint64_t>(1, nb) * 8);
-    res->d_block_mapped.ensure(std::max<uint64_t>(1, nb) * 8);
+    const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE, cnb = (std::max(n, res->reserve_reads) + SCAN_TILE - 1) / SCAN_TILE;
+    res->d_block_sums.ensure(std::max<uint64_t>(1, cnb) * 8);
+    res->d_block_mapped.ensure(std::max<uint64_t>(1, cnb) * 8);
     res->d_totals.ensure(32);
     Timed t(ix, res, timed_as);
     hipLaunchKernelGGL(scan_block_sums, dim3((uint32_t)nb), dim3(256), 0, s, sizes, n, res->d_block_sums.as<uint64_t>(),
@@ -523,9 +527,10 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
     hipStream_t s = res->stream;
     const uint64_t n = res->n;
     const uint32_t W = ix->dc.w32;
-    res->d_bitmap.ensure(n * W * 4 + 16);
-    res->d_counts.ensure(n * 4 + 16);
-    res->d_offsets.ensure((n + 1) * 8 + 16);
+    const uint64_t cap_n = std::max(n, res->reserve_reads);
+    res->d_bitmap.ensure(cap_n * W * 4 + 16);
+    res->d_counts.ensure(cap_n * 4 + 16);
+    res->d_offsets.ensure((cap_n + 1) * 8 + 16);
     res->total = res->mapped = 0;
     res->hit_rows = 0;
     res->small_mode = false;
@@ -577,7 +582,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         res->small_mode = ix->small_results && W >= 32 && SMALL_RESULT < ix->host.hybrid.sparse_thr && hits_fold;
         uint32_t* small_out = nullptr;
         if (res->small_mode) {
-            res->d_small.ensure(n * SMALL_RESULT * 4 + 16);
+            res->d_small.ensure(cap_n * SMALL_RESULT * 4 + 16);
             small_out = res->d_small.as<uint32_t>();
         }
         auto launch = [&](auto kernel) {
@@ -746,6 +751,15 @@ int fgpu_open(const char* path, int device, fgpu_index** out) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         ix->num_cus = prop.multiProcessorCount;
+        {   // the NUMA node of the device: the query reader keeps its threads on that node's cores (pinned host memory lives there)
+            char bus[64] = {0};
+            if (hipDeviceGetPCIBusId(bus, sizeof bus, device) == hipSuccess) {
+                std::string b(bus);
+                for (auto& ch : b) ch = (char)tolower((unsigned char)ch);
+                const std::string t = read_small_file("/sys/bus/pci/devices/" + b + "/numa_node");
+                if (!t.empty() && atoi(t.c_str()) >= 0) fastx_preferred_node().store(atoi(t.c_str()));
+            } else (void)hipGetLastError();
+        }
         HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
         LoadClock clk;
         upload_index(ix);
@@ -1097,8 +1111,9 @@ int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_rea
             const uint32_t W = ix->dc.w32, nc = ix->dc.n;
             const uint32_t sthr = ix->host.hybrid.sparse_thr, dthr = ix->host.hybrid.dense_thr;
             const uint64_t nb = (n + CFMT_BLOCK_READS - 1) / CFMT_BLOCK_READS;
-            res->d_fmt_sizes.ensure((n + 3 * nb) * 4 + 64);
-            res->d_fmt_off.ensure((nb + 1) * 8 + 48 + n * 4);
+            const uint64_t cn = std::max(n, res->reserve_reads), cnb = (cn + CFMT_BLOCK_READS - 1) / CFMT_BLOCK_READS;
+            res->d_fmt_sizes.ensure((cn + 3 * cnb) * 4 + 64);
+            res->d_fmt_off.ensure((cnb + 1) * 8 + 48 + cn * 4);
             uint32_t* bits = res->d_fmt_sizes.as<uint32_t>();
             uint32_t* block_bits = bits + n;
             uint32_t* block_bytes = block_bits + nb;
@@ -1117,7 +1132,7 @@ int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_rea
             HIP_TRY(hipMemcpyAsync(h, totals, 16, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             bytes = h[0];
-            res->d_fmt_out.ensure(bytes + 64);
+            res->d_fmt_out.ensure(std::max<uint64_t>(bytes, n < res->reserve_reads ? bytes / n * res->reserve_reads * 9 / 8 : 0) + 64);
             HIP_TRY(hipMemsetAsync(res->d_fmt_out.p, 0, bytes + 64, s));
             Timed t(ix, res, FGPU_K_FORMAT);
             // per-wave LDS stage of one record: the n bits of a bitmap record or the codes of at most n/4 gaps, plus its
@@ -1159,7 +1174,8 @@ int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_rea
             if (res->h_fmt) (void)hipHostFree(res->h_fmt);
             res->h_fmt = nullptr;
             res->h_fmt_cap = 0;
-            const size_t want = bytes + bytes / 4 + 4096;
+            size_t want = bytes + bytes / 4 + 4096;
+            if (n && n < res->reserve_reads) want = std::max<size_t>(want, bytes / n * res->reserve_reads * 5 / 4 + 4096);
             HIP_TRY(hipHostMalloc((void**)&res->h_fmt, want, hipHostMallocDefault));
             res->h_fmt_cap = want;
         }

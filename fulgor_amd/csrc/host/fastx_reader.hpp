@@ -15,6 +15,8 @@
 //     included, reads such a file as one stream.
 #pragma once
 #include <dlfcn.h>
+#include <pthread.h>
+#include <sched.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -22,6 +24,7 @@
 #include <zlib.h>
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -54,6 +57,11 @@ public:
     static SlabPool& get() { static SlabPool* p = new SlabPool(); return *p; }  // (never destroyed: no calls into HIP at exit)
     // a buffer of at least `want` bytes: the smallest pooled one that fits (and is not wastefully large), else a new one
     void* take(size_t want, size_t& got, bool& pinned) {
+        // sizes in coarse steps (64 KB, 128 KB, ... 1 MB, then whole megabytes): the chunks of a file ask for almost, not exactly,
+        // the same size range after range, and a slab that is a few bytes short would be pinned anew (0.16 ms per megabyte, and
+        // the pinning stalls the copies in flight)
+        if (want <= (1u << 20)) { size_t r = 1u << 16; while (r < want) r <<= 1; want = r; }
+        else want = (want + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
         {
             std::lock_guard<std::mutex> g(mu_);
             size_t best = free_.size();
@@ -72,6 +80,8 @@ public:
         const HostAllocHooks& h = host_alloc_hooks();
         void* p = nullptr;
         pinned = false;
+        fresh_ += 1;
+        fresh_bytes_ += want;
         if (h.alloc) p = h.alloc(want, &pinned);
         if (!p) { p = malloc(want); pinned = false; }
         if (!p) throw std::bad_alloc();
@@ -92,9 +102,14 @@ public:
         if (pinned && h.release) h.release(p, true); else free(p);
     }
 
+    // buffers that had to be allocated (pinned) because the pool had none that fit: count and bytes since the process began
+    uint64_t fresh_allocs() const { return fresh_.load(); }
+    uint64_t fresh_bytes() const { return fresh_bytes_.load(); }
+
 private:
     struct Slab { void* p; size_t bytes; bool pinned; };
     static constexpr size_t MAX_BYTES = (size_t)3 << 30, MAX_SLABS = 1024;
+    std::atomic<uint64_t> fresh_{0}, fresh_bytes_{0};
     std::mutex mu_;
     std::vector<Slab> free_;
     size_t held_ = 0;
@@ -303,6 +318,80 @@ inline bool fastx_file_rangeable(const std::string& path) {
     return got == 0 || fastx_head_rangeable(head.data(), got, kind);
 }
 
+// Optional confinement of the parser threads (FULGOR_READER_AFFINITY=1; off by default) to the first hardware thread of every core
+// of one NUMA node: the node of the GPU (where the runtime puts pinned host memory) when the engine has said which
+// (fastx_preferred_node), else the node of the calling thread. Measured on a two-socket, 256-thread host
+// (profiles/r5/e2e_breakdown_r5.txt): with the WHOLE process confined to the cores of the node that holds the file's pages
+// (taskset -c 0-63) ten million reads take 50 to 57 ms run after run, left to the scheduler 55 to 75 ms; confining only the
+// parser threads to the GPU's node made it worse (77 to 114 ms: the file's pages were on the other node, and reading them
+// through pread from the far socket is what a parser thread then spends its time on). Where the file's pages live is not
+// the reader's to choose, so the default leaves the threads to the scheduler.
+inline std::atomic<int>& fastx_preferred_node() { static std::atomic<int> n{-1}; return n; }
+inline std::vector<int> parse_cpu_list(const std::string& text) {
+    std::vector<int> out;
+    size_t i = 0;
+    while (i < text.size()) {
+        while (i < text.size() && !isdigit((unsigned char)text[i])) ++i;
+        if (i >= text.size()) break;
+        int a = 0;
+        while (i < text.size() && isdigit((unsigned char)text[i])) a = a * 10 + (text[i++] - '0');
+        int b = a;
+        if (i < text.size() && text[i] == '-') {
+            ++i;
+            b = 0;
+            while (i < text.size() && isdigit((unsigned char)text[i])) b = b * 10 + (text[i++] - '0');
+        }
+        for (int c = a; c <= b && out.size() < 4096; ++c) out.push_back(c);
+    }
+    return out;
+}
+inline std::string read_small_file(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return std::string();
+    char buf[4096];
+    const size_t n = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    return std::string(buf, n);
+}
+inline const std::vector<int>& fastx_parser_cpus() {
+    static const std::vector<int> cpus = [] {
+        std::vector<int> out;
+        const char* e = getenv("FULGOR_READER_AFFINITY");
+        if (!e || atoi(e) != 1) return out;
+        cpu_set_t allowed;
+        CPU_ZERO(&allowed);
+        if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return out;
+        int node = fastx_preferred_node().load();
+        if (node < 0) {  // the node this thread runs on
+            const int cpu = sched_getcpu();
+            for (int n = 0; n < 64 && node < 0; ++n) {
+                const std::string l = read_small_file("/sys/devices/system/node/node" + std::to_string(n) + "/cpulist");
+                if (l.empty()) { if (n > 0) break; else continue; }
+                for (int c : parse_cpu_list(l)) if (c == cpu) node = n;
+            }
+        }
+        if (node < 0) return out;
+        for (int c : parse_cpu_list(read_small_file("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist"))) {
+            if (c >= CPU_SETSIZE || !CPU_ISSET(c, &allowed)) continue;
+            const std::vector<int> sib = parse_cpu_list(read_small_file("/sys/devices/system/cpu/cpu" + std::to_string(c) + "/topology/thread_siblings_list"));
+            if (!sib.empty() && *std::min_element(sib.begin(), sib.end()) != c) continue;  // one hardware thread per core
+            out.push_back(c);
+        }
+        if (out.size() < 4) out.clear();
+        return out;
+    }();
+    return cpus;
+}
+// confine the calling thread to the parser CPUs when they can seat `threads` threads
+inline void fastx_confine_parser_thread(unsigned threads) {
+    const std::vector<int>& cpus = fastx_parser_cpus();
+    if (cpus.size() < threads) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : cpus) CPU_SET(c, &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+}
+
 class FastxSource {
 public:
     virtual ~FastxSource() {}
@@ -464,7 +553,13 @@ public:
         struct stat st;
         if (fstat(fd_, &st) != 0) { close(fd_); throw std::runtime_error("cannot stat " + path); }
         size_ = (uint64_t)st.st_size;
-        if (size_) {
+        // The text is READ range by range into a buffer of the thread that parses the range (pread: one kernel copy out of the
+        // page cache, 316 bytes per 150-base read). Mapping the file instead costs nothing while parsing but 60-90 ms for a 3 GB
+        // file when the mapping goes (772 k page-table entries that up to a hundred threads have touched, under the process's
+        // mmap lock: the next reader's mmap and its threads' stacks wait for it; measured, profiles/r5/e2e_breakdown_r5.txt).
+        // FULGOR_READER_MMAP=1 maps (A/B measurements).
+        use_pread_ = !getenv("FULGOR_READER_MMAP");
+        if (size_ && !use_pread_) {
             map_ = (const char*)mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
             if (map_ == MAP_FAILED) { close(fd_); throw std::runtime_error("cannot map " + path); }
             madvise((void*)map_, size_, MADV_SEQUENTIAL);
@@ -475,7 +570,7 @@ public:
         shutdown();
         // tearing down the page tables of a multi-gigabyte mapping that hundreds of threads have touched takes tens of
         // milliseconds (60-90 ms for 3 GB on a 256-thread host): nobody has to wait for it
-        if (map_ && size_) {
+        if (map_ && size_ && !use_pread_) {
             const void* m = map_;
             const size_t sz = size_;
             if (sz >= (size_t)64 << 20) std::thread([m, sz] { munmap((void*)m, sz); }).detach();
@@ -501,14 +596,6 @@ public:
         std::lock_guard<std::mutex> g(m_);
         if (pool_.size() < 64) pool_.push_back(std::move(c));
     }
-    // first record boundary at or behind byte p (size_ if none). A record starts at a line start with '>' (FASTA files), or with '@' when the
-    // four lines from there look like a FASTQ record: third line '+...', fourth as long as the second (a quality line may
-    // begin with '@', but then the line after next is a sequence). FASTQ files with wrapped sequences offer no such
-    // boundaries: everything then falls to the first range, i.e. one thread parses the file with kseq's general grammar.
-    uint64_t record_start(uint64_t p) const {
-        bool sure;
-        return record_start_in(p, size_, sure);
-    }
     uint64_t size() const { return size_; }
 
 protected:
@@ -520,8 +607,8 @@ protected:
     void start(unsigned threads, uint64_t begin, uint64_t end) {
         if (size_) {  // FASTA or FASTQ, by the first header line: which line starts can open a record
             const uint64_t head = std::min<uint64_t>(size_, 1u << 20);
-            ensure(0, head);
-            if (!fastx_head_rangeable(map_, head, kind_))
+            Window w;
+            if (!fastx_head_rangeable(base(w, 0, head), head, kind_))
                 throw std::runtime_error("this FASTQ text has records that are not four lines long (wrapped lines): it cannot be cut into byte ranges");
         }
         begin_ = std::min(begin, size_);
@@ -543,17 +630,49 @@ protected:
         for (auto& w : workers_) w.join();
         workers_.clear();
     }
-    // record_start within the window [.., wend): sure = false when the window ended before the answer was certain
-    uint64_t record_start_in(uint64_t p, uint64_t wend, bool& sure) const {
+    // The bytes a thread looks at: M = base(w, a, b) makes the text bytes [a, b) readable as M[a] .. M[b - 1] (M is the mapping, or
+    // the thread's own buffer moved back by the buffer's position in the text).
+    struct Window {
+        char* buf = nullptr;
+        size_t cap = 0;
+        uint64_t a = 0, b = 0;
+        ~Window() { free(buf); }
+    };
+    const char* base(Window& w, uint64_t a, uint64_t b) {
+        if (!use_pread_) { ensure(a, b); return map_; }
+        if (a >= w.a && b <= w.b && w.buf) return w.buf - w.a;
+        const size_t need = (size_t)(b - a);
+        if (need > w.cap) {
+            free(w.buf);
+            w.cap = need + need / 8 + 4096;
+            w.buf = (char*)malloc(w.cap);
+            if (!w.buf) { w.cap = 0; throw std::bad_alloc(); }
+        }
+        size_t got = 0;
+        while (got < need) {
+            const ssize_t k = pread(fd_, w.buf + got, need - got, (off_t)(a + got));
+            if (k < 0) { if (errno == EINTR) continue; throw std::runtime_error("cannot read the query file"); }
+            if (k == 0) throw std::runtime_error("the query file shrank while it was read");
+            got += (size_t)k;
+        }
+        w.a = a;
+        w.b = b;
+        return w.buf - w.a;
+    }
+    // first record boundary at or behind byte p within the window [.., wend) of the text M (wend if none): sure = false when the
+    // window ended before the answer was certain. A record starts at a line start with '>' (FASTA files), or with '@' when the
+    // four lines from there look like a FASTQ record: third line '+...', fourth as long as the second (a quality line may
+    // begin with '@', but then the line after next is a sequence).
+    uint64_t record_start_in(const char* M, uint64_t p, uint64_t wend, bool& sure) const {
         sure = true;
         if (p == 0) return 0;
-        const char* nl = (const char*)memchr(map_ + p - 1, '\n', wend - (p - 1));  // p - 1: p itself may be a line start
-        uint64_t q = nl ? (uint64_t)(nl - map_) + 1 : wend;
+        const char* nl = (const char*)memchr(M + p - 1, '\n', wend - (p - 1));  // p - 1: p itself may be a line start
+        uint64_t q = nl ? (uint64_t)(nl - M) + 1 : wend;
         while (q < wend) {
-            if (map_[q] == '>' && kind_ != '@') return q;  // (in a FASTQ file a quality line may begin with '>')
-            if (map_[q] == '@' && kind_ != '>') {
-                const char* fin = map_ + wend;
-                const char* l1 = (const char*)memchr(map_ + q, '\n', wend - q);                    // end of the header
+            if (M[q] == '>' && kind_ != '@') return q;  // (in a FASTQ file a quality line may begin with '>')
+            if (M[q] == '@' && kind_ != '>') {
+                const char* fin = M + wend;
+                const char* l1 = (const char*)memchr(M + q, '\n', wend - q);                    // end of the header
                 const char* l2 = l1 ? (const char*)memchr(l1 + 1, '\n', (size_t)(fin - l1 - 1)) : nullptr;  // end of the sequence
                 if (!l2) {  // the text ends within two lines: a last quality line that begins with '@', or a record cut off behind its
                     // header. Not taken for a record start: whoever parses the lines in front decides with the full grammar.
@@ -574,29 +693,25 @@ protected:
                     return q;
                 }
             }
-            const char* e = (const char*)memchr(map_ + q, '\n', wend - q);
-            q = e ? (uint64_t)(e - map_) + 1 : wend;
+            const char* e = (const char*)memchr(M + q, '\n', wend - q);
+            q = e ? (uint64_t)(e - M) + 1 : wend;
         }
         sure = wend == size_;
         return wend;
     }
-    // first record boundary at or behind p, with the bytes it looks at made available first
-    uint64_t boundary(uint64_t p) {
-        if (!lazy()) return record_start(p);
-        for (uint64_t margin = 1u << 20;; margin *= 4) {
-            const uint64_t wend = std::min(size_, p + margin);
-            ensure(p ? p - 1 : 0, wend);
-            bool sure;
-            const uint64_t q = record_start_in(p, wend, sure);
-            if (sure || wend == size_) return q;
+    // records that start in range r: text bytes [lo, hi), both ends at record boundaries, readable through the returned M. One load
+    // covers the range and what the two boundary searches look at beyond its ends (the margin grows in the rare case of a record
+    // longer than the margin).
+    const char* range_bounds(uint64_t r, uint64_t& lo, uint64_t& hi, Window& w) {
+        const uint64_t a0 = begin_ + r * range_, b0 = r + 1 == num_ranges_ ? end_ : begin_ + (r + 1) * range_;
+        for (uint64_t margin = 64u << 10;; margin *= 4) {
+            const uint64_t la = a0 ? a0 - 1 : 0, lb = std::min(size_, b0 + margin);
+            const char* M = base(w, la, lb);
+            bool sure_lo, sure_hi = true;
+            lo = record_start_in(M, a0, lb, sure_lo);
+            hi = (r + 1 == num_ranges_ && end_ == size_) ? size_ : record_start_in(M, b0, lb, sure_hi);
+            if ((sure_lo && sure_hi) || lb == size_) return M;
         }
-    }
-
-    // records that start in range r: bytes [lo, hi), both ends at record boundaries, made available
-    void range_bounds(uint64_t r, uint64_t& lo, uint64_t& hi) {
-        lo = boundary(begin_ + r * range_);
-        hi = r + 1 == num_ranges_ ? (end_ == size_ ? size_ : boundary(end_)) : boundary(begin_ + (r + 1) * range_);
-        ensure(lo, hi);
     }
 
 public:
@@ -605,19 +720,20 @@ public:
         std::mutex em;
         std::string err;
         auto body = [&] {
+            Window w;
             for (;;) {
                 const uint64_t r = next++;
                 if (r >= num_ranges_) return;
                 try {
                     uint64_t lo, hi;
-                    range_bounds(r, lo, hi);
+                    const char* M = range_bounds(r, lo, hi, w);
                     uint64_t pos = lo;
                     CountSink cs;
                     parse_fastx_records(
                         [&](const char*& s, size_t& n) {
                             if (pos >= hi) return false;
-                            const char* nl = (const char*)memchr(map_ + pos, '\n', hi - pos);
-                            s = map_ + pos;
+                            const char* nl = (const char*)memchr(M + pos, '\n', hi - pos);
+                            s = M + pos;
                             n = nl ? (size_t)(nl - s) : (size_t)(hi - pos);
                             pos += n + 1;
                             if (n && s[n - 1] == '\r') --n;
@@ -634,7 +750,7 @@ public:
         };
         std::vector<std::thread> th;
         const unsigned nt = (unsigned)std::min<uint64_t>(std::max(1u, threads), std::max<uint64_t>(1, num_ranges_));
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back(body);
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back([&body, nt] { fastx_confine_parser_thread(nt); body(); });
         body();
         for (auto& t : th) t.join();
         if (!err.empty()) throw std::runtime_error(err);
@@ -644,6 +760,8 @@ public:
 
 protected:
     void work() {
+        fastx_confine_parser_thread(nthreads_);
+        Window w;
         for (;;) {
             uint64_t r;
             FastxChunk c;
@@ -659,7 +777,7 @@ protected:
             wait_ns_ += t_parse - t_wait;
             try {
                 uint64_t lo, hi;
-                range_bounds(r, lo, hi);
+                const char* M = range_bounds(r, lo, hi, w);
                 uint64_t pos = lo;
                 unsigned odd = 0;
                 c.want_names = want_names_.load();
@@ -668,8 +786,8 @@ protected:
                 parse_fastx_records(
                     [&](const char*& s, size_t& n) {
                         if (pos >= hi) return false;
-                        const char* nl = (const char*)memchr(map_ + pos, '\n', hi - pos);
-                        s = map_ + pos;
+                        const char* nl = (const char*)memchr(M + pos, '\n', hi - pos);
+                        s = M + pos;
                         n = nl ? (size_t)(nl - s) : (size_t)(hi - pos);
                         pos += n + 1;
                         if (n && s[n - 1] == '\r') --n;
@@ -697,6 +815,7 @@ protected:
 
 protected:
     int fd_ = -1;
+    bool use_pread_ = false;  // (derived sources hand out their own buffer as map_)
     const char* map_ = nullptr;
     uint64_t size_ = 0, begin_ = 0, end_ = 0, range_, num_ranges_ = 0, window_ = 4;
     char kind_ = 0;  // '>' FASTA, '@' FASTQ, 0 unknown (both kinds of record start are looked for)

@@ -59,7 +59,7 @@ struct StreamRun {
     std::mutex err_mu;
     std::string error;
     std::atomic<uint64_t> reads{0}, mapped{0}, out_bytes{0};
-    uint64_t t0 = 0;
+    uint64_t t0 = 0, slabs0 = 0, slab_bytes0 = 0;
     std::mutex log_mu;
     std::vector<StreamBatchLog> log;
 
@@ -311,6 +311,8 @@ int fgpu_pseudoalign_stream(fgpu_index* ix, fgpu_fastx* query, int out_fd, int a
         run.batch_reads = batch_reads;
         run.next_id = first_read_id;
         run.t0 = now_ns();
+        run.slabs0 = SlabPool::get().fresh_allocs();
+        run.slab_bytes0 = SlabPool::get().fresh_bytes();
         query->reader.set_want_names(false);
         if (out_fd >= 0 && write_header && format == FGPU_FMT_COMPRESSED) {  // the file header (src/ps_utils.cpp:158-164)
             CompressedFormatter f;
@@ -328,6 +330,7 @@ int fgpu_pseudoalign_stream(fgpu_index* ix, fgpu_fastx* query, int out_fd, int a
             if (fgpu_result_create(ix, &w.res)) throw std::runtime_error(fgpu_last_error());
             states.push_back(w);
         }
+        for (auto& w : states) w.res->reserve_reads = batch_reads + batch_reads / 16;
         std::vector<std::thread> th;
         for (unsigned i = 1; i < workers; ++i) th.emplace_back([&run, &states, i] { stream_worker(run, states[i]); });
         stream_worker(run, states[0]);
@@ -351,7 +354,8 @@ int fgpu_pseudoalign_stream(fgpu_index* ix, fgpu_fastx* query, int out_fd, int a
         o << "stream: " << run.reads.load() << " reads, " << run.log.size() << " batches, " << workers << " workers, " << st.threads
           << " parser threads, " << t_end / 1e6 << " ms, " << run.out_bytes.load() << " output bytes\n";
         o << "parser: " << st.bytes << " text bytes in " << st.ranges << " ranges; per thread " << st.parse_ns / 1e6 / std::max(1u, st.threads)
-          << " ms parsing, " << st.wait_ns / 1e6 / std::max(1u, st.threads) << " ms waiting for the workers\n";
+          << " ms parsing, " << st.wait_ns / 1e6 / std::max(1u, st.threads) << " ms waiting for the workers; host buffers pinned anew during the run: "
+          << SlabPool::get().fresh_allocs() - run.slabs0 << " (" << (SlabPool::get().fresh_bytes() - run.slab_bytes0) / 1e6 << " MB)\n";
         o << "# seq reads bases out_bytes | ms since start: begin acquired copied-in issued colours formatted+copied-out turn written\n";
         for (const StreamBatchLog& l : run.log)
             o << l.seq << " " << l.reads << " " << l.bases << " " << l.out_bytes << " | " << l.t_begin / 1e6 << " " << l.t_acquired / 1e6 << " " << l.t_copied / 1e6 << " "
