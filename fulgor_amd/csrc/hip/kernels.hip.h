@@ -1112,13 +1112,17 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 4 : 2)) void k3a
 // its REGISTERS: no LDS at all; spreading a row word over them costs one shift, one mask and one multiply-add per plane.
 // Ids and multiplicities arrive through scalar loads (once per round), the row words of up to four lists are in flight at once.
 // ---------------------------------------------------------------------------------------------
+// word at byte offset `bo` (32-bit, per lane) of a row whose base is wave-uniform: scalar base + 32-bit vector offset, the form the
+// global loads take without a 64-bit address per lane and load (two VGPRs and a v_lshl_add_u64 each)
+__device__ __forceinline__ uint32_t row_word(const uint32_t* row, uint32_t bo) { return *(const uint32_t*)((const char*)row + bo); }
+
 template <int K, int BITS>
 __device__ __forceinline__ void rows_spread(const uint32_t* __restrict__ rows, uint32_t W, const u32x4 id, const u32x4 mult, uint32_t wi,
                                             uint32_t (&cnt)[BITS]) {
     constexpr uint32_t ONES = BITS == 8 ? 0x01010101u : (BITS == 16 ? 0x00010001u : 1u);
     uint32_t x[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) x[j] = rows[(uint64_t)id[j] * W + wi];
+    for (int j = 0; j < K; ++j) x[j] = row_word(rows + (uint64_t)id[j] * W, wi << 2);
 #pragma unroll
     for (int j = 0; j < K; ++j)
 #pragma unroll
@@ -1132,25 +1136,39 @@ __device__ __forceinline__ void rows_spread(const uint32_t* __restrict__ rows, u
 // colours of a word): a node is lo | (x_l & hi) with hi >= lo, one v_and_or; the leaves are the table's constants, so a node
 // of the first level is one of {0, x_0, ~0} = (x_0 | lo) & hi. About 3 * 2^(L-1) operations per word against 24 L + 22 for
 // the byte counters: 48 against 142 for five lists.
+#ifndef FG_MUX_INLINE
+#define FG_MUX_INLINE __forceinline__
+#endif
 constexpr uint32_t K3R_MUX_LISTS = 6;  // reads of up to this many lists take the multiplexer tree (2^L = one ballot)
-template <int LEVEL>
-__device__ __forceinline__ uint32_t mux_tree(const uint32_t (&x)[K3R_MUX_LISTS], uint64_t table, uint32_t p) {  // p: pattern of the lists above LEVEL
+// R row words per lane go through the tree together: the two scalars of a leaf (bits 2p and 2p + 1 of the table as masks) are made
+// where the leaf stands and used at once by its 2 R instructions. (With one word per lane inside a loop over the rounds of a row the
+// compiler hoisted the 2^L leaf scalars of every inlined variant out of the loop: 175 SGPR spills, 542 of 1446 static VALU
+// instructions were v_writelane / v_readlane on the spill registers — round-4 review, item 3.)
+template <int LEVEL, int R, uint32_t P>  // P: pattern of the lists above LEVEL
+__device__ __forceinline__ void mux_tree(const uint32_t (&x)[K3R_MUX_LISTS][R], uint32_t table_lo, uint32_t table_hi, uint32_t (&out)[R]) {
     if constexpr (LEVEL == 1) {
-        const uint32_t lo = 0u - (uint32_t)((table >> (2 * p)) & 1ull), hi = 0u - (uint32_t)((table >> (2 * p + 1)) & 1ull);  // (scalars)
-        return (x[0] | lo) & hi;
+        // table bits 2P and 2P + 1 as all-zeros / all-ones masks, made HERE (the statements keep their order): s_bfe_i32 with width 1
+        uint32_t lo, hi;
+        constexpr uint32_t at = (2 * P) & 31u;
+        const uint32_t word = 2 * P < 32 ? table_lo : table_hi;
+        asm volatile("s_bfe_i32 %0, %2, %3\n\ts_bfe_i32 %1, %2, %4" : "=&s"(lo), "=s"(hi) : "s"(word), "n"(0x10000u | at), "n"(0x10000u | (at + 1)) : "scc");
+#pragma unroll
+        for (int r = 0; r < R; ++r) out[r] = (x[0][r] | lo) & hi;
     } else {
-        const uint32_t lo = mux_tree<LEVEL - 1>(x, table, 2 * p), hi = mux_tree<LEVEL - 1>(x, table, 2 * p + 1);
-        return lo | (x[LEVEL - 1] & hi);
+        uint32_t lo[R], hi[R];
+        mux_tree<LEVEL - 1, R, 2 * P>(x, table_lo, table_hi, lo);
+        mux_tree<LEVEL - 1, R, 2 * P + 1>(x, table_lo, table_hi, hi);
+#pragma unroll
+        for (int r = 0; r < R; ++r) out[r] = lo[r] | (x[LEVEL - 1][r] & hi[r]);
     }
 }
-// The whole read: rounds of 64 row words, one per lane; returns the lane's share of the result's cardinality. `id` = the L lists
-// that go through the tree; the lists in `mand` (a mask over the lanes, whose `id_l` is the lane's list) must contain every
-// result colour: their rows are ANDed in (two in flight).
-template <int L>
-__device__ __forceinline__ uint32_t mux_union_read(const uint32_t* __restrict__ rows, uint32_t W, uint32_t Wn, uint32_t n, const uint32_t (&id)[K3R_MUX_LISTS],
+// The whole read: chunks of R rounds of 64 row words, R words per lane; returns the lane's share of the result's cardinality. `id` =
+// the L lists that go through the tree; the lists in `mand` (a mask over the lanes, whose `id_l` is the lane's list) must contain
+// every result colour: their rows are ANDed in (the first two with the loads of the tree's lists).
+template <int L, int R>
+__device__ FG_MUX_INLINE uint32_t mux_union_read(const uint32_t* __restrict__ rows, uint32_t W, uint32_t Wn, uint32_t n, const uint32_t (&id)[K3R_MUX_LISTS],
                                                    uint64_t table, uint64_t mand, uint32_t id_l, uint32_t* __restrict__ bm, int lane) {
     uint32_t pc = 0;
-    // the first two mandatory lists travel with the lists of the tree (one wait per round); further ones are rare
     uint64_t rest = mand;
     const bool m0 = rest != 0;
     const uint32_t i0 = m0 ? (uint32_t)__builtin_amdgcn_readlane((int)id_l, (int)__builtin_ctzll(rest)) : 0u;
@@ -1158,25 +1176,54 @@ __device__ __forceinline__ uint32_t mux_union_read(const uint32_t* __restrict__ 
     const bool m1 = rest != 0;
     const uint32_t i1 = m1 ? (uint32_t)__builtin_amdgcn_readlane((int)id_l, (int)__builtin_ctzll(rest)) : 0u;
     rest &= rest - 1;
-    for (uint32_t w0 = 0; w0 < Wn; w0 += 64) {
-        const uint32_t w = w0 + (uint32_t)lane;
-        const uint32_t wi = min(w, W - 1);  // (lanes past the row load its last word and store nothing)
-        uint32_t x[K3R_MUX_LISTS];
+    for (uint32_t w0 = 0; w0 < Wn; w0 += 64 * R) {
+        uint32_t wi[R];
 #pragma unroll
-        for (int l = 0; l < L; ++l) x[l] = rows[(uint64_t)id[l] * W + wi];
-        uint32_t y0 = 0xFFFFFFFFu, y1 = 0xFFFFFFFFu;
-        if (m0) y0 = rows[(uint64_t)i0 * W + wi];  // (wave-uniform)
-        if (m1) y1 = rows[(uint64_t)i1 * W + wi];
-        uint32_t m;
-        if constexpr (L == 0) m = 0u - (uint32_t)(table & 1ull);
-        else m = mux_tree<L>(x, table, 0u);
-        m &= y0 & y1;
-        for (uint64_t mm = rest; mm; mm &= mm - 1)  // (wave-uniform)
-            m &= rows[(uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)id_l, (int)__builtin_ctzll(mm)) * W + wi];
-        if (w >= (n >> 5)) m &= w == (n >> 5) ? (1u << (n & 31u)) - 1u : 0u;  // (only the last words hold colours >= n)
-        if (w < W) {
-            bm[w] = m;
-            pc += __popc(m);
+        for (int r = 0; r < R; ++r) wi[r] = min(w0 + 64u * r + (uint32_t)lane, W - 1) << 2;  // byte offset in a row (lanes past the row load its last word and store nothing)
+        uint32_t x[K3R_MUX_LISTS][R];
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const uint32_t* row = rows + (uint64_t)id[l] * W;
+#pragma unroll
+            for (int r = 0; r < R; ++r) x[l][r] = row_word(row, wi[r]);
+        }
+        uint32_t m[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) m[r] = 0xFFFFFFFFu;
+        if (m0) {  // (wave-uniform)
+            const uint32_t* row = rows + (uint64_t)i0 * W;
+#pragma unroll
+            for (int r = 0; r < R; ++r) m[r] = row_word(row, wi[r]);
+        }
+        if (m1) {
+            const uint32_t* row = rows + (uint64_t)i1 * W;
+#pragma unroll
+            for (int r = 0; r < R; ++r) m[r] &= row_word(row, wi[r]);
+        }
+        if constexpr (L == 0) {
+            const uint32_t all = 0u - (uint32_t)(table & 1ull);
+#pragma unroll
+            for (int r = 0; r < R; ++r) m[r] &= all;
+        } else {
+            uint32_t t[R];
+            mux_tree<L, R, 0u>(x, (uint32_t)table, (uint32_t)(table >> 32), t);
+#pragma unroll
+            for (int r = 0; r < R; ++r) m[r] &= t[r];
+        }
+        for (uint64_t mm = rest; mm; mm &= mm - 1) {  // (wave-uniform; more than two mandatory lists are rare)
+            const uint32_t* row = rows + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)id_l, (int)__builtin_ctzll(mm)) * W;
+#pragma unroll
+            for (int r = 0; r < R; ++r) m[r] &= row_word(row, wi[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t w = w0 + 64u * r + (uint32_t)lane;
+            uint32_t v = m[r];
+            if (w >= (n >> 5)) v &= w == (n >> 5) ? (1u << (n & 31u)) - 1u : 0u;  // (only the last words hold colours >= n)
+            if (w < W) {
+                bm[w] = v;
+                pc += __popc(v);
+            }
         }
     }
     return pc;
@@ -1205,24 +1252,29 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 6 : 4)) void k3r
         const uint32_t min_l = (uint32_t)(unsigned long long)((double)np_l * tau);  // ps_threshold_union.cpp:389
         for (uint32_t ri = 0; ri < t_count; ++ri) {
             const uint64_t r = t_first + ri;
+            // (the lane number is made opaque once per read: everything derived from it — two dozen lane masks of this loop nest — would
+            // otherwise be computed once in front of the ticket loop and kept in scalar register pairs, more of them than there are
+            // registers: they were spilled to vector lanes and read back instruction by instruction)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
             const uint32_t nl = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, ri);
             const uint32_t min_score = (uint32_t)__builtin_amdgcn_readlane((int)min_l, ri);
             const uint32_t positive = (uint32_t)__builtin_amdgcn_readlane((int)np_l, ri);
             const uint64_t off = readlane_u64(off_l, ri);
             uint32_t* bm = out_bitmap + r * W;
             if (nl == 0) {
-                for (uint32_t w = lane; w < W; w += 64) bm[w] = 0;
-                if (lane == 0) out_count[r] = 0;
+                for (uint32_t w = ln; w < W; w += 64) bm[w] = 0;
+                if (ln == 0) out_count[r] = 0;
                 if (SCORES)
-                    for (uint32_t cc = lane; cc < n; cc += 64) scores_out[r * (uint64_t)n + cc] = 0;
+                    for (uint32_t cc = ln; cc < n; cc += 64) scores_out[r * (uint64_t)n + cc] = 0;
                 continue;
             }
             // A colour that is not in list l scores at most P - m_l: a list with m_l > P - min_score is MANDATORY, every result colour
             // is in it (one AND per row word). What the others contribute is a monotone boolean function of which of them contain the
             // colour: with at most six of them, the multiplexer tree; no counters.
             if (!SCORES && nl <= 64u) {
-                const bool has = (uint32_t)lane < nl;
-                const uint32_t id_l = has ? ids_pool[off + lane] : 0u, mu_l = has ? cnt_pool[off + lane] : 0u;
+                const bool has = (uint32_t)ln < nl;
+                const uint32_t id_l = has ? ids_pool[off + ln] : 0u, mu_l = has ? cnt_pool[off + ln] : 0u;
                 const uint32_t slack = positive - min_score;
                 const uint64_t FREE = __ballot(has && mu_l <= slack), MAND = __ballot(has && mu_l > slack);
                 const uint32_t nfree = (uint32_t)__popcll(FREE);
@@ -1238,23 +1290,26 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 6 : 4)) void k3r
                         free_total += muf[j];
                         ff &= ff - 1;
                     }
-                    uint32_t score = positive - free_total;  // the mandatory lists + pattern `lane` of the others
+                    uint32_t score = positive - free_total;  // the mandatory lists + pattern `ln` of the others
 #pragma unroll
-                    for (uint32_t j = 0; j < K3R_MUX_LISTS; ++j) score += (((uint32_t)lane >> j) & 1u) ? muf[j] : 0u;
+                    for (uint32_t j = 0; j < K3R_MUX_LISTS; ++j) score += (((uint32_t)ln >> j) & 1u) ? muf[j] : 0u;
                     const uint64_t table = __ballot(score >= min_score);
                     uint32_t pcm = 0;
-                    switch (nfree) {  // (wave-uniform)
-                        case 0: pcm = mux_union_read<0>(rows, W, Wn, n, idf, table, MAND, id_l, bm, lane); break;
-                        case 1: pcm = mux_union_read<1>(rows, W, Wn, n, idf, table, MAND, id_l, bm, lane); break;
-                        case 2: pcm = mux_union_read<2>(rows, W, Wn, n, idf, table, MAND, id_l, bm, lane); break;
-                        case 3: pcm = mux_union_read<3>(rows, W, Wn, n, idf, table, MAND, id_l, bm, lane); break;
-                        case 4: pcm = mux_union_read<4>(rows, W, Wn, n, idf, table, MAND, id_l, bm, lane); break;
-                        case 5: pcm = mux_union_read<5>(rows, W, Wn, n, idf, table, MAND, id_l, bm, lane); break;
-                        default: pcm = mux_union_read<6>(rows, W, Wn, n, idf, table, MAND, id_l, bm, lane); break;
+                    {   // three rounds of 64 row words at a time (4546 colours: the whole row). One family of instantiations: a second one
+                        // for rows of a single round doubled the kernel and brought the scalar spills back (profiles/r5/k3r_variants_r5.txt)
+                        switch (nfree) {
+                            case 0: pcm = mux_union_read<0, 3>(rows, W, Wn, n, idf, table, MAND, id_l, bm, ln); break;
+                            case 1: pcm = mux_union_read<1, 3>(rows, W, Wn, n, idf, table, MAND, id_l, bm, ln); break;
+                            case 2: pcm = mux_union_read<2, 3>(rows, W, Wn, n, idf, table, MAND, id_l, bm, ln); break;
+                            case 3: pcm = mux_union_read<3, 3>(rows, W, Wn, n, idf, table, MAND, id_l, bm, ln); break;
+                            case 4: pcm = mux_union_read<4, 3>(rows, W, Wn, n, idf, table, MAND, id_l, bm, ln); break;
+                            case 5: pcm = mux_union_read<5, 3>(rows, W, Wn, n, idf, table, MAND, id_l, bm, ln); break;
+                            default: pcm = mux_union_read<6, 3>(rows, W, Wn, n, idf, table, MAND, id_l, bm, ln); break;
+                        }
                     }
-                    for (uint32_t w = ((Wn + 63) & ~63u) + lane; w < W; w += 64) bm[w] = 0;  // (padding words behind the last round)
+                    for (uint32_t w = ((Wn + 63) & ~63u) + ln; w < W; w += 64) bm[w] = 0;  // (padding words behind the last round)
                     pcm = wave_sum_u32(pcm);
-                    if (lane == 0) out_count[r] = pcm;
+                    if (ln == 0) out_count[r] = pcm;
                     continue;
                 }
             }
@@ -1263,9 +1318,9 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 6 : 4)) void k3r
             const uint32_t add7 = (thr_c & 0x7Fu) * 0x01010101u, top7 = (thr_c & 0x80u) ? 0xFFFFFFFFu : 0u;
             const uint32_t all_pass = min_score == 0 ? 0xFFFFFFFFu : 0u;
             uint32_t pc = 0;
-            // one round = 64 words of the rows, one per lane, with their PLANES counter words in this lane's registers
+            // one round = 64 words of the rows, one per ln, with their PLANES counter words in this ln's registers
             for (uint32_t w0 = 0; w0 < Wn; w0 += 64) {
-                const uint32_t w = w0 + (uint32_t)lane;
+                const uint32_t w = w0 + (uint32_t)ln;
                 const uint32_t wi = min(w, W - 1);  // (lanes past the row load its last word and store nothing)
                 uint32_t cnt[PLANES];
 #pragma unroll
@@ -1306,9 +1361,9 @@ __global__ __launch_bounds__(256, BITS == 8 ? 8 : (BITS == 16 ? 6 : 4)) void k3r
                     }
                 }
             }
-            for (uint32_t w = ((Wn + 63) & ~63u) + lane; w < W; w += 64) bm[w] = 0;  // (padding words behind the last round)
+            for (uint32_t w = ((Wn + 63) & ~63u) + ln; w < W; w += 64) bm[w] = 0;  // (padding words behind the last round)
             pc = wave_sum_u32(pc);
-            if (lane == 0) out_count[r] = pc;
+            if (ln == 0) out_count[r] = pc;
         }
     }
 }

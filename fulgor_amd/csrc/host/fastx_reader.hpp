@@ -1171,11 +1171,14 @@ public:
             else throw std::runtime_error("a FASTQ file with wrapped lines cannot be read in parts");
         }
     }
-    // parser threads when the caller names none: half of the host's hardware threads, at most 32 (FULGOR_READER_THREADS overrides);
-    // the multi-GPU driver divides them among the ranks of a host
+    // parser threads when the caller names none: half of the host's hardware threads, at most 24 (FULGOR_READER_THREADS overrides);
+    // the multi-GPU driver divides them among the ranks of a host. More do not help: the ranges are read with pread, and past 32
+    // threads on one file the reads get in each other's way in the kernel (record count of a 3.2 GB FASTQ file on a 256-thread
+    // host: 16 threads 74 GB/s, 32: 78, 64: 45, 128: 12; profiles/r5/e2e_grid_r5.txt), while 16 to 24 threads parse 250 M reads/s
+    // and the worker loop behind them takes 200 M
     static unsigned default_threads() {
         if (const char* e = getenv("FULGOR_READER_THREADS")) { const long v = atol(e); if (v > 0) return (unsigned)std::min<long>(v, 1024); }
-        return std::min(32u, std::max(1u, std::thread::hardware_concurrency() / 2));
+        return std::min(24u, std::max(1u, std::thread::hardware_concurrency() / 2));
     }
     // bytes of text per parsed range (= per chunk handed to the worker loop; FULGOR_READER_RANGE_KB overrides)
     static uint64_t default_range_bytes() {

@@ -294,8 +294,11 @@ int fgpu_pseudoalign_stream(fgpu_index* ix, fgpu_fastx* query, int out_fd, int a
         return fail(-EINVAL, "threshold must be a float in (0.0,1.0]");  // tools/pseudoalign.cpp:275-278
     if (format != FGPU_FMT_ASCII && format != FGPU_FMT_BINARY && format != FGPU_FMT_COMPRESSED)
         return fail(-EINVAL, "Unknown output format. Supported formats: ascii, binary, compressed.");  // tools/pseudoalign.cpp:317-320
-    if (batch_reads == 0) batch_reads = env_u64("FULGOR_STREAM_BATCH", 1u << 19);
-    if (workers == 0) workers = (unsigned)env_u64("FULGOR_STREAM_WORKERS", 4);
+    // defaults from the grid of profiles/e2e_stream.py (profiles/r5/e2e_grid_r5.txt): 16 to 32 parser threads, 4 to 6 workers and
+    // batches of 2^18 or 2^19 reads all land within the run-to-run spread of each other; smaller batches fill the pipeline sooner
+    // and pin less host memory
+    if (batch_reads == 0) batch_reads = env_u64("FULGOR_STREAM_BATCH", 1u << 18);
+    if (workers == 0) workers = (unsigned)env_u64("FULGOR_STREAM_WORKERS", 5);
     workers = std::min(workers, 16u);
     std::vector<StreamWorkerState> states;
     fgpu_stream_cache* cache = nullptr;

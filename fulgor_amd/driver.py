@@ -242,12 +242,12 @@ def rank_env():
 
 def reader_threads_per_rank(io_threads, world):
     """parser threads of one rank: what the caller named, else half of the host's hardware threads divided among the ranks that
-    share the host (at most 32 per rank, at least 2)"""
+    share the host (at most 24 per rank, at least 2)"""
     if io_threads:
         return int(io_threads)
     import os
     hw = os.cpu_count() or 2
-    return max(2, min(32, hw // (2 * max(1, world))))
+    return max(2, min(24, hw // (2 * max(1, world))))
 
 
 def _place_part(part, output, offset):
@@ -270,7 +270,7 @@ def _place_part(part, output, offset):
 
 
 def pseudoalign_sharded(open_index, query, output, algo=FULL_INTERSECTION, threshold=0.0, fmt="ascii", rank=0, world=1,
-                        io_threads=0, device_for_reduce=None, batch=1 << 19):
+                        io_threads=0, device_for_reduce=None, batch=0):
     """One rank of a multi-GPU `pseudoalign`. Reads are independent units (tools/pseudoalign.cpp:22-51 keeps no state across
     reads but two counters): rank r opens the r-th of `world` byte ranges of the (plain or block-compressed) query file ONCE,
     counts its records by a walk over the record boundaries that copies nothing (fgpu_fastx_count_part), the ranks exchange
@@ -291,7 +291,7 @@ def pseudoalign_sharded(open_index, query, output, algo=FULL_INTERSECTION, thres
         begin, end = size * rank // world, size * (rank + 1) // world
     else:
         begin, end = 0, (1 << 64) - 1
-    batches = FastxReader(query, batch=batch, copy=False, threads=reader_threads_per_rank(io_threads, world), begin=begin, end=end)
+    batches = FastxReader(query, batch=batch or 1 << 18, copy=False, threads=reader_threads_per_rank(io_threads, world), begin=begin, end=end)
     first_id = 0
     if world > 1:
         mine = torch.tensor([batches.count()], dtype=torch.int64, device=device_for_reduce)

@@ -176,7 +176,7 @@ int fgpu_formatter_finish(fgpu_formatter* f, char** out, uint64_t* out_len);
  * file): every GPU of a multi-GPU run takes one part; fgpu_fastx_text_size gives the length of that text (the file size, or
  * the inflated size) and whether the file can be read in parts at all (an ordinary gzip stream cannot); fgpu_fastx_count
  * returns the number of records of a part (their global read ids follow from the counts of the parts in front).
- * threads = 0: half of the host's hardware threads, at most 32. */
+ * threads = 0: half of the host's hardware threads, at most 24. */
 typedef struct fgpu_fastx fgpu_fastx;
 int fgpu_fastx_open(const char* path, fgpu_fastx** out);
 int fgpu_fastx_open_part(const char* path, unsigned threads, uint64_t begin, uint64_t end, fgpu_fastx** out);
@@ -200,7 +200,7 @@ int fgpu_fastx_ring(void);
  * out_fd in `format` (FGPU_FMT_*), records in file order, read ids counting from first_read_id (src/ps_utils.cpp:276,286: read id =
  * position in the file); write_header != 0 puts the compressed format's 8-byte file header in front. out_fd < 0: nothing is
  * formatted or written (counters only). Returns when everything is written. The loop keeps `workers` batches of at most
- * batch_reads reads in flight (0 = defaults: 4 and 2^19): the reader's threads parse byte ranges of the file into pinned
+ * batch_reads reads in flight (0 = defaults: 5 and 2^18): the reader's threads parse byte ranges of the file into pinned
  * memory, each range goes to the device as it lies, lookup -> colour stage -> device-side formatter -> copy out run per batch on
  * the batch's own stream, so that the copy in of one batch, the kernels of another and the copy out of a third overlap. The u32
  * colour lists are not built for the compressed format. num_reads / num_mapped: the two counters of ps_options

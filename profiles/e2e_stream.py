@@ -69,22 +69,20 @@ try:
             rd.close()
             dt = time.perf_counter() - t0
         print("fgpu_fastx_next (parse + gather into pinned batches), %3d threads: %.1f ms  %.1f M reads/s  %.1f GB/s of text" % (threads, dt * 1e3, tot / dt / 1e6, size / dt / 1e9))
-    grid = [(32, 4, 1 << 19), (64, 4, 1 << 19)] if quick else [
-        (16, 4, 1 << 19), (32, 4, 1 << 19), (48, 4, 1 << 19), (64, 4, 1 << 19), (96, 4, 1 << 19), (128, 4, 1 << 19),
-        (64, 2, 1 << 19), (64, 3, 1 << 19), (64, 6, 1 << 19), (64, 8, 1 << 19),
-        (64, 4, 1 << 17), (64, 4, 1 << 18), (64, 4, 1 << 20), (64, 6, 1 << 18), (64, 8, 1 << 18), (96, 6, 1 << 18)]
+    grid = [(32, 4, 1 << 19), (24, 4, 1 << 19)] if quick else [(t, w, b_) for b_ in (1 << 17, 1 << 18, 1 << 19) for w in (3, 4, 5, 6) for t in (16, 24, 32, 48)]
     best = None
+    run(ix, 32, 6, 1 << 19)  # (pins the host buffers, sizes the device buffers)
     for threads, workers, batch in grid:
-        ts = [run(ix, threads, workers, batch) for _ in range(3)]
+        ts = [run(ix, threads, workers, batch) for _ in range(4)]
         dt = min(ts)
         print("stream compressed: %3d parser threads, %d workers, batch %7d: %.1f ms  %.1f M reads/s (runs: %s)"
               % (threads, workers, batch, dt * 1e3, n / dt / 1e6, " ".join("%.1f" % (t * 1e3) for t in ts)))
         if best is None or dt < best[0]:
             best = (dt, threads, workers, batch)
     _, threads, workers, batch = best
-    for kb in (1024, 2048, 4096, 16384):
+    for kb in (2048, 4096, 16384):
         os.environ["FULGOR_READER_RANGE_KB"] = str(kb)
-        ts = [run(ix, threads, workers, batch) for _ in range(3)]
+        ts = [run(ix, threads, workers, batch) for _ in range(4)]
         print("stream compressed, ranges of %5d KB (%d threads, %d workers, batch %d): %.1f ms  %.1f M reads/s" % (kb, threads, workers, batch, min(ts) * 1e3, n / min(ts) / 1e6))
     del os.environ["FULGOR_READER_RANGE_KB"]
     ix.timing_enable(True)
