@@ -27,7 +27,7 @@ import re, subprocess, sys
 notes, dis, classes = open(sys.argv[1]).read(), open(sys.argv[2]).read(), sys.argv[3]
 def demangle(n):
     try:
-        return subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", n], capture_output=True, text=True).stdout.strip()
+        return subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip() or n
     except Exception:
         return n
 meta = {}
