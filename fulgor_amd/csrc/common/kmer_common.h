@@ -117,8 +117,9 @@ FG_HD uint32_t dict_hash(uint32_t lo, uint32_t hi, uint32_t seed) {
 // share those consecutive overflow buckets, and every query that meets the redirect reads the first REDIRECT_DIRECT
 // of them at once (a record is verified by its context: records of other keys simply do not match).
 // spill (bit 31 of w3 of a bucket's last slot): the query goes on with the next bucket. Set on the overflow
-// buckets of a run from the REDIRECT_DIRECT-th on (but the last), and on a hashed bucket when more than four keys
-// live there (rare), whose surplus keys then sit in the following buckets.
+// buckets of a run from the REDIRECT_DIRECT-th on (but the last); never on a hashed bucket (when more than four keys
+// live in one — rare — the surplus keys go to its overflow run too). A bucket thus hands a query on to at most three
+// others if it is a hashed one and to at most one if not, which bounds the lookup kernel's ring of waiting buckets.
 // Needs 2k - m <= 45 and k - m <= 15 (k = 31, m = 17: exactly 45 bases, 15 windows: 16 runs per 150-base read, so that four
 // reads fill a pass of the lookup kernel; round 2 had 43 bases for m = 19 and a 31-bit colour-set id).
 constexpr uint32_t REC_WORDS = 4;

@@ -987,7 +987,9 @@ int fgpu_result_create(fgpu_index* ix, fgpu_result** out) {
         HIP_TRY(hipHostMalloc((void**)&r->h_totals, 32));
         // FULGOR_CU_SPLIT=<n>: CUs [0, n) of the device's CU mask serve the lookup streams, the others the colour streams (a pass's
         // lookup then overlaps another pass's colour stage without the two kernels sharing a CU: fgpu_run_lookup / fgpu_run_colours).
-        // FULGOR_CU_RANGE=<lo>:<hi> binds both to CUs [lo, hi) (scaling measurements).
+        // FULGOR_CU_RANGE=<lo>:<hi> binds both to CUs [lo, hi) (scaling measurements). (Streams with a CU mask are blocking streams:
+        // they synchronise implicitly with the legacy default stream, the others do not; split and unsplit timings of a caller
+        // that also uses the default stream are therefore not strictly comparable.)
         const uint64_t split = env_u64("FULGOR_CU_SPLIT", 0);
         const char* range = getenv("FULGOR_CU_RANGE");
         auto masked = [&](hipStream_t* st, uint32_t lo, uint32_t hi) {
@@ -1000,7 +1002,10 @@ int fgpu_result_create(fgpu_index* ix, fgpu_result** out) {
             masked(&r->stream, (uint32_t)split, (uint32_t)ix->num_cus);
             HIP_TRY(hipEventCreateWithFlags(&r->ev_lookup, hipEventDisableTiming));
         } else if (range && strchr(range, ':')) {
-            masked(&r->stream, (uint32_t)atoi(range), (uint32_t)atoi(strchr(range, ':') + 1));
+            const long lo = atol(range), hi = atol(strchr(range, ':') + 1);
+            if (!(lo >= 0 && lo < hi && hi <= (long)ix->num_cus))
+                throw std::runtime_error("FULGOR_CU_RANGE=" + std::string(range) + ": need 0 <= lo < hi <= " + std::to_string(ix->num_cus));
+            masked(&r->stream, (uint32_t)lo, (uint32_t)hi);
             r->stream_lookup = r->stream;
         } else {
             HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
@@ -1010,7 +1015,7 @@ int fgpu_result_create(fgpu_index* ix, fgpu_result** out) {
         HIP_TRY(hipStreamCreateWithFlags(&r->stream_in, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&r->stream_out, hipStreamNonBlocking));
     });
-    if (rc) { delete r; return rc; }
+    if (rc) { fgpu_result_free(r); return rc; }  // (what was created so far goes with it)
     *out = r;
     return 0;
 }

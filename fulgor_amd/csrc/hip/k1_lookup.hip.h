@@ -126,7 +126,11 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
     constexpr int HCAP = KMAX;              // heads per pass; a single unit has at most one head per k-mer
     constexpr uint32_t POSM = (1u << ORDER_POS_BITS) - 1u;
     constexpr uint32_t FIRST = 0x80000000u;
-    constexpr uint32_t PAIRS = 256;         // ring of (bucket << 6 | source lane) pairs waiting for a lane (at most 4 new ones per lane and batch)
+    // ring of (bucket << 6 | source lane) pairs waiting for a lane. It cannot overflow: the 64 run lanes of a pass look at hashed
+    // buckets, which leave at most REDIRECT_DIRECT = 3 overflow buckets each (192 pairs), and an overflow bucket that is looked at
+    // leaves at most one (the next of its run) in the place of the pair it took (host/dict_build.hpp builds it so; fgpu_selfcheck
+    // verifies it)
+    constexpr uint32_t PAIRS = 256;
     // M_UNIT: unit within the ticket | span position of its first base << 8; M_KEND: span position behind its last k-mer's first base
     enum { M_UNIT = 0, M_QA = 1, M_QB = 2, M_NIDS = 3, M_NPOS = 4, M_HA = 5, M_HB = 6, M_KEND = 7, M_WORDS = 8 };
     // one block of LDS per wave, every array at a constant offset from the wave's base address (one address register

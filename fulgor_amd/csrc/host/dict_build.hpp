@@ -62,9 +62,8 @@ inline uint64_t record_key(const uint32_t* w, uint32_t k, uint32_t m) {
     return lmer_key(lo, hi);
 }
 
-// Places the records into the bucket table. Hashed region: a sweep over the buckets in order; the keys living
-// in a bucket (those hashed to it, plus keys carried over from a bucket with more than four keys) keep all their
-// records there while the bucket has room (keys with fewer records first). If they do not all fit, the bucket's LAST
+// Places the records into the bucket table. Hashed region: a sweep over the buckets in order; the keys hashed to a
+// bucket keep all their records there while the bucket has room (keys with fewer records first). If they do not all fit, the bucket's LAST
 // slot becomes its REDIRECT and the keys that are left share one run of consecutive buckets in the overflow region
 // (a record is verified by its context, so records of several keys may lie side by side). ~0.6 records per bucket on average.
 inline void build_dict_table(Dict& d) {
@@ -73,7 +72,17 @@ inline void build_dict_table(Dict& d) {
     // 1.625 buckets per record (0.6 records per bucket); FULGOR_DICT_BUCKET_FACTOR overrides it (measurements: the table is rebuilt at every open)
     double factor = 1.625;
     if (const char* e = getenv("FULGOR_DICT_BUCKET_FACTOR")) { const double v = atof(e); if (v >= 1.0 && v <= 16.0) factor = v; }
-    d.num_buckets = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>((uint64_t)((double)nrec * factor), DICT_MAX_BUCKETS - DICT_TAIL_BUCKETS - nrec / 4 - 4096));
+    // at most 2^26 buckets in all (a bucket and a lane pack into 32 bits in the lookup kernel): the hashed region leaves room for an
+    // overflow region of a quarter of the records; a collection that does not fit is refused here, not at the first redirect
+    const int64_t cap = (int64_t)DICT_MAX_BUCKETS - (int64_t)DICT_TAIL_BUCKETS - (int64_t)(nrec / 4) - 4096;
+    if (cap < (int64_t)(nrec / 2))
+        throw std::runtime_error("the k-mer dictionary of this collection needs more than 2^26 buckets (" + std::to_string(nrec) +
+                                 " super-k-mer records; the limit is about 80 M): not supported by this build");
+    const uint64_t want_buckets = (uint64_t)((double)nrec * factor);
+    if ((int64_t)want_buckets > cap)
+        fprintf(stderr, "fulgor_amd: dictionary table capped at %lld buckets for %llu records (%.2f buckets per record instead of %.2f): more keys behind redirects\n",
+                (long long)cap, (unsigned long long)nrec, (double)cap / (double)nrec, factor);
+    d.num_buckets = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(want_buckets, (uint64_t)cap));
     const uint64_t nb_hashed = (uint64_t)d.num_buckets + DICT_TAIL_BUCKETS;
     struct Ref { uint32_t home; uint32_t rec; uint64_t key; };
     // The table is rebuilt from the records whenever an index is opened: the sort of the records by (home bucket, key) is
@@ -139,7 +148,7 @@ inline void build_dict_table(Dict& d) {
             }
     });
     struct Item { uint64_t first, count; };  // a key: refs[first, first + count)
-    std::vector<Item> carry, items;
+    std::vector<Item> items;
     std::vector<uint32_t> overflow;  // the overflow region, appended behind the hashed region at the end
     // the records in table order (gathered by all threads: the sweep below then reads them front to back instead of
     // missing the cache once per record)
@@ -157,8 +166,7 @@ inline void build_dict_table(Dict& d) {
     };
     uint64_t at = 0;
     for (uint64_t b = 0; b < nb_hashed; ++b) {
-        items.swap(carry);
-        carry.clear();
+        items.clear();
         while (at < nrec && refs[at].home == b) {
             uint64_t e = at;
             while (e < nrec && refs[e].home == b && refs[e].key == refs[at].key) ++e;
@@ -167,10 +175,10 @@ inline void build_dict_table(Dict& d) {
         }
         if (items.empty()) continue;
         uint32_t* bw = &d.table[b * BUCKET_WORDS];
-        if (items.size() > BUCKET_RECS) {  // more keys than slots: the surplus keys move on to the next bucket
-            carry.assign(items.begin() + BUCKET_RECS, items.end());
-            items.resize(BUCKET_RECS);
-        }
+        // (more keys than slots: the surplus keys go to the bucket's overflow run like every key that does not fit. A hashed bucket
+        // never hands a query on to the next hashed bucket: a bucket met by a query leaves at most REDIRECT_DIRECT new buckets to look
+        // at if it is a hashed one, at most one — the next of its run — if it is an overflow bucket, which bounds the lookup
+        // kernel's ring of waiting buckets: 64 runs x 3.)
         // whole keys while they fit, fewest records first; with a redirect the bucket has one slot less
         std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.count < y.count; });
         uint64_t total = 0;
@@ -203,9 +211,7 @@ inline void build_dict_table(Dict& d) {
             dst[2] = REC_W2_REDIRECT;
             dst[3] = (uint32_t)nb;
         }
-        if (!carry.empty()) bw[(BUCKET_RECS - 1) * REC_WORDS + 3] |= REC_SPILL;
     }
-    if (!carry.empty()) throw std::runtime_error("dictionary table: keys carried past the tail buckets");
     d.table.insert(d.table.end(), overflow.begin(), overflow.end());
 }
 
@@ -367,6 +373,15 @@ inline uint32_t dict_lookup(const Dict& d, uint32_t klo, uint32_t khi, uint32_t*
 // every k-mer of every unitig must be found exactly once, on both strands, with its unitig's colour-set id
 inline void verify_dict(const Dict& d, uint64_t stride = 1) {
     const uint32_t k = d.k;
+    {   // what bounds the lookup kernel's ring of waiting buckets (k1_lookup, PAIRS): a hashed bucket hands a query on to at most
+        // REDIRECT_DIRECT overflow buckets and never to the next hashed bucket; an overflow bucket to at most the next of its run
+        const uint64_t nb_hashed = (uint64_t)d.num_buckets + DICT_TAIL_BUCKETS, nb = d.table.size() / BUCKET_WORDS;
+        for (uint64_t b = 0; b < nb; ++b) {
+            const uint32_t* last = &d.table[b * BUCKET_WORDS + (BUCKET_RECS - 1) * REC_WORDS];
+            const bool redirect = (last[2] & 0x80000000u) != 0, spill = (last[3] & REC_SPILL) != 0;
+            if (b < nb_hashed ? spill : redirect) throw std::runtime_error("dictionary self-check failed (a hashed bucket spills, or an overflow bucket redirects)");
+        }
+    }
     for (uint64_t u = 0; u < d.num_unitigs(); u += stride) {
         for (uint64_t s = d.unitig_off[u]; s + k <= d.unitig_off[u + 1]; ++s) {
             uint32_t lo, hi, c = 0;

@@ -20,6 +20,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 #include <zlib.h>
 #include <algorithm>
@@ -318,14 +319,12 @@ inline bool fastx_file_rangeable(const std::string& path) {
     return got == 0 || fastx_head_rangeable(head.data(), got, kind);
 }
 
-// Optional confinement of the parser threads (FULGOR_READER_AFFINITY=1; off by default) to the first hardware thread of every core
-// of one NUMA node: the node of the GPU (where the runtime puts pinned host memory) when the engine has said which
-// (fastx_preferred_node), else the node of the calling thread. Measured on a two-socket, 256-thread host
-// (profiles/r5/e2e_breakdown_r5.txt): with the WHOLE process confined to the cores of the node that holds the file's pages
-// (taskset -c 0-63) ten million reads take 50 to 57 ms run after run, left to the scheduler 55 to 75 ms; confining only the
-// parser threads to the GPU's node made it worse (77 to 114 ms: the file's pages were on the other node, and reading them
-// through pread from the far socket is what a parser thread then spends its time on). Where the file's pages live is not
-// the reader's to choose, so the default leaves the threads to the scheduler.
+// Where the parser threads run: left to the scheduler. They can be confined (FULGOR_READER_AFFINITY = file | device | <node>) to the
+// first hardware thread of every core of one NUMA node — the node that holds the file's cached pages (fastx_file_node samples a few),
+// the node of the GPU, or a given one. Measured on two-socket, 256-thread hosts by taking turns inside one process
+// (profiles/e2e_ab.py, profiles/r5/e2e_breakdown_r5.txt): scheduler 77 ms median / 54 ms best for ten million reads, file's node
+// 82 / 64, device's node 86 / 64 — none of the confinements helps. (The whole PROCESS started under `taskset` on the cores of one
+// node, file written from there too, runs 50 to 57 ms every time: what that buys is not the parser threads' placement.)
 inline std::atomic<int>& fastx_preferred_node() { static std::atomic<int> n{-1}; return n; }
 inline std::vector<int> parse_cpu_list(const std::string& text) {
     std::vector<int> out;
@@ -353,44 +352,57 @@ inline std::string read_small_file(const std::string& path) {
     fclose(f);
     return std::string(buf, n);
 }
-inline const std::vector<int>& fastx_parser_cpus() {
-    static const std::vector<int> cpus = [] {
-        std::vector<int> out;
-        const char* e = getenv("FULGOR_READER_AFFINITY");
-        if (!e || atoi(e) != 1) return out;
-        cpu_set_t allowed;
-        CPU_ZERO(&allowed);
-        if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return out;
-        int node = fastx_preferred_node().load();
-        if (node < 0) {  // the node this thread runs on
-            const int cpu = sched_getcpu();
-            for (int n = 0; n < 64 && node < 0; ++n) {
-                const std::string l = read_small_file("/sys/devices/system/node/node" + std::to_string(n) + "/cpulist");
-                if (l.empty()) { if (n > 0) break; else continue; }
-                for (int c : parse_cpu_list(l)) if (c == cpu) node = n;
-            }
-        }
-        if (node < 0) return out;
-        for (int c : parse_cpu_list(read_small_file("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist"))) {
-            if (c >= CPU_SETSIZE || !CPU_ISSET(c, &allowed)) continue;
-            const std::vector<int> sib = parse_cpu_list(read_small_file("/sys/devices/system/cpu/cpu" + std::to_string(c) + "/topology/thread_siblings_list"));
-            if (!sib.empty() && *std::min_element(sib.begin(), sib.end()) != c) continue;  // one hardware thread per core
-            out.push_back(c);
-        }
-        if (out.size() < 4) out.clear();
-        return out;
-    }();
-    return cpus;
+// first hardware thread of every core of `node` that this process may run on (empty: unknown node, or fewer than 4 CPUs)
+inline std::vector<int> fastx_node_cpus(int node) {
+    std::vector<int> out;
+    if (node < 0) return out;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return out;
+    for (int c : parse_cpu_list(read_small_file("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist"))) {
+        if (c >= CPU_SETSIZE || !CPU_ISSET(c, &allowed)) continue;
+        const std::vector<int> sib = parse_cpu_list(read_small_file("/sys/devices/system/cpu/cpu" + std::to_string(c) + "/topology/thread_siblings_list"));
+        if (!sib.empty() && *std::min_element(sib.begin(), sib.end()) != c) continue;  // one hardware thread per core
+        out.push_back(c);
+    }
+    if (out.size() < 4) out.clear();
+    return out;
 }
-// confine the calling thread to the parser CPUs when they can seat `threads` threads
-inline void fastx_confine_parser_thread(unsigned threads) {
-    const std::vector<int>& cpus = fastx_parser_cpus();
+// NUMA node that holds (most of) the cached pages of bytes [begin, end) of an open file: a few pages across the range are mapped,
+// touched and asked for their node (move_pages with no target nodes). -1: unknown (not Linux NUMA, nothing to sample).
+inline int fastx_file_node(int fd, uint64_t begin, uint64_t end) {
+    if (end <= begin) return -1;
+    const long page = sysconf(_SC_PAGESIZE);
+    constexpr int SAMPLES = 16;
+    int votes[64] = {0};
+    for (int i = 0; i < SAMPLES; ++i) {
+        const uint64_t at = (begin + (end - begin) / SAMPLES * i) / (uint64_t)page * (uint64_t)page;
+        void* m = mmap(nullptr, (size_t)page, PROT_READ, MAP_PRIVATE, fd, (off_t)at);
+        if (m == MAP_FAILED) continue;
+        volatile char touch = *(volatile const char*)m;
+        (void)touch;
+        void* pages[1] = {m};
+        int status[1] = {-1};
+        if (syscall(SYS_move_pages, 0, 1ul, pages, nullptr, status, 0) == 0 && status[0] >= 0 && status[0] < 64) votes[status[0]]++;
+        munmap(m, (size_t)page);
+    }
+    int best = -1;
+    for (int n = 0; n < 64; ++n) if (votes[n] > (best < 0 ? 0 : votes[best])) best = n;
+    return best;
+}
+// confine the calling thread to `cpus` when they can seat `threads` threads
+inline void fastx_confine_thread(const std::vector<int>& cpus, unsigned threads) {
     if (cpus.size() < threads) return;
     cpu_set_t set;
     CPU_ZERO(&set);
     for (int c : cpus) CPU_SET(c, &set);
     (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
 }
+
+// a text whose records cannot be found from the middle (FASTQ with wrapped lines): the caller falls back to one stream
+struct NotRangeable : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
 
 class FastxSource {
 public:
@@ -609,13 +621,23 @@ protected:
             const uint64_t head = std::min<uint64_t>(size_, 1u << 20);
             Window w;
             if (!fastx_head_rangeable(base(w, 0, head), head, kind_))
-                throw std::runtime_error("this FASTQ text has records that are not four lines long (wrapped lines): it cannot be cut into byte ranges");
+                throw NotRangeable("this FASTQ text has records that are not four lines long (wrapped lines): it cannot be cut into byte ranges");
         }
         begin_ = std::min(begin, size_);
         end_ = std::min(end, size_);
         num_ranges_ = begin_ < end_ ? (end_ - begin_ + range_ - 1) / range_ : 0;
         window_ = 2 * std::max(1u, threads) + 2;
         nthreads_ = std::max(1u, threads);
+        {   // where the parser threads run: FULGOR_READER_AFFINITY = 0 (default: the scheduler's choice) | file | device | <node number>
+            const char* e = getenv("FULGOR_READER_AFFINITY");
+            const std::string mode = e ? e : "0";
+            int node = -1;
+            if (mode == "file") node = fd_ >= 0 && use_pread_ ? fastx_file_node(fd_, begin_, end_) : -1;
+            else if (mode == "device") node = fastx_preferred_node().load();
+            else if (mode != "0" && !mode.empty() && isdigit((unsigned char)mode[0])) node = atoi(mode.c_str());
+            cpus_ = fastx_node_cpus(node);
+            if (getenv("FULGOR_TRACE_READER")) fprintf(stderr, "[reader] parser threads: mode %s, node %d (device on %d), %zu cpus\n", mode.c_str(), node, fastx_preferred_node().load(), cpus_.size());
+        }
         const uint64_t t_th = fastx_now_ns();
         for (unsigned t = 0; t < std::max(1u, threads) && t < num_ranges_; ++t) workers_.emplace_back([this] { work(); });
         if (getenv("FULGOR_TRACE_READER")) fprintf(stderr, "[reader] %zu parser threads started in %.2f ms\n", workers_.size(), (fastx_now_ns() - t_th) / 1e6);
@@ -750,7 +772,7 @@ public:
         };
         std::vector<std::thread> th;
         const unsigned nt = (unsigned)std::min<uint64_t>(std::max(1u, threads), std::max<uint64_t>(1, num_ranges_));
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back([&body, nt] { fastx_confine_parser_thread(nt); body(); });
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back([this, &body, nt] { fastx_confine_thread(cpus_, nt); body(); });
         body();
         for (auto& t : th) t.join();
         if (!err.empty()) throw std::runtime_error(err);
@@ -760,7 +782,7 @@ public:
 
 protected:
     void work() {
-        fastx_confine_parser_thread(nthreads_);
+        fastx_confine_thread(cpus_, nthreads_);
         Window w;
         for (;;) {
             uint64_t r;
@@ -815,6 +837,7 @@ protected:
 
 protected:
     int fd_ = -1;
+    std::vector<int> cpus_;   // CPUs the parser threads are confined to (empty: left to the scheduler)
     bool use_pread_ = false;  // (derived sources hand out their own buffer as map_)
     const char* map_ = nullptr;
     uint64_t size_ = 0, begin_ = 0, end_ = 0, range_, num_ranges_ = 0, window_ = 4;
@@ -1153,8 +1176,8 @@ public:
                 // reader, which takes block-compressed files as any gzip reader does; parts of it stay an error)
                 try {
                     src_.reset(new BgzfFastxSource(path, threads, begin, end, range_bytes));
-                } catch (const std::runtime_error& e) {
-                    if (begin != 0 || end != ~0ULL || std::string(e.what()).find("wrapped lines") == std::string::npos) throw;
+                } catch (const NotRangeable&) {
+                    if (begin != 0 || end != ~0ULL) throw;
                     src_.reset(new StreamFastxSource(path));
                 }
             } else {

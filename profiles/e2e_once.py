@@ -23,9 +23,25 @@ rec[:, 165:-1] = ord("I")
 rec[:, -1] = ord("\n")
 rec.tofile(path)
 del rec, b, o
+if os.environ.get("E2E_TORCH"):  # (what bench.py has in its process: torch's HIP context, a tensor, an all-reduce-sized copy)
+    import torch
+    t = torch.zeros(4548, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    if os.environ["E2E_TORCH"] == "2":
+        big = torch.empty(3 << 30, dtype=torch.uint8, device="cuda:0")
+        host = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
 try:
     ix = fulgor_amd.Index(fg, device=0)
     reps = []
+    if os.environ.get("E2E_BIND"):  # the calling thread (and the threads it starts from here on) onto the first hardware thread of every core of one node
+        node = int(os.environ["E2E_BIND"])
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b_ = part.partition("-")
+            cpus.update(range(int(a), int(b_ or a) + 1))
+        keep = {c for c in cpus if min(int(x) for x in open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().replace("-", ",").split(",")) == c}
+        os.sched_setaffinity(0, keep & os.sched_getaffinity(0))
+        print("bound to %d cpus of node %d" % (len(os.sched_getaffinity(0)), node))
     for r in range(runs):
         time.sleep(float(os.environ.get("E2E_SLEEP", "0")))
         t0 = time.perf_counter()

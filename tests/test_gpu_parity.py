@@ -1403,8 +1403,10 @@ def test_s4546_dense_rows_serve_every_codec(s4546, index_type, psize, csize):
     iy.close()
 
 
-def test_bench_two_ranks_on_the_synthetic_4546_colour_index():
-    """first contact of the multi-GPU bench (the driver's 8-GPU run) as far as one GPU can show it: `bench.py --gpus 2` on the
+@pytest.mark.parametrize("index_type", ["hybrid", "meta-diff"])
+def test_bench_two_ranks_on_the_synthetic_4546_colour_index(index_type):
+    """(meta-diff: the codec of configs[4], the 8-GPU configuration, on two ranks at reduced size)
+    first contact of the multi-GPU bench (the driver's 8-GPU run) as far as one GPU can show it: `bench.py --gpus 2` on the
     BASELINE workload itself — rank 0 builds the synthetic 4546-colour index (tens of seconds on a cold box) while rank 1 waits
     for the marker file, both open it, every rank announces its device on stderr, the hit vector is all-reduced and checked"""
     import json
@@ -1413,10 +1415,13 @@ def test_bench_two_ranks_on_the_synthetic_4546_colour_index():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "FULGOR_S4546_DUMP"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "s4546syn", "--reads", "200000", "--steps", "2",
-                        "--warmup", "1", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+                        "--warmup", "1", "--no-cpu-baseline", "--index-type", index_type], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["collective_backend"] == "gloo" and line["scaling"] == "weak"
+    assert line["reads_counted_all_ranks"] == 2 * 200000 and 0 < line["mapped_all_ranks"] <= 2 * 200000
+    assert ("meta-diff" in line["config"]["workload"]) == (index_type == "meta-diff")
     assert line["data"] == "synthetic" and "SYNTHETIC" in line["config"]["workload"] and line["config"]["reads_per_gpu"] == 200000
     assert line["value"] > 0 and 0 < line["roofline"]["frac"] < 1
     for rank in (0, 1):
