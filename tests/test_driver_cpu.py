@@ -477,11 +477,13 @@ def test_reader_parts_fuzz(built, tmp_path):
     def collect(path, **kw):
         seqs, names = [], []
         rd = FastxReader(path, copy=True, batch=37, threads=3, **kw)
+        counted = rd.count()  # (fgpu_fastx_count_part: the grammar walked without copies, on the same handle, before anything is consumed)
         for bases, offs in rd:
             b = bytes(bases)
             seqs += [b[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
             names += rd.names()
         rd.close()
+        assert counted == len(seqs), (path, kw, counted, len(seqs))
         return seqs, names
 
     for trial in range(1500):
@@ -667,3 +669,43 @@ def test_bench_real_dump_hook_ingests_a_dump_and_labels_the_line(built, tmp_path
     os.remove(mine + ".filenames.txt")
     with pytest.raises(SystemExit, match="filenames.txt is missing"):
         bench.real_dump_workload(mine, data)
+
+
+def test_reader_mapped_and_read_ranges_agree(built, tmp_path):
+    """the ranges of a plain file are read with pread into per-thread buffers; FULGOR_READER_MMAP=1 (an A/B knob) maps the file
+    instead. Same records, same counts, whole and in parts, FASTA and FASTQ (the knob is read when a reader opens: subprocess)."""
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    recs = [bytes(alpha[rng.integers(0, 5, size=int(rng.integers(1, 400)))]) for _ in range(60000)]
+    fq, fa = tmp_path / "r.fq", tmp_path / "r.fa"
+    fq.write_bytes(b"".join(b"@q%d x\n%s\n+\n%s\n" % (i, s, b"@" * len(s)) for i, s in enumerate(recs)))
+    fa.write_bytes(b"".join(b">q%d\n%s\n" % (i, b"\n".join(s[j:j + 70] for j in range(0, len(s), 70))) for i, s in enumerate(recs)))
+    code = r'''
+import hashlib, os, sys
+sys.path.insert(0, %r)
+from fulgor_amd.reads import FastxReader
+os.environ["FULGOR_READER_RANGE_KB"] = "256"
+for path in sys.argv[1:]:
+    size = os.path.getsize(path)
+    for a, b in ((0, (1 << 64) - 1), (0, size // 3), (size // 3, size - 1000), (size - 1000, size)):
+        h, n = hashlib.sha256(), 0
+        rd = FastxReader(path, copy=True, batch=5000, threads=4, begin=a, end=b)
+        c = rd.count()
+        for bases, offs in rd:
+            h.update(bytes(bases)); h.update(offs.tobytes()); n += len(offs) - 1
+            h.update("|".join(rd.names()).encode())
+        rd.close()
+        assert c == n
+        print(os.path.basename(path), a, b, n, h.hexdigest())
+''' % ROOT
+    outs = []
+    for mode in ("", "1"):
+        env = dict(os.environ)
+        env.pop("FULGOR_READER_MMAP", None)
+        if mode:
+            env["FULGOR_READER_MMAP"] = mode
+        r = subprocess.run([sys.executable, "-c", code, str(fq), str(fa)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] and outs[0].count("\n") == 8
+    assert " 60000 " in outs[0].splitlines()[0]
