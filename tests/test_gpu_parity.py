@@ -1534,3 +1534,84 @@ def test_gpu_matches_golden_at_4546_colours(s4546small, colour_stage, index_type
     assert csr_to_lists(*fi) == load_golden_tsv("s4546small_full_intersection.tsv.gz")
     for tau in (0.8, 0.3):
         assert csr_to_lists(*tu[tau]) == load_golden_tsv("s4546small_threshold_union_%s.tsv.gz" % tau)
+
+
+# ---- round 5: the native worker loop (fgpu_pseudoalign_stream) ------------------------------------------------------------------
+def _stream(ix, path, fmt, algo=fulgor_amd.FULL_INTERSECTION, tau=0.0, first_id=0, batch=0, workers=0, threads=3, **reader_kw):
+    """one run of the native loop into a temporary file; returns (bytes, reads, mapped)"""
+    import tempfile
+    from fulgor_amd.reads import FastxReader
+    rd = FastxReader(path, copy=False, threads=threads, **reader_kw)
+    with tempfile.TemporaryFile() as out:
+        n, mapped = ix.pseudoalign_stream(rd, out.fileno(), algo, tau, fmt, first_id, True, batch, workers)
+        rd.close()
+        out.seek(0)
+        return out.read(), n, mapped
+
+
+def test_stream_loop_equals_batch_calls_on_ragged_and_long_reads(s10_gpu, s10_oracle, tmp_path, monkeypatch):
+    """fgpu_pseudoalign_stream against the host-buffer calls and the oracle: reads of 0 .. 60000 bases in one FASTA file (multi-line
+    records; reads above 512 k-mers take the loop's segment path), ranges of 64 KB so that the file is many chunks, batches of 7 to 4000
+    reads on 1 to 6 workers, the three output formats, full intersection and threshold union, read ids counted from an offset"""
+    from oracle.kmer_oracle import read_fasta
+    from oracle.pyoracle import parse_compressed
+    from fulgor_amd.driver import Formatter
+    monkeypatch.setenv("FULGOR_READER_RANGE_KB", "64")
+    src = max(read_fasta(S10_GENOMES[5]), key=len)
+    rng = np.random.default_rng(5)
+    lens = [1054, 700, 300, 151, 31, 30, 0, 64, 5000, 60000, 1100] + [int(x) for x in rng.integers(0, 400, size=3000)] + [2078, 150, 150]
+    reads = [src[(i * 977) % 3000000:(i * 977) % 3000000 + l] for i, l in enumerate(lens)]
+    reads[20] = reads[20].replace(b"A", b"N", 2)
+    fa = tmp_path / "ragged.fa"
+    with open(fa, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b">r%d some text\n" % i + b"".join(r[j:j + 80] + b"\n" for j in range(0, len(r), 80)) + (b"\n" if not r else b""))
+    b, o = pack_reads(reads)
+    fo, fc = s10_oracle.full_intersection(b, o)
+    to, tc = s10_oracle.threshold_union(b, o, 0.7)
+    nc = s10_gpu.num_colors()
+    for batch, workers in ((7, 3), (500, 6), (4000, 1), (0, 0)):
+        out, n, mapped = _stream(s10_gpu, str(fa), 0, batch=batch, workers=workers, first_id=1000)
+        assert n == len(reads) and mapped == int((np.diff(fo.astype(np.int64)) > 0).sum())
+        assert out == Formatter("ascii", nc).add(1000, fo, fc), (batch, workers)
+    out, n, _ = _stream(s10_gpu, str(fa), 1, batch=900, workers=4)
+    assert out == Formatter("binary", nc).add(0, fo, fc)
+    out, n, mapped = _stream(s10_gpu, str(fa), 2, fulgor_amd.THRESHOLD_UNION, 0.7, batch=333, workers=5, first_id=17)
+    ids, po, pc = parse_compressed(out)
+    assert np.array_equal(ids, np.arange(17, 17 + len(reads), dtype=np.uint32)) and np.array_equal(po, to) and np.array_equal(pc, tc)
+    assert mapped == int((np.diff(to.astype(np.int64)) > 0).sum())
+
+
+def test_stream_loop_on_empty_wrapped_and_broken_files(s10_gpu, s10_oracle, tmp_path):
+    """an empty query file gives the header and no records; a FASTQ file that turns into wrapped lines behind a four-line head offers no record
+    boundaries in its tail, which then falls to one range and the full grammar: same records as the oracle's; a gzip file with a flipped byte
+    in the middle ends the run with the reader's error — no hang, no partial success — and the loop works again afterwards"""
+    import gzip
+    from fulgor_amd.driver import Formatter
+    empty = tmp_path / "empty.fq"
+    empty.write_bytes(b"")
+    out, n, mapped = _stream(s10_gpu, str(empty), 2)
+    assert (n, mapped) == (0, 0) and out == Formatter("compressed", s10_gpu.num_colors()).header
+    out, n, mapped = _stream(s10_gpu, str(empty), 0)
+    assert (n, mapped, out) == (0, 0, b"")
+    seqs = [r for r in load_golden_reads()[:3000]]
+    good = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(seqs))
+    tail = b"".join(b"@w%d\n%s\n%s\n+\n%s\n%s\n" % (i, r[:70], r[70:], b"@" * 70, b"I" * (len(r) - 70)) for i, r in enumerate(seqs[:1500]) if len(r) > 70)
+    p = tmp_path / "wrapped_tail.fq"
+    p.write_bytes(good + tail)
+    b, o = pack_reads(seqs + [r for r in seqs[:1500] if len(r) > 70])
+    fo, fc = s10_oracle.full_intersection(b, o)
+    os.environ["FULGOR_READER_RANGE_KB"] = "64"
+    try:
+        out, n, mapped = _stream(s10_gpu, str(p), 0, batch=1000, workers=4)
+        assert n == len(o) - 1 and out == Formatter("ascii", s10_gpu.num_colors()).add(0, fo, fc)
+        z = bytearray(gzip.compress(good * 4, 6))
+        z[len(z) // 2] ^= 0x55
+        pz = tmp_path / "broken.fq.gz"
+        pz.write_bytes(bytes(z))
+        with pytest.raises(RuntimeError):
+            _stream(s10_gpu, str(pz), 0, batch=1000, workers=4)
+        out2, n2, _ = _stream(s10_gpu, str(p), 0, batch=1000, workers=4)
+        assert n2 == n and out2 == out
+    finally:
+        del os.environ["FULGOR_READER_RANGE_KB"]
