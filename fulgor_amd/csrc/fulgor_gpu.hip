@@ -287,16 +287,17 @@ void upload_index(fgpu_index* ix) {
     ix->dc = DevColors{ix->d_bmp_rows.as<uint32_t>(), ix->d_offsets.as<uint64_t>(), ix->d_set_desc.as<ListDesc>(),
                        ix->d_blk_words.as<uint32_t>(), h.num_colors, h.sparse_thr, h.dense_thr, w32};
     // Dense rows (k2r_intersect): every colour set as a plain bitmap row, built on the device from the forms above, while
-    // they fit the budget (default: a quarter of the device's memory; FULGOR_ROWS_MAX_BYTES, 0 = never) and a row fits the
-    // registers of a wave (at most 4 groups of 128 bits per lane = 32768 colours)
+    // they fit the budget (default: a quarter of the device's memory; FULGOR_ROWS_MAX_BYTES, 0 = never). Any number of colours:
+    // a row of more than 32768 (4 groups of 128 bits per lane) goes through the kernels in tiles
     {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         const uint64_t budget = env_u64("FULGOR_ROWS_MAX_BYTES", total_b / 4);
         const uint64_t need = (uint64_t)h.num_sets() * w32 * 4;
-        if (h.num_sets() && need <= budget && need + (1ull << 30) <= free_b && w32 / 4 <= 256) {
+        if (h.num_sets() && need <= budget && need + (1ull << 30) <= free_b && (size_t)4 * w32 * 4 <= 160 * 1024) {  // (k_rows_build: four rows in LDS per block, up to 327680 colours)
             ix->d_rows.ensure(need + 64);
             const size_t lds = (size_t)4 * w32 * 4;
+            if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k_rows_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const uint32_t grid = (uint32_t)std::min<uint64_t>((h.num_sets() + 3) / 4, (uint64_t)ix->num_cus * 8);
             hipLaunchKernelGGL(k_rows_build, dim3(grid), dim3(256), lds, s, ix->dc, (uint64_t)h.num_sets(), ix->d_rows.as<uint32_t>());
             HIP_TRY(hipGetLastError());
@@ -579,7 +580,7 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
         // small results travel as colours when a row is much larger than SMALL_RESULT colours, every such result is of the
         // sparse kind of the compressed formatter, and nobody needs the rows (k_hits counts from them when the expand
         // kernel's histogram does not fit)
-        res->small_mode = ix->small_results && W >= 32 && SMALL_RESULT < ix->host.hybrid.sparse_thr && hits_fold;
+        res->small_mode = ix->small_results && W >= 32 && SMALL_RESULT < ix->host.hybrid.sparse_thr && hits_fold && W / 4 <= 256;  // (a row of one tile in k2r_intersect)
         uint32_t* small_out = nullptr;
         if (res->small_mode) {
             res->d_small.ensure(cap_n * SMALL_RESULT * 4 + 16);

@@ -828,56 +828,67 @@ const u32x4* __restrict__ rows4, uint32_t W, const uint32_t* __restrict__ nids,
         uint64_t r = (uint32_t)__builtin_amdgcn_readlane((int)rd_l, 0);
         const uint32_t* ids = ids_pool + readlane_u64(off_l, 0);
         for (uint32_t ri = 0; ri < t_count; ++ri) {
-            u32x4 acc[G];
-#pragma unroll
-            for (int q = 0; q < G; ++q) acc[q] = nl && q * 64 + (uint32_t)lane < W4 ? u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu} : u32x4{0u, 0u, 0u, 0u};
-            auto round8 = [&](const uint32_t* p, uint32_t left) {  // (left wave-uniform) the rows of up to eight lists in one round
-                const u32x8 id = *(ids8_ptr)p;
-                switch (min(left, 8u)) {
-                    case 1: rows_and<1, G>(rows4, W4, id, lo, acc); break;
-                    case 2: rows_and<2, G>(rows4, W4, id, lo, acc); break;
-                    case 3: rows_and<3, G>(rows4, W4, id, lo, acc); break;
-                    case 4: rows_and<4, G>(rows4, W4, id, lo, acc); break;
-                    case 5: rows_and<5, G>(rows4, W4, id, lo, acc); break;
-                    case 6: rows_and<6, G>(rows4, W4, id, lo, acc); break;
-                    case 7: rows_and<7, G>(rows4, W4, id, lo, acc); break;
-                    default: rows_and<8, G>(rows4, W4, id, lo, acc); break;
-                }
-            };
-            if (nl) round8(ids, nl);
-            if (nl > 8)  // (a read in twenty)
-                for (uint32_t i = 8; i < nl; i += 8) round8(ids + i, nl - i);
+            // A row wider than G groups per lane (more than 32768 colours: G = 4) goes through in TILES of 64 G groups: the ids are
+            // fetched again for every tile (scalar loads out of the scalar cache), the cardinality adds up over the tiles. One trip otherwise.
             uint32_t pc = 0;
+            uint32_t t0 = 0;
+            do {
+                if (G == 4) {
 #pragma unroll
-            for (int q = 0; q < G; ++q) pc += __popc(acc[q].x) + __popc(acc[q].y) + __popc(acc[q].z) + __popc(acc[q].w);
-            pc = wave_sum_u32(pc);
-            if (lane == 0) out_count[r] = pc;
-            if (small_out && pc <= SMALL_RESULT) {  // (wave-uniform) the colours themselves, no row
-                if (pc) {
-                    uint32_t* so = small_out + r * SMALL_RESULT;
-                    uint32_t at = 0;
-#pragma unroll
-                    for (int q = 0; q < G; ++q) {
-                        const u32x4 x = acc[q];
-                        const uint32_t mq = __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
-                        const uint32_t incl = wave_incl_scan_u32(mq);
-                        uint32_t pos = at + incl - mq;
-                        const uint32_t c0w = (q * 64 + (uint32_t)lane) * 128u;
-                        for (uint32_t y = x.x; y; y &= y - 1) so[pos++] = c0w + (uint32_t)__builtin_ctz(y);
-                        for (uint32_t y = x.y; y; y &= y - 1) so[pos++] = c0w + 32u + (uint32_t)__builtin_ctz(y);
-                        for (uint32_t y = x.z; y; y &= y - 1) so[pos++] = c0w + 64u + (uint32_t)__builtin_ctz(y);
-                        for (uint32_t y = x.w; y; y &= y - 1) so[pos++] = c0w + 96u + (uint32_t)__builtin_ctz(y);
-                        at += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    }
+                    for (int q = 0; q < G; ++q) lo[q] = min(t0 + q * 64 + (uint32_t)lane, W4 - 1);
                 }
-            } else {
-                // streamed past the L2 (nontemporal): the result rows are read back by another kernel, the L2 is for the lists
-                u32x4* bm4 = (u32x4*)(out_bitmap + r * W);
+                u32x4 acc[G];
 #pragma unroll
-                for (int q = 0; q < G; ++q)
-                    if (q * 64 + (uint32_t)lane < W4)
-                        __builtin_nontemporal_store((u32x4){acc[q].x, acc[q].y, acc[q].z, acc[q].w}, &bm4[q * 64 + lane]);
-            }
+                for (int q = 0; q < G; ++q) acc[q] = nl && t0 + q * 64 + (uint32_t)lane < W4 ? u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu} : u32x4{0u, 0u, 0u, 0u};
+                auto round8 = [&](const uint32_t* p, uint32_t left) {  // (left wave-uniform) the rows of up to eight lists in one round
+                    const u32x8 id = *(ids8_ptr)p;
+                    switch (min(left, 8u)) {
+                        case 1: rows_and<1, G>(rows4, W4, id, lo, acc); break;
+                        case 2: rows_and<2, G>(rows4, W4, id, lo, acc); break;
+                        case 3: rows_and<3, G>(rows4, W4, id, lo, acc); break;
+                        case 4: rows_and<4, G>(rows4, W4, id, lo, acc); break;
+                        case 5: rows_and<5, G>(rows4, W4, id, lo, acc); break;
+                        case 6: rows_and<6, G>(rows4, W4, id, lo, acc); break;
+                        case 7: rows_and<7, G>(rows4, W4, id, lo, acc); break;
+                        default: rows_and<8, G>(rows4, W4, id, lo, acc); break;
+                    }
+                };
+                if (nl) round8(ids, nl);
+                if (nl > 8)  // (a read in twenty)
+                    for (uint32_t i = 8; i < nl; i += 8) round8(ids + i, nl - i);
+                uint32_t pct = 0;
+#pragma unroll
+                for (int q = 0; q < G; ++q) pct += __popc(acc[q].x) + __popc(acc[q].y) + __popc(acc[q].z) + __popc(acc[q].w);
+                pct = wave_sum_u32(pct);
+                pc += pct;
+                if (small_out && pct <= SMALL_RESULT) {  // (wave-uniform; small_out only when a row is ONE tile) the colours themselves, no row
+                    if (pct) {
+                        uint32_t* so = small_out + r * SMALL_RESULT;
+                        uint32_t at = 0;
+#pragma unroll
+                        for (int q = 0; q < G; ++q) {
+                            const u32x4 x = acc[q];
+                            const uint32_t mq = __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
+                            const uint32_t incl = wave_incl_scan_u32(mq);
+                            uint32_t pos = at + incl - mq;
+                            const uint32_t c0w = (q * 64 + (uint32_t)lane) * 128u;
+                            for (uint32_t y = x.x; y; y &= y - 1) so[pos++] = c0w + (uint32_t)__builtin_ctz(y);
+                            for (uint32_t y = x.y; y; y &= y - 1) so[pos++] = c0w + 32u + (uint32_t)__builtin_ctz(y);
+                            for (uint32_t y = x.z; y; y &= y - 1) so[pos++] = c0w + 64u + (uint32_t)__builtin_ctz(y);
+                            for (uint32_t y = x.w; y; y &= y - 1) so[pos++] = c0w + 96u + (uint32_t)__builtin_ctz(y);
+                            at += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        }
+                    }
+                } else {
+                    // streamed past the L2 (nontemporal): the result rows are read back by another kernel, the L2 is for the lists
+                    u32x4* bm4 = (u32x4*)(out_bitmap + r * W);
+#pragma unroll
+                    for (int q = 0; q < G; ++q)
+                        if (t0 + q * 64 + (uint32_t)lane < W4)
+                            __builtin_nontemporal_store((u32x4){acc[q].x, acc[q].y, acc[q].z, acc[q].w}, &bm4[t0 + q * 64 + lane]);
+                }
+            } while (G == 4 && (t0 += 64u * G) < W4);
+            if (lane == 0) out_count[r] = pc;
             const uint32_t nx = min(ri + 1, 63u);  // (lanes past the ticket hold empty reads)
             nl = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, nx);
             r = (uint32_t)__builtin_amdgcn_readlane((int)rd_l, nx);

@@ -666,19 +666,23 @@ def test_gpu_more_than_65535_colours(built, tmp_path):
                                                     for _ in range(rng.integers(1, 4)))))
     reads += [u[:150] for u in unitigs]
     b, o = pack_reads(reads)
-    go, gc = ix.pseudoalign_full_intersection_batch(b, o)
     oo, oc = orc.full_intersection(b, o, threads=8, self_check=True)
-    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
-    for tau in (0.3, 1.0):
-        go, gc = ix.pseudoalign_threshold_union_batch(b, o, tau)
-        oo, oc = orc.threshold_union(b, o, tau, threads=8)
-        assert np.array_equal(go, oo) and np.array_equal(gc, oc)
-    lists = [np.unique(rng.integers(0, nsets, size=l)).astype(np.uint32) for l in rng.integers(1, 6, size=300)]
+    lists = [np.unique(rng.integers(0, nsets, size=l)).astype(np.uint32) for l in rng.integers(1, 12, size=300)]
     ido = np.zeros(len(lists) + 1, dtype=np.uint64)
     ido[1:] = np.cumsum([len(l) for l in lists])
-    go, gc = ix.intersect_ids_batch(np.concatenate(lists), ido)
-    oo, oc = orc.intersect_ids(np.concatenate(lists), ido, threads=8)
-    assert np.array_equal(go, oo) and np.array_equal(gc, oc)
+    io, ic = orc.intersect_ids(np.concatenate(lists), ido, threads=8)
+    # on the dense rows (round 5: rows of more than 32768 colours go through k2r_intersect in tiles of 32768) and on the packed blocks
+    for rows in (True, False):
+        ix.tune(dense_rows=rows)
+        go, gc = ix.pseudoalign_full_intersection_batch(b, o)
+        assert np.array_equal(go, oo) and np.array_equal(gc, oc), rows
+        for tau in (0.3, 1.0):
+            go, gc = ix.pseudoalign_threshold_union_batch(b, o, tau)
+            uo, uc = orc.threshold_union(b, o, tau, threads=8)
+            assert np.array_equal(go, uo) and np.array_equal(gc, uc), (rows, tau)
+        go, gc = ix.intersect_ids_batch(np.concatenate(lists), ido)
+        assert np.array_equal(go, io) and np.array_equal(gc, ic), rows
+    ix.tune(dense_rows=True)
     # per-colour hit counts: this many colours do not fit the expand kernel's LDS histogram (bitmap path)
     import torch
     rd, res = ix.upload_reads(b, o), ix.new_result()
