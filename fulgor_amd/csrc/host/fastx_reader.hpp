@@ -195,10 +195,10 @@ struct FastxChunk {
     std::vector<uint64_t> name_offs{0};
     uint64_t max_len = 0;     // longest read of the chunk
     bool want_names = true;
-    FastxChunk() { offs.assign(1, 0); }
+    FastxChunk() {}  // (no buffer yet: an empty chunk is made and moved around all the time)
     FastxChunk(FastxChunk&&) = default;
     FastxChunk& operator=(FastxChunk&&) = default;
-    uint64_t reads() const { return offs.size() - 1; }
+    uint64_t reads() const { return offs.size() ? offs.size() - 1 : 0; }
     // the parser's sink
     bool any() const { return reads() > 0; }
     void on_name(const char* s, size_t n) {
@@ -210,12 +210,13 @@ struct FastxChunk {
     }
     void on_seq(const char* s, size_t n) { bases.append(s, n); }
     void on_record(uint64_t len) {
+        if (offs.size() == 0) offs.push_back(0);
         offs.push_back(bases.size());
         if (len > max_len) max_len = len;
     }
     void clear() {
         bases.clear();
-        offs.assign(1, 0);
+        offs.clear();
         names.clear();
         name_offs.assign(1, 0);
         max_len = 0;
