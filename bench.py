@@ -379,6 +379,22 @@ def main():
                   small_results=None if args.small is None else bool(args.small),
                   dense_rows=None if args.rows is None else bool(args.rows))
     algo = fulgor_amd.FULL_INTERSECTION if args.algo == "full-intersection" else fulgor_amd.THRESHOLD_UNION
+    # The PCIe-inclusive legs (never `value`) run FIRST, on the freshly opened index, as a `pseudoalign` process would find the device:
+    # behind passes of 10 M reads the same legs run 20-40 % slower for the rest of the process on some boxes (profiles/e2e_after_what.py,
+    # profiles/r5/e2e_breakdown_r5.txt section 6; clocks as sysfs shows them unchanged). FULGOR_BENCH_E2E_TWICE=1 repeats them at the end.
+    legs = {}
+
+    def pcie_legs(tag=""):
+        legs["end_to_end" + tag] = end_to_end(w.ix, w.bases, w.offs, algo, args.tau, min(n_reads, 1 << 20), 0)
+        legs["end_to_end_compressed_one_pass" + tag] = end_to_end(w.ix, w.bases, w.offs, algo, args.tau, min(n_reads, 1 << 20), 2)
+        legs["end_to_end_compressed" + tag] = end_to_end_stream(w.ix, w.bases, w.offs, algo, args.tau, min(n_reads, 10_000_000), 2)
+        try:
+            legs["cli_end_to_end" + tag] = cli_end_to_end(w.ix, w.bases, w.offs, algo, args.tau, min(n_reads, 10_000_000), args.read_len)
+        except Exception as e:  # (no room for the FASTQ file, ...): the bench line must not depend on this leg
+            legs["cli_end_to_end" + tag] = {"value": None, "error": str(e)[:200]}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        pcie_legs()
     m = measure(w, algo, args.tau, args.chunk, args.steps, args.warmup, args.streams, local_rank, world, dist, share, pipeline=bool(args.pipeline))
 
     if rank == 0:
@@ -420,13 +436,9 @@ def main():
         if world == 1 and not args.no_secondary and args.workload == "s4546syn" and w.itype == 0 and algo == fulgor_amd.FULL_INTERSECTION:
             out["secondary"] = secondary(w, args, local_rank)
         if world == 1 and not args.no_cpu_baseline:
-            out["end_to_end"] = end_to_end(w.ix, w.bases, w.offs, algo, args.tau, min(n_reads, 1 << 20), 0)
-            out["end_to_end_compressed_one_pass"] = end_to_end(w.ix, w.bases, w.offs, algo, args.tau, min(n_reads, 1 << 20), 2)
-            out["end_to_end_compressed"] = end_to_end_stream(w.ix, w.bases, w.offs, algo, args.tau, min(n_reads, 10_000_000), 2)
-            try:
-                out["cli_end_to_end"] = cli_end_to_end(w.ix, w.bases, w.offs, algo, args.tau, min(n_reads, 10_000_000), args.read_len)
-            except Exception as e:  # (no room for the FASTQ file, ...): the bench line must not depend on this leg
-                out["cli_end_to_end"] = {"value": None, "error": str(e)[:200]}
+            if os.environ.get("FULGOR_BENCH_E2E_TWICE"):  # (measurement: the same legs again behind the headline steps and the secondary workloads)
+                pcie_legs("_after_everything")
+            out.update(legs)
             out["cpu_baseline"] = cpu_baseline(w.ix, w.bases, w.offs, algo, args.tau, w.itype, args.partition_size, args.cluster_size)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -58,6 +58,39 @@ bb = bytes(np.asarray(b))
 same = all(conservation_triples(ki[int(ko[j]):int(ko[j + 1])]) == orc.kmer_conservation(bb[int(o[j]):int(o[j + 1])]) for j in range(20000))
 bad += not same
 print("%-46s %s" % ("k-mer conservation triples, 20000 reads", "equal" if same else "DIFFERENT"), flush=True)
+# (round 5) the streamed worker loop (fgpu_pseudoalign_stream: parser threads -> pinned chunks -> five workers -> compressed records in file
+# order) on a FASTQ file of the same kind of reads: its records, parsed back by the oracle's reader, against the oracle's results
+from oracle.pyoracle import parse_compressed
+from fulgor_amd.reads import FastxReader
+ns = n // 2
+b, o = gen.generate(300_000_000, ns, 150, 13)
+path = "/dev/shm/soak_%d.fq" % os.getpid()
+rec = np.empty((ns, 316), dtype=np.uint8)
+idn = np.arange(ns, dtype=np.int64)
+rec[:, 0], rec[:, 1], rec[:, 11] = ord("@"), ord("r"), ord("\n")
+for d in range(9):
+    rec[:, 2 + d] = ord("0") + (idn // 10 ** (8 - d)) % 10
+rec[:, 12:162] = np.asarray(b).reshape(ns, 150)
+rec[:, 162:165] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+rec[:, 165:-1] = ord("I")
+rec[:, -1] = ord("\n")
+rec.tofile(path)
+del rec
+try:
+    for algo, tau, want in ((0, 0.0, orc.full_intersection(b, o, threads=T)), (1, 0.8, orc.threshold_union(b, o, 0.8, threads=T))):
+        out = path + ".out"
+        rd = FastxReader(path, copy=False)
+        fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+        got, mapped = ix.pseudoalign_stream(rd, fd, algo, tau, 2, 0, True, 0, 0)
+        os.close(fd)
+        rd.close()
+        ids, po, pc = parse_compressed(open(out, "rb").read())
+        os.remove(out)
+        ok_ids = got == ns and np.array_equal(ids, np.arange(ns, dtype=np.uint32)) and mapped == int((np.diff(want[0].astype(np.int64)) > 0).sum())
+        check("streamed loop, %s, %d reads (ids and counters %s)" % ("threshold union 0.8" if algo else "full intersection", ns, "ok" if ok_ids else "WRONG"), (po, pc), want)
+        bad += not ok_ids
+finally:
+    os.remove(path)
 # the other codecs against the hybrid result of the same reads (both HIP; the codecs meet the oracle on the small index)
 b, o = gen.generate(200_000_000, n // 2, 150, 12)
 ref_fi = ix.pseudoalign_full_intersection_batch(b, o)
