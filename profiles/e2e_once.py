@@ -53,6 +53,8 @@ try:
         dt = time.perf_counter() - t0
         print("run %d: %d reads in %.1f ms = %.1f M reads/s" % (r, got, dt * 1e3, got / dt / 1e6))
         reps.append((dt, r, ix.last_stream_report()))
+    for dt_, r_, rep_ in reps:
+        print("run %d: %s" % (r_, rep_.splitlines()[1][rep_.splitlines()[1].index("per thread"):]))
     if os.environ.get("E2E_COLD"):
         print("first run of the process (%d):\n%s" % (reps[0][1], reps[0][2]))
     steady = sorted(reps[2:] or reps)
