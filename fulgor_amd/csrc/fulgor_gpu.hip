@@ -762,6 +762,11 @@ int fgpu_open(const char* path, int device, fgpu_index** out) {
             } else (void)hipGetLastError();
         }
         HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+        {   // the runtime sets up its pinned-memory path at the first hipHostMalloc of a process (50 ms): here, not in the first batch of reads
+            void* warm = nullptr;
+            if (hipHostMalloc(&warm, 4096, hipHostMallocDefault) == hipSuccess) (void)hipHostFree(warm);
+            else (void)hipGetLastError();
+        }
         LoadClock clk;
         upload_index(ix);
         if (ix->host.type != IDX_HYBRID) upload_generic(ix);
