@@ -201,6 +201,10 @@ struct FastxChunk {
     uint64_t reads() const { return offs.size() ? offs.size() - 1 : 0; }
     // the parser's sink
     bool any() const { return reads() > 0; }
+    void expect(uint64_t text_bytes, bool fastq) {  // (a FASTQ record spends as many bytes on qualities as on bases)
+        bases.reserve(fastq ? text_bytes / 2 + 64 : text_bytes);
+        offs.reserve(text_bytes / 256 + 16);
+    }
     void on_name(const char* s, size_t n) {
         if (!want_names) return;
         size_t e = 0;
@@ -260,9 +264,44 @@ void parse_fastx_records(NextLine&& next, Sink& c, Emit&& emit, unsigned* odd = 
     }
 }
 
+// Four-line FASTQ records of the text M from `pos` on, up to `hi` (a record boundary or the end of the text): '@' header, one
+// sequence line, a '+' line, a quality line of the sequence line's length.
+// Stops in front of the first record that does not have this shape (wrapped lines, an empty sequence, a '>' header, a quality
+// of another length, a text that ends early) and leaves it to parse_fastx_records, whose result for the records taken here is
+// the same. last = false: `hi` is only where the bytes at hand end (a piece of a range), a record that touches it is not taken.
+// Returns the position of the first record not taken.
+template <typename Sink>
+uint64_t parse_fastq4(const char* M, uint64_t pos, uint64_t hi, Sink& c, bool last = true) {
+    const char* const fin = M + hi;
+    const char* p = M + pos;
+    while (p < fin && *p == '@') {
+        const char* l1 = (const char*)memchr(p, '\n', (size_t)(fin - p));  // end of the header
+        if (!l1 || l1 + 1 >= fin) break;
+        const char* sq = l1 + 1;
+        if (*sq == '>' || *sq == '@' || *sq == '+' || *sq == '\n' || *sq == '\r') break;
+        const char* l2 = (const char*)memchr(sq, '\n', (size_t)(fin - sq));  // end of the sequence
+        if (!l2 || l2 + 2 >= fin || l2[1] != '+') break;
+        const char* l3 = l2[2] == '\n' ? l2 + 2 : (const char*)memchr(l2 + 2, '\n', (size_t)(fin - l2 - 2));  // end of the '+' line
+        if (!l3) break;
+        const size_t raw = (size_t)(l2 - sq);
+        const char* e = l3 + 1 + raw;  // where the quality line ends if it is as long as the sequence line
+        if (e > fin || (e < fin ? *e != '\n' : !last)) break;
+        if (memchr(l3 + 1, '\n', raw)) break;  // (a shorter quality line: the grammar reads on into the next lines)
+        size_t hn = (size_t)(l1 - p) - 1, len = raw;
+        if (hn && p[hn] == '\r') --hn;
+        if (sq[len - 1] == '\r' && --len == 0) break;
+        c.on_name(p + 1, hn);
+        c.on_seq(sq, len);
+        c.on_record(len);
+        p = e < fin ? e + 1 : fin;
+    }
+    return (uint64_t)(p - M);
+}
+
 struct CountSink {
     uint64_t n = 0;
     bool any() const { return n > 0; }
+    void expect(uint64_t, bool) {}
     void on_name(const char*, size_t) {}
     void on_seq(const char*, size_t) {}
     void on_record(uint64_t) { ++n; }
@@ -571,7 +610,13 @@ public:
         // file when the mapping goes (772 k page-table entries that up to a hundred threads have touched, under the process's
         // mmap lock: the next reader's mmap and its threads' stacks wait for it; measured, profiles/r5/e2e_breakdown_r5.txt).
         // FULGOR_READER_MMAP=1 maps (A/B measurements).
-        use_pread_ = !getenv("FULGOR_READER_MMAP");
+        const char* mm = getenv("FULGOR_READER_MMAP");
+        use_pread_ = !mm || mm[0] == '2';
+        map_windows_ = mm && mm[0] == '2';
+        if (const char* e = getenv("FULGOR_READER_PIECE_KB")) {
+            const long kb = atol(e);
+            piece_ = kb > 0 ? (uint64_t)kb << 10 : ~0ULL;
+        }
         if (size_ && !use_pread_) {
             map_ = (const char*)mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
             if (map_ == MAP_FAILED) { close(fd_); throw std::runtime_error("cannot map " + path); }
@@ -659,10 +704,23 @@ protected:
         char* buf = nullptr;
         size_t cap = 0;
         uint64_t a = 0, b = 0;
-        ~Window() { free(buf); }
+        void* map = nullptr;
+        size_t map_len = 0;
+        ~Window() { free(buf); if (map) munmap(map, map_len); }
     };
     const char* base(Window& w, uint64_t a, uint64_t b) {
         if (!use_pread_) { ensure(a, b); return map_; }
+        if (map_windows_) {
+            if (a >= w.a && b <= w.b && w.map) return (const char*)w.map - w.a;
+            if (w.map) munmap(w.map, w.map_len);
+            const uint64_t a0 = a & ~(uint64_t)4095;
+            w.map_len = (size_t)(b - a0);
+            w.map = mmap(nullptr, w.map_len, PROT_READ, MAP_SHARED | MAP_POPULATE, fd_, (off_t)a0);
+            if (w.map == MAP_FAILED) { w.map = nullptr; throw std::runtime_error("cannot map a range of the query file"); }
+            w.a = a0;
+            w.b = b;
+            return (const char*)w.map - w.a;
+        }
         if (a >= w.a && b <= w.b && w.buf) return w.buf - w.a;
         const size_t need = (size_t)(b - a);
         if (need > w.cap) {
@@ -737,6 +795,60 @@ protected:
         }
     }
 
+    // first record boundary at or behind byte p > 0 (the text's end if none): a small load around p
+    uint64_t boundary_at(uint64_t p, Window& w) {
+        for (uint64_t margin = 64u << 10;; margin *= 4) {
+            const uint64_t lb = std::min(size_, p + margin);
+            const char* M = base(w, p - 1, lb);
+            bool sure;
+            const uint64_t q = record_start_in(M, p, lb, sure);
+            if (sure || lb == size_) return q;
+        }
+    }
+    // The records that start in range r go to the sink; [lo, hi) = their text bytes. Plain four-line FASTQ records of a file that is
+    // read (not mapped) are taken piece by piece: half a megabyte is read and parsed while it is still in the core's cache (an 8 MB
+    // window is written to memory and read back: 566 against 449 M reads/s for 24 threads, 700 against 437 for 48;
+    // profiles/r5/reader_pieces_r5.txt). Whatever the fast path leaves (other record shapes, FASTA) goes through the grammar.
+    template <typename Sink>
+    void parse_range(uint64_t r, Window& w, Sink& c, unsigned& odd, uint64_t& lo, uint64_t& hi) {
+        const bool pieces = use_pread_ && !map_windows_ && kind_ == '@' && piece_ < range_;
+        const char* M = nullptr;
+        if (pieces) {
+            const uint64_t a0 = begin_ + r * range_, b0 = r + 1 == num_ranges_ ? end_ : begin_ + (r + 1) * range_;
+            lo = a0 ? boundary_at(a0, w) : 0;
+            hi = (r + 1 == num_ranges_ && end_ == size_) ? size_ : boundary_at(b0, w);
+        } else {
+            M = range_bounds(r, lo, hi, w);
+        }
+        c.expect(hi - lo, kind_ == '@');
+        uint64_t pos = lo;
+        if (pieces) {
+            for (uint64_t piece = piece_; pos < hi;) {
+                const uint64_t pe = std::min(hi, pos + piece);
+                const char* P = base(w, pos, pe);
+                const uint64_t q = parse_fastq4(P, pos, pe, c, pe == hi);
+                if (q == pos) break;  // not a plain four-line record, or one longer than the piece
+                if (q - pos < (pe - pos) / 2 && piece < range_) piece *= 4;  // (long reads: fewer bytes read twice)
+                pos = q;
+            }
+            if (pos < hi) M = base(w, pos, hi);
+        } else if (kind_ == '@') {
+            pos = parse_fastq4(M, pos, hi, c);
+        }
+        if (pos >= hi) return;
+        parse_fastx_records(
+            [&](const char*& s, size_t& n) {
+                if (pos >= hi) return false;
+                const char* nl = (const char*)memchr(M + pos, '\n', hi - pos);
+                s = M + pos;
+                n = nl ? (size_t)(nl - s) : (size_t)(hi - pos);
+                pos += n + 1;
+                if (n && s[n - 1] == '\r') --n;
+                return true;
+            },
+            c, [](Sink&) { return true; }, &odd);
+    }
+
 public:
     bool count_records(unsigned threads, uint64_t& total) override {
         std::atomic<uint64_t> next{0}, sum{0};
@@ -749,20 +861,9 @@ public:
                 if (r >= num_ranges_) return;
                 try {
                     uint64_t lo, hi;
-                    const char* M = range_bounds(r, lo, hi, w);
-                    uint64_t pos = lo;
+                    unsigned odd = 0;
                     CountSink cs;
-                    parse_fastx_records(
-                        [&](const char*& s, size_t& n) {
-                            if (pos >= hi) return false;
-                            const char* nl = (const char*)memchr(M + pos, '\n', hi - pos);
-                            s = M + pos;
-                            n = nl ? (size_t)(nl - s) : (size_t)(hi - pos);
-                            pos += n + 1;
-                            if (n && s[n - 1] == '\r') --n;
-                            return true;
-                        },
-                        cs, [](CountSink&) { return true; });
+                    parse_range(r, w, cs, odd, lo, hi);
                     sum += cs.n;
                 } catch (std::exception& e) {
                     std::lock_guard<std::mutex> g(em);
@@ -800,23 +901,9 @@ protected:
             wait_ns_ += t_parse - t_wait;
             try {
                 uint64_t lo, hi;
-                const char* M = range_bounds(r, lo, hi, w);
-                uint64_t pos = lo;
                 unsigned odd = 0;
                 c.want_names = want_names_.load();
-                c.bases.reserve(kind_ == '@' ? (hi - lo) / 2 + 64 : hi - lo);  // (a FASTQ record spends as many bytes on qualities as on bases)
-                c.offs.reserve((hi - lo) / 256 + 16);
-                parse_fastx_records(
-                    [&](const char*& s, size_t& n) {
-                        if (pos >= hi) return false;
-                        const char* nl = (const char*)memchr(M + pos, '\n', hi - pos);
-                        s = M + pos;
-                        n = nl ? (size_t)(nl - s) : (size_t)(hi - pos);
-                        pos += n + 1;
-                        if (n && s[n - 1] == '\r') --n;
-                        return true;
-                    },
-                    c, [](FastxChunk&) { return true; }, &odd);
+                parse_range(r, w, c, odd, lo, hi);
                 // a range that starts at a record boundary and ends at one holds whole records and nothing else
                 if ((odd & 1u) || ((odd & 2u) && hi != size_))  // (a quality cut short by the end of the text is the file's business)
                     throw std::runtime_error("the query file does not parse as whole records in byte ranges (FASTQ with wrapped lines behind "
@@ -840,6 +927,8 @@ protected:
     int fd_ = -1;
     std::vector<int> cpus_;   // CPUs the parser threads are confined to (empty: left to the scheduler)
     bool use_pread_ = false;  // (derived sources hand out their own buffer as map_)
+    uint64_t piece_ = 512u << 10;  // bytes read and parsed at a time inside a range (FULGOR_READER_PIECE_KB; 0: the whole range)
+    bool map_windows_ = false;  // FULGOR_READER_MMAP=2: every thread maps the range it parses (and unmaps it behind itself)
     const char* map_ = nullptr;
     uint64_t size_ = 0, begin_ = 0, end_ = 0, range_, num_ranges_ = 0, window_ = 4;
     char kind_ = 0;  // '>' FASTA, '@' FASTQ, 0 unknown (both kinds of record start are looked for)

@@ -465,11 +465,16 @@ def test_multi_rank_cli_path_on_gloo(s10_dump, tmp_path, world):
         assert open(out2, "rb").read() == want
 
 
-def test_reader_parts_fuzz(built, tmp_path):
-    """seeded fuzz of the range logic: 4-line FASTQ and single- or multi-line FASTA with every nasty line start (quality lines
+@pytest.mark.parametrize("piece_kb", [None, "1"])
+def test_reader_parts_fuzz(built, tmp_path, monkeypatch, piece_kb):
+    """(piece_kb: plain FASTQ records of a range are read and parsed in pieces of half a megabyte; pieces of 1 KB put a piece end
+    into nearly every record of these small files)
+    seeded fuzz of the range logic: 4-line FASTQ and single- or multi-line FASTA with every nasty line start (quality lines
     beginning with '@', '>' or '+', names with blanks, CRLF, no final newline, empty sequences in FASTA), cut into parts at
     random positions: the parts must partition the records, names included, whatever the cuts"""
     from fulgor_amd.reads import FastxReader, count_reads
+    if piece_kb:
+        monkeypatch.setenv("FULGOR_READER_PIECE_KB", piece_kb)
     rng = np.random.default_rng(2024)
     alpha = np.frombuffer(b"ACGTNacgt", dtype=np.uint8)
     qual_first = b"@>+!I5#"
@@ -486,8 +491,8 @@ def test_reader_parts_fuzz(built, tmp_path):
         assert counted == len(seqs), (path, kw, counted, len(seqs))
         return seqs, names
 
-    for trial in range(1500):
-        fastq = trial % 2 == 0
+    for trial in range(600 if piece_kb else 1500):
+        fastq = trial % 2 == 0 or bool(piece_kb)
         eol = b"\r\n" if trial % 5 == 3 else b"\n"
         n = int(rng.integers(1, 120))
         want_s, want_n, text = [], [], []
@@ -672,11 +677,13 @@ def test_bench_real_dump_hook_ingests_a_dump_and_labels_the_line(built, tmp_path
 
 
 def test_reader_mapped_and_read_ranges_agree(built, tmp_path):
-    """the ranges of a plain file are read with pread into per-thread buffers; FULGOR_READER_MMAP=1 (an A/B knob) maps the file
-    instead. Same records, same counts, whole and in parts, FASTA and FASTQ (the knob is read when a reader opens: subprocess)."""
+    """the ranges of a plain file are read with pread into per-thread buffers, plain FASTQ records in pieces of half a megabyte;
+    A/B knobs: FULGOR_READER_MMAP=1 maps the file instead, =2 maps range by range, FULGOR_READER_PIECE_KB sets the piece (0: the
+    whole range at once). Same records, same counts, whole and in parts, FASTA and FASTQ (the knobs are read when a reader opens:
+    subprocess)."""
     rng = np.random.default_rng(77)
     alpha = np.frombuffer(b"ACGTN", dtype=np.uint8)
-    recs = [bytes(alpha[rng.integers(0, 5, size=int(rng.integers(1, 400)))]) for _ in range(60000)]
+    recs = [bytes(alpha[rng.integers(0, 5, size=3000 if i % 5000 == 77 else int(rng.integers(1, 400)))]) for i in range(60000)]  # (a few longer than a piece)
     fq, fa = tmp_path / "r.fq", tmp_path / "r.fa"
     fq.write_bytes(b"".join(b"@q%d x\n%s\n+\n%s\n" % (i, s, b"@" * len(s)) for i, s in enumerate(recs)))
     fa.write_bytes(b"".join(b">q%d\n%s\n" % (i, b"\n".join(s[j:j + 70] for j in range(0, len(s), 70))) for i, s in enumerate(recs)))
@@ -699,13 +706,16 @@ for path in sys.argv[1:]:
         print(os.path.basename(path), a, b, n, h.hexdigest())
 ''' % ROOT
     outs = []
-    for mode in ("", "1"):
+    for mode, piece in (("", ""), ("1", ""), ("2", ""), ("", "0"), ("", "1"), ("", "3"), ("", "64")):
         env = dict(os.environ)
         env.pop("FULGOR_READER_MMAP", None)
+        env.pop("FULGOR_READER_PIECE_KB", None)
         if mode:
             env["FULGOR_READER_MMAP"] = mode
+        if piece:
+            env["FULGOR_READER_PIECE_KB"] = piece
         r = subprocess.run([sys.executable, "-c", code, str(fq), str(fa)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout)
-    assert outs[0] == outs[1] and outs[0].count("\n") == 8
+    assert all(o == outs[0] for o in outs) and outs[0].count("\n") == 8
     assert " 60000 " in outs[0].splitlines()[0]
