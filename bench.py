@@ -602,7 +602,7 @@ def cli_end_to_end(ix, bases, offs, algo, tau, n, read_len):
             runs.append(time.perf_counter() - t0)
         best = min(runs)
         assert got == n
-        report = ix.last_stream_report().splitlines()[:2]
+        report = ix.last_stream_report().splitlines()[:3]
     finally:
         if os.path.exists(path):
             os.remove(path)

@@ -39,7 +39,7 @@ def build_gpu(force=False):
         return LIB_GPU
     if force or _newer(LIB_GPU, srcs):
         _run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-              os.path.join(CSRC, "fulgor_gpu.hip"), "-o", LIB_GPU, "-lz", "-ldl"])
+              os.path.join(CSRC, "fulgor_gpu.hip"), "-o", LIB_GPU, "-lz", "-ldl", "-lhsa-runtime64"])
     return LIB_GPU
 
 

@@ -1,0 +1,119 @@
+// The bulk copies of the streamed path (reads up, records down) on copy engines of OUR choice, through the HSA runtime that the
+// HIP runtime sits on. Why not hipMemcpyAsync: the HIP runtime picks a copy engine per call by what looks free at that moment.
+// Measured on MI355X (profiles/micro/d2h_engine.hip, profiles/r5/d2h_engine_r5.txt; runtime log of the worker loop):
+//   * of the 16 engines only four carry 55 GB/s over PCIe, the others 7-13 GB/s (they are built for the links between GPUs) — and
+//     the runtime put one copy in fifty on a slow one;
+//   * it puts copies of both directions on the same engine: an engine works in order, so a 44 MB copy out waits behind the twenty
+//     pieces of another batch's copy in, and the link runs in one direction at a time (67 of the 94 GB/s it carries both ways).
+// Here: the fast engines are found once per process by timing a 4 MB copy on each; the copies in of a batch go to one of two of them
+// (by worker), every copy out to a third (first in, first out: the batch that has to be written first is copied first); the lowest
+// fast engine is left to the HIP runtime's own small copies. If anything about this fails, the HIP calls are used.
+#pragma once
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace {
+
+class CopyEngines {
+public:
+    static CopyEngines& get() { static CopyEngines c; return c; }
+    // (call with the device current) true: bulk copies go through h2d() / d2h()
+    bool usable() {
+        std::call_once(once_, [this] { init(); });
+        return ok_.load(std::memory_order_relaxed);
+    }
+    hsa_signal_t new_signal() {
+        hsa_signal_t s{0};
+        if (hsa_signal_create(0, 0, nullptr, &s) != HSA_STATUS_SUCCESS) s.handle = 0;
+        return s;
+    }
+    void free_signal(hsa_signal_t s) { if (s.handle) (void)hsa_signal_destroy(s); }
+    // `copies` copies will count the signal down to zero
+    void arm(hsa_signal_t s, int64_t copies) { hsa_signal_store_relaxed(s, copies); }
+    // (a copy that was armed for but not issued)
+    void disarm(hsa_signal_t s, int64_t copies) { if (copies) hsa_signal_subtract_relaxed(s, copies); }
+    bool h2d(void* dst, const void* src, size_t n, hsa_signal_t s, unsigned lane) {
+        return hsa_amd_memory_async_copy_on_engine(dst, gpu_, src, cpu_, n, 0, nullptr, s, (hsa_amd_sdma_engine_id_t)in_[lane % in_.size()], false) == HSA_STATUS_SUCCESS;
+    }
+    bool d2h(void* dst, const void* src, size_t n, hsa_signal_t s) {
+        return hsa_amd_memory_async_copy_on_engine(dst, cpu_, src, gpu_, n, 0, nullptr, s, (hsa_amd_sdma_engine_id_t)out_, false) == HSA_STATUS_SUCCESS;
+    }
+    void wait(hsa_signal_t s) {
+        while (hsa_signal_wait_scacquire(s, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+    }
+    void disable() { ok_.store(false); }
+    std::string report() const { return report_; }
+
+private:
+    std::once_flag once_;
+    std::atomic<bool> ok_{false};
+    hsa_agent_t gpu_{0}, cpu_{0};
+    std::vector<uint32_t> in_;
+    uint32_t out_ = 0;
+    std::string report_ = "copy engines: the HIP runtime's choice";
+
+    static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    static bool owner_of(const void* p, hsa_agent_t& a) {
+        hsa_amd_pointer_info_t pi;
+        memset(&pi, 0, sizeof pi);
+        pi.size = sizeof pi;
+        if (hsa_amd_pointer_info(p, &pi, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS || pi.type == HSA_EXT_POINTER_TYPE_UNKNOWN) return false;
+        a = pi.agentOwner;
+        return a.handle != 0;
+    }
+    void init() {
+        const char* e = getenv("FULGOR_COPY_ENGINES");  // 0: hipMemcpyAsync for everything (A/B measurements)
+        if (e && e[0] == '0') return;
+        constexpr size_t PROBE = 4u << 20;
+        void *d = nullptr, *h = nullptr;
+        hsa_signal_t sig{0};
+        struct Release {
+            void*& d; void*& h; hsa_signal_t& s;
+            ~Release() { if (d) (void)hipFree(d); if (h) (void)hipHostFree(h); if (s.handle) (void)hsa_signal_destroy(s); }
+        } release{d, h, sig};
+        if (hipMalloc(&d, PROBE) != hipSuccess || hipHostMalloc(&h, PROBE, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (hipMemset(d, 0, PROBE) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return; }
+        if (!owner_of(d, gpu_) || !owner_of(h, cpu_)) return;
+        uint32_t mask = 0;
+        if (hsa_amd_memory_copy_engine_status(cpu_, gpu_, &mask) != HSA_STATUS_SUCCESS || !mask) return;
+        if (hsa_signal_create(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) { sig.handle = 0; return; }
+        std::vector<std::pair<uint32_t, double>> rate;  // engine, GB/s of a 4 MB copy out
+        for (uint32_t eng = 1; eng && eng <= mask; eng <<= 1) {
+            if (!(mask & eng)) continue;
+            double best = 0;
+            for (int rep = 0; rep < 2; ++rep) {
+                hsa_signal_store_relaxed(sig, 1);
+                const double t0 = now_ms();
+                if (hsa_amd_memory_async_copy_on_engine(h, cpu_, d, gpu_, PROBE, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t)eng, false) != HSA_STATUS_SUCCESS) { best = 0; break; }
+                wait(sig);
+                best = std::max(best, PROBE / (now_ms() - t0) / 1e6);
+            }
+            if (best > 0) rate.push_back({eng, best});
+        }
+        double top = 0;
+        for (auto& r : rate) top = std::max(top, r.second);
+        std::vector<uint32_t> fast;
+        for (auto& r : rate) if (r.second >= 0.7 * top) fast.push_back(r.first);
+        std::ostringstream os;
+        os << "copy engines (GB/s of a 4 MB copy out):";
+        for (auto& r : rate) os << " 0x" << std::hex << r.first << std::dec << ":" << (int)(r.second + 0.5);
+        if (fast.size() >= 4) { in_ = {fast[1], fast[2]}; out_ = fast[3]; }
+        else if (fast.size() == 3) { in_ = {fast[1]}; out_ = fast[2]; }
+        else if (fast.size() == 2) { in_ = {fast[0]}; out_ = fast[1]; }
+        else { report_ = os.str() + "; fewer than two fast ones: the HIP runtime's choice"; return; }
+        os << "; reads go up on";
+        for (uint32_t x : in_) os << " 0x" << std::hex << x << std::dec;
+        os << ", records come down on 0x" << std::hex << out_ << std::dec;
+        report_ = os.str();
+        ok_.store(true);
+    }
+};
+
+}  // namespace

@@ -15,6 +15,7 @@
 #include "hip/kernels.hip.h"
 #include "host/formatters.hpp"
 #include "host/index_io.hpp"
+#include "copy_engines.hip.h"
 
 using namespace fg;
 
@@ -45,6 +46,8 @@ struct DevBuf {
         size_t want = bytes + bytes / 8 + 256;
         HIP_TRY(hipMalloc(&p, want));
         cap = want;
+        static const bool trace = getenv("FULGOR_TRACE_ALLOC") != nullptr;  // (which buffer ends where a faulting address begins)
+        if (trace) fprintf(stderr, "[alloc] %p .. %p (%zu bytes for %zu asked) buffer object %p\n", p, (char*)p + want, want, bytes, (void*)this);
     }
     void release() {
         if (p) (void)hipFree(p);
@@ -110,6 +113,11 @@ struct fgpu_index {
         return e;
     }
     // call only after the recording streams have been synchronised
+    void add_timing(int kernel, double t_ms) {  // (a copy timed by the host's clock: the copy engines driven through the HSA runtime have no HIP events)
+        std::lock_guard<std::mutex> g(tmu);
+        ms[kernel] += t_ms;
+        launches[kernel] += 1;
+    }
     void collect_timing(std::vector<Pending>& mine) {
         std::lock_guard<std::mutex> g(tmu);
         for (auto& p : mine) {
@@ -183,6 +191,9 @@ struct fgpu_result {
     // that the lookup and formatter kernels of the other batches occupy; on a kernel-free stream it goes to a copy engine and
     // runs beside them (profiles/micro/pcie_rates.hip: 80 MB up or down in 1.5 ms beside a kernel that holds every wave slot).
     hipStream_t stream_in = nullptr, stream_out = nullptr;
+    // ... unless the copy engines are driven directly (copy_engines.hip.h): then the streams idle and these count the copies down
+    hsa_signal_t sig_in{0}, sig_out{0};
+    unsigned lane = 0;  // which of the engines for copies in this result's batches use
     std::vector<fgpu_index::Pending> pending;     // timing events recorded on that stream
     DevBuf d_nids, d_npos, d_idoff, d_ids_pool, d_cnt_pool, d_cursor, d_bitmap, d_counts, d_offsets, d_block_sums,
         d_block_mapped, d_totals, d_colors, d_acct, d_partial, d_tickets, d_idcsr, d_desc, d_kmer_ids, d_scores;
@@ -767,6 +778,7 @@ int fgpu_open(const char* path, int device, fgpu_index** out) {
             if (hipHostMalloc(&warm, 4096, hipHostMallocDefault) == hipSuccess) (void)hipHostFree(warm);
             else (void)hipGetLastError();
         }
+        (void)CopyEngines::get().usable();  // (times a small copy on every copy engine, once per process)
         LoadClock clk;
         upload_index(ix);
         if (ix->host.type != IDX_HYBRID) upload_generic(ix);
@@ -1020,6 +1032,12 @@ int fgpu_result_create(fgpu_index* ix, fgpu_result** out) {
         r->d_totals.ensure(32);
         HIP_TRY(hipStreamCreateWithFlags(&r->stream_in, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&r->stream_out, hipStreamNonBlocking));
+        if (CopyEngines::get().usable()) {
+            static std::atomic<unsigned> lanes{0};
+            r->lane = lanes++;
+            r->sig_in = CopyEngines::get().new_signal();
+            r->sig_out = CopyEngines::get().new_signal();
+        }
     });
     if (rc) { fgpu_result_free(r); return rc; }  // (what was created so far goes with it)
     *out = r;
@@ -1037,6 +1055,8 @@ void fgpu_result_free(fgpu_result* r) {
     if (r->h_totals) (void)hipHostFree(r->h_totals);
     if (r->h_fmt) (void)hipHostFree(r->h_fmt);
     if (r->stream_lookup && r->stream_lookup != r->stream) (void)hipStreamDestroy(r->stream_lookup);
+    CopyEngines::get().free_signal(r->sig_in);
+    CopyEngines::get().free_signal(r->sig_out);
     if (r->stream_in) (void)hipStreamDestroy(r->stream_in);
     if (r->stream_out) (void)hipStreamDestroy(r->stream_out);
     if (r->ev_lookup) (void)hipEventDestroy(r->ev_lookup);
@@ -1192,11 +1212,26 @@ int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_rea
         }
         HIP_TRY(hipStreamSynchronize(s));  // the records are complete; their copy out runs on the kernel-free stream (a copy engine)
         if (bytes) {
-            {
-                Timed t(ix, res, FGPU_K_D2H, res->stream_out);
-                HIP_TRY(hipMemcpyAsync(res->h_fmt, res->d_fmt_out.p, bytes, hipMemcpyDeviceToHost, res->stream_out));
+            CopyEngines& ce = CopyEngines::get();
+            bool done = false;
+            if (ce.usable() && res->sig_out.handle) {  // the engine that carries every copy out, first in first out
+                const uint64_t t0 = fastx_now_ns();
+                ce.arm(res->sig_out, 1);
+                if (ce.d2h(res->h_fmt, res->d_fmt_out.p, bytes, res->sig_out)) {
+                    ce.wait(res->sig_out);
+                    done = true;
+                    if (ix->timing) ix->add_timing(FGPU_K_D2H, (fastx_now_ns() - t0) / 1e6);
+                } else {
+                    ce.disable();
+                }
             }
-            HIP_TRY(hipStreamSynchronize(res->stream_out));
+            if (!done) {
+                {
+                    Timed t(ix, res, FGPU_K_D2H, res->stream_out);
+                    HIP_TRY(hipMemcpyAsync(res->h_fmt, res->d_fmt_out.p, bytes, hipMemcpyDeviceToHost, res->stream_out));
+                }
+                HIP_TRY(hipStreamSynchronize(res->stream_out));
+            }
         }
         if (ix->timing) ix->collect_timing(res->pending);
         *out = res->h_fmt ? res->h_fmt : "";

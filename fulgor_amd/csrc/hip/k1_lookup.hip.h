@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                                                                       uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
                                                                       uint32_t* __restrict__ cnt_pool, uint32_t stride, unsigned int* tickets,
                                                                       uint32_t* __restrict__ kmer_out) {
+    foreign_writes_acquire();  // (the bases and offsets may have been written by a copy engine that the HIP runtime knows nothing about)
     constexpr int KMAX = 128 * HALVES;      // k-mers per unit
     constexpr uint32_t TICKET = HALVES == 1 ? K1_TICKET : (HALVES == 2 ? 6 : 1);  // longer units: one to three per pass, and the planes of a ticket's span live in LDS: short tickets
     constexpr int NA = 2 * HALVES + 1;      // rounds of 64 m-mer positions (the last one: 16 positions)
@@ -186,13 +187,17 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
             const uint64_t sb = ((uint64_t)sb_hi << 32) | sb_lo;
             const uint64_t se = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)off_hi, (int)t_count) << 32) |
                                 (uint32_t)__builtin_amdgcn_readlane((int)off_lo, (int)t_count);
-            const uint32_t nchunks = min((uint32_t)((se - sb + 15u) >> 4), (uint32_t)NIT * 64u);  // (units are at most KMAX + 30 bases long)
+            // (units are at most KMAX + 30 bases long. At least one chunk: a ticket whose units are all empty — a batch that is one read
+            // without bases — has se = sb, and "nchunks - 1" below would let every lane read its own chunk, 1 KB per round, off a
+            // buffer that may be 1 KB long; at the end of a mapped block that is a memory fault, seen once in a dozen runs of the
+            // ragged-reads test)
+            const uint32_t nchunks = max(1u, min((uint32_t)((se - sb + 15u) >> 4), (uint32_t)NIT * 64u));
             const u32x4* src = (const u32x4*)(bases + sb);
             u32x4 x[NIT];
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const uint32_t c = 64u * it + (uint32_t)lane;
-                x[it] = src[min(c, nchunks - 1u)];  // (nchunks >= 1: a ticket holds at least one unit and offsets are monotone; an empty span reads its first 16 bytes, inside the buffer's slack)
+                x[it] = src[min(c, nchunks - 1u)];  // (an empty span reads its first 16 bytes, inside the buffer's slack)
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {

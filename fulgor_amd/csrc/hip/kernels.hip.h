@@ -38,6 +38,15 @@ constexpr uint32_t SMALL_RESULT = 16;  // results of at most this many colours m
 enum { D_ENC_NONE = -1, D_ENC_DELTA_GAPS = 0, D_ENC_BITMAP = 1, D_ENC_COMPLEMENT = 2 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// First thing in a kernel that reads buffers which a copy engine driven through the HSA runtime may have filled (copy_engines.hip.h):
+// the HIP runtime orders and fences the copies IT issues — it makes the first dispatch behind one of its copies invalidate the caches
+// — and knows nothing of these. Without this the lookup kernel read offsets of the batch before (lines left in an XCD's L2) and
+// faulted, once in a few hundred batches. System-scope acquire: the vector caches and the non-local lines of the wave's L2
+// (buffer_inv sc0 sc1), and the scalar cache.
+__device__ __forceinline__ void foreign_writes_acquire() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __builtin_amdgcn_s_dcache_inv();
+}
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t src) {  // src wave-uniform
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32) |
            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
@@ -2300,6 +2309,7 @@ struct RebaseTable {
     uint32_t count;
 };
 __global__ __launch_bounds__(256) void k_offs_rebase(uint64_t* __restrict__ offs, RebaseTable t) {
+    foreign_writes_acquire();
     // offs[r + 1] = end of read r
     const uint64_t r0 = t.first_read[0], r1 = t.first_read[t.count];
     for (uint64_t r = r0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < r1; r += (uint64_t)gridDim.x * blockDim.x) {

@@ -137,19 +137,53 @@ void stream_one_batch(StreamRun& run, StreamWorkerState& w, StreamBatch& b, Stre
         hipStream_t s = res->stream_lookup, sin = res->stream_in;
         w.d_bases.ensure(b.bases + 1024);  // the lookup kernel reads up to 576 bases past a unit's start unconditionally
         w.d_offs.ensure((b.reads + 1) * 8);
-        {   // every chunk as it lies, on the kernel-free copy stream (a copy engine: beside the kernels of the other batches)
-            Timed t(ix, res, FGPU_K_H2D, sin);
-            uint64_t at = 0, r = 0;
-            for (const FastxChunk& c : b.chunks) {
-                if (c.bases.size()) HIP_TRY(hipMemcpyAsync(w.d_bases.as<char>() + at, c.bases.data(), c.bases.size(), hipMemcpyHostToDevice, sin));
-                // (the first chunk brings offs[0] = 0 along)
-                if (r == 0) HIP_TRY(hipMemcpyAsync(w.d_offs.as<uint64_t>(), c.offs.data(), (c.reads() + 1) * 8, hipMemcpyHostToDevice, sin));
-                else HIP_TRY(hipMemcpyAsync(w.d_offs.as<uint64_t>() + r + 1, c.offs.data() + 1, c.reads() * 8, hipMemcpyHostToDevice, sin));
-                at += c.bases.size();
-                r += c.reads();
+        {   // every chunk as it lies: two copies per chunk, beside the kernels of the other batches, on a copy engine for copies in
+            // (copy_engines.hip.h) or, failing that, on the result's kernel-free copy stream
+            CopyEngines& ce = CopyEngines::get();
+            const bool direct = ce.usable() && res->sig_in.handle;
+            const uint64_t t_h2d = now_ns();
+            // (an engine reads the host memory as it is mapped for the device: only buffers of the pinned pool go that way — a buffer
+            // that the pool handed out before an index was open, or beyond its cap, is plain memory, which the HIP call stages)
+            int64_t armed = 0;
+            if (direct) {
+                for (const FastxChunk& c : b.chunks) if (c.reads()) armed += (c.bases.size() && c.bases.pinned() ? 1 : 0) + (c.offs.pinned() ? 1 : 0);
+                ce.arm(res->sig_in, armed);
             }
+            bool engines = direct, staged = false;
+            auto piece = [&](void* dst, const void* src, size_t n, bool pinned) {
+                if (!n) return;
+                if (engines && pinned) {
+                    if (ce.h2d(dst, src, n, res->sig_in, res->lane)) { --armed; return; }
+                    engines = false;  // (refused: this piece and the rest through the HIP runtime; the engines are left alone from now on)
+                    ce.disable();
+                }
+                staged = true;
+                HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, sin));
+            };
+            {
+                Timed t(ix, res, direct ? -1 : FGPU_K_H2D, sin);
+                uint64_t at = 0, r = 0;
+                bool first = true;
+                for (const FastxChunk& c : b.chunks) {
+                    // a range inside one long record holds no read: its chunk has no offsets at all (not even the leading 0 — copying
+                    // "offs[0]" of such a chunk at the head of a batch put whatever the buffer held in front of the batch's offsets)
+                    if (!c.reads()) continue;
+                    if (c.bases.size()) piece(w.d_bases.as<char>() + at, c.bases.data(), c.bases.size(), c.bases.pinned());
+                    // (the first chunk with reads brings offs[0] = 0 along)
+                    if (first) piece(w.d_offs.as<uint64_t>(), c.offs.data(), (c.reads() + 1) * 8, c.offs.pinned());
+                    else piece(w.d_offs.as<uint64_t>() + r + 1, c.offs.data() + 1, c.reads() * 8, c.offs.pinned());
+                    first = false;
+                    at += c.bases.size();
+                    r += c.reads();
+                }
+            }
+            if (direct) {
+                ce.disarm(res->sig_in, armed);  // (pieces that went the other way)
+                ce.wait(res->sig_in);
+                if (ix->timing) ix->add_timing(FGPU_K_H2D, (now_ns() - t_h2d) / 1e6);
+            }
+            if (!direct || staged) HIP_TRY(hipStreamSynchronize(sin));
         }
-        HIP_TRY(hipStreamSynchronize(sin));
         lg.t_copied = now_ns() - run.t0;
         {   // offsets of a chunk count from the chunk's first base: add its position in the batch
             uint64_t at = 0, r = 0;
@@ -163,6 +197,7 @@ void stream_one_batch(StreamRun& run, StreamWorkerState& w, StreamBatch& b, Stre
                 tab.count = 0;
             };
             for (const FastxChunk& c : b.chunks) {
+                if (!c.reads()) continue;
                 tab.first_read[tab.count] = r;
                 tab.base[tab.count] = at;
                 ++tab.count;
@@ -359,6 +394,7 @@ int fgpu_pseudoalign_stream(fgpu_index* ix, fgpu_fastx* query, int out_fd, int a
         o << "parser: " << st.bytes << " text bytes in " << st.ranges << " ranges; per thread " << st.parse_ns / 1e6 / std::max(1u, st.threads)
           << " ms parsing, " << st.wait_ns / 1e6 / std::max(1u, st.threads) << " ms waiting for the workers; host buffers pinned anew during the run: "
           << SlabPool::get().fresh_allocs() - run.slabs0 << " (" << (SlabPool::get().fresh_bytes() - run.slab_bytes0) / 1e6 << " MB)\n";
+        o << CopyEngines::get().report() << "\n";
         o << "# seq reads bases out_bytes | ms since start: begin acquired copied-in issued colours formatted+copied-out turn written\n";
         for (const StreamBatchLog& l : run.log)
             o << l.seq << " " << l.reads << " " << l.bases << " " << l.out_bytes << " | " << l.t_begin / 1e6 << " " << l.t_acquired / 1e6 << " " << l.t_copied / 1e6 << " "

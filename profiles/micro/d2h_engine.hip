@@ -2,8 +2,10 @@
 // by a copy engine (SDMA); one that has to wait for the kernel is a shader copy (__amd_rocclr_copyBuffer), which competes with the
 // kernels of the pipeline for the CUs. The streamed worker loop has 5 workers x 4 streams: does the number of streams, the thread
 // that issues the copy, or a kernel having written the source matter?
-//   hipcc --offload-arch=gfx950 -O3 -o d2h_engine d2h_engine.hip && ./d2h_engine
+//   hipcc --offload-arch=gfx950 -O3 -o d2h_engine d2h_engine.hip -lhsa-runtime64 && ./d2h_engine
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -106,6 +108,124 @@ int main() {
         const double t2 = now_ms();
         CK(hipStreamSynchronize(s_spin));
         printf("D2H + H2D at once: D2H done after %.2f, H2D after %.2f ms, kernel after %.2f ms\n", t1 - t0, t2 - t0, now_ms() - t0);
+    }
+    // every hardware queue busy: a short kernel is pending on each of the 24 streams (the runtime multiplexes them onto its hardware
+    // queues) when the copy out is issued on a kernel-free stream of normal / of high priority
+    {
+        int least = 0, greatest = 0;
+        CK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        hipStream_t s_hi, s_hi_in;
+        CK(hipStreamCreateWithPriority(&s_hi, hipStreamNonBlocking, greatest));
+        CK(hipStreamCreateWithPriority(&s_hi_in, hipStreamNonBlocking, greatest));
+        uint32_t* d_sinks;
+        CK(hipMalloc((void**)&d_sinks, 4 * 32));
+        auto busy = [&] { for (size_t i = 0; i < many.size(); ++i) hipLaunchKernelGGL(k_spin, dim3(8), dim3(256), 0, many[i], d_sinks + i, 200000u); };
+        busy(); probe("D2H, kernel-free stream of NORMAL priority, kernels pending on 24 other streams", s_out3, h_b, d_b, hipMemcpyDeviceToHost);
+        CK(hipDeviceSynchronize());
+        busy(); probe("D2H, kernel-free stream of HIGH priority (range %d..%d), kernels pending on 24 other streams", s_hi, h_b, d_b, hipMemcpyDeviceToHost);
+        CK(hipDeviceSynchronize());
+        busy(); probe("H2D, kernel-free stream of NORMAL priority, kernels pending on 24 other streams", s_in, d_a, h_a, hipMemcpyHostToDevice);
+        CK(hipDeviceSynchronize());
+        printf("(stream priorities: least %d, greatest %d)\n", least, greatest);
+    }
+    // the copy out through the HSA runtime on an engine of our choice: rate per engine, alone and beside 2 x 20 H2D pieces of the HIP runtime
+    {
+        hsa_amd_pointer_info_t pi;
+        memset(&pi, 0, sizeof pi);
+        pi.size = sizeof pi;
+        hsa_agent_t gpu{}, cpu{};
+        if (hsa_amd_pointer_info(d_b, &pi, nullptr, nullptr, nullptr) == HSA_STATUS_SUCCESS) gpu = pi.agentOwner;
+        memset(&pi, 0, sizeof pi);
+        pi.size = sizeof pi;
+        if (hsa_amd_pointer_info(h_b, &pi, nullptr, nullptr, nullptr) == HSA_STATUS_SUCCESS) cpu = pi.agentOwner;
+        uint32_t mask = 0, rec = 0;
+        hsa_status_t st = hsa_amd_memory_copy_engine_status(cpu, gpu, &mask);
+        hsa_amd_memory_get_preferred_copy_engine(cpu, gpu, &rec);
+        printf("HSA: gpu agent %llx, cpu agent %llx, D2H engine status %d, free mask 0x%x, preferred mask 0x%x\n", (unsigned long long)gpu.handle, (unsigned long long)cpu.handle, (int)st, mask, rec);
+        uint32_t mask_in = 0;
+        hsa_amd_memory_copy_engine_status(gpu, cpu, &mask_in);
+        printf("HSA: H2D free mask 0x%x\n", mask_in);
+        hsa_signal_t sig;
+        hsa_signal_create(1, 0, nullptr, &sig);
+        hipStream_t s_in2;
+        CK(hipStreamCreateWithFlags(&s_in2, hipStreamNonBlocking));
+        char* d_c;
+        CK(hipMalloc((void**)&d_c, N));
+        for (uint32_t e = 1; e <= 0x8000u; e <<= 1) {
+            if (!(mask & e)) continue;
+            double alone = 0, beside = 0, h2d_done = 0;
+            bool failed = false;
+            for (int rep = 0; rep < 3 && !failed; ++rep) {
+                hsa_signal_store_relaxed(sig, 1);
+                const double t0 = now_ms();
+                if (hsa_amd_memory_async_copy_on_engine(h_b, cpu, d_b, gpu, N, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t)e, false) != HSA_STATUS_SUCCESS) { failed = true; break; }
+                hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
+                alone = now_ms() - t0;
+            }
+            for (int rep = 0; rep < 3 && !failed; ++rep) {
+                hsa_signal_store_relaxed(sig, 1);
+                const double t0 = now_ms();
+                const size_t step = N / 20;
+                for (int i = 0; i < 20; ++i) {
+                    CK(hipMemcpyAsync(d_a + i * step, h_a + i * step, step, hipMemcpyHostToDevice, s_in));
+                    CK(hipMemcpyAsync(d_c + i * step, h_a + i * step, step, hipMemcpyHostToDevice, s_in2));
+                }
+                if (hsa_amd_memory_async_copy_on_engine(h_b, cpu, d_b, gpu, N, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t)e, false) != HSA_STATUS_SUCCESS) { failed = true; break; }
+                hsa_signal_wait_scacquire(sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
+                beside = now_ms() - t0;
+                CK(hipStreamSynchronize(s_in));
+                CK(hipStreamSynchronize(s_in2));
+                h2d_done = now_ms() - t0;
+            }
+            if (failed) printf("HSA D2H on engine 0x%04x: refused\n", e);
+            else printf("HSA D2H of 44 MB on engine 0x%04x: alone %.2f ms (%.1f GB/s); issued behind 2 x 20 H2D pieces (88 MB, HIP): D2H done after %.2f ms, H2D after %.2f ms\n", e, alone, N / alone / 1e6, beside, h2d_done);
+        }
+    }
+    // as in the worker loop: the copy in of two other batches is queued in pieces on two more streams when the copy out is issued
+    {
+        hipStream_t s_in2;
+        CK(hipStreamCreateWithFlags(&s_in2, hipStreamNonBlocking));
+        char* d_c;
+        CK(hipMalloc((void**)&d_c, N));
+        for (int rep = 0; rep < 2; ++rep) {
+            hipLaunchKernelGGL(k_spin, dim3(2048), dim3(256), 0, s_spin, d_sink, 200000u);
+            const double t0 = now_ms();
+            const size_t step = N / 20;
+            for (int i = 0; i < 20; ++i) {
+                CK(hipMemcpyAsync(d_a + i * step, h_a + i * step, step, hipMemcpyHostToDevice, s_in));
+                CK(hipMemcpyAsync(d_c + i * step, h_a + i * step, step, hipMemcpyHostToDevice, s_in2));
+            }
+            CK(hipMemcpyAsync(h_b, d_b, N, hipMemcpyDeviceToHost, s_out3));
+            CK(hipStreamSynchronize(s_out3));
+            const double t1 = now_ms();
+            CK(hipStreamSynchronize(s_in));
+            CK(hipStreamSynchronize(s_in2));
+            const double t2 = now_ms();
+            CK(hipStreamSynchronize(s_spin));
+            if (rep) printf("D2H issued behind 2 x 20 H2D pieces on two other streams: D2H done after %.2f, the H2D after %.2f ms, kernel after %.2f ms\n", t1 - t0, t2 - t0, now_ms() - t0);
+        }
+    }
+    // five threads, each: kernel on its own stream, synchronise, D2H on its own kernel-free stream (no slot-filling kernel: wall time)
+    {
+        std::vector<std::thread> th;
+        const double t0 = now_ms();
+        for (int t = 0; t < 5; ++t) th.emplace_back([&, t] {
+            CK(hipSetDevice(0));
+            hipStream_t sk, so;
+            CK(hipStreamCreateWithFlags(&sk, hipStreamNonBlocking));
+            CK(hipStreamCreateWithFlags(&so, hipStreamNonBlocking));
+            char *d, *h;
+            CK(hipMalloc((void**)&d, N));
+            CK(hipHostMalloc((void**)&h, N, hipHostMallocDefault));
+            for (int it = 0; it < 8; ++it) {
+                hipLaunchKernelGGL(k_fill, dim3(1024), dim3(256), 0, sk, (uint32_t*)d, N / 4, (uint32_t)it);
+                CK(hipStreamSynchronize(sk));
+                CK(hipMemcpyAsync(h, d, N, hipMemcpyDeviceToHost, so));
+                CK(hipStreamSynchronize(so));
+            }
+        });
+        for (auto& t : th) t.join();
+        printf("5 threads x 8 x (fill kernel, sync, D2H of 44 MB on the thread's kernel-free stream): %.2f ms (count __amd_rocclr_copyBuffer under rocprofv3 --kernel-trace)\n", now_ms() - t0);
     }
     return 0;
 }

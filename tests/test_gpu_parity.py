@@ -1586,6 +1586,26 @@ def test_stream_loop_equals_batch_calls_on_ragged_and_long_reads(s10_gpu, s10_or
     assert mapped == int((np.diff(to.astype(np.int64)) > 0).sum())
 
 
+def test_batches_that_hold_only_empty_reads(s10_gpu, tmp_path):
+    """a batch whose reads have no bases at all (one empty record between two batch cuts of a ragged file): the lookup kernel's span of
+    such a ticket is empty, and it used to read a kilobyte per round off a base buffer that may be a kilobyte long (a memory fault
+    whenever the buffer ended a mapped block: once in a dozen runs of the ragged test above). Host-buffer calls and the streamed loop."""
+    from fulgor_amd.driver import Formatter
+    nc = s10_gpu.num_colors()
+    for n in (1, 2, 5, 64, 65, 300):
+        b, o = pack_reads([b""] * n)
+        offs, cols = s10_gpu.pseudoalign_full_intersection_batch(b, o)
+        assert len(cols) == 0 and np.array_equal(offs, np.zeros(n + 1, dtype=offs.dtype))
+        offs, cols = s10_gpu.pseudoalign_threshold_union_batch(b, o, 0.5)
+        assert len(cols) == 0 and len(offs) == n + 1
+    fa = tmp_path / "empties.fa"
+    fa.write_bytes(b"".join(b">e%d\n\n" % i for i in range(40)))
+    for batch, workers in ((1, 3), (7, 2), (0, 0)):
+        for _ in range(5):
+            out, n, mapped = _stream(s10_gpu, str(fa), 0, batch=batch, workers=workers)
+            assert (n, mapped) == (40, 0) and out == Formatter("ascii", nc).add(0, np.zeros(41, dtype=np.uint64), np.zeros(0, dtype=np.uint32))
+
+
 def test_stream_loop_on_empty_wrapped_and_broken_files(s10_gpu, s10_oracle, tmp_path):
     """an empty query file gives the header and no records; a FASTQ file that turns into wrapped lines behind a four-line head offers no record
     boundaries in its tail, which then falls to one range and the full grammar: same records as the oracle's; a gzip file with a flipped byte
