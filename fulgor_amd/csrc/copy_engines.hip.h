@@ -24,10 +24,11 @@ namespace {
 class CopyEngines {
 public:
     static CopyEngines& get() { static CopyEngines c; return c; }
-    // (call with the device current) true: bulk copies go through h2d() / d2h()
-    bool usable() {
-        std::call_once(once_, [this] { init(); });
-        return ok_.load(std::memory_order_relaxed);
+    // (call with the device current) true: the bulk copies of this device go through h2d() / d2h(). One device per process — the first
+    // that asks (one process per GPU is how the command line and the bench run); indexes on other devices use the HIP calls.
+    bool usable(int device) {
+        std::call_once(once_, [this, device] { device_ = device; init(); });
+        return device == device_ && ok_.load(std::memory_order_relaxed);
     }
     hsa_signal_t new_signal() {
         hsa_signal_t s{0};
@@ -54,6 +55,7 @@ public:
 private:
     std::once_flag once_;
     std::atomic<bool> ok_{false};
+    int device_ = -1;
     hsa_agent_t gpu_{0}, cpu_{0};
     std::vector<uint32_t> in_;
     uint32_t out_ = 0;

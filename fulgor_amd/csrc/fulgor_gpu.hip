@@ -778,7 +778,7 @@ int fgpu_open(const char* path, int device, fgpu_index** out) {
             if (hipHostMalloc(&warm, 4096, hipHostMallocDefault) == hipSuccess) (void)hipHostFree(warm);
             else (void)hipGetLastError();
         }
-        (void)CopyEngines::get().usable();  // (times a small copy on every copy engine, once per process)
+        (void)CopyEngines::get().usable(device);  // (times a small copy on every copy engine, once per process)
         LoadClock clk;
         upload_index(ix);
         if (ix->host.type != IDX_HYBRID) upload_generic(ix);
@@ -1032,7 +1032,7 @@ int fgpu_result_create(fgpu_index* ix, fgpu_result** out) {
         r->d_totals.ensure(32);
         HIP_TRY(hipStreamCreateWithFlags(&r->stream_in, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&r->stream_out, hipStreamNonBlocking));
-        if (CopyEngines::get().usable()) {
+        if (CopyEngines::get().usable(ix->device)) {
             static std::atomic<unsigned> lanes{0};
             r->lane = lanes++;
             r->sig_in = CopyEngines::get().new_signal();
@@ -1214,7 +1214,7 @@ int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_rea
         if (bytes) {
             CopyEngines& ce = CopyEngines::get();
             bool done = false;
-            if (ce.usable() && res->sig_out.handle) {  // the engine that carries every copy out, first in first out
+            if (res->sig_out.handle && ce.usable(ix->device)) {  // the engine that carries every copy out, first in first out
                 const uint64_t t0 = fastx_now_ns();
                 ce.arm(res->sig_out, 1);
                 if (ce.d2h(res->h_fmt, res->d_fmt_out.p, bytes, res->sig_out)) {

@@ -140,7 +140,7 @@ void stream_one_batch(StreamRun& run, StreamWorkerState& w, StreamBatch& b, Stre
         {   // every chunk as it lies: two copies per chunk, beside the kernels of the other batches, on a copy engine for copies in
             // (copy_engines.hip.h) or, failing that, on the result's kernel-free copy stream
             CopyEngines& ce = CopyEngines::get();
-            const bool direct = ce.usable() && res->sig_in.handle;
+            const bool direct = res->sig_in.handle && ce.usable(ix->device);
             const uint64_t t_h2d = now_ns();
             // (an engine reads the host memory as it is mapped for the device: only buffers of the pinned pool go that way — a buffer
             // that the pool handed out before an index was open, or beyond its cap, is plain memory, which the HIP call stages)

@@ -1606,6 +1606,62 @@ def test_batches_that_hold_only_empty_reads(s10_gpu, tmp_path):
             assert (n, mapped) == (40, 0) and out == Formatter("ascii", nc).add(0, np.zeros(41, dtype=np.uint64), np.zeros(0, dtype=np.uint32))
 
 
+def test_stream_loop_fuzz_against_the_batch_calls(s10_gpu, tmp_path, monkeypatch):
+    """seeded fuzz of the worker loop: FASTA (single- or multi-line) and four-line FASTQ files of reads of every awkward length (0, k - 1, k,
+    129 .. 600 k-mers, one of 20000 bases, runs of empty records, N bases), ranges of 4 .. 256 KB, FASTQ pieces of 1 .. 64 KB, batches of 1 .. 5000
+    reads on 1 .. 7 workers, both algorithms, ascii and binary records: byte-identical to the formatter over the host-buffer calls
+    (which the tests above hold against the oracle); compressed records parse back to the same lists"""
+    from oracle.kmer_oracle import read_fasta
+    from oracle.pyoracle import parse_compressed
+    from fulgor_amd.driver import Formatter
+    src = max(read_fasta(S10_GENOMES[3]), key=len)
+    rng = np.random.default_rng(20250930)
+    nc = s10_gpu.num_colors()
+    special = [0, 0, 0, 30, 31, 32, 150, 158, 159, 160, 286, 287, 542, 543, 630, 20000]
+    for trial in range(160):
+        n = int(rng.integers(1, 2500))
+        lens = [int(x) for x in rng.integers(0, int(rng.choice([40, 200, 400, 700])), size=n)]
+        for _ in range(int(rng.integers(0, 12))):
+            lens[int(rng.integers(0, n))] = int(rng.choice(special))
+        if trial % 3 == 0:  # a run of empty records long enough to fill batches of their own
+            at = int(rng.integers(0, n))
+            lens[at:at + 70] = [0] * len(lens[at:at + 70])
+        reads = []
+        for i, l in enumerate(lens):
+            st = int(rng.integers(0, len(src) - 20001))
+            r = bytearray(src[st:st + l])
+            if l and i % 97 == 5:
+                r[int(rng.integers(0, l))] = ord("N")
+            reads.append(bytes(r))
+        fastq = trial % 2 == 1
+        path = tmp_path / ("fuzz%d.%s" % (trial, "fq" if fastq else "fa"))
+        with open(path, "wb") as f:
+            for i, r in enumerate(reads):
+                if fastq:
+                    f.write(b"@q%d\n%s\n+\n%s\n" % (i, r, b"@" * len(r)))
+                else:
+                    w = int(rng.choice([60, 80, 100000]))
+                    f.write(b">s%d t\n" % i + b"".join(r[j:j + w] + b"\n" for j in range(0, len(r), w)) + (b"\n" if not r else b""))
+        monkeypatch.setenv("FULGOR_READER_RANGE_KB", str(int(rng.choice([4, 16, 64, 256]))))
+        monkeypatch.setenv("FULGOR_READER_PIECE_KB", str(int(rng.choice([1, 3, 64]))))
+        b, o = pack_reads(reads)
+        algo, tau = (fulgor_amd.THRESHOLD_UNION, float(rng.choice([0.3, 0.8, 1.0]))) if trial % 4 >= 2 else (fulgor_amd.FULL_INTERSECTION, 0.0)
+        if algo == fulgor_amd.THRESHOLD_UNION:
+            eo, ec = s10_gpu.pseudoalign_threshold_union_batch(b, o, tau)
+        else:
+            eo, ec = s10_gpu.pseudoalign_full_intersection_batch(b, o)
+        first_id = int(rng.integers(0, 1000))
+        for rep in range(3):
+            batch, workers, fmt = int(rng.choice([1, 7, 64, 333, 5000])), int(rng.integers(1, 8)), rep
+            out, got, mapped = _stream(s10_gpu, str(path), fmt, algo, tau, first_id=first_id, batch=batch, workers=workers, threads=int(rng.integers(1, 5)))
+            assert got == n and mapped == int((np.diff(eo.astype(np.int64)) > 0).sum()), (trial, rep)
+            if fmt == 2:
+                ids, po, pc = parse_compressed(out)
+                assert np.array_equal(ids, np.arange(first_id, first_id + n, dtype=np.uint32)) and np.array_equal(po, eo) and np.array_equal(pc, ec), (trial, batch, workers)
+            else:
+                assert out == Formatter(("ascii", "binary")[fmt], nc).add(first_id, eo, ec), (trial, batch, workers, fmt)
+
+
 def test_stream_loop_on_empty_wrapped_and_broken_files(s10_gpu, s10_oracle, tmp_path):
     """an empty query file gives the header and no records; a FASTQ file that turns into wrapped lines behind a four-line head offers no record
     boundaries in its tail, which then falls to one range and the full grammar: same records as the oracle's; a gzip file with a flipped byte
