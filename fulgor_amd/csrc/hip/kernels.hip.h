@@ -44,8 +44,10 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // faulted, once in a few hundred batches. System-scope acquire: the vector caches and the non-local lines of the wave's L2
 // (buffer_inv sc0 sc1), and the scalar cache.
 __device__ __forceinline__ void foreign_writes_acquire() {
+#ifndef FG_NO_FOREIGN_ACQUIRE  // (variant build: what the fence costs the lookup kernel)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     __builtin_amdgcn_s_dcache_inv();
+#endif
 }
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t src) {  // src wave-uniform
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src) << 32) |
