@@ -562,6 +562,11 @@ def test_reader_under_sanitizers(tmp_path):
                 lines = r.stdout.strip().splitlines()
                 assert len(lines) == 3 and len(set(lines)) == 1
                 outs.add((tuple(args[1:]), lines[0]))
+        # the plain file again in ranges of 256 KB read in pieces of 3 KB (a piece end inside nearly every tenth record)
+        r = subprocess.run([exe, str(tmp_path / "p.fq"), "6"], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, FULGOR_READER_RANGE_KB="256", FULGOR_READER_PIECE_KB="3"))
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+        outs.add(((), r.stdout.strip().splitlines()[0]))
         assert len(outs) == 2  # plain and block-compressed agree, whole and in parts
 
 
