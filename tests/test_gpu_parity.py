@@ -1606,7 +1606,8 @@ def test_batches_that_hold_only_empty_reads(s10_gpu, tmp_path):
             assert (n, mapped) == (40, 0) and out == Formatter("ascii", nc).add(0, np.zeros(41, dtype=np.uint64), np.zeros(0, dtype=np.uint32))
 
 
-def test_stream_loop_fuzz_against_the_batch_calls(s10_gpu, tmp_path, monkeypatch):
+@pytest.mark.parametrize("which", ["s10", "s4546small"])
+def test_stream_loop_fuzz_against_the_batch_calls(which, s10_gpu, s4546small, tmp_path, monkeypatch):
     """seeded fuzz of the worker loop: FASTA (single- or multi-line) and four-line FASTQ files of reads of every awkward length (0, k - 1, k,
     129 .. 600 k-mers, one of 20000 bases, runs of empty records, N bases), ranges of 4 .. 256 KB, FASTQ pieces of 1 .. 64 KB, batches of 1 .. 5000
     reads on 1 .. 7 workers, both algorithms, ascii and binary records: byte-identical to the formatter over the host-buffer calls
@@ -1614,11 +1615,14 @@ def test_stream_loop_fuzz_against_the_batch_calls(s10_gpu, tmp_path, monkeypatch
     from oracle.kmer_oracle import read_fasta
     from oracle.pyoracle import parse_compressed
     from fulgor_amd.driver import Formatter
-    src = max(read_fasta(S10_GENOMES[3]), key=len)
+    # (the 4546-colour index: results of hundreds of colours, every record kind of the compressed format, rows of 144 words)
+    ix = s10_gpu if which == "s10" else s4546small[0]
+    s10_gpu = ix
+    src = max(read_fasta(S10_GENOMES[3 if which == "s10" else 0]), key=len)
     rng = np.random.default_rng(20250930)
     nc = s10_gpu.num_colors()
     special = [0, 0, 0, 30, 31, 32, 150, 158, 159, 160, 286, 287, 542, 543, 630, 20000]
-    for trial in range(160):
+    for trial in range(160 if which == "s10" else 120):
         n = int(rng.integers(1, 2500))
         lens = [int(x) for x in rng.integers(0, int(rng.choice([40, 200, 400, 700])), size=n)]
         for _ in range(int(rng.integers(0, 12))):
