@@ -332,7 +332,10 @@ int fgpu_pseudoalign_stream(fgpu_index* ix, fgpu_fastx* query, int out_fd, int a
     // defaults from the grid of profiles/e2e_stream.py (profiles/r5/e2e_grid_r5.txt): 16 to 32 parser threads, 4 to 6 workers and
     // batches of 2^18 or 2^19 reads all land within the run-to-run spread of each other; smaller batches fill the pipeline sooner
     // and pin less host memory
-    if (batch_reads == 0) batch_reads = env_u64("FULGOR_STREAM_BATCH", 1u << 18);
+    // default batch: 2^18 reads for the compressed records; 2^15 for ascii / binary, whose records are an order of magnitude larger
+    // (3 KB per read on a 4546-colour collection: the copy out is the whole run at any batch size — 18.7 M reads/s = 54.6 GB/s
+    // from 2^14 to 2^18, profiles/r5/e2e_formats_r5.txt — and five result buffers of 2^18 reads would pin 4 GB of host memory)
+    if (batch_reads == 0) batch_reads = env_u64("FULGOR_STREAM_BATCH", format == FGPU_FMT_COMPRESSED ? 1u << 18 : 1u << 15);
     if (workers == 0) workers = (unsigned)env_u64("FULGOR_STREAM_WORKERS", 5);
     workers = std::min(workers, 16u);
     std::vector<StreamWorkerState> states;

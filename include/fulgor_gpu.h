@@ -200,7 +200,7 @@ int fgpu_fastx_ring(void);
  * out_fd in `format` (FGPU_FMT_*), records in file order, read ids counting from first_read_id (src/ps_utils.cpp:276,286: read id =
  * position in the file); write_header != 0 puts the compressed format's 8-byte file header in front. out_fd < 0: nothing is
  * formatted or written (counters only). Returns when everything is written. The loop keeps `workers` batches of at most
- * batch_reads reads in flight (0 = defaults: 5 and 2^18): the reader's threads parse byte ranges of the file into pinned
+ * batch_reads reads in flight (0 = defaults: 5, and 2^18 for compressed records, 2^15 for ascii and binary ones): the reader's threads parse byte ranges of the file into pinned
  * memory, each range goes to the device as it lies, lookup -> colour stage -> device-side formatter -> copy out run per batch on
  * the batch's own stream, so that the copy in of one batch, the kernels of another and the copy out of a third overlap. The u32
  * colour lists are not built for the compressed format. num_reads / num_mapped: the two counters of ps_options
