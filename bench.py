@@ -164,7 +164,10 @@ def measure(w, algo, tau, chunk, steps, warmup, streams, local_rank, world=1, di
         stage of pass t is waited for (two results in flight; with FULGOR_CU_SPLIT on disjoint parts of the device)"""
         if not pipeline:
             for _ in range(k):
+                t_a = time.perf_counter()
                 step()
+                torch.cuda.synchronize()  # (the next step begins with the same wait: this only dates the end of this one)
+                step_ms.append(round((time.perf_counter() - t_a) * 1e3, 3))
             return
         seq = [(s_, i) for s_ in range(k) for i in range(len(chunks))]
         torch.cuda.synchronize()
@@ -203,7 +206,12 @@ def measure(w, algo, tau, chunk, steps, warmup, streams, local_rank, world=1, di
             else:
                 dist.all_reduce(hits)
 
+    import gc
+    gc.collect()  # (whatever the legs before left to the collector — pinned buffers of hundreds of megabytes take tens of milliseconds to release — goes now, not inside a timed step)
+    torch.cuda.synchronize()
+    step_ms = []
     run_steps(warmup)
+    del step_ms[:]
     ix.timing_enable(True)
     ix.timing_reset()
     torch.cuda.synchronize()
@@ -242,7 +250,7 @@ def measure(w, algo, tau, chunk, steps, warmup, streams, local_rank, world=1, di
     stage_kernel = "k2_intersect" if algo == fulgor_amd.FULL_INTERSECTION else "k3_union"
     kbytes = {"k1_lookup": acct["lookup"], stage_kernel: acct["lists"], "k2b_expand": acct["output"]}
     return {"elapsed": elapsed, "timing": timing, "acct": acct, "kbytes": kbytes, "stage_kernel": stage_kernel,
-            "total_colors": total_colors, "reads_job": int(h[w.ncol]), "mapped_job": int(h[w.ncol + 1]), "steps": steps,
+            "total_colors": total_colors, "reads_job": int(h[w.ncol]), "mapped_job": int(h[w.ncol + 1]), "steps": steps, "step_ms": step_ms,
             "launches_per_step": len(chunks)}
 
 
@@ -288,8 +296,8 @@ def load_traffic(workload, itype, algo_name, chunk, n_reads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("FULGOR_BENCH_WORKLOAD", "s4546syn"), choices=["s4546syn", "s4546core", "s10"])
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the BASELINE config size)")
     ap.add_argument("--algo", default="full-intersection", choices=["full-intersection", "threshold-union"])
@@ -410,6 +418,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(m["elapsed"] / args.steps * 1e3, 3),
+            "step_ms": m["step_ms"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
