@@ -73,7 +73,6 @@ private:
     void init() {
         const char* e = getenv("FULGOR_COPY_ENGINES");  // 0: hipMemcpyAsync for everything (A/B measurements)
         if (e && e[0] == '0') return;
-        if (getenv("FULGOR_GUARD_ALLOC")) return;  // (the debugging allocator maps its buffers itself; its copies stay with the HIP runtime)
         constexpr size_t PROBE = 4u << 20;
         void *d = nullptr, *h = nullptr;
         hsa_signal_t sig{0};
