@@ -579,6 +579,25 @@ def end_to_end_stream(ix, bases, offs, algo, tau, n, fmt, batch=1 << 18, workers
                         "lists for the compressed format), device-side %s formatting, D2H into a pinned buffer" % (len(parts), workers, "ascii" if fmt == 0 else "compressed")}
 
 
+def host_description():
+    """what the command-line figure depends on besides the GPU: it differs by 20 % between boxes of the same kind"""
+    import glob
+    out = {"hardware_threads": os.cpu_count()}
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")]
+        out["cpu"] = model[0] if model else None
+        out["numa_nodes"] = len(glob.glob("/sys/devices/system/node/node[0-9]*"))
+        nodes = []
+        for d in glob.glob("/sys/class/drm/card*/device"):
+            if os.path.exists(os.path.join(d, "mem_info_vram_total")):
+                nodes.append(int(open(os.path.join(d, "numa_node")).read().strip() or -1))
+        out["gpu_numa_nodes"] = nodes
+        out["loadavg"] = open("/proc/loadavg").read().split()[:3]
+    except (OSError, ValueError):
+        pass
+    return out
+
+
 def cli_end_to_end(ix, bases, offs, algo, tau, n, read_len, fmt="compressed", repeats=6):
     """Wall clock of the command-line path (`python -m fulgor_amd pseudoalign`: driver.pseudoalign_sharded) on a bounded
     sample: an uncompressed FASTQ file on tmpfs -> parallel parse into pinned batches -> H2D -> kernels -> records in the
@@ -627,7 +646,7 @@ def cli_end_to_end(ix, bases, offs, algo, tau, n, read_len, fmt="compressed", re
                             "carries down the link (55 GB/s)" % (fmt, out_bytes // max(1, n))}
     return {"value": round(n / best, 1), "unit": "reads/s", "reads": int(n), "fastq_bytes": int(size),
             "runs_ms": [round(t * 1e3, 1) for t in runs], "first_run_value": round(n / runs[0], 1),
-            "median_value": round(n / sorted(runs[1:])[len(runs[1:]) // 2], 1), "last_run": report,
+            "median_value": round(n / sorted(runs[1:])[len(runs[1:]) // 2], 1), "last_run": report, "host": host_description(),
             "includes": "FASTQ file on tmpfs -> byte ranges read and parsed by the reader's threads into pinned chunks -> H2D of every chunk "
                         "(copy engine) -> lookup, intersection (no u32 colour lists), compressed records built on the device -> D2H (copy "
                         "engine) -> /dev/null, batches of 2^18 reads on 5 streams (fgpu_pseudoalign_stream); index already resident; value = best of "
