@@ -410,6 +410,8 @@ def main():
     m = measure(w, algo, args.tau, args.chunk, args.steps, args.warmup, args.streams, local_rank, world, dist, share, pipeline=bool(args.pipeline))
 
     if rank == 0:
+        dev_state = device_state()
+        print("[bench] device state right after the timed steps: %s" % dev_state, file=sys.stderr, flush=True)
         traffic, traffic_src = load_traffic(args.workload, w.itype, args.algo, args.chunk, n_reads)
         per_kernel = kernel_rooflines(m, traffic)
         dom = max(per_kernel, key=lambda k_: per_kernel[k_]["avg_launch_ms"])
@@ -423,6 +425,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(m["elapsed"] / args.steps * 1e3, 3),
             "step_ms": m["step_ms"],
+            "device_state": dev_state,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -577,6 +580,34 @@ def end_to_end_stream(ix, bases, offs, algo, tau, n, fmt, batch=1 << 18, workers
     return {"value": round(n / best, 1), "unit": "reads/s", "reads": int(n), "output_bytes": int(sum(out_bytes)), "runs_ms": [round(t * 1e3, 1) for t in runs],
             "includes": "pipelined: %d batches of 2^18 host-resident reads (pageable memory), %d in flight; per batch H2D, all kernels (no u32 colour "
                         "lists for the compressed format), device-side %s formatting, D2H into a pinned buffer" % (len(parts), workers, "ascii" if fmt == 0 else "compressed")}
+
+
+def device_state():
+    """clocks, power and temperatures of the card this process uses (the one with the most memory in use), from sysfs: they are logged
+    beside the kernel times because the expansion kernel differs by 10 % between boxes (profiles/r5/k2b_box_spread.txt: not the clocks)"""
+    import glob
+    cards = [c for c in glob.glob("/sys/class/drm/card*/device") if os.path.exists(c + "/mem_info_vram_used")]
+    if not cards:
+        return {}
+    try:
+        card = max(cards, key=lambda c: int(open(c + "/mem_info_vram_used").read() or 0))
+        out = {}
+        for name in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk"):
+            try:
+                cur = [l for l in open(card + "/" + name).read().splitlines() if l.endswith("*")]
+                out[name[7:]] = cur[0].split(":")[1].strip(" *") if cur else None
+            except OSError:
+                pass
+        for hw in glob.glob(card + "/hwmon/hwmon*"):
+            for f, key, scale in (("power1_average", "power_W", 1e-6), ("power1_cap", "power_cap_W", 1e-6), ("temp1_input", "temp_edge_C", 1e-3),
+                                  ("temp2_input", "temp_junction_C", 1e-3), ("temp3_input", "temp_mem_C", 1e-3)):
+                try:
+                    out[key] = round(int(open(os.path.join(hw, f)).read()) * scale, 1)
+                except (OSError, ValueError):
+                    pass
+        return out
+    except (OSError, ValueError):
+        return {}
 
 
 def host_description():
