@@ -88,7 +88,10 @@ inline void build_dict_table(Dict& d) {
     // The table is rebuilt from the records whenever an index is opened: the sort of the records by (home bucket, key) is
     // most of the time of opening one, so it runs on several threads — the records are dealt into ranges of home buckets
     // (the hash spreads them evenly), every range is sorted on its own, and the ranges follow each other in the order.
-    const unsigned T = (unsigned)std::min<uint64_t>(std::max(1u, std::min(32u, std::thread::hardware_concurrency())), nrec / 65536 + 1);
+#ifndef FG_DICT_THREADS
+#define FG_DICT_THREADS 32u
+#endif
+    const unsigned T = (unsigned)std::min<uint64_t>(std::max(1u, std::min(FG_DICT_THREADS, std::thread::hardware_concurrency())), nrec / 65536 + 1);
     auto parallel = [&](uint64_t n, auto fn) {  // fn(thread, begin, end) over [0, n) in T contiguous pieces
         if (T == 1) { fn(0u, (uint64_t)0, n); return; }
         std::vector<std::thread> th;
