@@ -1701,6 +1701,28 @@ def test_stream_loop_on_empty_wrapped_and_broken_files(s10_gpu, s10_oracle, tmp_
         del os.environ["FULGOR_READER_RANGE_KB"]
 
 
+def test_stream_loop_reports_an_output_that_cannot_be_written(s10_gpu, tmp_path):
+    """the records cannot be written (a descriptor opened for reading; /dev/full): the call fails with the system's message instead of
+    hanging or dropping records silently (tools/pseudoalign.cpp lets the stream's failure surface the same way), the workers and the
+    reader's threads wind down, and the next run on the same index is complete"""
+    from fulgor_amd.reads import FastxReader
+    fq = tmp_path / "w.fq"
+    fq.write_bytes(b"".join(b"@r%d\n%s\n+\n%s\n" % (i, b"ACGT" * 40, b"I" * 160) for i in range(30000)))
+    for target, flags in ((str(fq), os.O_RDONLY), ("/dev/full", os.O_WRONLY)):
+        if not os.path.exists(target):
+            continue
+        rd = FastxReader(str(fq), copy=False, threads=3)
+        fd = os.open(target, flags)
+        try:
+            with pytest.raises(RuntimeError, match="cannot write the output"):
+                s10_gpu.pseudoalign_stream(rd, fd, fulgor_amd.FULL_INTERSECTION, 0.0, 0, 0, True, 1000, 4)
+        finally:
+            os.close(fd)
+            rd.close()
+    out, n, _ = _stream(s10_gpu, str(fq), 0, batch=1000, workers=4)
+    assert n == 30000 and out.count(b"\n") == 30000
+
+
 def test_no_kernel_leaves_its_buffers_under_the_guard_allocator(built):
     """FULGOR_GUARD_ALLOC=1: every device buffer is exactly as long as asked for and is followed by unmapped addresses, so a kernel
     that reads or writes past a buffer faults at once (the lookup kernel's empty-ticket read of round 5 needed a buffer that ended a
