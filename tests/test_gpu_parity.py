@@ -1723,6 +1723,37 @@ def test_stream_loop_reports_an_output_that_cannot_be_written(s10_gpu, tmp_path)
     assert n == 30000 and out.count(b"\n") == 30000
 
 
+def test_two_streamed_runs_at_once_on_one_index(s10_gpu, tmp_path):
+    """two callers stream two different files through the same index at the same time (a server that answers two requests): each gets
+    its own workers from the index's cache, the pinned slabs and the copy engines are shared; both outputs equal what the runs give
+    one after the other, several times over"""
+    import threading
+    from oracle.kmer_oracle import read_fasta
+    src = max(read_fasta(S10_GENOMES[1]), key=len)
+    files = []
+    for k_, n in ((0, 40000), (1, 25000)):
+        p = tmp_path / ("c%d.fq" % k_)
+        with open(p, "wb") as f:
+            for i in range(n):
+                st = (i * 7919 + k_ * 1000003) % (len(src) - 200)
+                r = src[st:st + 100 + (i % 60)]
+                f.write(b"@x%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)))
+        files.append((str(p), n))
+    alone = [_stream(s10_gpu, path, 0, batch=3000, workers=3) for path, _ in files]
+    for rep in range(4):
+        got = [None, None]
+
+        def run(k_):
+            got[k_] = _stream(s10_gpu, files[k_][0], 0, batch=3000 - 500 * rep, workers=2 + rep % 3)
+        ts = [threading.Thread(target=run, args=(k_,)) for k_ in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for k_ in range(2):
+            assert got[k_] is not None and got[k_][1] == files[k_][1] and got[k_][0] == alone[k_][0], (rep, k_)
+
+
 def test_no_kernel_leaves_its_buffers_under_the_guard_allocator(built):
     """FULGOR_GUARD_ALLOC=1: every device buffer is exactly as long as asked for and is followed by unmapped addresses, so a kernel
     that reads or writes past a buffer faults at once (the lookup kernel's empty-ticket read of round 5 needed a buffer that ended a
