@@ -1254,7 +1254,13 @@ __device__ FG_MUX_INLINE uint32_t mux_union_read(const uint32_t* __restrict__ ro
 template <int BITS, bool BIASED = true, bool SCORES = false>
 // (7 waves per SIMD for the 8-bit counters: 72 VGPRs and 94 SGPRs leave 4 scalars spilled and no scratch, and it is the fastest of 6 / 7 / 8:
 // 7.08 / 6.43 / 6.58 ms, profiles/r5/k3r_variants_r5.txt)
-__global__ __launch_bounds__(256, BITS == 8 ? 7 : (BITS == 16 ? 6 : 4)) void k3r_union(const uint32_t* __restrict__ rows, uint32_t W, uint32_t n,
+#ifndef FG_K3R_WAVES16  // (variant builds: waves per SIMD of the 16- and 32-bit counter instantiations)
+#define FG_K3R_WAVES16 6
+#endif
+#ifndef FG_K3R_WAVES32
+#define FG_K3R_WAVES32 4
+#endif
+__global__ __launch_bounds__(256, BITS == 8 ? 7 : (BITS == 16 ? FG_K3R_WAVES16 : FG_K3R_WAVES32)) void k3r_union(const uint32_t* __restrict__ rows, uint32_t W, uint32_t n,
                                                                   const uint32_t* __restrict__ npos, const uint32_t* __restrict__ nids,
                                                                   const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
                                                                   const uint32_t* __restrict__ cnt_pool, double tau, uint64_t n_reads,
