@@ -1606,23 +1606,37 @@ def test_batches_that_hold_only_empty_reads(s10_gpu, tmp_path):
             assert (n, mapped) == (40, 0) and out == Formatter("ascii", nc).add(0, np.zeros(41, dtype=np.uint64), np.zeros(0, dtype=np.uint32))
 
 
-@pytest.mark.parametrize("which", ["s10", "s4546small"])
-def test_stream_loop_fuzz_against_the_batch_calls(which, s10_gpu, s4546small, tmp_path, monkeypatch):
+@pytest.mark.parametrize("which", ["s10", "s4546small", "s4546small-blocks", "s4546small-metadiff-codec", "s10-diff-codec"])
+def test_stream_loop_fuzz_against_the_batch_calls(which, s10_gpu, s10_fgidx, s10_oracle, s4546small, tmp_path, monkeypatch):
     """seeded fuzz of the worker loop: FASTA (single- or multi-line) and four-line FASTQ files of reads of every awkward length (0, k - 1, k,
     129 .. 600 k-mers, one of 20000 bases, runs of empty records, N bases), ranges of 4 .. 256 KB, FASTQ pieces of 1 .. 64 KB, batches of 1 .. 5000
     reads on 1 .. 7 workers, both algorithms, ascii and binary records: byte-identical to the formatter over the host-buffer calls
-    (which the tests above hold against the oracle); compressed records parse back to the same lists"""
+    (which the tests above hold against the oracle, and every fourth file here again: the codec of an index changes nothing about
+    its answers, so the hybrid oracle serves the converted indexes too); compressed records parse back to the same lists"""
     from oracle.kmer_oracle import read_fasta
     from oracle.pyoracle import parse_compressed
     from fulgor_amd.driver import Formatter
     # (the 4546-colour index: results of hundreds of colours, every record kind of the compressed format, rows of 144 words)
-    ix = s10_gpu if which == "s10" else s4546small[0]
+    # (-blocks: the hybrid lists on their own packed-block kernels; -codec: a converted index on the codec's kernels, no dense rows)
+    own = None
+    if which == "s10":
+        ix = s10_gpu
+    elif which == "s10-diff-codec":
+        ix = own = fulgor_amd.Index(s10_fgidx, device=0).convert(fulgor_amd.DIFF, 10, 4)
+    elif which == "s4546small-metadiff-codec":
+        ix = own = fulgor_amd.Index(s4546small[3], device=0).convert(fulgor_amd.META_DIFF, 160, 16)
+    elif which == "s4546small-blocks":
+        ix = own = fulgor_amd.Index(s4546small[3], device=0)
+    else:
+        ix = s4546small[0]
+    if own is not None:
+        own.tune(dense_rows=False)
     s10_gpu = ix
-    src = max(read_fasta(S10_GENOMES[3 if which == "s10" else 0]), key=len)
+    src = max(read_fasta(S10_GENOMES[3 if which.startswith("s10") else 0]), key=len)
     rng = np.random.default_rng(20250930)
     nc = s10_gpu.num_colors()
     special = [0, 0, 0, 30, 31, 32, 150, 158, 159, 160, 286, 287, 542, 543, 630, 20000]
-    for trial in range(160 if which == "s10" else 120):
+    for trial in range(160 if which == "s10" else (120 if which == "s4546small" else 40)):
         n = int(rng.integers(1, 2500))
         lens = [int(x) for x in rng.integers(0, int(rng.choice([40, 200, 400, 700])), size=n)]
         for _ in range(int(rng.integers(0, 12))):
@@ -1654,6 +1668,10 @@ def test_stream_loop_fuzz_against_the_batch_calls(which, s10_gpu, s4546small, tm
             eo, ec = s10_gpu.pseudoalign_threshold_union_batch(b, o, tau)
         else:
             eo, ec = s10_gpu.pseudoalign_full_intersection_batch(b, o)
+        if trial % 4 == 0:
+            orc = s10_oracle if which.startswith("s10") else s4546small[1]
+            oo, oc = orc.threshold_union(b, o, tau) if algo == fulgor_amd.THRESHOLD_UNION else orc.full_intersection(b, o)
+            assert np.array_equal(eo, oo) and np.array_equal(ec, oc), (which, trial)
         first_id = int(rng.integers(0, 1000))
         for rep in range(3):
             batch, workers, fmt = int(rng.choice([1, 7, 64, 333, 5000])), int(rng.integers(1, 8)), rep
