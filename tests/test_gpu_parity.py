@@ -1719,6 +1719,46 @@ def test_stream_loop_on_empty_wrapped_and_broken_files(s10_gpu, s10_oracle, tmp_
         del os.environ["FULGOR_READER_RANGE_KB"]
 
 
+@pytest.mark.parametrize("which", ["s10", "s4546small"])
+def test_kmer_tools_fuzz_against_the_oracle(which, s10_gpu, s10_oracle, s4546small):
+    """kmer-conservation and kmer-matches (src/kmer_conservation.cpp:7-54, src/kmer_matches.cpp:7-30) on batches of awkward reads — empty, shorter
+    than k, exactly k, 129 / 257 / 513 k-mers, N bases, lower case, one of 9000 bases, runs of empty reads — against the oracle read by read:
+    per-k-mer colour-set ids as conservation triples, positive-k-mer flags, per-colour match counts"""
+    from oracle.kmer_oracle import read_fasta
+    from fulgor_amd.index import conservation_triples
+    ix, orc = (s10_gpu, s10_oracle) if which == "s10" else (s4546small[0], s4546small[1])
+    src = max(read_fasta(S10_GENOMES[2 if which == "s10" else 0]), key=len)
+    rng = np.random.default_rng(777)
+    special = [0, 0, 1, 30, 31, 32, 158, 159, 160, 286, 287, 288, 542, 543, 544, 9000]
+    for trial in range(60):
+        n = int(rng.integers(1, 400))
+        lens = [int(x) for x in rng.integers(0, int(rng.choice([50, 200, 600])), size=n)]
+        for _ in range(int(rng.integers(1, 10))):
+            lens[int(rng.integers(0, n))] = int(rng.choice(special))
+        if trial % 3 == 1:
+            lens[:70] = [0] * len(lens[:70])
+        reads = []
+        for i, l in enumerate(lens):
+            st = int(rng.integers(0, len(src) - 9001))
+            r = bytearray(src[st:st + l])
+            if l and i % 11 == 3:
+                r[int(rng.integers(0, l))] = ord("N")
+            if l and i % 7 == 2:
+                r = bytearray(bytes(r).lower())
+            reads.append(bytes(r))
+        b, o = pack_reads(reads)
+        ko, ki = ix.kmer_color_set_ids_batch(b, o)
+        mo, pos, counts = ix.kmer_matches_batch(b, o)
+        assert np.array_equal(ko, mo) and len(ko) == n + 1
+        for j, r in enumerate(reads):
+            a, e = int(ko[j]), int(ko[j + 1])
+            assert e - a == max(0, len(r) - 30), (trial, j)
+            assert conservation_triples(ki[a:e]) == orc.kmer_conservation(r), (which, trial, j, len(r))
+            if j % 5 == 0 or len(r) in special:
+                opos, ocnt = orc.kmer_matches(r)
+                assert np.array_equal(pos[a:e], opos) and np.array_equal(counts[j], ocnt), (which, trial, j, len(r))
+
+
 def test_stream_loop_reports_an_output_that_cannot_be_written(s10_gpu, tmp_path):
     """the records cannot be written (a descriptor opened for reading; /dev/full): the call fails with the system's message instead of
     hanging or dropping records silently (tools/pseudoalign.cpp lets the stream's failure surface the same way), the workers and the
