@@ -1660,6 +1660,16 @@ def test_stream_loop_fuzz_against_the_batch_calls(which, s10_gpu, s10_fgidx, s10
                 else:
                     w = int(rng.choice([60, 80, 100000]))
                     f.write(b">s%d t\n" % i + b"".join(r[j:j + w] + b"\n" for j in range(0, len(r), w)) + (b"\n" if not r else b""))
+        if trial % 5 == 2:  # the same text as an ordinary gzip file (inflated whole and parsed in ranges, or streamed: FULGOR_GZIP_STREAM)
+            import gzip
+            gz = str(path) + ".gz"
+            with open(path, "rb") as f, open(gz, "wb") as g_:
+                g_.write(gzip.compress(f.read(), 1))
+            path = gz
+            if trial % 10 == 2:
+                monkeypatch.setenv("FULGOR_GZIP_STREAM", "1")
+            else:
+                monkeypatch.delenv("FULGOR_GZIP_STREAM", raising=False)
         monkeypatch.setenv("FULGOR_READER_RANGE_KB", str(int(rng.choice([4, 16, 64, 256]))))
         monkeypatch.setenv("FULGOR_READER_PIECE_KB", str(int(rng.choice([1, 3, 64]))))
         b, o = pack_reads(reads)
