@@ -1683,6 +1683,17 @@ def test_stream_loop_fuzz_against_the_batch_calls(which, s10_gpu, s10_fgidx, s10
             oo, oc = orc.threshold_union(b, o, tau) if algo == fulgor_amd.THRESHOLD_UNION else orc.full_intersection(b, o)
             assert np.array_equal(eo, oo) and np.array_equal(ec, oc), (which, trial)
         first_id = int(rng.integers(0, 1000))
+        if trial % 7 == 3 and not str(path).endswith(".gz"):
+            # as the ranks of `--gpus N` do: byte ranges of the file cut anywhere, read ids continued from part to part
+            size = os.path.getsize(path)
+            cuts = sorted({0, size} | {int(x) for x in rng.integers(0, size + 1, size=int(rng.integers(1, 4)))})
+            joined, at = b"", 0
+            for a_, b_ in zip(cuts[:-1], cuts[1:]):
+                out, got, _ = _stream(s10_gpu, str(path), 0, algo, tau, first_id=first_id + at, batch=int(rng.choice([7, 333, 5000])),
+                                      workers=int(rng.integers(1, 6)), begin=a_, end=b_)
+                joined += out
+                at += got
+            assert at == n and joined == Formatter("ascii", nc).add(first_id, eo, ec), (which, trial, cuts)
         for rep in range(3):
             batch, workers, fmt = int(rng.choice([1, 7, 64, 333, 5000])), int(rng.integers(1, 8)), rep
             out, got, mapped = _stream(s10_gpu, str(path), fmt, algo, tau, first_id=first_id, batch=batch, workers=workers, threads=int(rng.integers(1, 5)))
