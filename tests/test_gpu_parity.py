@@ -1636,7 +1636,8 @@ def test_stream_loop_fuzz_against_the_batch_calls(which, s10_gpu, s10_fgidx, s10
     rng = np.random.default_rng(20250930)
     nc = s10_gpu.num_colors()
     special = [0, 0, 0, 30, 31, 32, 150, 158, 159, 160, 286, 287, 542, 543, 630, 20000]
-    for trial in range(160 if which == "s10" else (120 if which == "s4546small" else 40)):
+    scale = int(os.environ.get("FULGOR_TEST_FUZZ_SCALE", "1"))  # (a one-off soak: FULGOR_TEST_FUZZ_SCALE=10)
+    for trial in range(scale * (160 if which == "s10" else (120 if which == "s4546small" else 40))):
         n = int(rng.integers(1, 2500))
         lens = [int(x) for x in rng.integers(0, int(rng.choice([40, 200, 400, 700])), size=n)]
         for _ in range(int(rng.integers(0, 12))):
@@ -1751,7 +1752,7 @@ def test_kmer_tools_fuzz_against_the_oracle(which, s10_gpu, s10_oracle, s4546sma
     src = max(read_fasta(S10_GENOMES[2 if which == "s10" else 0]), key=len)
     rng = np.random.default_rng(777)
     special = [0, 0, 1, 30, 31, 32, 158, 159, 160, 286, 287, 288, 542, 543, 544, 9000]
-    for trial in range(60):
+    for trial in range(60 * int(os.environ.get("FULGOR_TEST_FUZZ_SCALE", "1"))):
         n = int(rng.integers(1, 400))
         lens = [int(x) for x in rng.integers(0, int(rng.choice([50, 200, 600])), size=n)]
         for _ in range(int(rng.integers(1, 10))):
