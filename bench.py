@@ -456,10 +456,93 @@ def main():
                 pcie_legs("_after_everything")
             out.update(legs)
             out["cpu_baseline"] = cpu_baseline(w.ix, w.bases, w.offs, algo, args.tau, w.itype, args.partition_size, args.cluster_size)
-        print(json.dumps(out), flush=True)
+        line = compact_line(out)
+        detail = write_detail(out)
+        if detail:
+            line["detail"] = detail
+        print(json.dumps(line, separators=(",", ":")), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def write_detail(out):
+    """everything that was measured, as one JSON file beside the line (the driver keeps 9 KB of stdout: the printed line is the
+    compact form, under 8 KB; this file has the per-kernel launch tables, workload descriptions, run lists and stage reports)"""
+    for d in (os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "data")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, "bench_detail.json")
+            with open(path, "w") as f:
+                json.dump(out, f, indent=1)
+            return os.path.relpath(path, ROOT)
+        except OSError:
+            continue
+    return None
+
+
+def _kernel_row(entry):
+    """{kernel: [average launch ms, fraction of the 8 TB/s roofline or null]} of a measured entry"""
+    rk = entry.get("roofline_kernels") or {}
+    return {k_: [round(v["avg_ms"], 3), (round(rk[k_]["frac"], 3) if k_ in rk else None)] for k_, v in (entry.get("kernels") or {}).items()}
+
+
+def compact_line(out):
+    """the printed line: every key the bench contract names, the per-kernel table of the headline, and the secondary configurations
+    and PCIe-inclusive legs as short records (workload descriptions once, in `workloads`); under 8 KB"""
+    line = {k_: out[k_] for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                   "vs_baseline", "dtype", "data") if k_ in out}
+    sm = sorted(out.get("step_ms") or [])
+    if sm:
+        line["step_ms_min_med_max"] = [sm[0], sm[len(sm) // 2], sm[-1]]
+    line["config"] = out["config"]
+    for k_ in ("rccl_ranks", "collective_backend", "reads_counted_all_ranks", "mapped_all_ranks", "ranks"):
+        if k_ in out:
+            line[k_] = out[k_]
+    r = dict(out["roofline"])
+    r["kernels"] = {k_: {"ms": v["avg_launch_ms"], "GB": round(v["algorithmic_bytes_per_launch"] / 1e9, 3), "frac": round(v["frac"], 4),
+                         "traffic_GB": (round(v["traffic"] / 1e9, 2) if v.get("traffic") else None)} for k_, v in r.get("kernels", {}).items()}
+    if "stage" in r:
+        r["stage"] = {"ms": r["stage"]["ms_per_step"], "GB": round(r["stage"]["bytes_per_step"] / 1e9, 2), "frac": round(r["stage"]["frac"], 4)}
+    line["roofline"] = r
+    line["kernels_ms"] = {k_: v["avg_ms"] for k_, v in out.get("kernels", {}).items()}
+    sec = out.get("secondary")
+    if sec:
+        workloads, cs = {}, {}
+
+        def short(e):
+            if not isinstance(e, dict) or e.get("value") is None:
+                return {"value": None, "error": (e or {}).get("error") if isinstance(e, dict) else None}
+            key = next((k_ for k_, d in workloads.items() if d == e["workload"]), None)
+            if key is None:
+                key = "w%d" % len(workloads)
+                workloads[key] = e["workload"]
+            return {"value": e["value"], "ms_per_step": e["ms_per_step"], "reads": e["reads"], "steps": e["steps"], "workload": key,
+                    "colours_per_read": e["avg_colours_per_read"], "kernels_ms_frac": _kernel_row(e), "stage_frac": round(e["stage"]["frac"], 4)}
+
+        for k_, e in sec.items():
+            if isinstance(e, dict) and "value" not in e and "error" not in e:  # (a group: hybrid_packed_blocks)
+                cs[k_] = {k2: short(e2) for k2, e2 in e.items()}
+            else:
+                cs[k_] = short(e)
+        # (descriptions that only repeat the headline's workload text are cut to what they add)
+        head = out["config"]["workload"]
+        for key, d in list(workloads.items()):
+            base = head.split(", full-intersection")[0].split(", threshold-union")[0]
+            workloads[key] = "= config.workload" + d[len(base):] if d.startswith(base) else d
+        line["secondary"] = cs
+        line["secondary_unit"] = "reads/s; kernels_ms_frac = {kernel: [average launch ms, fraction of 8 TB/s]}"
+        line["workloads"] = workloads
+    for k_, v in out.items():  # the PCIe-inclusive legs: numbers only (what each includes is in DESIGN.md section 6 and in the detail file)
+        if isinstance(v, dict) and k_ not in line and k_ not in ("secondary", "kernels", "cpu_baseline", "device_state") and ("value" in v or "wall_s" in v):
+            line[k_] = {a: b for a, b in v.items() if a not in ("includes", "last_run", "host", "unit", "timeline", "stderr_tail") and not isinstance(b, (dict,)) or a == "stages"}
+            if "host" in v:
+                line[k_]["host"] = {a: v["host"].get(a) for a in ("hardware_threads", "loadavg")}
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = {a: out["cpu_baseline"][a] for a in ("value", "unit", "cores", "kind", "sample", "per_thread") if a in out["cpu_baseline"]}
+    if "device_state" in out:
+        line["device_state"] = out["device_state"]
+    return line
 
 
 def secondary(w, args, local_rank):

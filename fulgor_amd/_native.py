@@ -86,6 +86,7 @@ def lib():
                                           u64p, u64p]
     L.fgpu_last_stream_report.argtypes = [C.POINTER(vp)]
     L.fgpu_result_algorithmic_bytes.argtypes = [vp, u64p, u64p, u64p]
+    L.fgpu_result_checksum.argtypes = [vp, u64p, u64p]
     L.fgpu_tune.argtypes = [vp, C.c_int, C.c_uint64]
     L.fgpu_timing_enable.argtypes = [vp, C.c_int]
     L.fgpu_timing_reset.argtypes = [vp]

@@ -8,9 +8,18 @@ import time
 
 import numpy as np
 
-from . import driver
-from .index import FULL_INTERSECTION, THRESHOLD_UNION, Index
-from .reads import FastxReader
+_T_IMPORT = time.time()
+
+from . import driver  # noqa: E402
+from .index import FULL_INTERSECTION, THRESHOLD_UNION, Index  # noqa: E402
+from .reads import FastxReader  # noqa: E402
+
+
+def _mark(what):
+    """FULGOR_CLI_TIMELINE=<epoch seconds at which the command was started>: the stages of one command on stderr"""
+    t0 = os.environ.get("FULGOR_CLI_TIMELINE")
+    if t0:
+        print("[cli] +%.3f s %s" % (time.time() - float(t0), what), file=sys.stderr, flush=True)
 
 
 def _launch_ranks(argv, gpus):

@@ -16,6 +16,7 @@
 #include <chrono>
 #include <mutex>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -46,8 +47,22 @@ public:
     bool d2h(void* dst, const void* src, size_t n, hsa_signal_t s) {
         return hsa_amd_memory_async_copy_on_engine(dst, cpu_, src, gpu_, n, 0, nullptr, s, (hsa_amd_sdma_engine_id_t)out_, false) == HSA_STATUS_SUCCESS;
     }
+    // returns when the armed copies have completed; throws when one of them failed (the runtime reports a failed asynchronous copy
+    // by making the completion signal negative: what the copy was to bring must not be taken for there)
     void wait(hsa_signal_t s) {
-        while (hsa_signal_wait_scacquire(s, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+        hsa_signal_value_t v;
+        while ((v = hsa_signal_wait_scacquire(s, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED)) >= 1) {}
+        if (v < 0) {
+            disable();  // (the HIP calls from now on)
+            throw std::runtime_error("a copy on a copy engine failed (completion signal " + std::to_string((long long)v) + ")");
+        }
+    }
+    // the same without the verdict: on a path that is failing already, so that no engine still reads or writes a buffer that is let go
+    void drain(hsa_signal_t s) noexcept {
+        if (!s.handle) return;
+        while (hsa_signal_wait_scacquire(s, HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED) >= 1) {
+            if (hsa_signal_load_relaxed(s) >= 1 && ++spins_ > 30) break;  // (a minute: give up rather than hang on a dead engine)
+        }
     }
     void disable() { ok_.store(false); }
     std::string report() const { return report_; }
@@ -55,6 +70,7 @@ public:
 private:
     std::once_flag once_;
     std::atomic<bool> ok_{false};
+    std::atomic<unsigned> spins_{0};
     int device_ = -1;
     hsa_agent_t gpu_{0}, cpu_{0};
     std::vector<uint32_t> in_;

@@ -935,7 +935,8 @@ int fgpu_reads_upload(fgpu_index* ix, const char* bases, const uint64_t* offs, u
             const uint64_t len0 = n ? offs[1] - offs[0] : 0;
             uint64_t differ = 0;
             for (uint64_t i = 0; i < n; ++i) differ |= (offs[i + 1] - offs[i]) ^ len0;
-            if (n && !differ && offs[0] == 0) {
+            // (equal steps DOWN are equal unsigned differences too: the offsets of a batch also add up)
+            if (n && !differ && offs[0] == 0 && len0 <= ~0ull / n && offs[n] == len0 * n) {
                 rd->uniform = true;
                 rd->uni_len = len0;
                 rd->uni_nk = len0 >= k ? len0 - k + 1 : 0;
@@ -1324,6 +1325,31 @@ int fgpu_result_accumulate_hits(fgpu_index* ix, const fgpu_result* r, void* devi
         }
         HIP_TRY(hipStreamSynchronize(r->stream));
         if (ix->timing) ix->collect_timing(const_cast<fgpu_result*>(r)->pending);
+    });
+}
+
+int fgpu_result_checksum(fgpu_result* r, uint64_t* from_lists, uint64_t* from_rows) {
+    if (!r || !from_lists || !from_rows) return fail(-EINVAL, "null argument");
+    fgpu_index* ix = r->ix;
+    return guarded([&] {
+        HIP_TRY(hipSetDevice(ix->device));
+        stage_expand(ix, r);
+        hipStream_t s = r->stream;
+        r->d_acct.ensure(64);
+        HIP_TRY(hipMemsetAsync(r->d_acct.p, 0, 48, s));
+        unsigned long long* out = r->d_acct.as<unsigned long long>();
+        if (r->n && r->total) {
+            const uint32_t grid = (uint32_t)ix->num_cus * 8;
+            hipLaunchKernelGGL(k_checksum_lists, dim3(grid), dim3(256), 0, s, r->d_colors.as<uint32_t>(), r->d_offsets.as<uint64_t>() + r->n, out);
+            hipLaunchKernelGGL(k_checksum_rows, dim3(grid), dim3(256), 0, s, r->d_bitmap.as<uint32_t>(), r->d_counts.as<uint32_t>(),
+                               r->d_offsets.as<uint64_t>(), r->n, ix->dc.w32,
+                               r->small_mode ? r->d_small.as<uint32_t>() : (const uint32_t*)nullptr, out + 3);
+            HIP_TRY(hipGetLastError());
+        }
+        uint64_t h[6];
+        HIP_TRY(hipMemcpyAsync(h, out, 48, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (int i = 0; i < 3; ++i) { from_lists[i] = h[i]; from_rows[i] = h[3 + i]; }
     });
 }
 

@@ -2354,4 +2354,66 @@ __global__ __launch_bounds__(256) void k_account(DevColors c, const uint32_t* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Verification aid (fgpu_result_checksum; the spirit of util::check_intersection / check_union, include/util.hpp:106-208): a
+// checksum of the u32 colour lists of a pass, taken twice by kernels that share nothing — from the lists themselves
+// (entry p of the CSR holds colour c: v = (c + 1) * (p + 1); out = {#entries, sum of v, xor of v * odd constant}) and from
+// what the colour stage left behind (result rows / small-result slots + sizes + CSR offsets: the rank of a set bit inside its
+// row gives its position in the read's list). Equal triples: k2b_expand wrote every colour of every read at its place.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void checksum_fold(uint64_t cnt, uint64_t sum, uint64_t x, unsigned long long* out) {
+    for (int o = 32; o; o >>= 1) { cnt += __shfl_xor(cnt, o); sum += __shfl_xor(sum, o); x ^= __shfl_xor(x, o); }
+    if (lane_id() == 0) {
+        if (cnt) atomicAdd(out, (unsigned long long)cnt);
+        if (sum) atomicAdd(out + 1, (unsigned long long)sum);
+        if (x) atomicXor(out + 2, (unsigned long long)x);
+    }
+}
+constexpr uint64_t CHECKSUM_MIX = 0x9E3779B97F4A7C15ull;
+__global__ __launch_bounds__(256) void k_checksum_lists(const uint32_t* __restrict__ colors, const uint64_t* __restrict__ last_offset, unsigned long long* __restrict__ out) {
+    const uint64_t total = *last_offset;  // the CSR's own end, not the host's count
+    uint64_t cnt = 0, sum = 0, x = 0;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t v = ((uint64_t)colors[p] + 1) * (p + 1);
+        ++cnt; sum += v; x ^= v * CHECKSUM_MIX;
+    }
+    checksum_fold(cnt, sum, x, out);
+}
+// one wave per read
+__global__ __launch_bounds__(256) void k_checksum_rows(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ counts,
+                                                       const uint64_t* __restrict__ offsets, uint64_t n_reads, uint32_t W,
+                                                       const uint32_t* __restrict__ small, unsigned long long* __restrict__ out) {
+    const uint32_t lane = lane_id();
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    uint64_t cnt = 0, sum = 0, x = 0;
+    for (uint64_t r = wave; r < n_reads; r += waves) {
+        const uint32_t size = counts[r];
+        const uint64_t p0 = offsets[r];
+        if (size == 0) continue;  // (an empty result may have left no row)
+        if (small && size <= SMALL_RESULT) {  // the colours themselves, ascending, in the read's slot
+            if (lane < size) {
+                const uint64_t v = ((uint64_t)small[r * SMALL_RESULT + lane] + 1) * (p0 + lane + 1);
+                ++cnt; sum += v; x ^= v * CHECKSUM_MIX;
+            }
+            continue;
+        }
+        uint32_t before = 0;  // set bits of the row in front of this round's words
+        for (uint32_t w0 = 0; w0 < W; w0 += 64) {
+            uint32_t word = w0 + lane < W ? bitmap[r * W + w0 + lane] : 0u;
+            const uint32_t pc = __popc(word);
+            uint32_t incl = pc;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if ((int)lane >= o) incl += y; }
+            uint32_t rank = before + incl - pc;
+            while (word) {
+                const uint32_t b = __ffs(word) - 1;
+                word &= word - 1;
+                const uint64_t v = ((uint64_t)((w0 + lane) * 32 + b) + 1) * (p0 + rank + 1);
+                ++rank; ++cnt; sum += v; x ^= v * CHECKSUM_MIX;
+            }
+            before += __shfl(incl, 63);
+        }
+    }
+    checksum_fold(cnt, sum, x, out);
+}
+
 }  // namespace fg

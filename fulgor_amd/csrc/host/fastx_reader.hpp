@@ -867,14 +867,21 @@ protected:
 
 public:
     bool count_records(unsigned threads, uint64_t& total) override {
-        std::atomic<uint64_t> next{0}, sum{0};
+        total = count_ranges(0, num_ranges_, threads);
+        return true;
+    }
+
+protected:
+    // records that start in ranges [r0, r1): the grammar walked by `threads` threads, nothing copied
+    uint64_t count_ranges(uint64_t r0, uint64_t r1, unsigned threads) {
+        std::atomic<uint64_t> next{r0}, sum{0};
         std::mutex em;
         std::string err;
         auto body = [&] {
             Window w;
             for (;;) {
                 const uint64_t r = next++;
-                if (r >= num_ranges_) return;
+                if (r >= r1) return;
                 try {
                     uint64_t lo, hi;
                     unsigned odd = 0;
@@ -889,16 +896,14 @@ public:
             }
         };
         std::vector<std::thread> th;
-        const unsigned nt = (unsigned)std::min<uint64_t>(std::max(1u, threads), std::max<uint64_t>(1, num_ranges_));
+        const unsigned nt = (unsigned)std::min<uint64_t>(std::max(1u, threads), std::max<uint64_t>(1, r1 - r0));
         for (unsigned t = 1; t < nt; ++t) th.emplace_back([this, &body, nt] { fastx_confine_thread(cpus_, nt); body(); });
         body();
         for (auto& t : th) t.join();
         if (!err.empty()) throw std::runtime_error(err);
-        total = sum.load();
-        return true;
+        return sum.load();
     }
 
-protected:
     void work() {
         fastx_confine_thread(cpus_, nthreads_);
         Window w;
@@ -908,9 +913,10 @@ protected:
             const uint64_t t_wait = fastx_now_ns();
             {
                 std::unique_lock<std::mutex> g(m_);
-                cv_space_.wait(g, [this] { return stop_ || next_in_ >= num_ranges_ || next_in_ < next_out_ + window_; });
+                cv_space_.wait(g, [this] { return stop_ || (!paused_ && (next_in_ >= num_ranges_ || next_in_ < next_out_ + window_)); });
                 if (stop_ || next_in_ >= num_ranges_) return;
                 r = next_in_++;
+                ++active_;
                 if (!pool_.empty()) { c = std::move(pool_.back()); pool_.pop_back(); }
             }
             const uint64_t t_parse = fastx_now_ns();
@@ -934,9 +940,27 @@ protected:
             {
                 std::lock_guard<std::mutex> g(m_);
                 done_[r] = std::move(c);
+                --active_;
             }
             cv_data_.notify_all();
         }
+    }
+    // the parser threads take no new range until resume_parsers(); returns when none of them is inside a range
+    void pause_parsers() {
+        std::unique_lock<std::mutex> g(m_);
+        paused_ = true;
+        cv_data_.wait(g, [this] { return active_ == 0; });
+    }
+    void resume_parsers() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            paused_ = false;
+        }
+        cv_space_.notify_all();
+    }
+    uint64_t handed_out() {
+        std::lock_guard<std::mutex> g(m_);
+        return next_out_;
     }
 
 protected:
@@ -956,7 +980,8 @@ private:
     std::map<uint64_t, FastxChunk> done_;  // parsed ranges waiting for their turn
     std::vector<FastxChunk> pool_;
     uint64_t next_in_ = 0, next_out_ = 0;
-    bool stop_ = false;
+    unsigned active_ = 0;  // parser threads inside a range
+    bool stop_ = false, paused_ = false;
     std::string error_;
 };
 
@@ -1096,12 +1121,38 @@ public:
                 madvise(b, size_ + 1, MADV_HUGEPAGE);  // (first touch by page: fewer faults for the inflating threads)
                 map_ = (const char*)b;
             }
+            start(threads, begin, end);  // (throws NotRangeable for wrapped FASTQ: the caller falls back to one stream)
         } catch (...) {
+            shutdown();
+            if (map_ && size_) munmap((void*)map_, size_ + 1);
+            map_ = nullptr;  // (the base destructor finds nothing to unmap)
+            size_ = 0;
             munmap((void*)cmap_, csize_);
             close(cfd_);
             throw;
         }
-        start(threads, begin, end);
+    }
+    // Counting inflates what it walks: the parser threads are held while it runs, the ranges are counted a strip at a time, and what
+    // lies behind a strip goes back to the system (members marked not inflated again), so that the count of a part keeps a few
+    // dozen megabytes resident, not the part (N ranks of a multi-GPU run each count their part before they stream it). Only before
+    // the first chunk has been handed out: behind the reader the text is gone.
+    bool count_records(unsigned threads, uint64_t& total) override {
+        if (handed_out() > 0) return false;
+        pause_parsers();
+        struct Resume { BgzfFastxSource* s; ~Resume() { s->resume_parsers(); } } resume{this};
+        const uint64_t strip = std::max<uint64_t>(4, 2ull * std::max(1u, threads));
+        uint64_t n = 0;
+        size_t released = 0;  // members in front of this one are not inflated (any more)
+        for (uint64_t r0 = 0; r0 < num_ranges_; r0 += strip) {
+            const uint64_t r1 = std::min(num_ranges_, r0 + strip);
+            n += count_ranges(r0, r1, threads);
+            // nobody reads now; the next strip looks back one byte from its start: keep the member that holds it
+            const uint64_t keep_from = r1 == num_ranges_ ? size_ : begin_ + r1 * range_ - 1;
+            release_members(released, keep_from);
+        }
+        release_members(released, size_);  // (what the parser threads had inflated ahead as well: they inflate again what they need)
+        total = n;
+        return true;
     }
     ~BgzfFastxSource() override {
         shutdown();  // (the workers use this object's hooks: they end before it does)
@@ -1183,6 +1234,20 @@ protected:
         const uint64_t page = 4096, lo = (begin_ + (r - 2) * range_ + page - 1) / page * page, hi = (begin_ + (r - 1) * range_) / page * page;
         if (hi > lo && hi <= size_) madvise((void*)(map_ + lo), hi - lo, MADV_DONTNEED);
     }
+    // members [from, first member that reaches byte `keep_from` of the text): marked not inflated, their pages given back (those
+    // that no kept member shares). Call only while no thread reads the text. `from` moves to the first member kept.
+    void release_members(size_t& from, uint64_t keep_from) {
+        size_t to = from;
+        while (to < members_.size() && members_[to].uoff + members_[to].isize <= keep_from) ++to;
+        if (to == from) return;
+        for (size_t i = from; i < to; ++i) state_[i].store(0);
+        const uint64_t page = 4096;
+        const uint64_t lo = (members_[from].uoff + page - 1) / page * page;
+        const uint64_t end = to < members_.size() ? members_[to].uoff : size_;
+        const uint64_t hi = to < members_.size() ? end / page * page : (end + page - 1) / page * page;
+        if (hi > lo) madvise((void*)(map_ + lo), hi - lo, MADV_DONTNEED);
+        from = to;
+    }
 
 private:
     struct Member { uint64_t data_at, data_len, crc_at, uoff; uint32_t isize; };
@@ -1238,7 +1303,16 @@ public:
         if (d) ld.release(d);
         munmap((void*)cm, csize);
         if (!good) { free(buf); return nullptr; }
-        return new InflatedFastxSource(buf, out, threads);
+        {   // FASTQ with wrapped lines cannot be cut into ranges: the caller streams the file with the full grammar, as the reference does
+            char kind = 0;
+            if (out && !fastx_head_rangeable(buf, (size_t)std::min<uint64_t>(out, 1u << 20), kind)) { free(buf); return nullptr; }
+        }
+        try {
+            return new InflatedFastxSource(buf, out, threads);
+        } catch (...) {  // (the constructor has let go of the buffer)
+            free(buf);
+            return nullptr;
+        }
     }
     ~InflatedFastxSource() override {
         shutdown();
@@ -1251,7 +1325,15 @@ private:
     InflatedFastxSource(char* buf, uint64_t n, unsigned threads) : MappedFastxSource(8u << 20), buf_(buf) {
         map_ = buf;
         size_ = n;
-        start(threads, 0, ~0ULL);
+        try {
+            start(threads, 0, ~0ULL);
+        } catch (...) {  // (the base destructor must not unmap a malloc'd buffer; try_open releases it)
+            shutdown();
+            map_ = nullptr;
+            size_ = 0;
+            buf_ = nullptr;
+            throw;
+        }
     }
     char* buf_;
 };

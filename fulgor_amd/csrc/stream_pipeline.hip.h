@@ -160,6 +160,16 @@ void stream_one_batch(StreamRun& run, StreamWorkerState& w, StreamBatch& b, Stre
                 staged = true;
                 HIP_TRY(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, sin));
             };
+            // (if anything below throws while copies are in flight, the chunks' pinned slabs must not go back to the pool under an
+            // engine that still reads them: the copies issued so far are waited for first)
+            struct DrainOnFailure {
+                CopyEngines& ce; fgpu_result* res; int64_t& armed; bool direct, done = false;
+                ~DrainOnFailure() {
+                    if (done) return;
+                    if (direct) { ce.disarm(res->sig_in, armed); ce.drain(res->sig_in); }
+                    (void)hipStreamSynchronize(res->stream_in);
+                }
+            } drain_on_failure{ce, res, armed, direct};
             {
                 Timed t(ix, res, direct ? -1 : FGPU_K_H2D, sin);
                 uint64_t at = 0, r = 0;
@@ -179,10 +189,12 @@ void stream_one_batch(StreamRun& run, StreamWorkerState& w, StreamBatch& b, Stre
             }
             if (direct) {
                 ce.disarm(res->sig_in, armed);  // (pieces that went the other way)
+                armed = 0;
                 ce.wait(res->sig_in);
                 if (ix->timing) ix->add_timing(FGPU_K_H2D, (now_ns() - t_h2d) / 1e6);
             }
             if (!direct || staged) HIP_TRY(hipStreamSynchronize(sin));
+            drain_on_failure.done = true;
         }
         lg.t_copied = now_ns() - run.t0;
         {   // offsets of a chunk count from the chunk's first base: add its position in the batch

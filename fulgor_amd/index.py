@@ -123,6 +123,13 @@ class Result:
         _native.check(self._L.fgpu_result_algorithmic_bytes(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"lists": a.value, "output": b.value, "lookup": c.value}
 
+    def checksum(self):
+        """(from the lists, from the rows): two independent device-side checksums of the u32 colour lists of the last pass —
+        {#entries, sum, xor} each; equal when the expansion kernel wrote every colour at its place (fgpu_result_checksum)"""
+        a, b = (C.c_uint64 * 3)(), (C.c_uint64 * 3)()
+        _native.check(self._L.fgpu_result_checksum(self._h, a, b))
+        return tuple(a), tuple(b)
+
     def close(self):
         if self._h:
             self._L.fgpu_result_free(self._h)

@@ -120,6 +120,12 @@ int fgpu_result_download(const fgpu_result* res, uint64_t* offsets /* n+1 */, ui
 /* adds this result's per-colour hit counts (#reads whose result contains colour c) followed by
  * {num_reads, num_mapped} into a DEVICE array of num_colors+2 uint64 (the vector RCCL all-reduces) */
 int fgpu_result_accumulate_hits(fgpu_index* idx, const fgpu_result* res, void* device_u64_hits);
+/* Verification aid in the spirit of util::check_intersection / check_union (include/util.hpp:106-208): a checksum of the u32 colour
+ * lists of the last pass (materialised first if they were not), taken twice on the device by kernels that share nothing —
+ * from_lists from the CSR itself (entry p holds colour c: v = (c + 1)(p + 1); {#entries, sum of v mod 2^64, xor of v * odd constant}),
+ * from_rows from what the colour stage left (result rows / small-result slots, sizes, CSR offsets). Equal triples: the expansion
+ * kernel wrote every colour of every read at its place. Three uint64 each. */
+int fgpu_result_checksum(fgpu_result* res, uint64_t* from_lists, uint64_t* from_rows);
 /* algorithmic bytes of the last run. Colour-intersection stage, per read:
  *   list side   = sum over its colour-set ids of ceil(list bits / 8) + 16 (two offsets) + 4 (the id)
  *   output side = 4 * |result| + 8 (CSR offset)

@@ -724,3 +724,84 @@ for path in sys.argv[1:]:
         outs.append(r.stdout)
     assert all(o == outs[0] for o in outs) and outs[0].count("\n") == 8
     assert " 60000 " in outs[0].splitlines()[0]
+
+
+def test_gzip_of_wrapped_fastq_and_counting_a_block_compressed_part(built, tmp_path):
+    """ADVICE r5. (1) An ordinary gzip of a FASTQ file with wrapped lines: with libdeflate the file is inflated whole, and the text
+    then cannot be cut into ranges — the reader must fall back to the one-stream reader (kseq's grammar, as the reference reads
+    it), not fail to open. (2) Counting the records of a block-compressed part (what every rank of a multi-GPU run does before it
+    streams) walks the inflated text a strip at a time and gives it back: the count keeps tens of megabytes resident, not the
+    part; the reader then delivers every record; and a count asked for after chunks were handed out is refused, not wrong."""
+    import gzip
+    from fulgor_amd.reads import FastxReader
+    rng = np.random.default_rng(5)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = [bytes(alpha[rng.integers(0, 4, size=250)]) for _ in range(2000)]
+    text = b"".join(b"@w%d\n" % i + b"".join(s[j:j + 60] + b"\n" for j in range(0, 250, 60)) + b"+\n" +
+                    b"".join((b"I" * 250)[j:j + 60] + b"\n" for j in range(0, 250, 60)) for i, s in enumerate(seqs))
+    pz = tmp_path / "wrapped.fq.gz"
+    pz.write_bytes(gzip.compress(text, 1))
+    got = []
+    rd = FastxReader(str(pz), copy=True, batch=700, threads=3)
+    for bases, offs in rd:
+        b = bytes(bases)
+        got += [b[int(offs[i]):int(offs[i + 1])] for i in range(len(offs) - 1)]
+    rd.close()
+    assert got == seqs
+    # (2) 1.2 M four-line records, 190 MB of text, block-compressed; in a subprocess so that the resident size is this reader's
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from fulgor_amd.reads import FastxReader
+def rss_mb():
+    return int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGESIZE") / 1e6
+path, n = sys.argv[1], int(sys.argv[2])
+rd = FastxReader(path, copy=False, batch=100000, threads=4)
+r0 = rss_mb()
+c = rd.count()
+r1 = rss_mb()
+assert c == n, (c, n)
+assert r1 - r0 < 90, "counting left %%d MB resident" %% (r1 - r0)
+total = first = 0
+for bases, offs in rd:
+    total += len(offs) - 1
+    if not first:
+        first = 1
+        try:
+            rd.count()
+            raise SystemExit("a count behind the reader was not refused")
+        except RuntimeError:
+            pass
+assert total == n, (total, n)
+rd.close()
+# a part of the text: counted, then read
+rd = FastxReader(path, copy=False, batch=100000, threads=4, begin=50_000_000, end=120_000_000)
+c = rd.count()
+assert c == sum(len(o) - 1 for _, o in rd)
+rd.close()
+print("ok", c)
+''' % ROOT
+    n = 1_200_000
+    rows = np.empty((n, 10 + 74 + 3 + 74 + 1), dtype=np.uint8)  # "@rrrrrrrr\n" + 74 bases + "\n+\n" + 74 quality characters + "\n"
+    rows[:, 0] = ord("@")
+    rows[:, 1:9] = ord("r")
+    rows[:, 9] = ord("\n")
+    rows[:, 10:84] = alpha[rng.integers(0, 4, size=(n, 74))]
+    rows[:, 84:87] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rows[:, 87:161] = ord("@")  # (quality lines that begin with '@')
+    rows[:, 161] = ord("\n")
+    data = rows.tobytes()
+    import zlib, struct
+    blocks = []
+    for at in range(0, len(data), 65280):  # (zlib level 1: the test is about the reader, not the compressor)
+        blk = data[at:at + 65280]
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        cd = co.compress(blk) + co.flush()
+        blocks.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cd) + 25) + cd +
+                      struct.pack("<II", zlib.crc32(blk) & 0xFFFFFFFF, len(blk)))
+    blocks.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x1b\x00\x03\x00\x00\x00\x00\x00\x00\x00\x00\x00")
+    pb = tmp_path / "big.fq.gz"
+    pb.write_bytes(b"".join(blocks))
+    r = subprocess.run([sys.executable, "-c", code, str(pb), str(n)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout + r.stderr)[-2000:]

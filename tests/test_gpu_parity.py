@@ -133,6 +133,11 @@ def test_gpu_edge_batches(s10_gpu):
         s10_gpu.pseudoalign_threshold_union_batch(b, o, 0.0)
     with pytest.raises(RuntimeError, match="threshold"):
         s10_gpu.pseudoalign_threshold_union_batch(b, o, 1.5)
+    # offsets that are not monotone are refused, also when they step DOWN by a constant (equal unsigned differences: ADVICE r5)
+    base = np.frombuffer(b"ACGT" * 100, dtype=np.uint8)
+    for bad in ([0, 200, 100, 300], [0, (1 << 64) - 150, (1 << 64) - 300, (1 << 64) - 450]):
+        with pytest.raises(RuntimeError, match="monotone"):
+            s10_gpu.pseudoalign_full_intersection_batch(base, np.array(bad, dtype=np.uint64))
 
 
 @pytest.mark.parametrize("windows", [2, 3, 4])
@@ -321,7 +326,13 @@ def test_colour_lists_are_materialised_only_on_demand(s4546small, colour_stage, 
         res2.expand()
         folded = torch.zeros(n + 2, dtype=torch.int64, device="cuda:0")
         res2.accumulate_hits(folded.data_ptr())
+        from_lists, from_rows = res2.checksum()
         ix.timing_enable(False)
+    # the two device-side checksums of the colour lists (what the config-size tests rely on) against numpy on the downloaded lists
+    v = (gc.astype(np.uint64) + np.uint64(1)) * (np.arange(len(gc), dtype=np.uint64) + np.uint64(1))
+    with np.errstate(over="ignore"):
+        want_sum = (len(gc), int(v.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(v * np.uint64(0x9E3779B97F4A7C15))) if len(gc) else 0)
+    assert tuple(int(x) for x in from_lists) == want_sum and tuple(int(x) for x in from_rows) == want_sum
     assert total == len(gc) and mapped == int((np.diff(go.astype(np.int64)) > 0).sum())
     ids, po, pc = parse_compressed(Formatter("compressed", n).header + rec)
     assert np.array_equal(ids, np.arange(11, 11 + nr, dtype=np.uint32)) and np.array_equal(po, go) and np.array_equal(pc, gc)
@@ -904,11 +915,19 @@ def test_s4546_config_size_10M_reads_properties(s4546):
     res = ix.new_result()
     nc = ix.num_colors()
 
-    def hit_vector(algo, tau, chunk):
+    def hit_vector(algo, tau, chunk, expand=False):
+        """expand: the u32 colour lists of every pass are built (k2b_expand, what bench.py times), the hit vector then comes from
+        the expansion kernel's histogram, and the lists are checked by two independent device-side checksums"""
         hits = torch.zeros(nc + 2, dtype=torch.int64, device="cuda:0")
         total = mapped = 0
         for first in range(0, N, chunk):
             ix.run(reads, res, algo, tau, first, min(chunk, N - first))
+            if expand:
+                res.expand()
+                from_lists, from_rows = res.checksum()
+                # #entries of the CSR (its last offset, read on the device) = #set bits of the rows = the pass's total; sum and xor of
+                # (colour + 1) * (position + 1) agree: every colour of every read is at its place
+                assert from_lists == from_rows and from_lists[0] == res.sizes()[1] and from_lists[1] != 0
             res.accumulate_hits(hits.data_ptr())
             _, t, m = res.sizes()
             total += t
@@ -923,6 +942,14 @@ def test_s4546_config_size_10M_reads_properties(s4546):
     tu_a = hit_vector(fulgor_amd.THRESHOLD_UNION, 0.8, 2_500_000)
     tu_b = hit_vector(fulgor_amd.THRESHOLD_UNION, 0.8, 3_333_333)
     assert np.array_equal(tu_a, tu_b)
+    # the same passes ending in the u32 colour lists (src/ps_full_intersection.cpp:376-400: the `colors` vector), as the bench times
+    # them: the expansion kernel at config size, its histogram against the row-counting one, its lists against the rows
+    ix.timing_enable(True)
+    ix.timing_reset()
+    assert np.array_equal(hit_vector(fulgor_amd.FULL_INTERSECTION, 0.0, 2_500_000, expand=True), fi_a)
+    assert np.array_equal(hit_vector(fulgor_amd.THRESHOLD_UNION, 0.8, 2_500_000, expand=True), tu_a)
+    assert ix.timing()["k2b_expand"][1] >= 8  # (eight launches of 2.5 M reads each)
+    ix.timing_enable(False)
     # a read mapped by the full intersection has >= 1 positive k-mer, so the union at 0.8 maps it too; per colour the
     # union can only add reads
     assert tu_a[nc + 1] >= fi_a[nc + 1] and (tu_a[:nc] >= fi_a[:nc]).all()
@@ -959,12 +986,16 @@ def test_s4546_config_metadiff_12M5_reads_per_gpu_properties(s4546):
     b, o = gen.generate(3 * N, N, 150, 42)  # the slice rank 3 of the 8-GPU job owns
     nc = iy.num_colors()
 
-    def hit_vector(index, chunk):
+    def hit_vector(index, chunk, expand=False):
         reads = index.upload_reads(b, o)
         res = index.new_result()
         hits = torch.zeros(nc + 2, dtype=torch.int64, device="cuda:0")
         for first in range(0, N, chunk):
             index.run(reads, res, fulgor_amd.FULL_INTERSECTION, 0.0, first, min(chunk, N - first))
+            if expand:  # the u32 colour lists of the pass, checked against the rows by two independent device-side checksums
+                res.expand()
+                from_lists, from_rows = res.checksum()
+                assert from_lists == from_rows and from_lists[0] == res.sizes()[1] and from_lists[1] != 0
             res.accumulate_hits(hits.data_ptr())
         res.close()
         reads.close()
@@ -973,6 +1004,11 @@ def test_s4546_config_metadiff_12M5_reads_per_gpu_properties(s4546):
     md_a = hit_vector(iy, 2_500_000)
     md_b = hit_vector(iy, 1_700_000)  # ragged last pass
     assert np.array_equal(md_a, md_b) and md_a[nc] == N
+    iy.timing_enable(True)
+    iy.timing_reset()
+    assert np.array_equal(hit_vector(iy, 2_500_000, expand=True), md_a)  # (the expansion kernel's histogram against the row-counting one)
+    assert iy.timing()["k2b_expand"][1] >= 5
+    iy.timing_enable(False)
     assert np.array_equal(md_a, hit_vector(ix, 2_500_000))  # codecs do not change results
     from oracle.pyoracle import OracleIndex
     orc = OracleIndex.from_export(ix.export()).convert(fulgor_amd.META_DIFF, 160, 16)
