@@ -72,6 +72,12 @@ def real_dump_workload(base, data):
         ix.save(fg + ".tmp")
         ix.close()
         os.replace(fg + ".tmp", fg)
+    if os.environ.get("FULGOR_S4546_DUMP_READS") == "synthetic":
+        # dry run of this hook on a dump of the synthetic index itself (profiles/dump_roundtrip.py): the reads of the synthetic workload,
+        # so that the line can be held against the synthetic line number for number
+        from fulgor_amd import synth
+        _, extra = synth.ensure_s4546(data, s10_genomes())
+        return fg, ReadGenerator(s10_genomes(), raw_sequences=extra), REAL_DUMP_PREFIX + "%s (a dump of the synthetic index; the synthetic workload's reads)" % os.path.basename(base)
     seqs = []
     with open(base + ".unitigs.fa", "rb") as f:
         for line in f:
@@ -382,6 +388,14 @@ def main():
         rank, world, local_rank, torch.cuda.get_device_name(local_rank), free_b / 1e9, total_b / 1e9, n_reads, args.read_len),
         file=sys.stderr, flush=True)
     w = Workload(args.workload, rank, local_rank, n_reads, args.read_len, args.index_type, args.partition_size, args.cluster_size, prepared)
+    # what a first run on a multi-GPU node shows per rank: the device it got, its free memory, the copy engines its library chose
+    report = w.ix.device_report()
+    print("[bench] rank %d/%d, %s ranks: %s" % (rank, world, ("RCCL" if backend == "nccl" else backend) if world > 1 else "no collective,", report), file=sys.stderr, flush=True)
+    rank_reports = [None] * world
+    if world > 1:
+        dist.all_gather_object(rank_reports, {"rank": rank, "device": local_rank, "report": report})
+    else:
+        rank_reports = [{"rank": 0, "device": local_rank, "report": report}]
     if args.order is not None or args.small is not None or args.rows is not None:
         w.ix.tune(order_min_reads=None if args.order is None else (16384 if args.order else -1),
                   small_results=None if args.small is None else bool(args.small),
@@ -441,6 +455,11 @@ def main():
                        "avg_colours_per_read": round(m["total_colors"] / n_reads, 2)},
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "collective_backend": backend,
+            "ranks": [{"rank": r["rank"], "device": r["device"],
+                       # "device 3 (AMD Instinct MI355X, 0000:..., 256 CUs), 270.1 of 288.0 GB free, ...; copy engines ...; reads go up on 0x2 0x4, records come down on 0x8"
+                       "free_GB": (float(r["report"].split("CUs), ")[1].split(" of ")[0]) if "CUs), " in r["report"] else None),
+                       "engines": (r["report"].split("; reads go up on ")[1] if "; reads go up on " in r["report"] else r["report"].split("; ")[-1])}
+                      for r in rank_reports if r],
             # the all-reduced vector's entry behind the colours counts the reads of every rank (checked in measure(): the line is not
             # printed otherwise)
             "reads_counted_all_ranks": m["reads_job"], "mapped_all_ranks": m["mapped_job"],
@@ -496,9 +515,12 @@ def compact_line(out):
     if sm:
         line["step_ms_min_med_max"] = [sm[0], sm[len(sm) // 2], sm[-1]]
     line["config"] = out["config"]
-    for k_ in ("rccl_ranks", "collective_backend", "reads_counted_all_ranks", "mapped_all_ranks", "ranks"):
+    for k_ in ("rccl_ranks", "collective_backend", "reads_counted_all_ranks", "mapped_all_ranks"):
         if k_ in out:
             line[k_] = out[k_]
+    if out.get("ranks"):  # (one entry per rank; ranks that chose the same engines share the text)
+        line["ranks"] = [[r["rank"], r["device"], r["free_GB"], r["engines"] if i == 0 or r["engines"] != out["ranks"][0]["engines"] else "="]
+                         for i, r in enumerate(out["ranks"])]
     r = dict(out["roofline"])
     r["kernels"] = {k_: {"ms": v["avg_launch_ms"], "GB": round(v["algorithmic_bytes_per_launch"] / 1e9, 3), "frac": round(v["frac"], 4),
                          "traffic_GB": (round(v["traffic"] / 1e9, 2) if v.get("traffic") else None)} for k_, v in r.get("kernels", {}).items()}

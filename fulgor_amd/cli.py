@@ -124,16 +124,33 @@ def pseudoalign(argv):
             torch.cuda.set_device(device)
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))  # RCCL on ROCm
             reduce_device = "cuda:%d" % device
-    t1 = time.time()
+    _mark("imports and arguments done (package import began at +%.3f s)" % (_T_IMPORT - float(os.environ.get("FULGOR_CLI_TIMELINE") or _T_IMPORT)))
+    clock = {}
+
+    def open_index():
+        """essentials::load(index, index_filename) (tools/pseudoalign.cpp:338-341); the query clock starts behind it, where the
+        reference starts its own (pseudoalign_orchestrator, tools/pseudoalign.cpp:59-60)"""
+        if a.verbose and rank == 0:
+            print("*** START: loading the index")
+        t_open = time.time()
+        ix = Index(a.index_filename, device=device)
+        clock["open_s"] = time.time() - t_open
+        if a.verbose and rank == 0:
+            print("*** DONE: loading the index (%d millisec)" % (clock["open_s"] * 1000))
+            print("performing queries from file '%s'..." % a.query_filename)
+        _mark("index open (%.3f s)" % clock["open_s"])
+        clock["t_query"] = time.time()
+        return ix
+
     try:
         if a.deduplicate:
-            index = Index(a.index_filename, device=device)
+            index = open_index()
             batches = FastxReader(a.query_filename, batch=1 << 19, copy=False, threads=a.num_threads)
             with open(a.output_filename, "wb") as out:
                 n, mapped = driver.pseudoalign_stream(index, batches, algo, 0.0, sink=out, fmt=a.format, deduplicate=True)
             batches.close()
         else:  # read id = 0-based file order (src/ps_utils.cpp:276,286); parsing overlaps with the GPU passes
-            n, mapped = driver.pseudoalign_sharded(lambda: Index(a.index_filename, device=device), a.query_filename,
+            n, mapped = driver.pseudoalign_sharded(open_index, a.query_filename,
                                                    a.output_filename, algo, a.threshold or 0.0, a.format, rank, world,
                                                    io_threads=a.num_threads, device_for_reduce=reduce_device)
     except (RuntimeError, ValueError) as e:
@@ -144,7 +161,18 @@ def pseudoalign(argv):
             import torch.distributed as dist
             if dist.is_initialized():
                 dist.destroy_process_group()
-    el = (time.time() - t1) * 1000.0
+    el = (time.time() - clock.get("t_query", time.time())) * 1000.0
+    _mark("query done (%.3f s)" % (el / 1000))
+    if os.environ.get("FULGOR_CLI_TIMELINE") and rank == 0 and not a.deduplicate:
+        try:
+            from . import _native
+            import ctypes as C
+            p = C.c_void_p()
+            if _native.lib().fgpu_last_stream_report(C.byref(p)) == 0:
+                print(C.string_at(p.value).decode(), file=sys.stderr)
+                _native.lib().fgpu_free(p)
+        except Exception:  # noqa: BLE001 — instrumentation only
+            pass
     if a.verbose and rank == 0:  # tools/pseudoalign.cpp:79-88
         print("processed %d reads" % n)
         print("elapsed = %d millisec / %d sec / %d min / %g musec/read" % (el, el / 1000, el / 60000, el * 1000 / max(1, n)))

@@ -9,6 +9,9 @@
 // (by worker), every copy out to a third (first in, first out: the batch that has to be written first is copied first); the lowest
 // fast engine is left to the HIP runtime's own small copies. If anything about this fails, the HIP calls are used.
 #pragma once
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 #include <algorithm>
@@ -77,6 +80,19 @@ private:
     uint32_t out_ = 0;
     std::string report_ = "copy engines: the HIP runtime's choice";
 
+    // the engines that carry host traffic at full rate: those within half of the best (they differ by a factor of four from the
+    // rest: 50 against 7-13 GB/s); three or four of them is what the hardware has, anything else is not trusted
+public:
+    static std::vector<uint32_t> classify(const std::vector<std::pair<uint32_t, double>>& rate) {
+        double top = 0;
+        for (auto& r : rate) top = std::max(top, r.second);
+        std::vector<uint32_t> fast;
+        for (auto& r : rate) if (r.second >= 0.5 * top) fast.push_back(r.first);
+        if (fast.size() < 3 || fast.size() > 4) fast.clear();
+        return fast;
+    }
+
+private:
     static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     static bool owner_of(const void* p, hsa_agent_t& a) {
         hsa_amd_pointer_info_t pi;
@@ -102,30 +118,46 @@ private:
         uint32_t mask = 0;
         if (hsa_amd_memory_copy_engine_status(cpu_, gpu_, &mask) != HSA_STATUS_SUCCESS || !mask) return;
         if (hsa_signal_create(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) { sig.handle = 0; return; }
-        std::vector<std::pair<uint32_t, double>> rate;  // engine, GB/s of a 4 MB copy out
+        // One process per GPU probes at the same moment when a multi-GPU run starts: the probes take turns under a host-wide lock
+        // (each is 64 copies of 4 MB, about 20 ms), so that a rank's engines are timed against an otherwise quiet host.
+        int lock_fd = ::open("/tmp/fulgor_amd_copy_engines.lock", O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+        if (lock_fd >= 0 && flock(lock_fd, LOCK_EX) != 0) { ::close(lock_fd); lock_fd = -1; }
+        struct Unlock { int fd; ~Unlock() { if (fd >= 0) { (void)flock(fd, LOCK_UN); ::close(fd); } } } unlock{lock_fd};
+        std::vector<std::pair<uint32_t, double>> rate;  // engine, GB/s of a 4 MB copy out (best of four)
         for (uint32_t eng = 1; eng && eng <= mask; eng <<= 1) {
             if (!(mask & eng)) continue;
             double best = 0;
-            for (int rep = 0; rep < 2; ++rep) {
+            for (int rep = 0; rep < 4; ++rep) {
                 hsa_signal_store_relaxed(sig, 1);
                 const double t0 = now_ms();
                 if (hsa_amd_memory_async_copy_on_engine(h, cpu_, d, gpu_, PROBE, 0, nullptr, sig, (hsa_amd_sdma_engine_id_t)eng, false) != HSA_STATUS_SUCCESS) { best = 0; break; }
-                wait(sig);
+                try { wait(sig); } catch (std::exception&) { best = 0; break; }
                 best = std::max(best, PROBE / (now_ms() - t0) / 1e6);
             }
             if (best > 0) rate.push_back({eng, best});
         }
-        double top = 0;
-        for (auto& r : rate) top = std::max(top, r.second);
-        std::vector<uint32_t> fast;
-        for (auto& r : rate) if (r.second >= 0.7 * top) fast.push_back(r.first);
+        ok_.store(false);  // (wait() may have switched it off; it is decided below)
         std::ostringstream os;
         os << "copy engines (GB/s of a 4 MB copy out):";
         for (auto& r : rate) os << " 0x" << std::hex << r.first << std::dec << ":" << (int)(r.second + 0.5);
+        const std::vector<uint32_t> fast = classify(rate);
         if (fast.size() >= 4) { in_ = {fast[1], fast[2]}; out_ = fast[3]; }
         else if (fast.size() == 3) { in_ = {fast[1]}; out_ = fast[2]; }
-        else if (fast.size() == 2) { in_ = {fast[0]}; out_ = fast[1]; }
-        else { report_ = os.str() + "; fewer than two fast ones: the HIP runtime's choice"; return; }
+        else {
+            // Ambiguous (a busy host, another process's traffic on the link): the engines that carry host traffic at full rate on every
+            // MI355X measured so far are 0x1, 0x2, 0x4, 0x8; 0x1 stays with the HIP runtime's own small copies
+            std::vector<uint32_t> dflt;
+            for (uint32_t e : {0x2u, 0x4u, 0x8u})
+                for (auto& r : rate) if (r.first == e) dflt.push_back(e);
+            if (dflt.size() == 3) {
+                in_ = {dflt[0], dflt[1]};
+                out_ = dflt[2];
+                os << "; classification ambiguous (" << fast.size() << " engines within half of the best): the default engines";
+            } else {
+                report_ = os.str() + "; classification ambiguous and the default engines are not there: the HIP runtime's choice";
+                return;
+            }
+        }
         os << "; reads go up on";
         for (uint32_t x : in_) os << " 0x" << std::hex << x << std::dec;
         os << ", records come down on 0x" << std::hex << out_ << std::dec;

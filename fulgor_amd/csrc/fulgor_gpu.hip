@@ -8,11 +8,13 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fulgor_gpu.h"
 #include "host/fastx_reader.hpp"
 #include "hip/kernels.hip.h"
+#include "hip/dict_build.hip.h"
 #include "host/formatters.hpp"
 #include "host/index_io.hpp"
 #include "copy_engines.hip.h"
@@ -130,6 +132,7 @@ struct fgpu_index {
     bool small_results = env_u64("FULGOR_SMALL", 1) != 0;
     bool dense_rows = env_u64("FULGOR_DENSE_ROWS", 1) != 0;  // use the dense rows (when they were built: d_rows)
     DevBuf d_table, d_bmp_rows, d_offsets, d_set_desc, d_blk_words, d_set_rank, d_rows;
+    uint64_t table_buckets = 0;  // buckets of d_table (hashed region, tail, overflow region)
     DevBuf d_gops, d_gset_ops_off, d_gset_ops, d_garena, d_gblk_hdr, d_gblk_words, d_gset_bytes;
     DevDict dd{};
     DevColors dc{};
@@ -275,68 +278,154 @@ Timed::Timed(fgpu_index* i, fgpu_result* r, int k, hipStream_t on_stream) : ix(i
 
 namespace {
 
+// rank of every colour set by the number of k-mers that carry it (rarest first): the sort key of k_order_keys. Only the optional
+// locality order of a pass reads it (off by default): computed when that is first asked for, not at every open.
+void ensure_set_rank(fgpu_index* ix) {
+    if (ix->d_set_rank.p) return;
+    const Dict& d = ix->host.dict;
+    const uint64_t ns = ix->host.hybrid.num_sets();
+    std::vector<uint64_t> weight(ns, 0);
+    for (uint64_t u = 0; u < d.num_unitigs(); ++u)
+        if (d.unitig_csid[u] < ns) weight[d.unitig_csid[u]] += d.unitig_off[u + 1] - d.unitig_off[u] - d.k + 1;
+    std::vector<uint32_t> by_weight(ns), rank(ns);
+    for (uint64_t i = 0; i < ns; ++i) by_weight[i] = (uint32_t)i;
+    std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t a, uint32_t b) { return weight[a] < weight[b]; });
+    for (uint64_t i = 0; i < ns; ++i) rank[by_weight[i]] = (uint32_t)i;
+    upload(ix->d_set_rank, rank, ix->stream);
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+}
+
+// The dictionary table in HBM, built there from the records (hip/dict_build.hip.h) by the rule the host builder follows
+// (common/dict_place.h): sort by minimizer, sort by home bucket (both stable: the order is (home, minimizer, record number)),
+// count the overflow buckets every hashed bucket needs, scan, and let every hashed bucket write itself and its overflow run.
+void build_table_on_device(fgpu_index* ix) {
+    const Dict& d = ix->host.dict;
+    hipStream_t s = ix->stream;
+    const uint64_t nrec = d.num_records();
+    const uint64_t nb_hashed = (uint64_t)d.num_buckets + DICT_TAIL_BUCKETS;
+    static_assert(DICT_TAIL_BUCKETS == DICT_TAIL_BUCKETS_, "one tail length");
+    DevBuf recs, keyA, keyB, idxA, idxB, homeA, homeB, posA, posB, bstart, nb_over, over_off, tmp;
+    struct Release { std::vector<DevBuf*> v; ~Release() { for (DevBuf* b : v) b->release(); } }
+        release{{&recs, &keyA, &keyB, &idxA, &idxB, &homeA, &homeB, &posA, &posB, &bstart, &nb_over, &over_off, &tmp}};
+    upload(recs, d.records, s);
+    for (DevBuf* b : {&keyA, &keyB}) b->ensure(std::max<uint64_t>(1, nrec) * 8);
+    for (DevBuf* b : {&idxA, &idxB, &homeA, &homeB, &posA, &posB}) b->ensure(std::max<uint64_t>(1, nrec) * 4);
+    for (DevBuf* b : {&bstart, &nb_over, &over_off}) b->ensure((nb_hashed + 1) * 4);
+    const uint32_t grid = (uint32_t)ix->num_cus * 8;
+    uint32_t total_over = 0;
+    if (nrec) {
+        hipLaunchKernelGGL(k_dict_keys, dim3(grid), dim3(256), 0, s, recs.as<uint32_t>(), nrec, d.k, d.m, keyA.as<unsigned long long>(), idxA.as<uint32_t>());
+        size_t need = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, keyA.as<unsigned long long>(), keyB.as<unsigned long long>(), idxA.as<uint32_t>(), idxB.as<uint32_t>(),
+                                          (size_t)nrec, 0u, 32u + d.m, s));
+        tmp.ensure(need + 256);
+        need = tmp.cap;
+        HIP_TRY(rocprim::radix_sort_pairs(tmp.p, need, keyA.as<unsigned long long>(), keyB.as<unsigned long long>(), idxA.as<uint32_t>(), idxB.as<uint32_t>(),
+                                          (size_t)nrec, 0u, 32u + d.m, s));
+        hipLaunchKernelGGL(k_dict_homes, dim3(grid), dim3(256), 0, s, keyB.as<unsigned long long>(), nrec, d.seed, d.num_buckets, homeA.as<uint32_t>(), posA.as<uint32_t>());
+        uint32_t home_bits = 1;
+        while (home_bits < 32 && (1ull << home_bits) < d.num_buckets) ++home_bits;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, homeA.as<uint32_t>(), homeB.as<uint32_t>(), posA.as<uint32_t>(), posB.as<uint32_t>(), (size_t)nrec, 0u, home_bits, s));
+        tmp.ensure(need + 256);
+        need = tmp.cap;
+        HIP_TRY(rocprim::radix_sort_pairs(tmp.p, need, homeA.as<uint32_t>(), homeB.as<uint32_t>(), posA.as<uint32_t>(), posB.as<uint32_t>(), (size_t)nrec, 0u, home_bits, s));
+    }
+    HIP_TRY(hipMemsetAsync(bstart.p, 0xFF, (nb_hashed + 1) * 4, s));
+    if (nrec)
+        hipLaunchKernelGGL(k_dict_gather, dim3(grid), dim3(256), 0, s, homeB.as<uint32_t>(), posB.as<uint32_t>(), keyB.as<unsigned long long>(), idxB.as<uint32_t>(), nrec,
+                           keyA.as<unsigned long long>(), idxA.as<uint32_t>(), bstart.as<uint32_t>());
+    hipLaunchKernelGGL(k_dict_count, dim3(grid), dim3(256), 0, s, homeB.as<uint32_t>(), keyA.as<unsigned long long>(), nrec, bstart.as<uint32_t>(), nb_hashed, nb_over.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    {
+        size_t need = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, need, nb_over.as<uint32_t>(), over_off.as<uint32_t>(), 0u, (size_t)nb_hashed, rocprim::plus<uint32_t>(), s));
+        tmp.ensure(need + 256);
+        need = tmp.cap;
+        HIP_TRY(rocprim::exclusive_scan(tmp.p, need, nb_over.as<uint32_t>(), over_off.as<uint32_t>(), 0u, (size_t)nb_hashed, rocprim::plus<uint32_t>(), s));
+        uint32_t last[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(&last[0], over_off.as<uint32_t>() + (nb_hashed - 1), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&last[1], nb_over.as<uint32_t>() + (nb_hashed - 1), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        total_over = last[0] + last[1];
+    }
+    if (nb_hashed + total_over >= DICT_MAX_BUCKETS) throw std::runtime_error("dictionary table exceeds 2^26 buckets");
+    ix->d_table.ensure((nb_hashed + total_over) * (uint64_t)BUCKET_WORDS * 4);
+    ix->table_buckets = nb_hashed + total_over;
+    hipLaunchKernelGGL(k_dict_fill, dim3(grid), dim3(256), 0, s, recs.as<uint32_t>(), homeB.as<uint32_t>(), keyA.as<unsigned long long>(), idxA.as<uint32_t>(), nrec,
+                       bstart.as<uint32_t>(), over_off.as<uint32_t>(), nb_hashed, ix->d_table.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+}
+
 void upload_index(fgpu_index* ix) {
     const Dict& d = ix->host.dict;
     const HybridSets& h = ix->host.hybrid;
     hipStream_t s = ix->stream;
-    upload(ix->d_table, d.table, s);  // the whole k-mer dictionary: one table of 64-byte buckets
+    LoadClock clk;
+    // the whole k-mer dictionary: one table of 64-byte buckets, built on the device from the records (or uploaded, when the host built it)
+    if (d.table.empty()) { build_table_on_device(ix); clk.lap("dictionary table (built on the device)"); }
+    else { upload(ix->d_table, d.table, s); ix->table_buckets = d.table.size() / BUCKET_WORDS; HIP_TRY(hipStreamSynchronize(s)); clk.lap("dictionary table (uploaded)"); }
     upload(ix->d_offsets, h.offsets, s);
     const uint32_t w32 = ((h.num_colors + 31) / 32 + 3) & ~3u;  // result bitmaps move as 128-bit groups
     {  // one resolved descriptor per colour set: everything a kernel needs about a list behind one gather
-        std::vector<ListDesc> sd(h.num_sets());
-        // the bitmap lists leave the bit stream (arbitrary bit offsets) for aligned rows of w32 words
-        std::vector<uint32_t> rows;
-        {
+        // (on all threads: 0.85 M descriptors and 155 MB of bitmap rows cut out of the bit stream took a tenth of a second on one)
+        const uint64_t ns = h.num_sets();
+        std::vector<ListDesc> sd(ns);
+        const unsigned T = (unsigned)std::min<uint64_t>(std::max(1u, std::min(32u, std::thread::hardware_concurrency())), ns / 4096 + 1);
+        auto parallel = [&](auto fn) {  // fn(thread, first id, last id + 1)
+            if (T == 1) { fn(0u, (uint64_t)0, ns); return; }
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < T; ++t) th.emplace_back([&, t] { fn(t, ns * t / T, ns * (t + 1) / T); });
+            for (auto& x : th) x.join();
+        };
+        const auto is_bitmap = [&](uint64_t id) { return h.set_size[id] >= h.sparse_thr && h.set_size[id] < h.dense_thr; };
+        // the bitmap lists leave the bit stream (arbitrary bit offsets) for aligned rows of w32 words, in id order
+        std::vector<uint64_t> first_row(T + 1, 0);
+        parallel([&](unsigned t, uint64_t a, uint64_t b) {
             uint64_t nb = 0;
-            for (uint64_t id = 0; id < sd.size(); ++id) nb += h.set_size[id] >= h.sparse_thr && h.set_size[id] < h.dense_thr;
-            rows.assign(nb * w32 + 4, 0u);
-        }
-        uint64_t next_row = 0;
+            for (uint64_t id = a; id < b; ++id) nb += is_bitmap(id);
+            first_row[t + 1] = nb;
+        });
+        for (unsigned t = 0; t < T; ++t) first_row[t + 1] += first_row[t];
+        std::vector<uint32_t> rows(first_row[T] * w32 + 4, 0u);
         const auto stream_bits = [&](uint64_t pos, uint32_t len) -> uint32_t {  // len <= 32 bits at bit `pos` of the stream
             const uint64_t w = pos >> 6, sh = pos & 63;
             uint64_t v = h.bits[w] >> sh;
             if (sh + len > 64) v |= h.bits[w + 1] << (64 - sh);
             return len == 32 ? (uint32_t)v : (uint32_t)v & ((1u << len) - 1u);
         };
-        for (uint64_t id = 0; id < sd.size(); ++id) {
-            const uint32_t size = h.set_size[id];
-            ListDesc& d = sd[id];
-            d.score = 0;
-            d.id = (uint32_t)id;
-            if (size >= h.sparse_thr && size < h.dense_thr) {  // bitmap list: its row
-                const uint64_t body = h.offsets[id] + delta_code_bits(size);
-                uint32_t* row = rows.data() + next_row * w32;
-                for (uint32_t c0 = 0; c0 < h.num_colors; c0 += 32) row[c0 >> 5] = stream_bits(body + c0, std::min(32u, h.num_colors - c0));
-                d.begin = next_row++ * w32;
-                d.soff = 0;
-                d.ncodes = 0;
-                d.meta = (uint32_t)D_ENC_BITMAP;
-            } else {  // gap-coded on the host, packed blocks here
-                d.begin = h.blk_wbase[id];
-                d.ncodes = (uint32_t)(h.blk_first[id + 1] - h.blk_first[id]);
-                d.soff = d.ncodes == 1 ? h.blk_hdr[h.blk_first[id]] : h.blk_first[id];  // single block: the header itself
-                d.meta = (uint32_t)(size < h.sparse_thr ? D_ENC_DELTA_GAPS : D_ENC_COMPLEMENT);
+        parallel([&](unsigned t, uint64_t a, uint64_t b) {
+            uint64_t next_row = first_row[t];
+            for (uint64_t id = a; id < b; ++id) {
+                const uint32_t size = h.set_size[id];
+                ListDesc& d = sd[id];
+                d.score = 0;
+                d.id = (uint32_t)id;
+                if (is_bitmap(id)) {  // bitmap list: its row
+                    const uint64_t body = h.offsets[id] + delta_code_bits(size);
+                    uint32_t* row = rows.data() + next_row * w32;
+                    for (uint32_t c0 = 0; c0 < h.num_colors; c0 += 32) row[c0 >> 5] = stream_bits(body + c0, std::min(32u, h.num_colors - c0));
+                    d.begin = next_row++ * w32;
+                    d.soff = 0;
+                    d.ncodes = 0;
+                    d.meta = (uint32_t)D_ENC_BITMAP;
+                } else {  // gap-coded on the host, packed blocks here
+                    d.begin = h.blk_wbase[id];
+                    d.ncodes = (uint32_t)(h.blk_first[id + 1] - h.blk_first[id]);
+                    d.soff = d.ncodes == 1 ? h.blk_hdr[h.blk_first[id]] : h.blk_first[id];  // single block: the header itself
+                    d.meta = (uint32_t)(size < h.sparse_thr ? D_ENC_DELTA_GAPS : D_ENC_COMPLEMENT);
+                }
             }
-        }
+        });
+        clk.lap("descriptors and bitmap rows (host)");
         upload(ix->d_set_desc, sd, s);
         upload(ix->d_bmp_rows, rows, s);
         HIP_TRY(hipStreamSynchronize(s));  // sd and rows are released at the end of this block
     }
     if (h.blk_words.size() >= (1ull << 32)) throw std::runtime_error("colour sets too large: the packed blocks exceed 2^32 words");  // BlockLane::word
     upload(ix->d_blk_words, h.blk_words, s);
-    {  // rank of every colour set by the number of k-mers that carry it (rarest first): the sort key of k_order_keys
-        const uint64_t ns = h.num_sets();
-        std::vector<uint64_t> weight(ns, 0);
-        for (uint64_t u = 0; u < d.num_unitigs(); ++u)
-            if (d.unitig_csid[u] < ns) weight[d.unitig_csid[u]] += d.unitig_off[u + 1] - d.unitig_off[u] - d.k + 1;
-        std::vector<uint32_t> by_weight(ns), rank(ns);
-        for (uint64_t i = 0; i < ns; ++i) by_weight[i] = (uint32_t)i;
-        std::stable_sort(by_weight.begin(), by_weight.end(), [&](uint32_t a, uint32_t b) { return weight[a] < weight[b]; });
-        for (uint64_t i = 0; i < ns; ++i) rank[by_weight[i]] = (uint32_t)i;
-        upload(ix->d_set_rank, rank, s);
-        HIP_TRY(hipStreamSynchronize(s));
-    }
     HIP_TRY(hipStreamSynchronize(s));
+    clk.lap("upload of descriptors, bitmap rows, packed blocks");
     ix->dd = DevDict{ix->d_table.as<uint32_t>(), d.num_buckets, d.k, d.m, d.seed};
     ix->dc = DevColors{ix->d_bmp_rows.as<uint32_t>(), ix->d_offsets.as<uint64_t>(), ix->d_set_desc.as<ListDesc>(),
                        ix->d_blk_words.as<uint32_t>(), h.num_colors, h.sparse_thr, h.dense_thr, w32};
@@ -356,6 +445,7 @@ void upload_index(fgpu_index* ix) {
             hipLaunchKernelGGL(k_rows_build, dim3(grid), dim3(256), lds, s, ix->dc, (uint64_t)h.num_sets(), ix->d_rows.as<uint32_t>());
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(s));
+            clk.lap("dense rows (built on the device)");
         }
     }
 }
@@ -556,6 +646,10 @@ const uint32_t* stage_order(fgpu_index* ix, fgpu_result* res) {
     if (n < ix->order_min_reads || n >= (1ull << 32)) return nullptr;
     hipStream_t s = res->stream;
     const uint64_t ns = ix->host.hybrid.num_sets();
+    {
+        std::lock_guard<std::mutex> g(ix->reads_mu);
+        ensure_set_rank(ix);
+    }
     res->d_order_keys.ensure(n * 4 + 16);
     res->d_order.ensure(n * 4 + 16);
     res->d_order_off.ensure((ns + 2) * 8 + 64);
@@ -792,40 +886,58 @@ int fgpu_open(const char* path, int device, fgpu_index** out) {
     *out = nullptr;
     fgpu_index* ix = nullptr;
     int rc = guarded([&] {
-        int ndev = 0;
-        if (device != FGPU_HOST_ONLY) {
-            if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-                throw std::runtime_error("no HIP device available: the pseudoalignment engine has no CPU execution path");
-            if (device < 0 || device >= ndev) throw std::runtime_error("invalid device ordinal");
-        }
+        if (device != FGPU_HOST_ONLY && device < 0) throw std::runtime_error("invalid device ordinal");
         ix = new fgpu_index();
-        open_index(path, ix->host);
         ix->device = device;
+        // The device side of opening (runtime start-up: a third of a second in a fresh process; stream, pinned-memory path, the timing
+        // of the copy engines) runs on its own thread WHILE this one reads the container and prepares the host forms.
+        std::string dev_error;
+        std::thread dev_init;
+        LoadClock clk_dev;
+        if (device != FGPU_HOST_ONLY)
+            dev_init = std::thread([&] {
+                try {
+                    int ndev = 0;  // (the first call into the runtime: this is where a fresh process spends its start-up time)
+                    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+                        throw std::runtime_error("no HIP device available: the pseudoalignment engine has no CPU execution path");
+                    if (device >= ndev) throw std::runtime_error("invalid device ordinal");
+                    HIP_TRY(hipSetDevice(device));
+                    hipDeviceProp_t prop;
+                    HIP_TRY(hipGetDeviceProperties(&prop, device));
+                    ix->num_cus = prop.multiProcessorCount;
+                    {   // the NUMA node of the device: the query reader keeps its threads on that node's cores (pinned host memory lives there)
+                        char bus[64] = {0};
+                        if (hipDeviceGetPCIBusId(bus, sizeof bus, device) == hipSuccess) {
+                            std::string b(bus);
+                            for (auto& ch : b) ch = (char)tolower((unsigned char)ch);
+                            const std::string t = read_small_file("/sys/bus/pci/devices/" + b + "/numa_node");
+                            if (!t.empty() && atoi(t.c_str()) >= 0) fastx_preferred_node().store(atoi(t.c_str()));
+                        } else (void)hipGetLastError();
+                    }
+                    HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+                    {   // the runtime sets up its pinned-memory path at the first hipHostMalloc of a process (50 ms): here, not in the first batch of reads
+                        void* warm = nullptr;
+                        if (hipHostMalloc(&warm, 4096, hipHostMallocDefault) == hipSuccess) (void)hipHostFree(warm);
+                        else (void)hipGetLastError();
+                    }
+                    (void)CopyEngines::get().usable(device);  // (times a small copy on every copy engine, once per process)
+                    clk_dev.lap("device start-up (beside the host's work)");
+                } catch (std::exception& e) {
+                    dev_error = e.what();
+                }
+            });
+        struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join{dev_init};
+        // (a handle on a device builds the dictionary's bucket table in HBM; FULGOR_DICT_ON_HOST=1: on the host and uploaded, for A/B measurements)
+        // (FULGOR_INGEST_THREADS: threads that ingest a dump, 0 = all; what is built does not depend on it)
+        open_index(path, ix->host, (unsigned)env_u64("FULGOR_INGEST_THREADS", 0), device == FGPU_HOST_ONLY || env_u64("FULGOR_DICT_ON_HOST", 0) != 0);
         if (device == FGPU_HOST_ONLY) return;  // ingestion / export / save only; queries are refused
-        HIP_TRY(hipSetDevice(device));
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device));
-        ix->num_cus = prop.multiProcessorCount;
-        {   // the NUMA node of the device: the query reader keeps its threads on that node's cores (pinned host memory lives there)
-            char bus[64] = {0};
-            if (hipDeviceGetPCIBusId(bus, sizeof bus, device) == hipSuccess) {
-                std::string b(bus);
-                for (auto& ch : b) ch = (char)tolower((unsigned char)ch);
-                const std::string t = read_small_file("/sys/bus/pci/devices/" + b + "/numa_node");
-                if (!t.empty() && atoi(t.c_str()) >= 0) fastx_preferred_node().store(atoi(t.c_str()));
-            } else (void)hipGetLastError();
-        }
-        HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
-        {   // the runtime sets up its pinned-memory path at the first hipHostMalloc of a process (50 ms): here, not in the first batch of reads
-            void* warm = nullptr;
-            if (hipHostMalloc(&warm, 4096, hipHostMallocDefault) == hipSuccess) (void)hipHostFree(warm);
-            else (void)hipGetLastError();
-        }
-        (void)CopyEngines::get().usable(device);  // (times a small copy on every copy engine, once per process)
         LoadClock clk;
+        dev_init.join();
+        if (!dev_error.empty()) throw std::runtime_error(dev_error);
+        clk.lap("waiting for the device start-up");
+        HIP_TRY(hipSetDevice(device));
         upload_index(ix);
         if (ix->host.type != IDX_HYBRID) upload_generic(ix);
-        clk.lap("descriptors, bitmap rows, upload");
     });
     if (rc) { delete ix; return rc; }
     *out = ix;
@@ -910,9 +1022,30 @@ int fgpu_debug_k1_stats(unsigned long long* out, int reset) {
 }
 #endif
 
-int fgpu_selfcheck(const fgpu_index* ix, uint64_t unitig_stride) {
-    if (!ix) return fail(-EINVAL, "null argument");
-    return guarded([&] { verify_dict(ix->host.dict, unitig_stride ? unitig_stride : 1); });
+int fgpu_selfcheck(const fgpu_index* cix, uint64_t unitig_stride) {
+    if (!cix) return fail(-EINVAL, "null argument");
+    fgpu_index* ix = const_cast<fgpu_index*>(cix);
+    return guarded([&] {
+        Dict& d = ix->host.dict;
+        if (ix->device != FGPU_HOST_ONLY && d.table.empty()) {
+            // the table this handle queries was built on the device: bring it here, build the host's from the same records, and the
+            // two must be the same bytes; then the walk below goes through the DEVICE's table
+            HIP_TRY(hipSetDevice(ix->device));
+            std::vector<uint32_t> dev(ix->table_buckets * BUCKET_WORDS);
+            HIP_TRY(hipMemcpy(dev.data(), ix->d_table.p, dev.size() * 4, hipMemcpyDeviceToHost));
+            build_dict_table(d);
+            if (d.table.size() != dev.size() || memcmp(d.table.data(), dev.data(), dev.size() * 4) != 0) {
+                d.table.clear();
+                d.table.shrink_to_fit();
+                throw std::runtime_error("dictionary self-check failed (the table built on the device differs from the host's)");
+            }
+            d.table.swap(dev);
+            struct Drop { Dict& d; ~Drop() { d.table.clear(); d.table.shrink_to_fit(); } } drop{d};
+            verify_dict(d, unitig_stride ? unitig_stride : 1);
+            return;
+        }
+        verify_dict(d, unitig_stride ? unitig_stride : 1);
+    });
 }
 
 #define NEED_DEVICE(ix)                                                                                         \
@@ -1379,6 +1512,37 @@ int fgpu_result_algorithmic_bytes(const fgpu_result* r, uint64_t* list_bytes, ui
     });
 }
 
+int fgpu_device_report(fgpu_index* ix, char** out) {
+    if (!ix || !out) return fail(-EINVAL, "null argument");
+    NEED_DEVICE(ix);
+    return guarded([&] {
+        HIP_TRY(hipSetDevice(ix->device));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, ix->device));
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, sizeof bus, ix->device) != hipSuccess) { (void)hipGetLastError(); bus[0] = 0; }
+        char line[512];
+        snprintf(line, sizeof line, "device %d (%s, %s, %d CUs), %.1f of %.1f GB free, host NUMA node %d; ", ix->device, prop.name, bus,
+                 prop.multiProcessorCount, free_b / 1e9, total_b / 1e9, fastx_preferred_node().load());
+        const std::string text = std::string(line) + (CopyEngines::get().usable(ix->device) ? "" : "(copies through the HIP runtime) ") + CopyEngines::get().report();
+        *out = (char*)malloc(text.size() + 1);
+        if (!*out) throw std::bad_alloc();
+        memcpy(*out, text.c_str(), text.size() + 1);
+    });
+}
+
+int fgpu_copy_engines_classify(const uint32_t* engines, const double* gb_per_s, uint32_t n, uint32_t* fast, uint32_t* num_fast) {
+    if (!engines || !gb_per_s || !fast || !num_fast) return fail(-EINVAL, "null argument");
+    std::vector<std::pair<uint32_t, double>> rate;
+    for (uint32_t i = 0; i < n; ++i) rate.push_back({engines[i], gb_per_s[i]});
+    const std::vector<uint32_t> f = CopyEngines::classify(rate);
+    for (size_t i = 0; i < f.size(); ++i) fast[i] = f[i];
+    *num_fast = (uint32_t)f.size();
+    return 0;
+}
+
 int fgpu_tune(fgpu_index* ix, int knob, uint64_t value) {
     if (!ix) return fail(-EINVAL, "null argument");
     if (knob == FGPU_TUNE_ORDER_MIN_READS) ix->order_min_reads = value;
@@ -1813,17 +1977,42 @@ int fgpu_dump(const fgpu_index* ix, const char* basename) {
         }
         fclose(f);
         f = open(".color_sets.txt");
-        std::vector<uint32_t> set;
-        std::string line;
-        for (uint64_t id = 0; id < h.num_sets(); ++id) {
-            hybrid_decode(h, id, set);
-            line = "size=" + std::to_string(set.size()) + " ";
-            for (size_t j = 0; j < set.size(); ++j) {
-                line += std::to_string(set[j]);
-                if (j + 1 != set.size()) line.push_back(' ');
+        {   // 0.9 G integers for a salmonella_4546-sized index: strips of sets are decoded and formatted by all threads, written in order
+            const uint64_t ns = h.num_sets();
+            const unsigned T = (unsigned)std::min<uint64_t>(std::max(1u, std::min(32u, std::thread::hardware_concurrency())), ns / 1024 + 1);
+            const uint64_t CH = 8192;
+            std::vector<std::string> bufs(T);
+            auto put_u32 = [](std::string& o, uint32_t x) {
+                char d[10];
+                int n = 0;
+                do { d[n++] = (char)('0' + x % 10u); x /= 10u; } while (x);
+                while (n) o.push_back(d[--n]);
+            };
+            for (uint64_t g0 = 0; g0 < ns; g0 += (uint64_t)T * CH) {
+                auto work = [&](unsigned t) {
+                    std::string& o = bufs[t];
+                    o.clear();
+                    std::vector<uint32_t> set;
+                    const uint64_t a = std::min(ns, g0 + t * CH), b = std::min(ns, a + CH);
+                    for (uint64_t id = a; id < b; ++id) {
+                        hybrid_decode(h, id, set);
+                        o += "size=";
+                        put_u32(o, (uint32_t)set.size());
+                        o.push_back(' ');
+                        for (size_t j = 0; j < set.size(); ++j) {
+                            put_u32(o, set[j]);
+                            if (j + 1 != set.size()) o.push_back(' ');
+                        }
+                        o.push_back('\n');
+                    }
+                };
+                std::vector<std::thread> th;
+                for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+                work(0);
+                for (auto& x : th) x.join();
+                for (unsigned t = 0; t < T; ++t)
+                    if (!bufs[t].empty() && fwrite(bufs[t].data(), 1, bufs[t].size(), f) != bufs[t].size()) { fclose(f); throw std::runtime_error("write error on the color sets file"); }
             }
-            line.push_back('\n');
-            fwrite(line.data(), 1, line.size(), f);
         }
         fclose(f);
     });

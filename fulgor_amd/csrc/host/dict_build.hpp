@@ -19,6 +19,7 @@
 #include <thread>
 #include <string>
 #include "index_model.hpp"
+#include "../common/dict_place.h"
 
 namespace fg {
 
@@ -62,11 +63,9 @@ inline uint64_t record_key(const uint32_t* w, uint32_t k, uint32_t m) {
     return lmer_key(lo, hi);
 }
 
-// Places the records into the bucket table. Hashed region: a sweep over the buckets in order; the keys hashed to a
-// bucket keep all their records there while the bucket has room (keys with fewer records first). If they do not all fit, the bucket's LAST
-// slot becomes its REDIRECT and the keys that are left share one run of consecutive buckets in the overflow region
-// (a record is verified by its context, so records of several keys may lie side by side). ~0.6 records per bucket on average.
-inline void build_dict_table(Dict& d) {
+// number of hashed buckets for the records of `d` (sets d.num_buckets); the table itself is built by build_dict_table (host) or by
+// the device builder (hip/dict_build.hip.h) from the same records by the same rule (common/dict_place.h)
+inline void dict_table_geometry(Dict& d) {
     const uint64_t nrec = d.num_records();
     if (nrec >= (1ULL << 31)) throw std::runtime_error("too many super-k-mer records");
     // 1.625 buckets per record (0.6 records per bucket); FULGOR_DICT_BUCKET_FACTOR overrides it (measurements: the table is rebuilt at every open)
@@ -74,15 +73,24 @@ inline void build_dict_table(Dict& d) {
     if (const char* e = getenv("FULGOR_DICT_BUCKET_FACTOR")) { const double v = atof(e); if (v >= 1.0 && v <= 16.0) factor = v; }
     // at most 2^26 buckets in all (a bucket and a lane pack into 32 bits in the lookup kernel): the hashed region leaves room for an
     // overflow region of a quarter of the records; a collection that does not fit is refused here, not at the first redirect
-    const int64_t cap = (int64_t)DICT_MAX_BUCKETS - (int64_t)DICT_TAIL_BUCKETS - (int64_t)(nrec / 4) - 4096;
-    if (cap < (int64_t)(nrec / 2))
+    bool capped = false;
+    const uint32_t nb = dict_hashed_buckets(nrec, factor, &capped);
+    if (nb == 0)
         throw std::runtime_error("the k-mer dictionary of this collection needs more than 2^26 buckets (" + std::to_string(nrec) +
                                  " super-k-mer records; the limit is about 80 M): not supported by this build");
-    const uint64_t want_buckets = (uint64_t)((double)nrec * factor);
-    if ((int64_t)want_buckets > cap)
-        fprintf(stderr, "fulgor_amd: dictionary table capped at %lld buckets for %llu records (%.2f buckets per record instead of %.2f): more keys behind redirects\n",
-                (long long)cap, (unsigned long long)nrec, (double)cap / (double)nrec, factor);
-    d.num_buckets = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(want_buckets, (uint64_t)cap));
+    if (capped)
+        fprintf(stderr, "fulgor_amd: dictionary table capped at %u buckets for %llu records (%.2f buckets per record instead of %.2f): more keys behind redirects\n",
+                nb, (unsigned long long)nrec, (double)nb / (double)nrec, factor);
+    d.num_buckets = nb;
+}
+
+// Places the records into the bucket table. Hashed region: a sweep over the buckets in order; the keys hashed to a
+// bucket keep all their records there while the bucket has room (keys with fewer records first). If they do not all fit, the bucket's LAST
+// slot becomes its REDIRECT and the keys that are left share one run of consecutive buckets in the overflow region
+// (a record is verified by its context, so records of several keys may lie side by side). ~0.6 records per bucket on average.
+inline void build_dict_table(Dict& d) {
+    const uint64_t nrec = d.num_records();
+    dict_table_geometry(d);
     const uint64_t nb_hashed = (uint64_t)d.num_buckets + DICT_TAIL_BUCKETS;
     struct Ref { uint32_t home; uint32_t rec; uint64_t key; };
     // The table is rebuilt from the records whenever an index is opened: the sort of the records by (home bucket, key) is
@@ -150,7 +158,6 @@ inline void build_dict_table(Dict& d) {
                 w[2] = REC_W2_EMPTY;
             }
     });
-    struct Item { uint64_t first, count; };  // a key: refs[first, first + count)
     // the records in table order (gathered by all threads: the sweep below then reads them front to back instead of
     // missing the cache once per record)
     std::vector<uint32_t> ordered(nrec * REC_WORDS);
@@ -168,50 +175,30 @@ inline void build_dict_table(Dict& d) {
     // The sweep over the hashed buckets, every thread a contiguous range of them: the overflow runs of a range go to the thread's own
     // piece of the overflow region, the redirects note the run's bucket number within that piece, and once the pieces' sizes are
     // known the numbers get their piece's start added. The pieces follow each other in bucket order: the table is the one a single
-    // sweep writes. (A quarter of the 0.85 s that the table of the bench index took to build was this sweep on one thread.)
+    // sweep writes (and the one the device builder writes: which record goes where is common/dict_place.h).
+    // (A bucket met by a query leaves at most REDIRECT_DIRECT new buckets to look at if it is a hashed one, at most one — the next
+    // of its run — if it is an overflow bucket, which bounds the lookup kernel's ring of waiting buckets: 64 runs x 3.)
     std::vector<std::vector<uint32_t>> piece(T);                 // overflow region by thread
     std::vector<std::vector<uint64_t>> redirects(T);             // hashed buckets that redirect, by thread
     std::vector<std::string> failure(T);
     parallel(nb_hashed, [&](unsigned t, uint64_t b0, uint64_t b1) {
-        std::vector<Item> items;
         std::vector<uint32_t>& overflow = piece[t];
         uint64_t at = (uint64_t)(std::lower_bound(refs.begin(), refs.end(), b0, [](const Ref& r, uint64_t b) { return r.home < b; }) - refs.begin());
+        const auto key = [&](uint64_t i) { return refs[i].key; };
         for (uint64_t b = b0; b < b1; ++b) {
-            items.clear();
-            while (at < nrec && refs[at].home == b) {
-                uint64_t e = at;
-                while (e < nrec && refs[e].home == b && refs[e].key == refs[at].key) ++e;
-                items.push_back(Item{at, e - at});
-                at = e;
-            }
-            if (items.empty()) continue;
+            const uint64_t a = at;
+            while (at < nrec && refs[at].home == b) ++at;
+            if (at == a) continue;
             uint32_t* bw = &d.table[b * BUCKET_WORDS];
-            // (more keys than slots: the surplus keys go to the bucket's overflow run like every key that does not fit. A hashed bucket
-            // never hands a query on to the next hashed bucket: a bucket met by a query leaves at most REDIRECT_DIRECT new buckets to look
-            // at if it is a hashed one, at most one — the next of its run — if it is an overflow bucket, which bounds the lookup
-            // kernel's ring of waiting buckets: 64 runs x 3.)
-            // whole keys while they fit, fewest records first; with a redirect the bucket has one slot less
-            std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) { return x.count < y.count; });
-            uint64_t total = 0;
-            for (const Item& it : items) total += it.count;
-            const uint32_t room = total <= BUCKET_RECS ? BUCKET_RECS : BUCKET_RECS - 1;
-            uint32_t slot = 0;
-            size_t kept = 0;
-            while (kept < items.size() && slot + items[kept].count <= room) {
-                for (uint64_t j = 0; j < items[kept].count; ++j) put(bw + (slot++) * REC_WORDS, items[kept].first + j);
-                ++kept;
-            }
-            if (kept < items.size()) {
-                uint64_t moved = 0;
-                for (size_t i = kept; i < items.size(); ++i) moved += items[i].count;
-                const uint64_t nb = (moved + BUCKET_RECS - 1) / BUCKET_RECS;
-                if (nb > REC_MAX_CSID) { failure[t] = "dictionary table: overflow run too long"; return; }
-                const size_t o0 = overflow.size();
-                overflow.resize(o0 + nb * BUCKET_WORDS, 0);
-                uint64_t j = 0;
-                for (size_t i = kept; i < items.size(); ++i)
-                    for (uint64_t r = 0; r < items[i].count; ++r, ++j) put(&overflow[o0 + j * REC_WORDS], items[i].first + r);
-                for (; j < nb * BUCKET_RECS; ++j) overflow[o0 + j * REC_WORDS + 2] = REC_W2_EMPTY;
+            const BucketPlan plan = plan_bucket(a, at, key);
+            const uint64_t nb = (plan.moved + BUCKET_RECS - 1) / BUCKET_RECS;
+            if (nb > REC_MAX_CSID) { failure[t] = "dictionary table: overflow run too long"; return; }
+            const size_t o0 = overflow.size();
+            if (nb) overflow.resize(o0 + nb * BUCKET_WORDS, 0);
+            place_bucket(a, at, plan, key, [&](uint32_t slot, uint64_t i) { put(bw + slot * REC_WORDS, i); },
+                         [&](uint64_t j, uint64_t i) { put(&overflow[o0 + j * REC_WORDS], i); });
+            if (nb) {
+                for (uint64_t j = plan.moved; j < nb * BUCKET_RECS; ++j) overflow[o0 + j * REC_WORDS + 2] = REC_W2_EMPTY;
                 // the query reads the first REDIRECT_DIRECT buckets at once; further ones hang on spill flags
                 for (uint64_t b2 = REDIRECT_DIRECT - 1; b2 + 1 < nb; ++b2) overflow[o0 + b2 * BUCKET_WORDS + (BUCKET_RECS - 1) * REC_WORDS + 3] |= REC_SPILL;
                 uint32_t* dst = bw + (BUCKET_RECS - 1) * REC_WORDS;
@@ -240,9 +227,10 @@ inline void build_dict_table(Dict& d) {
     d.table.insert(d.table.end(), overflow.begin(), overflow.end());
 }
 
+// host_table = false: the bucket table is left to the device builder (hip/dict_build.hip.h); only its geometry is fixed here
 inline void build_dict(Dict& d, uint32_t k, uint32_t m, const char* bases, uint64_t total_bases,
                        const std::vector<uint64_t>& unitig_off, const std::vector<uint32_t>& unitig_csid,
-                       unsigned nthreads = 0) {
+                       unsigned nthreads = 0, bool host_table = true) {
     check_dict_params(k, m);
     if (nthreads == 0) nthreads = std::max(1u, std::thread::hardware_concurrency());
     d.k = k;
@@ -356,7 +344,8 @@ inline void build_dict(Dict& d, uint32_t k, uint32_t m, const char* bases, uint6
     }
     d.num_kmers = 0;
     for (auto x : nk_parts) d.num_kmers += x;
-    build_dict_table(d);
+    if (host_table) build_dict_table(d);
+    else { d.table.clear(); dict_table_geometry(d); }
 }
 
 // Host walk of the same structure, used ONLY by the build-time self check (verify_dict below, the

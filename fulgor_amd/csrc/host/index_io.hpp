@@ -13,6 +13,11 @@
 // The reference's binary .fur/.mfur/.dfur/.mdfur files embed an SSHash dictionary whose layout is
 // defined by a submodule that is not vendored; they are rejected loudly by open_index().
 #pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -25,7 +30,123 @@
 
 namespace fg {
 
-inline void load_dump(const std::string& base, HostIndex& idx, uint32_t m = 0, unsigned nthreads = 0) {
+// <base>.color_sets.txt (src/index.cpp:100-118 writes it: "size=<n> c0 c1 ..." one set per line, id = line number) -> the hybrid
+// stream. A real salmonella_4546 dump is 4 GB of text holding 0.9 G integers: the file is mapped and cut at line starts into one
+// piece per thread; every thread parses its lines and encodes them into a bit stream of its own (the codec has no state across
+// sets), and the streams are joined bit by bit in line order — the same stream one encoder would have written front to back.
+inline void load_color_sets_text(const std::string& path, uint64_t num_colors, uint64_t num_color_sets, HybridSets& out, unsigned nthreads = 0) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("cannot open color sets file");
+    struct stat st;
+    if (fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error("cannot stat color sets file"); }
+    const uint64_t size = (uint64_t)st.st_size;
+    if (size == 0) { ::close(fd); throw std::runtime_error("color sets file is short"); }
+    const char* text = (const char*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (text == MAP_FAILED) throw std::runtime_error("cannot map color sets file");
+    struct Unmap { const char* p; uint64_t n; ~Unmap() { munmap((void*)p, n); } } unmap{text, size};
+    madvise((void*)text, size, MADV_SEQUENTIAL);
+    if (nthreads == 0) nthreads = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned T = (unsigned)std::min<uint64_t>(nthreads, size / (1u << 20) + 1);
+    std::vector<uint64_t> cut(T + 1, size);  // piece t = text bytes [cut[t], cut[t + 1]), both at line starts
+    cut[0] = 0;
+    for (unsigned t = 1; t < T; ++t) {
+        const uint64_t at = size / T * t;
+        const char* nl = (const char*)memchr(text + at, '\n', size - at);
+        cut[t] = nl ? (uint64_t)(nl - text) + 1 : size;
+    }
+    auto parallel = [&](auto fn) {
+        if (T == 1) { fn(0u); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; ++t) th.emplace_back(fn, t);
+        for (auto& x : th) x.join();
+    };
+    // lines in front of every piece (a last line without a line end counts)
+    std::vector<uint64_t> first_line(T + 1, 0);
+    parallel([&](unsigned t) {
+        uint64_t n = 0;
+        const char* p = text + cut[t];
+        const char* const e = text + cut[t + 1];
+        while (p < e) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+            ++n;
+            if (!nl) break;
+            p = nl + 1;
+        }
+        first_line[t + 1] = n;
+    });
+    for (unsigned t = 0; t < T; ++t) first_line[t + 1] += first_line[t];
+    if (first_line[T] < num_color_sets) throw std::runtime_error("color sets file is short");
+    std::vector<HybridEncoder> enc(T);
+    std::vector<std::string> err(T);
+    parallel([&](unsigned t) {
+        HybridEncoder& en = enc[t];
+        en.init(num_colors);
+        std::vector<uint32_t> v;
+        const char* p = text + cut[t];
+        const char* const e = text + cut[t + 1];
+        for (uint64_t line = first_line[t]; p < e && line < num_color_sets; ++line) {  // (whatever follows the last set is not looked at)
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+            const char* le = nl ? nl : e;
+            static const char key[] = "size=";
+            const char* c = std::search(p, le, key, key + 5);
+            if (c == le) { err[t] = "malformed color set line"; return; }
+            c += 5;
+            auto number = [&](uint64_t& x) {  // skips blanks, reads decimal digits; false if there are none
+                while (c < le && (*c == ' ' || *c == '\t' || *c == '\r')) ++c;
+                if (c >= le || *c < '0' || *c > '9') return false;
+                x = 0;
+                while (c < le && *c >= '0' && *c <= '9') { x = x * 10 + (uint64_t)(*c - '0'); if (x > (1ull << 40)) return false; ++c; }
+                return true;
+            };
+            uint64_t sz = 0;
+            if (!number(sz) || sz == 0 || sz > num_colors) { err[t] = "bad color set size"; return; }
+            v.resize(sz);
+            for (uint64_t j = 0; j < sz; ++j) {
+                uint64_t x;
+                if (!number(x)) { err[t] = "color set line is short"; return; }
+                if (x >= num_colors || (j && x <= v[j - 1])) { err[t] = "color set not increasing"; return; }
+                v[j] = (uint32_t)x;
+            }
+            en.encode(v.data(), v.size());
+            p = nl ? nl + 1 : e;
+        }
+    });
+    for (const std::string& e : err) if (!e.empty()) throw std::runtime_error(e);
+    // join: piece t's stream goes to bit position base[t] of the whole
+    std::vector<uint64_t> base(T + 1, 0), first_set(T + 1, 0);
+    for (unsigned t = 0; t < T; ++t) { base[t + 1] = base[t] + enc[t].bw.nbits; first_set[t + 1] = first_set[t] + (enc[t].offsets.size() - 1); }
+    if (first_set[T] != num_color_sets) throw std::runtime_error("color sets file is short");
+    out.num_colors = (uint32_t)num_colors;
+    out.sparse_thr = enc[0].sparse_thr;
+    out.dense_thr = enc[0].dense_thr;
+    out.nbits = base[T];
+    out.offsets.assign(num_color_sets + 1, 0);
+    out.bits.assign((out.nbits + 63) / 64 + 4, 0);
+    parallel([&](unsigned t) {
+        const HybridEncoder& en = enc[t];
+        for (size_t i = 0; i + 1 < en.offsets.size(); ++i) out.offsets[first_set[t] + i] = base[t] + en.offsets[i];
+        const uint64_t nw = (en.bw.nbits + 63) / 64;
+        if (!nw) return;
+        const uint64_t d0 = base[t] >> 6, sh = base[t] & 63;
+        uint64_t* dst = out.bits.data();
+        // the first and the last word this piece touches may be shared with its neighbours: OR-ed in atomically; the others are its own
+        const uint64_t last = (base[t] + en.bw.nbits - 1) >> 6;
+        auto put = [&](uint64_t w, uint64_t bits) {
+            if (!bits) return;
+            if (w == d0 || w == last) __atomic_fetch_or(&dst[w], bits, __ATOMIC_RELAXED);
+            else dst[w] |= bits;
+        };
+        for (uint64_t i = 0; i < nw; ++i) {
+            const uint64_t x = en.bw.words[i];
+            put(d0 + i, x << sh);
+            if (sh) put(d0 + i + 1, x >> (64 - sh));
+        }
+    });
+    out.offsets[num_color_sets] = out.nbits;
+}
+
+inline void load_dump(const std::string& base, HostIndex& idx, uint32_t m = 0, unsigned nthreads = 0, bool host_table = true) {
     uint64_t k = 0, num_kmers = 0, num_colors = 0, num_unitigs = 0, num_color_sets = 0;
     {
         std::ifstream in(base + ".metadata.txt");
@@ -57,34 +178,8 @@ inline void load_dump(const std::string& base, HostIndex& idx, uint32_t m = 0, u
         if (idx.filenames.size() != num_colors) throw std::runtime_error("filenames file is short");
     }
     // colour sets
-    {
-        std::ifstream in(base + ".color_sets.txt");
-        if (!in.is_open()) throw std::runtime_error("cannot open color sets file");
-        HybridEncoder enc;
-        enc.init(num_colors);
-        std::string line;
-        std::vector<uint32_t> v;
-        for (uint64_t i = 0; i < num_color_sets; ++i) {
-            if (!std::getline(in, line)) throw std::runtime_error("color sets file is short");
-            size_t p = line.find("size=");
-            if (p == std::string::npos) throw std::runtime_error("malformed color set line");
-            const char* c = line.c_str() + p + 5;
-            char* end = nullptr;
-            uint64_t size = std::strtoull(c, &end, 10);
-            if (size == 0 || size > num_colors) throw std::runtime_error("bad color set size");
-            v.clear();
-            c = end;
-            for (uint64_t j = 0; j < size; ++j) {
-                v.push_back((uint32_t)std::strtoul(c, &end, 10));
-                if (end == c) throw std::runtime_error("color set line is short");
-                c = end;
-                if (v.back() >= num_colors || (j && v[j] <= v[j - 1])) throw std::runtime_error("color set not increasing");
-            }
-            enc.encode(v.data(), v.size());
-        }
-        enc.finish(idx.hybrid);
-        hybrid_build_blocks(idx.hybrid, nthreads);
-    }
+    load_color_sets_text(base + ".color_sets.txt", num_colors, num_color_sets, idx.hybrid, nthreads);
+    hybrid_build_blocks(idx.hybrid, nthreads);
     // unitigs
     std::string bases;
     std::vector<uint64_t> off(1, 0);
@@ -109,7 +204,7 @@ inline void load_dump(const std::string& base, HostIndex& idx, uint32_t m = 0, u
     }
     if (m == 0) m = k >= 15 ? (uint32_t)k - 14 : 1;  // k=31 -> m=17: 15 windows, contexts of 45 bases
     idx.type = IDX_HYBRID;
-    build_dict(idx.dict, (uint32_t)k, m, bases.data(), bases.size(), off, csid, nthreads);
+    build_dict(idx.dict, (uint32_t)k, m, bases.data(), bases.size(), off, csid, nthreads, host_table);
     if (num_kmers && idx.dict.num_kmers != num_kmers) throw std::runtime_error("num_kmers does not match metadata");
 }
 
@@ -180,7 +275,7 @@ struct LoadClock {
     }
 };
 
-inline void load_binary(const std::string& path, HostIndex& idx) {
+inline void load_binary(const std::string& path, HostIndex& idx, bool host_table = true) {
     using namespace detail;
     LoadClock clk;
     std::ifstream i(path, std::ios::binary);
@@ -223,8 +318,12 @@ inline void load_binary(const std::string& path, HostIndex& idx) {
             if ((d.records[r * REC_WORDS + 3] & REC_MAX_CSID) >= nsets) bad("record colour-set id");
     }
     clk.lap("validate");
-    build_dict_table(d);
-    clk.lap("dictionary table from the records");
+    if (host_table) {
+        build_dict_table(d);
+        clk.lap("dictionary table from the records");
+    } else {
+        dict_table_geometry(d);  // (the table itself is built on the device: hip/dict_build.hip.h)
+    }
     h.bits.resize((h.nbits + 63) / 64 + 4, 0);  // the device reads up to 256 bits past a bitmap list
     hybrid_build_blocks(h);
     clk.lap("packed blocks of the gap lists");
@@ -263,7 +362,7 @@ inline void load_binary(const std::string& path, HostIndex& idx) {
 // A file in the reference's binary layout (fur_format.hpp: Fulgor-owned sections from the reference, primitive layouts from
 // memory of upstream and NOT validated on a real file, k2u section = the engine's own block): what fgpu_save writes under
 // a .fur / .mfur / .dfur / .mdfur name. A file written by the reference itself stops at its SSHash section.
-inline void load_fur(const std::string& path, HostIndex& idx, unsigned nthreads = 0) {
+inline void load_fur(const std::string& path, HostIndex& idx, unsigned nthreads = 0, bool host_table = true) {
     uint32_t psize = 0, csize = 0;
     fur::read_fur(path, idx, psize, csize);
     Dict& d = idx.dict;
@@ -275,7 +374,7 @@ inline void load_fur(const std::string& path, HostIndex& idx, unsigned nthreads 
     const std::vector<uint64_t> off = d.unitig_off;
     const std::vector<uint32_t> csid = d.unitig_csid;
     const uint64_t num_kmers = d.num_kmers;
-    build_dict(d, d.k, d.m, bases.data(), bases.size(), off, csid, nthreads);
+    build_dict(d, d.k, d.m, bases.data(), bases.size(), off, csid, nthreads, host_table);
     if (d.num_kmers != num_kmers) throw std::runtime_error("corrupt index file (num_kmers)");
     hybrid_build_blocks(idx.hybrid, nthreads);
     const int type = idx.type;
@@ -292,11 +391,12 @@ inline void save_fur(const HostIndex& idx, const std::string& path) {
 }
 
 // path dispatch: ".fgidx" container, a binary index in the reference's layout, or a dump basename
-inline void open_index(const std::string& path, HostIndex& idx, unsigned nthreads = 0) {
-    if (ends_with(path, ".fgidx")) { load_binary(path, idx); return; }
+// host_table = false (a handle on a device): the dictionary's bucket table is not built on the host
+inline void open_index(const std::string& path, HostIndex& idx, unsigned nthreads = 0, bool host_table = true) {
+    if (ends_with(path, ".fgidx")) { load_binary(path, idx, host_table); return; }
     // suffix sniffing order of the reference CLI: mdfur, mfur, dfur, fur (tools/pseudoalign.cpp:294-306)
-    if (ends_with(path, "fur")) { load_fur(path, idx, nthreads); return; }
-    load_dump(path, idx, 0, nthreads);
+    if (ends_with(path, "fur")) { load_fur(path, idx, nthreads, host_table); return; }
+    load_dump(path, idx, 0, nthreads, host_table);
 }
 
 }  // namespace fg

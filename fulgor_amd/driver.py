@@ -280,6 +280,7 @@ def pseudoalign_sharded(open_index, query, output, algo=FULL_INTERSECTION, thres
     the tensor lives on a GPU, gloo on the CPU). open_index() opens this rank's replica of the index.
     returns (num_reads, num_mapped_reads) of the whole job."""
     import os
+    import sys
     from .reads import FastxReader, text_size
     if world > 1:
         import torch
@@ -292,6 +293,9 @@ def pseudoalign_sharded(open_index, query, output, algo=FULL_INTERSECTION, thres
     else:
         begin, end = 0, (1 << 64) - 1
     batches = FastxReader(query, batch=batch or 1 << 18, copy=False, threads=reader_threads_per_rank(io_threads, world), begin=begin, end=end)
+    trace = os.environ.get("FULGOR_TRACE_OPENS") == "1"  # (tests: one open of the query part and one of the index per rank)
+    if trace:
+        print("[rank] query part opened (rank %d/%d, text bytes %d..%d)" % (rank, world, begin, min(end, 1 << 62)), file=sys.stderr, flush=True)
     first_id = 0
     if world > 1:
         mine = torch.tensor([batches.count()], dtype=torch.int64, device=device_for_reduce)
@@ -299,6 +303,10 @@ def pseudoalign_sharded(open_index, query, output, algo=FULL_INTERSECTION, thres
         dist.all_gather(counts, mine)
         first_id = int(sum(int(c.item()) for c in counts[:rank]))
     index = open_index()
+    if trace:
+        print("[rank] index opened (rank %d/%d)" % (rank, world), file=sys.stderr, flush=True)
+    if world > 1 and hasattr(index, "device_report"):  # every rank of a multi-GPU run says where it runs and which copy engines it chose
+        print("[rank %d/%d] first read id %d; %s" % (rank, world, first_id, index.device_report()), file=sys.stderr, flush=True)
     part = output if rank == 0 else "%s.part%d" % (output, rank)
     with open(part, "wb") as out:
         if hasattr(index, "pseudoalign_stream"):  # the engine: the native worker loop

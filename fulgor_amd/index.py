@@ -296,6 +296,15 @@ class Index:
         finally:
             self._L.fgpu_free(p)
 
+    def device_report(self):
+        """one line about the device of this handle and the copy engines the library chose (fgpu_device_report)"""
+        p = C.c_void_p()
+        _native.check(self._L.fgpu_device_report(self._h, C.byref(p)))
+        try:
+            return C.string_at(p.value).decode()
+        finally:
+            self._L.fgpu_free(p)
+
     def tune(self, order_min_reads=None, small_results=None, dense_rows=None):
         """execution knobs of the colour stage (fgpu_tune); results never depend on them"""
         if order_min_reads is not None:

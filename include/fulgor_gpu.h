@@ -149,6 +149,15 @@ int fgpu_result_algorithmic_bytes(const fgpu_result* res, uint64_t* list_bytes, 
 enum { FGPU_TUNE_ORDER_MIN_READS = 0, FGPU_TUNE_SMALL_RESULTS = 1, FGPU_TUNE_DENSE_ROWS = 2 };
 int fgpu_tune(fgpu_index* idx, int knob, uint64_t value);
 
+/* One line about the device a handle lives on — ordinal, name, PCI address, CUs, free / total memory, the host NUMA node, and which
+ * copy engines the library chose for the bulk copies of the streamed path with the rates it measured (csrc/copy_engines.hip.h) —
+ * what every rank of a multi-GPU run prints when it starts. malloc'd: fgpu_free. */
+int fgpu_device_report(fgpu_index* idx, char** out);
+/* the rule behind that choice, exposed for tests: of n engines with the rates measured, those that carry host traffic at full rate
+ * (within half of the best) — three or four of them, or none when the measurement is ambiguous (then the default engines are used).
+ * fast: room for n entries. */
+int fgpu_copy_engines_classify(const uint32_t* engines, const double* gb_per_s, uint32_t n, uint32_t* fast, uint32_t* num_fast);
+
 /* per-kernel HIP-event timing on the engine's stream (FGPU_K_H2D / FGPU_K_D2H: the copies of the streaming worker loop and of
  * the device-side formatters, bracketed the same way) */
 enum { FGPU_K_LOOKUP = 0, FGPU_K_INTERSECT = 1, FGPU_K_UNION = 2, FGPU_K_SCAN = 3, FGPU_K_EXPAND = 4,

@@ -1419,8 +1419,56 @@ def test_bench_starts_its_own_ranks_and_checks_the_reduction(tmp_path):
     assert line["value"] > 0 and line["steps"] == 2 and line["config"]["reads_per_gpu"] == 200000
     ks = line["roofline"]["kernels"]
     assert set(ks) == {"k1_lookup", "k2_intersect", "k2b_expand"}
-    assert all(0 < v["frac"] < 1 and v["avg_launch_ms"] > 0 for v in ks.values())
-    assert line["roofline"]["kernel"] in ks and line["roofline"]["frac"] == ks[line["roofline"]["kernel"]]["frac"]
+    assert all(0 < v["frac"] < 1 and v["ms"] > 0 and v["GB"] > 0 for v in ks.values())
+    assert line["roofline"]["kernel"] in ks and abs(line["roofline"]["frac"] - ks[line["roofline"]["kernel"]]["frac"]) < 1e-4
+    assert len(r.stdout.strip().splitlines()[-1]) < 8000  # (the driver keeps 9 KB of stdout: the line must fit)
+    assert [x[0] for x in line["ranks"]] == [0, 1] and "0x" in line["ranks"][0][3]  # every rank's device, free memory and copy engines
+    detail = json.load(open(os.path.join(ROOT, line["detail"])))  # everything that was measured, beside the compact line
+    assert detail["value"] == line["value"] and "avg_launch_ms" in detail["roofline"]["kernels"]["k1_lookup"]
+
+
+def test_eight_ranks_share_the_gpu_command_line_and_bench(s10_fgidx, s10_oracle, tmp_path):
+    """round-5 review, item 3: what an 8-GPU node runs first, on the one GPU of this box — `pseudoalign --gpus 8` and `bench.py --gpus 8`
+    with all eight ranks on cuda:0 (FULGOR_SHARE_GPU / FULGOR_BENCH_SHARE_GPU, counters over gloo): eight processes open the index,
+    time the copy engines (under the host-wide lock) and stream their part at once; the joined ascii output is the single-rank
+    output byte for byte and the oracle's; every rank reports its device and engines; the reduction counts the reads of all eight."""
+    import json
+    import subprocess
+    from fulgor_amd.reads import ReadGenerator
+    n = 120_000
+    b, o = ReadGenerator(S10_GENOMES).generate(3, n, 150, 8)
+    q = tmp_path / "reads.fq"
+    with open(q, "wb") as f:
+        for i in range(n):
+            f.write(b"@r%d\n%s\n+\n%s\n" % (i, bytes(b[int(o[i]):int(o[i + 1])]), b"I" * 150))
+    outs = {}
+    for gpus in (1, 8):
+        out = tmp_path / ("out_%d" % gpus)
+        env = dict(os.environ, FULGOR_SHARE_GPU="1", FULGOR_TRACE_OPENS="1")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, "-m", "fulgor_amd", "pseudoalign", "-i", s10_fgidx, "-q", str(q), "-o", str(out), "--format", "ascii",
+                            "--gpus", str(gpus), "--verbose"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "processed %d reads" % n in r.stdout
+        outs[gpus] = open(out, "rb").read()
+        if gpus == 8:  # one open of the query file and one of the index per rank, and every rank says where it runs
+            assert r.stderr.count("[rank] query part opened") == 8 and r.stderr.count("[rank] index opened") == 8, r.stderr[-3000:]
+            assert all(("[rank %d/8]" % k) in r.stderr for k in range(8)), r.stderr[-3000:]
+            assert not [p for p in os.listdir(tmp_path) if ".part" in p]
+    assert outs[1] == outs[8]
+    oo, oc = s10_oracle.full_intersection(b, o, threads=32)
+    assert outs[1] == s10_oracle.format_ascii(oo, oc)
+    env = dict(os.environ, FULGOR_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "s10", "--reads", "200000", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["rccl_ranks"] == 8 and line["reads_counted_all_ranks"] == 8 * 200000
+    assert [x[0] for x in line["ranks"]] == list(range(8))
+    assert r.stderr.count("[bench] rank ") >= 16  # (two lines per rank: device and memory before the workload, the device report after the open)
 
 
 @pytest.mark.parametrize("index_type,psize,csize", [(fulgor_amd.DIFF, 4546, 16), (fulgor_amd.META, 160, 1), (fulgor_amd.META_DIFF, 160, 16)])
