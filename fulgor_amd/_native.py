@@ -54,6 +54,10 @@ def lib():
         getattr(L, name).argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp)]
     L.fgpu_kmer_color_set_ids.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp)]
     L.fgpu_kmer_matches.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp)]
+    L.fgpu_kmer_emitter_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.fgpu_kmer_emitter_add.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.POINTER(vp), u64p]
+    L.fgpu_kmer_emitter_free.argtypes = [vp]
+    L.fgpu_kmer_emitter_free.restype = None
     L.fgpu_threshold_union.argtypes = [vp, vp, vp, C.c_uint64, C.c_double, C.POINTER(vp), C.POINTER(vp)]
     L.fgpu_intersect_ids.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp)]
     L.fgpu_reads_upload.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp)]
@@ -85,6 +89,8 @@ def lib():
     L.fgpu_pseudoalign_stream.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_int, C.c_uint64, C.c_uint,
                                           u64p, u64p]
     L.fgpu_last_stream_report.argtypes = [C.POINTER(vp)]
+    L.fgpu_prepare_host.argtypes = [C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]
+    L.fgpu_stream_prepare.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint, C.c_uint32, C.c_uint64]
     L.fgpu_result_algorithmic_bytes.argtypes = [vp, u64p, u64p, u64p]
     L.fgpu_result_checksum.argtypes = [vp, u64p, u64p]
     L.fgpu_tune.argtypes = [vp, C.c_int, C.c_uint64]

@@ -140,6 +140,7 @@ def pseudoalign(argv):
             print("performing queries from file '%s'..." % a.query_filename)
         _mark("index open (%.3f s)" % clock["open_s"])
         clock["t_query"] = time.time()
+        clock["index"] = ix  # (alive until the process ends: closing it — gigabytes of device buffers, one by one — is the operating system's job at exit)
         return ix
 
     try:
@@ -152,7 +153,8 @@ def pseudoalign(argv):
         else:  # read id = 0-based file order (src/ps_utils.cpp:276,286); parsing overlaps with the GPU passes
             n, mapped = driver.pseudoalign_sharded(open_index, a.query_filename,
                                                    a.output_filename, algo, a.threshold or 0.0, a.format, rank, world,
-                                                   io_threads=a.num_threads, device_for_reduce=reduce_device)
+                                                   io_threads=a.num_threads, device_for_reduce=reduce_device,
+                                                   prepare_device=None if os.environ.get("FULGOR_NO_PREPARE") else device)
     except (RuntimeError, ValueError) as e:
         print(str(e), file=sys.stderr)
         return 1
@@ -180,9 +182,10 @@ def pseudoalign(argv):
     return 0
 
 
-def _query_tool(argv, prog, emit):
+def _query_tool(argv, prog, tool):
     """common driver of the two per-k-mer tools (tools/kmer_conservation.cpp:58-127, tools/kmer_matches.cpp:57-126):
-    -i index -q reads -o output [-t threads] [--verbose]; one output line per record, in file order"""
+    -i index -q reads -o output [-t threads] [--verbose]; one output line per record, in file order. The lines are made by
+    the native emitters (fgpu_kmer_emitter_*: lookup and counts on the device, text on the host's threads)."""
     ap = argparse.ArgumentParser(prog="fulgor " + prog, add_help=True)
     ap.add_argument("-i", dest="index_filename", required=True)
     ap.add_argument("-q", dest="query_filename", required=True)
@@ -197,59 +200,38 @@ def _query_tool(argv, prog, emit):
     if not os.path.exists(a.query_filename):
         print("error in opening the file '%s'" % a.query_filename, file=sys.stderr)
         return 1
+    from .index import KmerEmitter
     try:
         index = Index(a.index_filename, device=a.device)
-        batches = FastxReader(a.query_filename, batch=4096, copy=False)
+        # kmer-matches: one count per colour and record (the dense table of a batch stays below a quarter of a gigabyte)
+        batch = 1 << 16 if tool == 0 else max(256, min(1 << 16, (1 << 26) // max(1, index.num_colors())))
+        batches = FastxReader(a.query_filename, batch=batch, copy=False)
+        emitter = KmerEmitter(index, tool)
     except RuntimeError as e:
         print(str(e), file=sys.stderr)
         return 1
     t0 = time.time()
     n = 0
     try:
-        out = open(a.output_filename, "w")
+        out = open(a.output_filename, "wb")
     except OSError:
         print("could not open output file " + a.output_filename, file=sys.stderr)
         return 1
     with out:
-        state = {}
-        for bases, offs in batches:
-            names = batches.names()
-            out.write(emit(index, bases, offs, names, state))
-            n += len(names)
+        while True:
+            pb, po, cnt = batches.next_raw()
+            if cnt == 0:
+                break
+            pn, pno = batches.names_raw()
+            out.write(emitter.add(pb, po, pn, pno, cnt))
+            n += cnt
+    emitter.close()
     batches.close()
     el = (time.time() - t0) * 1000.0
     if a.verbose:
         print("processed %d reads" % n)
         print("elapsed = %d millisec / %d sec / %d min / %g musec/read" % (el, el / 1000, el / 60000, el * 1000 / max(1, n)))
     return 0
-
-
-def _emit_conservation(index, bases, offs, names, state):
-    """`name <tab> #triples [<tab>(start num_kmers color_set_id)]...` (tools/kmer_conservation.cpp:26-36)"""
-    from .index import conservation_triples
-    ko, ki = index.kmer_color_set_ids_batch(bases, offs)
-    lines = []
-    for j, name in enumerate(names):
-        tr = conservation_triples(ki[int(ko[j]):int(ko[j + 1])])
-        lines.append(name + "\t%d" % len(tr) + "".join("\t(%d %d %d)" % t for t in tr) + "\n")
-    return "".join(lines)
-
-
-def _emit_matches(index, bases, offs, names, state):
-    """`name <tab> #k-mers [<tab>0|1 per k-mer] [<tab>count per colour]` (tools/kmer_matches.cpp:28-35). A record
-    shorter than k leaves the worker's buffers untouched in the reference (src/kmer_matches.cpp:11), so the line
-    repeats the previous record's flags and counts: reproduced here as one worker sees them, in file order."""
-    ko, pos, counts = index.kmer_matches_batch(bases, offs)
-    k = index.k()
-    lens = np.diff(np.asarray(offs).astype(np.int64))
-    lines = []
-    for j, name in enumerate(names):
-        if lens[j] >= k:
-            state["pos"], state["counts"] = pos[int(ko[j]):int(ko[j + 1])], counts[j]
-        p = state.get("pos", np.zeros(0, dtype=np.uint8))
-        c = state.get("counts", np.zeros(index.num_colors(), dtype=np.uint32))
-        lines.append(name + "\t%d" % len(p) + "".join("\t%d" % x for x in p) + "".join("\t%d" % x for x in c) + "\n")
-    return "".join(lines)
 
 
 def dump(argv):
@@ -271,8 +253,8 @@ def dump(argv):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     tools = {"pseudoalign": pseudoalign, "dump": dump,
-             "kmer-conservation": lambda av: _query_tool(av, "kmer-conservation", _emit_conservation),
-             "kmer-matches": lambda av: _query_tool(av, "kmer-matches", _emit_matches)}
+             "kmer-conservation": lambda av: _query_tool(av, "kmer-conservation", 0),
+             "kmer-matches": lambda av: _query_tool(av, "kmer-matches", 1)}
     if not argv or argv[0] not in tools:
         print("usage: python -m fulgor_amd <pseudoalign|kmer-conservation|kmer-matches|dump> -i <index> -q <reads> -o <out> "
               "[-r tau] [--format ascii|binary|compressed] [--deduplicate] [--verbose] [--gpus N] [-t io threads]")

@@ -122,6 +122,25 @@ uint64_t env_u64(const char* name, uint64_t dflt) {
 
 }  // namespace
 
+namespace {
+// the reader's buffers (fg::HostVec, fg::SlabPool) in pinned host memory: H2D copies out of them run at PCIe speed and overlap
+// with kernels; plain memory when there is no HIP device (host-only tools, CPU tests)
+void install_pinned_allocator() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        HostAllocHooks& h = host_alloc_hooks();
+        h.alloc = [](size_t bytes, bool* pinned) -> void* {
+            void* p = nullptr;
+            if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) { *pinned = true; return p; }
+            (void)hipGetLastError();
+            *pinned = false;
+            return nullptr;  // (the pool falls back to malloc)
+        };
+        h.release = [](void* p, bool) { (void)hipHostFree(p); };
+    });
+}
+}  // namespace
+
 struct fgpu_index {
     HostIndex host;
     int device = 0;
@@ -256,8 +275,9 @@ struct fgpu_result {
     uint64_t pool_units = 0;  // slabs of id_stride entries in d_ids_pool / d_cnt_pool (reads, or segments of long reads)
     uint32_t hit_rows = 0;  // rows of d_partial filled by the last expand launch (0: no colours, nothing to add)
     DevBuf d_fmt_sizes, d_fmt_off, d_fmt_out;  // device-side formatter
-    char* h_fmt = nullptr;                     // pinned host copy of the formatted records (recycled)
+    char* h_fmt = nullptr;                     // pinned host copy of the formatted records (recycled; a slab of the process-wide pool)
     size_t h_fmt_cap = 0;
+    bool h_fmt_pinned = false;
     bool hits_folded = true;  // false: too many colours for the expand kernel's LDS histogram; k_hits counts from the bitmaps
     // The u32 colour lists (CSR: d_offsets + d_colors) are materialised on demand (stage_expand): a pass leaves the result rows, the
     // small-result slots, the sizes and the CSR offsets; fgpu_result_expand, fgpu_result_download, the ascii / binary formatters and
@@ -357,7 +377,70 @@ void build_table_on_device(fgpu_index* ix) {
     HIP_TRY(hipStreamSynchronize(s));
 }
 
-void upload_index(fgpu_index* ix) {
+// what the device gets about the colour sets besides the packed blocks, prepared on the host (no device call: fgpu_open does this
+// while the device starts up)
+struct HostForms {
+    std::vector<ListDesc> sd;     // one resolved descriptor per colour set: everything a kernel needs about a list behind one gather
+    std::vector<uint32_t> rows;   // the bitmap lists as aligned rows of w32 words, in id order
+    uint32_t w32 = 0;
+};
+void build_host_forms(const HybridSets& h, HostForms& f) {
+    const uint32_t w32 = ((h.num_colors + 31) / 32 + 3) & ~3u;  // result bitmaps move as 128-bit groups
+    f.w32 = w32;
+    // (on all threads: 0.85 M descriptors and 155 MB of bitmap rows cut out of the bit stream took a tenth of a second on one)
+    const uint64_t ns = h.num_sets();
+    std::vector<ListDesc>& sd = f.sd;
+    sd.resize(ns);
+    const unsigned T = (unsigned)std::min<uint64_t>(std::max(1u, std::min(32u, std::thread::hardware_concurrency())), ns / 4096 + 1);
+    auto parallel = [&](auto fn) {  // fn(thread, first id, last id + 1)
+        if (T == 1) { fn(0u, (uint64_t)0, ns); return; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; ++t) th.emplace_back([&, t] { fn(t, ns * t / T, ns * (t + 1) / T); });
+        for (auto& x : th) x.join();
+    };
+    const auto is_bitmap = [&](uint64_t id) { return h.set_size[id] >= h.sparse_thr && h.set_size[id] < h.dense_thr; };
+    // the bitmap lists leave the bit stream (arbitrary bit offsets) for aligned rows of w32 words, in id order
+    std::vector<uint64_t> first_row(T + 1, 0);
+    parallel([&](unsigned t, uint64_t a, uint64_t b) {
+        uint64_t nb = 0;
+        for (uint64_t id = a; id < b; ++id) nb += is_bitmap(id);
+        first_row[t + 1] = nb;
+    });
+    for (unsigned t = 0; t < T; ++t) first_row[t + 1] += first_row[t];
+    std::vector<uint32_t>& rows = f.rows;
+    rows.assign(first_row[T] * w32 + 4, 0u);
+    const auto stream_bits = [&](uint64_t pos, uint32_t len) -> uint32_t {  // len <= 32 bits at bit `pos` of the stream
+        const uint64_t w = pos >> 6, sh = pos & 63;
+        uint64_t v = h.bits[w] >> sh;
+        if (sh + len > 64) v |= h.bits[w + 1] << (64 - sh);
+        return len == 32 ? (uint32_t)v : (uint32_t)v & ((1u << len) - 1u);
+    };
+    parallel([&](unsigned t, uint64_t a, uint64_t b) {
+        uint64_t next_row = first_row[t];
+        for (uint64_t id = a; id < b; ++id) {
+            const uint32_t size = h.set_size[id];
+            ListDesc& d = sd[id];
+            d.score = 0;
+            d.id = (uint32_t)id;
+            if (is_bitmap(id)) {  // bitmap list: its row
+                const uint64_t body = h.offsets[id] + delta_code_bits(size);
+                uint32_t* row = rows.data() + next_row * w32;
+                for (uint32_t c0 = 0; c0 < h.num_colors; c0 += 32) row[c0 >> 5] = stream_bits(body + c0, std::min(32u, h.num_colors - c0));
+                d.begin = next_row++ * w32;
+                d.soff = 0;
+                d.ncodes = 0;
+                d.meta = (uint32_t)D_ENC_BITMAP;
+            } else {  // gap-coded on the host, packed blocks here
+                d.begin = h.blk_wbase[id];
+                d.ncodes = (uint32_t)(h.blk_first[id + 1] - h.blk_first[id]);
+                d.soff = d.ncodes == 1 ? h.blk_hdr[h.blk_first[id]] : h.blk_first[id];  // single block: the header itself
+                d.meta = (uint32_t)(size < h.sparse_thr ? D_ENC_DELTA_GAPS : D_ENC_COMPLEMENT);
+            }
+        }
+    });
+}
+
+void upload_index(fgpu_index* ix, const HostForms& forms) {
     const Dict& d = ix->host.dict;
     const HybridSets& h = ix->host.hybrid;
     hipStream_t s = ix->stream;
@@ -366,62 +449,9 @@ void upload_index(fgpu_index* ix) {
     if (d.table.empty()) { build_table_on_device(ix); clk.lap("dictionary table (built on the device)"); }
     else { upload(ix->d_table, d.table, s); ix->table_buckets = d.table.size() / BUCKET_WORDS; HIP_TRY(hipStreamSynchronize(s)); clk.lap("dictionary table (uploaded)"); }
     upload(ix->d_offsets, h.offsets, s);
-    const uint32_t w32 = ((h.num_colors + 31) / 32 + 3) & ~3u;  // result bitmaps move as 128-bit groups
-    {  // one resolved descriptor per colour set: everything a kernel needs about a list behind one gather
-        // (on all threads: 0.85 M descriptors and 155 MB of bitmap rows cut out of the bit stream took a tenth of a second on one)
-        const uint64_t ns = h.num_sets();
-        std::vector<ListDesc> sd(ns);
-        const unsigned T = (unsigned)std::min<uint64_t>(std::max(1u, std::min(32u, std::thread::hardware_concurrency())), ns / 4096 + 1);
-        auto parallel = [&](auto fn) {  // fn(thread, first id, last id + 1)
-            if (T == 1) { fn(0u, (uint64_t)0, ns); return; }
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < T; ++t) th.emplace_back([&, t] { fn(t, ns * t / T, ns * (t + 1) / T); });
-            for (auto& x : th) x.join();
-        };
-        const auto is_bitmap = [&](uint64_t id) { return h.set_size[id] >= h.sparse_thr && h.set_size[id] < h.dense_thr; };
-        // the bitmap lists leave the bit stream (arbitrary bit offsets) for aligned rows of w32 words, in id order
-        std::vector<uint64_t> first_row(T + 1, 0);
-        parallel([&](unsigned t, uint64_t a, uint64_t b) {
-            uint64_t nb = 0;
-            for (uint64_t id = a; id < b; ++id) nb += is_bitmap(id);
-            first_row[t + 1] = nb;
-        });
-        for (unsigned t = 0; t < T; ++t) first_row[t + 1] += first_row[t];
-        std::vector<uint32_t> rows(first_row[T] * w32 + 4, 0u);
-        const auto stream_bits = [&](uint64_t pos, uint32_t len) -> uint32_t {  // len <= 32 bits at bit `pos` of the stream
-            const uint64_t w = pos >> 6, sh = pos & 63;
-            uint64_t v = h.bits[w] >> sh;
-            if (sh + len > 64) v |= h.bits[w + 1] << (64 - sh);
-            return len == 32 ? (uint32_t)v : (uint32_t)v & ((1u << len) - 1u);
-        };
-        parallel([&](unsigned t, uint64_t a, uint64_t b) {
-            uint64_t next_row = first_row[t];
-            for (uint64_t id = a; id < b; ++id) {
-                const uint32_t size = h.set_size[id];
-                ListDesc& d = sd[id];
-                d.score = 0;
-                d.id = (uint32_t)id;
-                if (is_bitmap(id)) {  // bitmap list: its row
-                    const uint64_t body = h.offsets[id] + delta_code_bits(size);
-                    uint32_t* row = rows.data() + next_row * w32;
-                    for (uint32_t c0 = 0; c0 < h.num_colors; c0 += 32) row[c0 >> 5] = stream_bits(body + c0, std::min(32u, h.num_colors - c0));
-                    d.begin = next_row++ * w32;
-                    d.soff = 0;
-                    d.ncodes = 0;
-                    d.meta = (uint32_t)D_ENC_BITMAP;
-                } else {  // gap-coded on the host, packed blocks here
-                    d.begin = h.blk_wbase[id];
-                    d.ncodes = (uint32_t)(h.blk_first[id + 1] - h.blk_first[id]);
-                    d.soff = d.ncodes == 1 ? h.blk_hdr[h.blk_first[id]] : h.blk_first[id];  // single block: the header itself
-                    d.meta = (uint32_t)(size < h.sparse_thr ? D_ENC_DELTA_GAPS : D_ENC_COMPLEMENT);
-                }
-            }
-        });
-        clk.lap("descriptors and bitmap rows (host)");
-        upload(ix->d_set_desc, sd, s);
-        upload(ix->d_bmp_rows, rows, s);
-        HIP_TRY(hipStreamSynchronize(s));  // sd and rows are released at the end of this block
-    }
+    const uint32_t w32 = forms.w32;
+    upload(ix->d_set_desc, forms.sd, s);
+    upload(ix->d_bmp_rows, forms.rows, s);
     if (h.blk_words.size() >= (1ull << 32)) throw std::runtime_error("colour sets too large: the packed blocks exceed 2^32 words");  // BlockLane::word
     upload(ix->d_blk_words, h.blk_words, s);
     HIP_TRY(hipStreamSynchronize(s));
@@ -860,6 +890,50 @@ void stage_expand(fgpu_index* ix, fgpu_result* res) {
     if (ix->timing) ix->collect_timing(res->pending);
 }
 
+// the result's pinned output buffer: a slab of the process-wide pool (pinned once, at 0.16 ms per megabyte, and kept for the next
+// result, reader or run of the process; fgpu_prepare_host pins them ahead of the first run)
+void take_out_buffer(fgpu_result* res, size_t want) {
+    if (res->h_fmt) SlabPool::get().give(res->h_fmt, res->h_fmt_cap, res->h_fmt_pinned);
+    res->h_fmt = nullptr;
+    res->h_fmt_cap = 0;
+    install_pinned_allocator();
+    size_t got = 0;
+    bool pinned = false;
+    res->h_fmt = (char*)SlabPool::get().take(want, got, pinned);
+    res->h_fmt_cap = got;
+    res->h_fmt_pinned = pinned;
+}
+
+// what a pass of `reads` reads of at most max_kmers k-mers each asks of a result's device buffers, asked for in one go (the stages ask
+// again with the same expressions: growing is idempotent). For a worker loop that knows its batch size before its first batch.
+void reserve_result(fgpu_index* ix, fgpu_result* res, uint64_t reads, uint32_t max_kmers, int format, uint64_t out_bytes) {
+    const uint32_t W = ix->dc.w32;
+    const uint32_t stride = std::max<uint32_t>(1, max_kmers);
+    res->d_nids.ensure(reads * 4 + 16);
+    res->d_npos.ensure(reads * 4 + 16);
+    res->d_idoff.ensure(reads * 8 + 16);
+    res->d_tickets.ensure(TICKET_BYTES);
+    res->d_ids_pool.ensure(reads * (uint64_t)stride * 4 + 64);
+    res->d_cnt_pool.ensure(reads * (uint64_t)stride * 4 + 64);
+    res->d_bitmap.ensure(reads * W * 4 + 16);
+    res->d_counts.ensure(reads * 4 + 16);
+    res->d_offsets.ensure((reads + 1) * 8 + 16);
+    if (ix->small_results && W >= 32) res->d_small.ensure(reads * SMALL_RESULT * 4 + 16);
+    const uint64_t snb = (reads + SCAN_TILE - 1) / SCAN_TILE;
+    res->d_block_sums.ensure(std::max<uint64_t>(1, snb) * 8);
+    res->d_block_mapped.ensure(std::max<uint64_t>(1, snb) * 8);
+    res->d_totals.ensure(32);
+    if (format == FGPU_FMT_COMPRESSED) {
+        const uint64_t cnb = (reads + CFMT_BLOCK_READS - 1) / CFMT_BLOCK_READS;
+        res->d_fmt_sizes.ensure((reads + 3 * cnb) * 4 + 64);
+        res->d_fmt_off.ensure((cnb + 1) * 8 + 48 + reads * 4);
+    }
+    if (out_bytes) {
+        if (format == FGPU_FMT_COMPRESSED) res->d_fmt_out.ensure(out_bytes + 64);
+        if (out_bytes > res->h_fmt_cap) take_out_buffer(res, out_bytes);
+    }
+}
+
 template <typename F>
 int guarded(F f) {
     try {
@@ -901,6 +975,7 @@ int fgpu_open(const char* path, int device, fgpu_index** out) {
                     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
                         throw std::runtime_error("no HIP device available: the pseudoalignment engine has no CPU execution path");
                     if (device >= ndev) throw std::runtime_error("invalid device ordinal");
+                    clk_dev.lap("device: runtime start-up (hipGetDeviceCount)");
                     HIP_TRY(hipSetDevice(device));
                     hipDeviceProp_t prop;
                     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -914,14 +989,18 @@ int fgpu_open(const char* path, int device, fgpu_index** out) {
                             if (!t.empty() && atoi(t.c_str()) >= 0) fastx_preferred_node().store(atoi(t.c_str()));
                         } else (void)hipGetLastError();
                     }
+                    clk_dev.lap("device: properties");
                     HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+                    clk_dev.lap("device: first stream");
                     {   // the runtime sets up its pinned-memory path at the first hipHostMalloc of a process (50 ms): here, not in the first batch of reads
                         void* warm = nullptr;
                         if (hipHostMalloc(&warm, 4096, hipHostMallocDefault) == hipSuccess) (void)hipHostFree(warm);
                         else (void)hipGetLastError();
                     }
+                    install_pinned_allocator();  // (the reader's chunks and the results' output buffers: pinned slabs of one pool)
+                    clk_dev.lap("device: first pinned allocation");
                     (void)CopyEngines::get().usable(device);  // (times a small copy on every copy engine, once per process)
-                    clk_dev.lap("device start-up (beside the host's work)");
+                    clk_dev.lap("device: copy engines timed");
                 } catch (std::exception& e) {
                     dev_error = e.what();
                 }
@@ -932,11 +1011,14 @@ int fgpu_open(const char* path, int device, fgpu_index** out) {
         open_index(path, ix->host, (unsigned)env_u64("FULGOR_INGEST_THREADS", 0), device == FGPU_HOST_ONLY || env_u64("FULGOR_DICT_ON_HOST", 0) != 0);
         if (device == FGPU_HOST_ONLY) return;  // ingestion / export / save only; queries are refused
         LoadClock clk;
+        HostForms forms;
+        build_host_forms(ix->host.hybrid, forms);
+        clk.lap("descriptors and bitmap rows (host)");
         dev_init.join();
         if (!dev_error.empty()) throw std::runtime_error(dev_error);
         clk.lap("waiting for the device start-up");
         HIP_TRY(hipSetDevice(device));
-        upload_index(ix);
+        upload_index(ix, forms);
         if (ix->host.type != IDX_HYBRID) upload_generic(ix);
     });
     if (rc) { delete ix; return rc; }
@@ -1230,7 +1312,7 @@ void fgpu_result_free(fgpu_result* r) {
                       &r->d_order_off, &r->d_order, &r->d_small})
         b->release();
     if (r->h_totals) (void)hipHostFree(r->h_totals);
-    if (r->h_fmt) (void)hipHostFree(r->h_fmt);
+    if (r->h_fmt) SlabPool::get().give(r->h_fmt, r->h_fmt_cap, r->h_fmt_pinned);
     if (r->stream_lookup && r->stream_lookup != r->stream) (void)hipStreamDestroy(r->stream_lookup);
     CopyEngines::get().free_signal(r->sig_in);
     CopyEngines::get().free_signal(r->sig_out);
@@ -1379,13 +1461,9 @@ int fgpu_result_format_view(const fgpu_result* r, int format, uint32_t first_rea
             HIP_TRY(hipGetLastError());
         }
         if (bytes > res->h_fmt_cap) {  // pinned: the copy runs at PCIe speed and the buffer is reused by later passes
-            if (res->h_fmt) (void)hipHostFree(res->h_fmt);
-            res->h_fmt = nullptr;
-            res->h_fmt_cap = 0;
             size_t want = bytes + bytes / 4 + 4096;
             if (n && n < res->reserve_reads) want = std::max<size_t>(want, bytes / n * res->reserve_reads * 5 / 4 + 4096);
-            HIP_TRY(hipHostMalloc((void**)&res->h_fmt, want, hipHostMallocDefault));
-            res->h_fmt_cap = want;
+            take_out_buffer(res, want);
         }
         HIP_TRY(hipStreamSynchronize(s));  // the records are complete; their copy out runs on the kernel-free stream (a copy engine)
         if (bytes) {
@@ -1766,6 +1844,199 @@ int fgpu_kmer_matches(fgpu_index* ix, const char* bases, const uint64_t* offs, u
     return rc;
 }
 
+// ---- the two per-k-mer tools as line emitters (tools/kmer_conservation.cpp:10-56, tools/kmer_matches.cpp:10-57) -----------------
+// One batch of records in, the tool's output lines out: the lookup (and, for kmer-matches, the un-thresholded union scores) on the
+// device, the text on all host threads. The reference's workers keep their buffers across records: a record shorter than k leaves
+// index::kmer_matches' outputs untouched (src/kmer_matches.cpp:11), so its line repeats the previous record's flags and counts — the
+// emitter carries that state from batch to batch, as ONE worker reading the file in order sees it.
+struct fgpu_kmer_emitter {
+    fgpu_index* ix = nullptr;
+    int tool = 0;
+    fgpu_result* res = nullptr;
+    std::vector<uint8_t> prev_flags;    // kmer-matches: what the last record of at least k bases left behind
+    std::vector<uint32_t> prev_counts;
+};
+
+}  // extern "C"
+
+namespace {
+
+inline void put_u32(std::string& o, uint32_t x) {
+    char d[10];
+    int n = 0;
+    do { d[n++] = (char)('0' + x % 10u); x /= 10u; } while (x);
+    while (n) o.push_back(d[--n]);
+}
+
+// per-k-mer colour-set ids of an uploaded batch on the host: o[r] .. o[r + 1] index v (0xFFFFFFFF = negative k-mer)
+void kmer_ids_to_host(fgpu_index* ix, const fgpu_reads* rd, fgpu_result* res, const uint64_t* offs, uint64_t n, std::vector<uint64_t>& o, std::vector<uint32_t>& v) {
+    const uint32_t k = ix->host.dict.k;
+    const uint64_t stride = std::max<uint32_t>(1, rd->max_kmers);
+    const uint64_t units = rd->has_long ? rd->seg_first[n] : n;
+    std::vector<uint32_t> raw(units * stride);
+    if (units) HIP_TRY(hipMemcpy(raw.data(), res->d_kmer_ids.p, units * stride * 4, hipMemcpyDeviceToHost));
+    o.resize(n + 1);
+    for (uint64_t r = 0; r <= n; ++r) o[r] = rd->kmers_before(r);
+    v.resize(std::max<uint64_t>(1, o[n]));
+    for (uint64_t r = 0; r < n; ++r) {
+        // segments of a long read hold consecutive, non-overlapping k-mer ranges
+        const uint64_t u0 = rd->has_long ? rd->seg_first[r] : r, u1 = rd->has_long ? rd->seg_first[r + 1] : r + 1;
+        uint64_t at = o[r];
+        for (uint64_t u = u0; u < u1; ++u) {
+            const uint64_t len = rd->has_long ? rd->seg_end[u] - rd->seg_start[u] : offs[r + 1] - offs[r];
+            const uint64_t nk = len >= k ? len - k + 1 : 0;
+            memcpy(v.data() + at, raw.data() + u * stride, nk * 4);
+            at += nk;
+        }
+    }
+}
+
+template <typename F>
+void parallel_ranges(uint64_t n, F fn) {  // fn(thread, begin, end) over [0, n)
+    const unsigned T = (unsigned)std::min<uint64_t>(std::max(1u, std::min(32u, std::thread::hardware_concurrency())), n / 64 + 1);
+    if (T == 1) { fn(0u, (uint64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t) th.emplace_back([&, t] { fn(t, n * t / T, n * (t + 1) / T); });
+    for (auto& x : th) x.join();
+}
+unsigned parallel_ranges_threads(uint64_t n) { return (unsigned)std::min<uint64_t>(std::max(1u, std::min(32u, std::thread::hardware_concurrency())), n / 64 + 1); }
+
+}  // namespace
+
+extern "C" {
+
+int fgpu_kmer_emitter_create(fgpu_index* ix, int tool, fgpu_kmer_emitter** out) {
+    if (!ix || !out) return fail(-EINVAL, "null argument");
+    NEED_DEVICE(ix);
+    if (tool != FGPU_TOOL_KMER_CONSERVATION && tool != FGPU_TOOL_KMER_MATCHES) return fail(-EINVAL, "unknown tool");
+    *out = nullptr;
+    auto* e = new fgpu_kmer_emitter();
+    e->ix = ix;
+    e->tool = tool;
+    if (fgpu_result_create(ix, &e->res)) { delete e; return -EIO; }
+    e->prev_counts.assign(ix->host.hybrid.num_colors, 0u);
+    *out = e;
+    return 0;
+}
+
+void fgpu_kmer_emitter_free(fgpu_kmer_emitter* e) {
+    if (!e) return;
+    fgpu_result_free(e->res);
+    delete e;
+}
+
+int fgpu_kmer_emitter_add(fgpu_kmer_emitter* e, const char* bases, const uint64_t* offs, uint64_t n, const char* names, const uint64_t* name_offs,
+                          char** out, uint64_t* out_len) {
+    if (!e || !offs || !name_offs || !out || !out_len || (n && (!bases || !names))) return fail(-EINVAL, "null argument");
+    *out = nullptr;
+    *out_len = 0;
+    fgpu_index* ix = e->ix;
+    fgpu_reads* rd = nullptr;
+    int rc = fgpu_reads_upload(ix, bases, offs, n, &rd);
+    if (!rc) rc = guarded([&] {
+        HIP_TRY(hipSetDevice(ix->device));
+        fgpu_result* res = e->res;
+        const uint32_t k = ix->host.dict.k;
+        const uint64_t nc = ix->dc.n;
+        res->want_kmer_ids = true;
+        res->want_scores = e->tool == FGPU_TOOL_KMER_MATCHES;
+        stage_lookup(ix, rd, 0, n, res);
+        std::vector<uint32_t> counts;
+        if (e->tool == FGPU_TOOL_KMER_MATCHES) {
+            stage_descriptors(ix, res, res->total_kmers, FGPU_THRESHOLD_UNION);
+            stage_colors(ix, FGPU_THRESHOLD_UNION, 1.0, res);  // (the threshold only shapes the discarded bitmap; the scores are the counts)
+            counts.resize(std::max<uint64_t>(1, n * nc));
+            if (n) HIP_TRY(hipMemcpy(counts.data(), res->d_scores.p, n * nc * 4, hipMemcpyDeviceToHost));
+        } else {
+            HIP_TRY(hipStreamSynchronize(res->stream));
+            if (ix->timing) ix->collect_timing(res->pending);
+        }
+        std::vector<uint64_t> ko;
+        std::vector<uint32_t> ki;
+        kmer_ids_to_host(ix, rd, res, offs, n, ko, ki);
+        const unsigned T = parallel_ranges_threads(n);
+        std::vector<std::string> parts(T);
+        if (e->tool == FGPU_TOOL_KMER_CONSERVATION) {
+            // `name <tab> #triples [<tab>(start num_kmers color_set_id)]...`: maximal runs of consecutive positive k-mers with one colour-set id
+            parallel_ranges(n, [&](unsigned t, uint64_t a, uint64_t b) {
+                std::string& o = parts[t];
+                std::string body;
+                for (uint64_t r = a; r < b; ++r) {
+                    o.append(names + name_offs[r], names + name_offs[r + 1]);
+                    o.push_back('\t');
+                    body.clear();
+                    uint32_t triples = 0;
+                    const uint32_t* id = ki.data() + ko[r];
+                    const uint64_t nk = ko[r + 1] - ko[r];
+                    for (uint64_t i = 0; i < nk;) {
+                        uint64_t j = i + 1;
+                        while (j < nk && id[j] == id[i]) ++j;
+                        if (id[i] != 0xFFFFFFFFu) {
+                            ++triples;
+                            body += "\t(";
+                            put_u32(body, (uint32_t)i);
+                            body.push_back(' ');
+                            put_u32(body, (uint32_t)(j - i));
+                            body.push_back(' ');
+                            put_u32(body, id[i]);
+                            body.push_back(')');
+                        }
+                        i = j;
+                    }
+                    put_u32(o, triples);
+                    o += body;
+                    o.push_back('\n');
+                }
+            });
+        } else {
+            // `name <tab> #k-mers [<tab>0|1 per k-mer] [<tab>count per colour]`; src[r] = the record whose flags and counts line r shows
+            std::vector<int64_t> src(n);
+            int64_t last = -1;
+            for (uint64_t r = 0; r < n; ++r) {
+                if (offs[r + 1] - offs[r] >= k) last = (int64_t)r;
+                src[r] = last;
+            }
+            parallel_ranges(n, [&](unsigned t, uint64_t a, uint64_t b) {
+                std::string& o = parts[t];
+                for (uint64_t r = a; r < b; ++r) {
+                    o.append(names + name_offs[r], names + name_offs[r + 1]);
+                    o.push_back('\t');
+                    if (src[r] < 0) {  // (no record of at least k bases yet in this batch: what the batches before left)
+                        put_u32(o, (uint32_t)e->prev_flags.size());
+                        for (uint8_t f : e->prev_flags) { o.push_back('\t'); o.push_back(f ? '1' : '0'); }
+                        for (uint32_t c : e->prev_counts) { o.push_back('\t'); put_u32(o, c); }
+                    } else {
+                        const uint64_t q = (uint64_t)src[r];
+                        const uint32_t* id = ki.data() + ko[q];
+                        const uint64_t nk = ko[q + 1] - ko[q];
+                        put_u32(o, (uint32_t)nk);
+                        for (uint64_t i = 0; i < nk; ++i) { o.push_back('\t'); o.push_back(id[i] != 0xFFFFFFFFu ? '1' : '0'); }
+                        const uint32_t* c = counts.data() + q * nc;
+                        for (uint64_t j = 0; j < nc; ++j) { o.push_back('\t'); put_u32(o, c[j]); }
+                    }
+                    o.push_back('\n');
+                }
+            });
+            if (last >= 0) {  // the state the next batch starts from
+                const uint64_t q = (uint64_t)last;
+                e->prev_flags.resize(ko[q + 1] - ko[q]);
+                for (uint64_t i = 0; i < e->prev_flags.size(); ++i) e->prev_flags[i] = ki[ko[q] + i] != 0xFFFFFFFFu;
+                e->prev_counts.assign(counts.begin() + q * nc, counts.begin() + (q + 1) * nc);
+            }
+        }
+        uint64_t total = 0;
+        for (const std::string& p : parts) total += p.size();
+        char* buf = (char*)malloc(std::max<uint64_t>(1, total));
+        if (!buf) throw std::bad_alloc();
+        uint64_t at = 0;
+        for (const std::string& p : parts) { memcpy(buf + at, p.data(), p.size()); at += p.size(); }
+        *out = buf;
+        *out_len = total;
+    });
+    fgpu_reads_free(rd);
+    return rc;
+}
+
 // ---- output formatters (host) ---------------------------------------------------------------------------
 struct fgpu_formatter {
     int format;
@@ -1817,25 +2088,6 @@ int fgpu_formatter_finish(fgpu_formatter* f, char** out, uint64_t* out_len) {
 }
 
 // ---- query reader -------------------------------------------------------------------------------------------
-namespace {
-// the reader's buffers (fg::HostVec, fg::SlabPool) in pinned host memory: H2D copies out of them run at PCIe speed and overlap
-// with kernels; plain memory when there is no HIP device (host-only tools, CPU tests)
-void install_pinned_allocator() {
-    static std::once_flag once;
-    std::call_once(once, [] {
-        HostAllocHooks& h = host_alloc_hooks();
-        h.alloc = [](size_t bytes, bool* pinned) -> void* {
-            void* p = nullptr;
-            if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) { *pinned = true; return p; }
-            (void)hipGetLastError();
-            *pinned = false;
-            return nullptr;  // (the pool falls back to malloc)
-        };
-        h.release = [](void* p, bool) { (void)hipHostFree(p); };
-    });
-}
-}  // namespace
-
 struct fgpu_fastx {
     static constexpr int RING = 4;  // batches alive at a time: a worker loop keeps several passes in flight
     FastxReader reader;

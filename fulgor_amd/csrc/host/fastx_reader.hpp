@@ -221,6 +221,11 @@ struct FastxChunk {
         bases.reserve_exact(fastq ? text_bytes / 2 + 64 : text_bytes);  // (upper bounds: they only grow for records of fewer than 250 bytes)
         offs.reserve_exact(text_bytes / 256 + 16);
     }
+    // the two pool requests expect() makes for a range of `text_bytes` (what a caller pins ahead of a run: fgpu_prepare_host)
+    static void slab_requests(uint64_t text_bytes, bool fastq, size_t& bases_bytes, size_t& offs_bytes) {
+        bases_bytes = (size_t)(fastq ? text_bytes / 2 + 64 : text_bytes) + 1024;
+        offs_bytes = (size_t)(text_bytes / 256 + 16) * sizeof(uint64_t) + 1024;
+    }
     void on_name(const char* s, size_t n) {
         if (!want_names) return;
         size_t e = 0;

@@ -420,6 +420,93 @@ int fgpu_pseudoalign_stream(fgpu_index* ix, fgpu_fastx* query, int out_fd, int a
     return 0;
 }
 
+int fgpu_prepare_host(int device, unsigned reader_threads, unsigned workers, uint64_t batch_reads, uint64_t text_bytes_per_read, int fastq,
+                      uint64_t out_bytes_per_read) {
+    if (device < 0) return fail(-EINVAL, "invalid device ordinal");
+    return guarded([&] {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+            throw std::runtime_error("no HIP device available: the pseudoalignment engine has no CPU execution path");
+        if (device >= ndev) throw std::runtime_error("invalid device ordinal");
+        HIP_TRY(hipSetDevice(device));
+        install_pinned_allocator();
+        if (reader_threads == 0) reader_threads = FastxReader::default_threads();
+        if (workers == 0) workers = (unsigned)env_u64("FULGOR_STREAM_WORKERS", 5);
+        if (batch_reads == 0) batch_reads = env_u64("FULGOR_STREAM_BATCH", 1u << 18);
+        const uint64_t range = FastxReader::default_range_bytes();
+        // chunks alive at a time: the ranges parsed ahead of the workers (the reader's window) and the batches in flight
+        const uint64_t per_batch = (batch_reads * std::max<uint64_t>(1, text_bytes_per_read) + range - 1) / range + 1;
+        const uint64_t chunks = std::min<uint64_t>((uint64_t)reader_threads + 8 + workers * per_batch, 256);
+        size_t bb = 0, ob = 0;
+        FastxChunk::slab_requests(range, fastq != 0, bb, ob);
+        struct Held { void* p; size_t bytes; bool pinned; };
+        std::vector<Held> held;
+        std::mutex mu;
+        // (pinning is a system call per buffer that the runtime does not serialise: a few threads share the list)
+        std::vector<size_t> want;
+        for (uint64_t c = 0; c < chunks; ++c) { want.push_back(bb); want.push_back(ob); }
+        const uint64_t out_bytes = out_bytes_per_read ? (batch_reads + batch_reads / 16) * out_bytes_per_read * 5 / 4 + 4096 : 0;
+        for (unsigned w = 0; out_bytes && w < workers; ++w) want.push_back((size_t)out_bytes);
+        std::atomic<size_t> next{0};
+        std::string error;
+        auto work = [&] {
+            try {
+                (void)hipSetDevice(device);
+                for (size_t i; (i = next++) < want.size();) {
+                    Held h{nullptr, 0, false};
+                    h.p = SlabPool::get().take(want[i], h.bytes, h.pinned);
+                    std::lock_guard<std::mutex> g(mu);
+                    held.push_back(h);
+                }
+            } catch (std::exception& e) {
+                std::lock_guard<std::mutex> g(mu);
+                error = e.what();
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < 4; ++t) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
+        for (const Held& h : held) SlabPool::get().give(h.p, h.bytes, h.pinned);  // (all taken first: a slab given back early would be handed out again)
+        if (!error.empty()) throw std::runtime_error(error);
+    });
+}
+
+int fgpu_stream_prepare(fgpu_index* ix, int format, uint64_t batch_reads, unsigned workers, uint32_t max_read_bases, uint64_t out_bytes_per_read) {
+    if (!ix) return fail(-EINVAL, "null argument");
+    NEED_DEVICE(ix);
+    if (format != FGPU_FMT_ASCII && format != FGPU_FMT_BINARY && format != FGPU_FMT_COMPRESSED) return fail(-EINVAL, "unknown format");
+    return guarded([&] {
+        HIP_TRY(hipSetDevice(ix->device));
+        if (batch_reads == 0) batch_reads = env_u64("FULGOR_STREAM_BATCH", format == FGPU_FMT_COMPRESSED ? 1u << 18 : 1u << 15);
+        if (workers == 0) workers = (unsigned)env_u64("FULGOR_STREAM_WORKERS", 5);
+        workers = std::min(workers, 16u);
+        const uint32_t k = ix->host.dict.k;
+        const uint32_t max_kmers = std::min<uint32_t>(max_read_bases >= k ? max_read_bases - k + 1 : 1, SEG_KMERS);
+        const uint64_t reads = batch_reads + batch_reads / 16;
+        fgpu_stream_cache* cache = cache_of(ix);
+        std::vector<StreamWorkerState> fresh;
+        {
+            std::lock_guard<std::mutex> g(cache->mu);
+            while (fresh.size() + cache->idle.size() < workers) fresh.emplace_back();
+        }
+        try {
+            for (StreamWorkerState& w : fresh) {
+                if (fgpu_result_create(ix, &w.res)) throw std::runtime_error(fgpu_last_error());
+                w.res->reserve_reads = reads;
+                reserve_result(ix, w.res, reads, max_kmers, format, out_bytes_per_read ? reads * out_bytes_per_read * 5 / 4 + 4096 : 0);
+                w.d_bases.ensure(reads * (uint64_t)std::max<uint32_t>(max_read_bases, 1) + 1024);
+                w.d_offs.ensure((reads + 1) * 8);
+            }
+        } catch (...) {
+            for (StreamWorkerState& w : fresh) { fgpu_result_free(w.res); w.d_bases.release(); w.d_offs.release(); }
+            throw;
+        }
+        std::lock_guard<std::mutex> g(cache->mu);
+        for (StreamWorkerState& w : fresh) cache->idle.push_back(w);
+    });
+}
+
 int fgpu_last_stream_report(char** out) {
     if (!out) return fail(-EINVAL, "null argument");
     std::lock_guard<std::mutex> g(g_report_mu);

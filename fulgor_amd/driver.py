@@ -232,6 +232,24 @@ def pseudoalign_stream(index, batches, algo=FULL_INTERSECTION, threshold=0.0, si
     return n, mapped
 
 
+def _mark(what):
+    """FULGOR_CLI_TIMELINE=<epoch seconds at which the command was started>: the stages of one command on stderr"""
+    import os
+    import sys
+    import time
+    t0 = os.environ.get("FULGOR_CLI_TIMELINE")
+    if t0:
+        print("[cli] +%.3f s %s" % (time.time() - float(t0), what), file=sys.stderr, flush=True)
+
+
+def _quiet(fn, *a, **kw):
+    """a preparation step that fails leaves the run to prepare itself"""
+    try:
+        fn(*a, **kw)
+    except RuntimeError:
+        pass
+
+
 # ---- several GPUs: one process per GPU, every rank takes one part of the query file (SURVEY 8e) --------------------------
 def rank_env():
     """(rank, world size, local rank) as torchrun / the CLI's own launcher export them"""
@@ -269,8 +287,39 @@ def _place_part(part, output, offset):
     os.remove(part)
 
 
+def query_head_stats(path, limit=1 << 18):
+    """(bytes of text per record, longest sequence, is FASTQ) from the first records of a plain FASTA / FASTQ file; defaults for
+    anything else (compressed, empty, odd): what the one-run preparation sizes its buffers by — a wrong guess costs time, nothing else"""
+    try:
+        with open(path, "rb") as f:
+            head = f.read(limit)
+        if head[:2] == b"\x1f\x8b" or head[:1] not in (b"@", b">"):
+            return 320, 150, True
+        fastq = head[:1] == b"@"
+        lines = head.split(b"\n")[:-1]
+        if fastq:
+            seqs = [len(lines[i].rstrip(b"\r")) for i in range(1, len(lines), 4)]
+            recs = len(lines) // 4
+        else:
+            seqs, cur = [], None
+            for l in lines:
+                if l[:1] == b">":
+                    if cur is not None:
+                        seqs.append(cur)
+                    cur = 0
+                elif cur is not None:
+                    cur += len(l.rstrip(b"\r"))
+            recs = len(seqs)
+        if not recs or not seqs:
+            return 320, 150, True
+        used = sum(len(l) + 1 for l in lines[:recs * 4]) if fastq else len(head)
+        return max(1, used // recs), max(seqs), fastq
+    except OSError:
+        return 320, 150, True
+
+
 def pseudoalign_sharded(open_index, query, output, algo=FULL_INTERSECTION, threshold=0.0, fmt="ascii", rank=0, world=1,
-                        io_threads=0, device_for_reduce=None, batch=0):
+                        io_threads=0, device_for_reduce=None, batch=0, prepare_device=None):
     """One rank of a multi-GPU `pseudoalign`. Reads are independent units (tools/pseudoalign.cpp:22-51 keeps no state across
     reads but two counters): rank r opens the r-th of `world` byte ranges of the (plain or block-compressed) query file ONCE,
     counts its records by a walk over the record boundaries that copies nothing (fgpu_fastx_count_part), the ranks exchange
@@ -292,17 +341,64 @@ def pseudoalign_sharded(open_index, query, output, algo=FULL_INTERSECTION, thres
         begin, end = size * rank // world, size * (rank + 1) // world
     else:
         begin, end = 0, (1 << 64) - 1
-    batches = FastxReader(query, batch=batch or 1 << 18, copy=False, threads=reader_threads_per_rank(io_threads, world), begin=begin, end=end)
+    prep = None
+    if prepare_device is not None:
+        # one command = one run of the worker loop: the host buffers it needs are pinned on a thread of their own while the reader
+        # starts and the index opens (fgpu_prepare_host; opt-in: a library user that never streams is not charged the pinned memory)
+        from .index import prepare_host
+        rec_bytes, max_len, fastq = query_head_stats(query)
+        # (output records: 256 bytes per read is typical of the compressed format on thousands of colours; ascii / binary records are
+        # sized by the first batch)
+        kw = dict(device=prepare_device, reader_threads=reader_threads_per_rank(io_threads, world), batch=batch, text_bytes_per_read=rec_bytes,
+                  fastq=fastq, out_bytes_per_read=256 if fmt == "compressed" else 0)
+        prep = threading.Thread(target=lambda: _quiet(prepare_host, **kw))
+        prep.start()
+    _mark("preparation thread started" if prep is not None else "no preparation thread")
     trace = os.environ.get("FULGOR_TRACE_OPENS") == "1"  # (tests: one open of the query part and one of the index per rank)
-    if trace:
-        print("[rank] query part opened (rank %d/%d, text bytes %d..%d)" % (rank, world, begin, min(end, 1 << 62)), file=sys.stderr, flush=True)
+    made = {}
+
+    def open_reader():
+        """this rank's part of the query file: opened once (its threads start parsing at once) and, for a multi-GPU run, counted"""
+        try:
+            made["reader"] = FastxReader(query, batch=batch or 1 << 18, copy=False, threads=reader_threads_per_rank(io_threads, world),
+                                         begin=begin, end=end)
+            _mark("query reader open")
+            if trace:
+                print("[rank] query part opened (rank %d/%d, text bytes %d..%d)" % (rank, world, begin, min(end, 1 << 62)), file=sys.stderr, flush=True)
+            if world > 1:
+                made["count"] = made["reader"].count()
+        except Exception as e:  # noqa: BLE001 — raised on the caller's thread below
+            made["error"] = e
+
+    index = None
+    if prepare_device is not None:
+        # (the command line: the reader opens on a thread of its own WHILE the index opens — both wait for the HIP runtime to start, a
+        # fifth of a second in a fresh process, and the container is read meanwhile)
+        th = threading.Thread(target=open_reader)
+        th.start()
+        try:
+            index = open_index()
+        finally:
+            th.join()
+    else:
+        open_reader()
+    if "error" in made:
+        raise made["error"]
+    batches = made["reader"]
     first_id = 0
     if world > 1:
-        mine = torch.tensor([batches.count()], dtype=torch.int64, device=device_for_reduce)
+        mine = torch.tensor([made["count"]], dtype=torch.int64, device=device_for_reduce)
         counts = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(counts, mine)
         first_id = int(sum(int(c.item()) for c in counts[:rank]))
-    index = open_index()
+    if index is None:
+        index = open_index()
+    if prep is not None:
+        prep.join()
+        _mark("host buffers pinned")
+        if hasattr(index, "stream_prepare"):
+            _quiet(index.stream_prepare, FORMATS[fmt], batch, 0, max_len, 256 if fmt == "compressed" else 0)
+        _mark("worker results created")
     if trace:
         print("[rank] index opened (rank %d/%d)" % (rank, world), file=sys.stderr, flush=True)
     if world > 1 and hasattr(index, "device_report"):  # every rank of a multi-GPU run says where it runs and which copy engines it chose
@@ -311,11 +407,14 @@ def pseudoalign_sharded(open_index, query, output, algo=FULL_INTERSECTION, thres
     with open(part, "wb") as out:
         if hasattr(index, "pseudoalign_stream"):  # the engine: the native worker loop
             out.flush()
+            _mark("stream starts")
             n, mapped = index.pseudoalign_stream(batches, out.fileno(), algo, threshold, FORMATS[fmt], first_id, rank == 0, batch)
+            _mark("stream done")
         else:  # (an index that is not the engine's: the CPU tests of this sharding logic)
             n, mapped = pseudoalign_stream(index, batches, algo, threshold, sink=out, fmt=fmt, first_id=first_id,
                                            write_header=rank == 0)
     batches.close()
+    _mark("reader closed")
     if world > 1:
         t = torch.tensor([n, mapped], dtype=torch.int64, device=device_for_reduce)
         dist.all_reduce(t)

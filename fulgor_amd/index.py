@@ -51,6 +51,13 @@ def _take_csr(L, n, p_off, p_val):
     return offs, vals
 
 
+def prepare_host(device=0, reader_threads=0, workers=0, batch=0, text_bytes_per_read=320, fastq=True, out_bytes_per_read=0):
+    """opt-in, needs no index (fgpu_prepare_host): starts the HIP runtime on `device` and pins the host buffers one run of the streamed
+    worker loop will use into the process-wide pool. The command line calls it on a thread of its own while the index opens."""
+    _native.check(_native.lib().fgpu_prepare_host(int(device), int(reader_threads), int(workers), int(batch), int(text_bytes_per_read),
+                                                  1 if fastq else 0, int(out_bytes_per_read)))
+
+
 class Reads:
     """A batch of reads resident in HBM."""
 
@@ -133,6 +140,34 @@ class Result:
     def close(self):
         if self._h:
             self._L.fgpu_result_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class KmerEmitter:
+    """one worker of `fulgor kmer-conservation` (tool 0) or `fulgor kmer-matches` (tool 1) as a native line emitter
+    (fgpu_kmer_emitter_*): add(reader) takes the reader's current batch and returns the tool's output lines for it"""
+
+    def __init__(self, index, tool):
+        self._L = _native.lib()
+        self.index = index
+        h = C.c_void_p()
+        _native.check(self._L.fgpu_kmer_emitter_create(index._h, int(tool), C.byref(h)))
+        self._h = h
+
+    def add(self, bases, offs, names, name_offs, n):
+        """bases / offs / names / name_offs: numpy arrays or raw addresses; n records -> bytes"""
+        def addr(x):
+            return C.c_void_p(x) if isinstance(x, int) else _ptr(x)
+        p, ln = C.c_void_p(), C.c_uint64()
+        _native.check(self._L.fgpu_kmer_emitter_add(self._h, addr(bases), addr(offs), int(n), addr(names), addr(name_offs), C.byref(p), C.byref(ln)))
+        return _native.take_bytes(p, ln.value)
+
+    def close(self):
+        if self._h:
+            self._L.fgpu_kmer_emitter_free(self._h)
             self._h = None
 
     def __del__(self):
@@ -286,6 +321,11 @@ class Index:
                                                       int(first_read_id), 1 if write_header else 0, int(batch), int(workers),
                                                       C.byref(n), C.byref(m)))
         return n.value, m.value
+
+    def stream_prepare(self, fmt=0, batch=0, workers=0, max_read_bases=150, out_bytes_per_read=0):
+        """opt-in, for a process that streams once (the command line): creates the worker loop's results — streams, device buffers
+        sized for its batches, pinned output buffers — ahead of pseudoalign_stream (fgpu_stream_prepare)"""
+        _native.check(self._L.fgpu_stream_prepare(self._h, int(fmt), int(batch), int(workers), int(max_read_bases), int(out_bytes_per_read)))
 
     def last_stream_report(self):
         """timeline of the last pseudoalign_stream of this process (text)"""

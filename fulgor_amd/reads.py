@@ -153,6 +153,22 @@ class FastxReader:
         self._N.check(self._L.fgpu_fastx_count_part(self._h, self._C.byref(n)))
         return n.value
 
+    def next_raw(self):
+        """the next batch as raw addresses into the reader's own buffers: (bases address, offsets address, n); n = 0 at the end
+        (for a caller that hands them straight to another native call)"""
+        C = self._C
+        pb, po, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._N.check(self._L.fgpu_fastx_next(self._h, self.batch, C.byref(pb), C.byref(po), C.byref(n)))
+        self._last_n = n.value
+        return pb.value or 0, po.value or 0, n.value
+
+    def names_raw(self):
+        """(names address, name offsets address) of the batch returned last: the names concatenated + (n + 1) offsets"""
+        C = self._C
+        pn, po = C.c_void_p(), C.c_void_p()
+        self._N.check(self._L.fgpu_fastx_names(self._h, C.byref(pn), C.byref(po)))
+        return pn.value or 0, po.value or 0
+
     def names(self):
         """names of the records of the batch returned last (header up to the first blank), as a list of str"""
         C = self._C

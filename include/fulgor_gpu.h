@@ -86,6 +86,17 @@ int fgpu_kmer_color_set_ids(fgpu_index* idx, const char* bases, const uint64_t* 
 /* index::kmer_matches counts (src/kmer_matches.cpp:7-30): out_counts[r * num_colors + c] = number of positive
  * k-mers of read r whose colour set contains c (all zero for reads shorter than k). Dense: size n by num_colors. */
 int fgpu_kmer_matches(fgpu_index* idx, const char* bases, const uint64_t* offs, uint64_t n, uint32_t** out_counts);
+/* The two tools as line emitters (tools/kmer_conservation.cpp:10-56: `name <tab> #triples [<tab>(start num_kmers color_set_id)]...`;
+ * tools/kmer_matches.cpp:10-57: `name <tab> #k-mers [<tab>0|1 per k-mer] [<tab>count per colour]`): a batch of records in — bases +
+ * (n + 1) offsets, names + (n + 1) offsets as fgpu_fastx_names gives them —, the tool's output lines for them out, in order (malloc'd:
+ * fgpu_free). Lookup and counts on the device, the text on the host's threads. An emitter is one worker of the reference reading the
+ * file in order: a record shorter than k repeats what the previous record left in the worker's buffers (src/kmer_matches.cpp:11). */
+typedef struct fgpu_kmer_emitter fgpu_kmer_emitter;
+enum { FGPU_TOOL_KMER_CONSERVATION = 0, FGPU_TOOL_KMER_MATCHES = 1 };
+int fgpu_kmer_emitter_create(fgpu_index* idx, int tool, fgpu_kmer_emitter** out);
+int fgpu_kmer_emitter_add(fgpu_kmer_emitter* e, const char* bases, const uint64_t* offs, uint64_t n, const char* names, const uint64_t* name_offs,
+                          char** out, uint64_t* out_len);
+void fgpu_kmer_emitter_free(fgpu_kmer_emitter* e);
 void fgpu_free(void* p);
 
 /* ---- device-resident calls (what the driver loop and bench.py use) -------------------------------- */
@@ -222,6 +233,20 @@ int fgpu_fastx_ring(void);
  * (src/ps_utils.cpp:417-448). The reader is consumed; it must not be used with fgpu_fastx_next at the same time. */
 int fgpu_pseudoalign_stream(fgpu_index* idx, fgpu_fastx* query, int out_fd, int algo, double tau, int format, uint64_t first_read_id,
                             int write_header, uint64_t batch_reads, unsigned workers, uint64_t* num_reads, uint64_t* num_mapped);
+/* Opt-in preparation of a process that is about to run fgpu_pseudoalign_stream ONCE (one `pseudoalign` command: the reference's only
+ * published figure is one command, tools/pseudoalign.cpp:340-369). The first run of a process otherwise pays for pinning 0.4-0.7 GB of
+ * host memory (0.16 ms per megabyte, and pinning stalls the copies in flight) and for creating the workers' streams and buffers.
+ *   fgpu_prepare_host needs no index: it starts the HIP runtime on `device` and pins the host buffers the loop will use — the reader's
+ *     chunks (reader_threads + 8 ranges parsed ahead and `workers` batches of batch_reads reads of text_bytes_per_read bytes of text each,
+ *     FASTQ or FASTA) and, if out_bytes_per_read is given, one output buffer per worker — into the process-wide pool the reader and the
+ *     results draw from. Meant to be called on a thread of its own WHILE fgpu_open runs on another.
+ *   fgpu_stream_prepare creates the workers' results (streams, device buffers sized for batches of batch_reads reads of at most
+ *     max_read_bases bases, output buffers if out_bytes_per_read is given) and keeps them with the index, where the loop finds them.
+ * 0 for reader_threads / workers / batch_reads: the loop's defaults. Neither is ever called by the library itself: a library user
+ * that never streams is not charged the pinned memory. */
+int fgpu_prepare_host(int device, unsigned reader_threads, unsigned workers, uint64_t batch_reads, uint64_t text_bytes_per_read, int fastq,
+                      uint64_t out_bytes_per_read);
+int fgpu_stream_prepare(fgpu_index* idx, int format, uint64_t batch_reads, unsigned workers, uint32_t max_read_bases, uint64_t out_bytes_per_read);
 /* timeline of the last fgpu_pseudoalign_stream of this process as text (per batch: when it was acquired from the parser, queued,
  * through the colour stage, formatted and copied out, written), plus what the parser threads spent; malloc'd: fgpu_free */
 int fgpu_last_stream_report(char** out);

@@ -1836,6 +1836,11 @@ def test_kmer_tools_fuzz_against_the_oracle(which, s10_gpu, s10_oracle, s4546sma
     src = max(read_fasta(S10_GENOMES[2 if which == "s10" else 0]), key=len)
     rng = np.random.default_rng(777)
     special = [0, 0, 1, 30, 31, 32, 158, 159, 160, 286, 287, 288, 542, 543, 544, 9000]
+    # the native line emitters of the two tools (fgpu_kmer_emitter_*: what the command line writes), fed the same batches one after the
+    # other: their state — what a record shorter than k repeats (src/kmer_matches.cpp:11) — carries over from batch to batch
+    from fulgor_amd.index import KmerEmitter
+    em_c, em_m = KmerEmitter(ix, 0), KmerEmitter(ix, 1)
+    prev = (np.zeros(0, dtype=np.uint8), np.zeros(ix.num_colors(), dtype=np.uint32))
     for trial in range(60 * int(os.environ.get("FULGOR_TEST_FUZZ_SCALE", "1"))):
         n = int(rng.integers(1, 400))
         lens = [int(x) for x in rng.integers(0, int(rng.choice([50, 200, 600])), size=n)]
@@ -1863,6 +1868,29 @@ def test_kmer_tools_fuzz_against_the_oracle(which, s10_gpu, s10_oracle, s4546sma
             if j % 5 == 0 or len(r) in special:
                 opos, ocnt = orc.kmer_matches(r)
                 assert np.array_equal(pos[a:e], opos) and np.array_equal(counts[j], ocnt), (which, trial, j, len(r))
+        # the emitters' lines for this batch against lines made of the answers above (those were checked against the oracle)
+        names = [("rec%d_%d" % (trial, j)).encode() for j in range(n)]
+        nb, no = pack_reads(names)
+        want_c, want_m = [], []
+        for j, r in enumerate(reads):
+            a, e = int(ko[j]), int(ko[j + 1])
+            tr = conservation_triples(ki[a:e])
+            want_c.append(names[j] + b"\t%d" % len(tr) + b"".join(b"\t(%d %d %d)" % t for t in tr) + b"\n")
+            if len(r) >= 31:
+                prev = (pos[a:e], counts[j])
+            want_m.append(names[j] + b"\t%d" % len(prev[0]) + b"".join(b"\t%d" % x for x in prev[0]) + b"".join(b"\t%d" % x for x in prev[1]) + b"\n")
+        assert bytes(em_c.add(b, o, nb, no, n)) == b"".join(want_c), (which, trial)
+        if which == "s10" or trial % 6 == 0:  # (4546 counts per line: a sixth of the batches)
+            assert bytes(em_m.add(b, o, nb, no, n)) == b"".join(want_m), (which, trial)
+        else:
+            prev_skip = [j for j, r in enumerate(reads) if len(r) >= 31]
+            if prev_skip:  # the emitter did not see this batch: bring its state along through a batch of that one record
+                j = prev_skip[-1]
+                b1, o1 = pack_reads([reads[j]])
+                n1, no1 = pack_reads([names[j]])
+                em_m.add(b1, o1, n1, no1, 1)
+    em_c.close()
+    em_m.close()
 
 
 def test_stream_loop_reports_an_output_that_cannot_be_written(s10_gpu, tmp_path):
