@@ -798,6 +798,16 @@ def cli_end_to_end(ix, bases, offs, algo, tau, n, read_len, fmt="compressed", re
         del rec
         best = None
         runs = []
+        prepared = False
+        if fmt == "compressed" and not os.environ.get("FULGOR_NO_PREPARE"):
+            # what the command line does beside the index open (fgpu_prepare_host + fgpu_stream_prepare: host buffers pinned, worker
+            # results created), done here in front of the first run and outside its clock: first_run_value is then what the command's own
+            # clock shows for a cold process (cli_cold.query_s is that, measured on a real one)
+            from fulgor_amd.index import prepare_host
+            rec_bytes, max_len, is_fq = driver.query_head_stats(path)
+            prepare_host(ix.device, text_bytes_per_read=rec_bytes, fastq=is_fq, out_bytes_per_read=256)
+            ix.stream_prepare(2, 0, 0, max_len, 256)
+            prepared = True
         for _ in range(repeats):  # the first run pins the host buffers and sizes the device buffers; the later ones find them (and spread by +-20 %)
             t0 = time.perf_counter()
             got, mapped = driver.pseudoalign_sharded(lambda: ix, path, "/dev/null", algo, tau, fmt)
@@ -822,10 +832,12 @@ def cli_end_to_end(ix, bases, offs, algo, tau, n, read_len, fmt="compressed", re
     return {"value": round(n / best, 1), "unit": "reads/s", "reads": int(n), "fastq_bytes": int(size),
             "runs_ms": [round(t * 1e3, 1) for t in runs], "first_run_value": round(n / runs[0], 1),
             "median_value": round(n / sorted(runs[1:])[len(runs[1:]) // 2], 1), "last_run": report, "host": host_description(),
+            "first_run_prepared": prepared,
             "includes": "FASTQ file on tmpfs -> byte ranges read and parsed by the reader's threads into pinned chunks -> H2D of every chunk "
                         "(copy engine) -> lookup, intersection (no u32 colour lists), compressed records built on the device -> D2H (copy "
                         "engine) -> /dev/null, batches of 2^18 reads on 5 streams (fgpu_pseudoalign_stream); index already resident; value = best of "
-                        "six runs in one process (the first pins the host buffers: first_run_value; median_value = median of the other five)"}
+                        "six runs in one process (first_run_value: the first of them, behind the preparation the command line runs beside the "
+                        "index open — fgpu_prepare_host + fgpu_stream_prepare — when first_run_prepared; median_value = median of the other five)"}
 
 
 def cpu_baseline(ix, bases, offs, algo, tau, itype=0, psize=160, csize=16):

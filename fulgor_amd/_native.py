@@ -94,6 +94,7 @@ def lib():
     L.fgpu_result_algorithmic_bytes.argtypes = [vp, u64p, u64p, u64p]
     L.fgpu_result_checksum.argtypes = [vp, u64p, u64p]
     L.fgpu_tune.argtypes = [vp, C.c_int, C.c_uint64]
+    L.fgpu_result_distinct_lists.argtypes = [vp, u64p]
     L.fgpu_device_report.argtypes = [vp, C.POINTER(vp)]
     L.fgpu_copy_engines_classify.argtypes = [u32p, C.POINTER(C.c_double), C.c_uint32, u32p, u32p]
     L.fgpu_timing_enable.argtypes = [vp, C.c_int]

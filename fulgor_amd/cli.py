@@ -99,9 +99,6 @@ def pseudoalign(argv):
         return 1
     rank, world, local = driver.rank_env()
     if a.gpus > 1 and "RANK" not in os.environ:
-        if a.deduplicate:
-            print("--deduplicate runs on one GPU", file=sys.stderr)
-            return 1
         return _launch_ranks(argv, a.gpus)
     if world != a.gpus:
         print("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
@@ -144,14 +141,16 @@ def pseudoalign(argv):
         return ix
 
     try:
-        if a.deduplicate:
+        if a.deduplicate and os.environ.get("FULGOR_DEDUPLICATE_ON_HOST"):  # (the round-2 path: grouping in numpy; kept for A/B runs)
             index = open_index()
             batches = FastxReader(a.query_filename, batch=1 << 19, copy=False, threads=a.num_threads)
             with open(a.output_filename, "wb") as out:
                 n, mapped = driver.pseudoalign_stream(index, batches, algo, 0.0, sink=out, fmt=a.format, deduplicate=True)
             batches.close()
         else:  # read id = 0-based file order (src/ps_utils.cpp:276,286); parsing overlaps with the GPU passes
-            n, mapped = driver.pseudoalign_sharded(open_index, a.query_filename,
+            # (--deduplicate: the same streamed path with the device-side grouping switched on — every distinct list of colour-set ids
+            # of a batch is intersected once; records leave in file order, whatever the format)
+            n, mapped = driver.pseudoalign_sharded((lambda: open_index().tune(deduplicate=True)) if a.deduplicate else open_index, a.query_filename,
                                                    a.output_filename, algo, a.threshold or 0.0, a.format, rank, world,
                                                    io_threads=a.num_threads, device_for_reduce=reduce_device,
                                                    prepare_device=None if os.environ.get("FULGOR_NO_PREPARE") else device)

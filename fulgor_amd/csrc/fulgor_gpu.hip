@@ -125,6 +125,11 @@ uint64_t env_u64(const char* name, uint64_t dflt) {
 namespace {
 // the reader's buffers (fg::HostVec, fg::SlabPool) in pinned host memory: H2D copies out of them run at PCIe speed and overlap
 // with kernels; plain memory when there is no HIP device (host-only tools, CPU tests)
+// opens whose device thread is still starting up (first stream, first pinned allocation, the copy engines' confirmation): pinning
+// hundreds of megabytes at the same time doubles the time those first calls take (profiles/r6/cli_cold_r6.txt), so fgpu_prepare_host
+// lets them finish first
+std::atomic<int> g_device_startups{0};
+
 void install_pinned_allocator() {
     static std::once_flag once;
     std::call_once(once, [] {
@@ -150,6 +155,7 @@ struct fgpu_index {
     uint64_t order_min_reads = env_u64("FULGOR_ORDER", 0) ? env_u64("FULGOR_ORDER_MIN_READS", 16384) : ~0ull;  // off: measured, no gain
     bool small_results = env_u64("FULGOR_SMALL", 1) != 0;
     bool dense_rows = env_u64("FULGOR_DENSE_ROWS", 1) != 0;  // use the dense rows (when they were built: d_rows)
+    bool deduplicate = env_u64("FULGOR_DEDUPLICATE", 0) != 0;  // full intersection: every distinct id list of a pass once (--deduplicate)
     DevBuf d_table, d_bmp_rows, d_offsets, d_set_desc, d_blk_words, d_set_rank, d_rows;
     uint64_t table_buckets = 0;  // buckets of d_table (hashed region, tail, overflow region)
     DevBuf d_gops, d_gset_ops_off, d_gset_ops, d_garena, d_gblk_hdr, d_gblk_words, d_gset_bytes;
@@ -266,6 +272,9 @@ struct fgpu_result {
     DevBuf d_order_keys, d_order_hist, d_order_off, d_order;      // locality order of a pass (k_order_*)
     uint64_t order_hist_sets = 0;  // entries of d_order_hist that are known to be zero
     DevBuf d_small;                // results of at most SMALL_RESULT colours as colours (small_mode)
+    // --deduplicate (stage_colors): order of the reads by id list, groups of equal lists, the results of one list per group
+    DevBuf d_dd_hash, d_dd_hash2, d_dd_idx, d_dd_idx2, d_dd_head, d_dd_goff, d_dd_group, d_dd_nids, d_dd_idoff, d_dd_bitmap, d_dd_counts, d_dd_small, d_dd_tmp;
+    uint64_t dd_groups = 0;        // distinct id lists of the last deduplicated pass
     bool small_mode = false;       // the last pass left no bitmap row for results of 0..SMALL_RESULT colours
     bool want_kmer_ids = false, want_scores = false;
     uint64_t total_ids = 0;
@@ -764,21 +773,70 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
             res->d_small.ensure(cap_n * SMALL_RESULT * 4 + 16);
             small_out = res->d_small.as<uint32_t>();
         }
+        // what the intersection kernel reads and writes: the reads' own lists and results, or (--deduplicate) one list per group of
+        // reads with equal lists and that group's result
+        uint64_t nl = n;
+        const uint32_t* in_nids = res->d_nids.as<uint32_t>();
+        const uint64_t* in_idoff = res->d_idoff.as<uint64_t>();
+        uint32_t* out_bitmap = res->d_bitmap.as<uint32_t>();
+        uint32_t* out_counts = res->d_counts.as<uint32_t>();
+        uint32_t* out_small = small_out;
+        const bool dedup = ix->deduplicate && n > 1 && n < (1ull << 32);
+        res->dd_groups = 0;
+        if (dedup) {
+            const uint32_t g256 = (uint32_t)std::min<uint64_t>((n + 255) / 256, (uint64_t)ix->num_cus * 16);
+            for (DevBuf* b : {&res->d_dd_hash, &res->d_dd_hash2}) b->ensure(cap_n * 8 + 16);
+            for (DevBuf* b : {&res->d_dd_idx, &res->d_dd_idx2, &res->d_dd_head, &res->d_dd_group}) b->ensure(cap_n * 4 + 16);
+            res->d_dd_goff.ensure((cap_n + 3) * 8 + 16);
+            Timed t(ix, res, FGPU_K_ORDER);
+            hipLaunchKernelGGL(k_dd_hash, dim3(g256), dim3(256), 0, s, in_nids, in_idoff, res->d_ids_pool.as<uint32_t>(), n,
+                               res->d_dd_hash.as<unsigned long long>(), res->d_dd_idx.as<uint32_t>());
+            size_t need = 0;
+            HIP_TRY(rocprim::radix_sort_pairs(nullptr, need, res->d_dd_hash.as<unsigned long long>(), res->d_dd_hash2.as<unsigned long long>(), res->d_dd_idx.as<uint32_t>(),
+                                              res->d_dd_idx2.as<uint32_t>(), (size_t)n, 0u, 64u, s));
+            res->d_dd_tmp.ensure(need + 256);
+            need = res->d_dd_tmp.cap;
+            HIP_TRY(rocprim::radix_sort_pairs(res->d_dd_tmp.p, need, res->d_dd_hash.as<unsigned long long>(), res->d_dd_hash2.as<unsigned long long>(), res->d_dd_idx.as<uint32_t>(),
+                                              res->d_dd_idx2.as<uint32_t>(), (size_t)n, 0u, 64u, s));
+            hipLaunchKernelGGL(k_dd_heads, dim3(g256), dim3(256), 0, s, res->d_dd_hash2.as<unsigned long long>(), res->d_dd_idx2.as<uint32_t>(), in_nids, in_idoff,
+                               res->d_ids_pool.as<uint32_t>(), n, res->d_dd_head.as<uint32_t>());
+            uint64_t* totals = res->d_dd_goff.as<uint64_t>() + (n + 1);  // scratch behind the offsets (keeps d_totals intact)
+            run_scan(ix, res, res->d_dd_head.as<uint32_t>(), n, res->d_dd_goff.as<uint64_t>(), totals, -1);  // (inside this bracket)
+            uint64_t h[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(h, totals, 16, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            nl = h[0];
+            res->dd_groups = nl;
+            res->d_dd_nids.ensure(nl * 4 + 16);
+            res->d_dd_idoff.ensure(nl * 8 + 16);
+            res->d_dd_bitmap.ensure(nl * W * 4 + 16);
+            res->d_dd_counts.ensure(nl * 4 + 16);
+            if (small_out) res->d_dd_small.ensure(nl * SMALL_RESULT * 4 + 16);
+            hipLaunchKernelGGL(k_dd_groups, dim3(g256), dim3(256), 0, s, res->d_dd_idx2.as<uint32_t>(), res->d_dd_head.as<uint32_t>(), res->d_dd_goff.as<uint64_t>(),
+                               in_nids, in_idoff, n, res->d_dd_group.as<uint32_t>(), res->d_dd_nids.as<uint32_t>(), res->d_dd_idoff.as<uint64_t>());
+            HIP_TRY(hipGetLastError());
+            in_nids = res->d_dd_nids.as<uint32_t>();
+            in_idoff = res->d_dd_idoff.as<uint64_t>();
+            out_bitmap = res->d_dd_bitmap.as<uint32_t>();
+            out_counts = res->d_dd_counts.as<uint32_t>();
+            out_small = small_out ? res->d_dd_small.as<uint32_t>() : nullptr;
+        }
+        const uint32_t* use_order = dedup ? nullptr : order;  // (the locality order is an order of the reads, not of the groups)
         auto launch = [&](auto kernel) {
             const uint32_t wpb = pick_waves(per_wave, (const void*)kernel);
-            const uint32_t grid = resident_grid(kernel, n, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
+            const uint32_t grid = resident_grid(kernel, nl, wpb, ix->num_cus, 64 * wpb, wpb * per_wave);
             Timed t(ix, res, FGPU_K_INTERSECT);
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, res->d_nids.as<uint32_t>(),
-                               res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), n, res->d_bitmap.as<uint32_t>(),
-                               res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, order, small_out);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wpb), wpb * per_wave, s, ix->dc, in_nids,
+                               in_idoff, res->d_ids_pool.as<uint32_t>(), nl, out_bitmap,
+                               out_counts, res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, use_order, out_small);
             HIP_TRY(hipGetLastError());
         };
         auto launch_rows = [&](auto kernel) {
-            const uint32_t grid = resident_grid(kernel, n, 4, ix->num_cus, 256, 0);
+            const uint32_t grid = resident_grid(kernel, nl, 4, ix->num_cus, 256, 0);
             Timed t(ix, res, FGPU_K_INTERSECT);
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, ix->d_rows.as<u32x4>(), W, res->d_nids.as<uint32_t>(),
-                               res->d_idoff.as<uint64_t>(), res->d_ids_pool.as<uint32_t>(), n, res->d_bitmap.as<uint32_t>(),
-                               res->d_counts.as<uint32_t>(), res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, order, small_out);
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, ix->d_rows.as<u32x4>(), W, in_nids,
+                               in_idoff, res->d_ids_pool.as<uint32_t>(), nl, out_bitmap,
+                               out_counts, res->d_tickets.as<unsigned int>() + 8 * TICKET_STRIDE, use_order, out_small);
             HIP_TRY(hipGetLastError());
         };
         if (ix->d_rows.p && ix->dense_rows) {
@@ -787,6 +845,14 @@ void stage_colors(fgpu_index* ix, int algo, double tau, fgpu_result* res) {
             else launch_rows(k2r_intersect<4>);
         } else if (pair) launch(k2a_intersect<true>);
         else launch(k2a_intersect<false>);
+        if (dedup) {  // every read takes the result of its group
+            Timed t(ix, res, FGPU_K_ORDER);
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 3) / 4, (uint64_t)ix->num_cus * 16);
+            hipLaunchKernelGGL(k_dd_fanout, dim3(grid), dim3(256), 0, s, res->d_dd_group.as<uint32_t>(), res->d_dd_bitmap.as<uint32_t>(), res->d_dd_counts.as<uint32_t>(),
+                               out_small ? res->d_dd_small.as<uint32_t>() : (const uint32_t*)nullptr, n, W, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
+                               small_out);
+            HIP_TRY(hipGetLastError());
+        }
     } else if (algo == FGPU_THRESHOLD_UNION) {
         // score counters from the longest read of the batch: biased 8-bit up to 127 k-mers, plain 8-bit up to 255, biased
         // 16-bit up to 32767, else 32-bit
@@ -968,8 +1034,10 @@ int fgpu_open(const char* path, int device, fgpu_index** out) {
         std::string dev_error;
         std::thread dev_init;
         LoadClock clk_dev;
+        if (device != FGPU_HOST_ONLY) g_device_startups.fetch_add(1);
         if (device != FGPU_HOST_ONLY)
             dev_init = std::thread([&] {
+                struct Done { ~Done() { g_device_startups.fetch_sub(1); } } done;
                 try {
                     int ndev = 0;  // (the first call into the runtime: this is where a fresh process spends its start-up time)
                     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -1309,7 +1377,8 @@ void fgpu_result_free(fgpu_result* r) {
     for (DevBuf* b : {&r->d_nids, &r->d_npos, &r->d_idoff, &r->d_ids_pool, &r->d_cnt_pool, &r->d_cursor, &r->d_bitmap,
                       &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct, &r->d_partial, &r->d_tickets, &r->d_idcsr, &r->d_desc, &r->d_kmer_ids, &r->d_scores, &r->d_fmt_sizes, &r->d_fmt_off, &r->d_fmt_out,
                       &r->d_nids2, &r->d_npos2, &r->d_idoff2, &r->d_ids_pool2, &r->d_cnt_pool2, &r->d_order_keys, &r->d_order_hist,
-                      &r->d_order_off, &r->d_order, &r->d_small})
+                      &r->d_order_off, &r->d_order, &r->d_small, &r->d_dd_hash, &r->d_dd_hash2, &r->d_dd_idx, &r->d_dd_idx2, &r->d_dd_head, &r->d_dd_goff,
+                      &r->d_dd_group, &r->d_dd_nids, &r->d_dd_idoff, &r->d_dd_bitmap, &r->d_dd_counts, &r->d_dd_small, &r->d_dd_tmp})
         b->release();
     if (r->h_totals) (void)hipHostFree(r->h_totals);
     if (r->h_fmt) SlabPool::get().give(r->h_fmt, r->h_fmt_cap, r->h_fmt_pinned);
@@ -1626,7 +1695,14 @@ int fgpu_tune(fgpu_index* ix, int knob, uint64_t value) {
     if (knob == FGPU_TUNE_ORDER_MIN_READS) ix->order_min_reads = value;
     else if (knob == FGPU_TUNE_SMALL_RESULTS) ix->small_results = value != 0;
     else if (knob == FGPU_TUNE_DENSE_ROWS) ix->dense_rows = value != 0;
+    else if (knob == FGPU_TUNE_DEDUPLICATE) ix->deduplicate = value != 0;
     else return fail(-EINVAL, "unknown knob");
+    return 0;
+}
+
+int fgpu_result_distinct_lists(const fgpu_result* r, uint64_t* num_lists) {
+    if (!r || !num_lists) return fail(-EINVAL, "null argument");
+    *num_lists = r->dd_groups;
     return 0;
 }
 

@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                                                                       uint32_t* __restrict__ kmer_out) {
     foreign_writes_acquire();  // (the bases and offsets may have been written by a copy engine that the HIP runtime knows nothing about)
     constexpr int KMAX = 128 * HALVES;      // k-mers per unit
-    constexpr uint32_t TICKET = HALVES == 1 ? K1_TICKET : (HALVES == 2 ? 6 : 1);  // longer units: one to three per pass, and the planes of a ticket's span live in LDS: short tickets
+#ifndef FG_K1_TICKET2
+#define FG_K1_TICKET2 6
+#endif
+    constexpr uint32_t TICKET = HALVES == 1 ? K1_TICKET : (HALVES == 2 ? FG_K1_TICKET2 : 1);  // longer units: one to three per pass, and the planes of a ticket's span live in LDS: short tickets
     constexpr int NA = 2 * HALVES + 1;      // rounds of 64 m-mer positions (the last one: 16 positions)
     constexpr int SPAN_BASES = (int)TICKET * (KMAX + 30) + 16;  // the units of a ticket + what the 16-byte alignment of its first load adds
     constexpr int NIT = (SPAN_BASES + 1023) / 1024;              // rounds of 64 lanes x 16 bases that cover the span
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
+                if (it > 0 && 64u * it >= nchunks) break;  // (wave-uniform) rounds behind the ticket's last base: nothing of them is looked at
                 uint32_t lo16, hi16, bad;
                 encode16(x[it], lo16, hi16, bad);
                 uint32_t iv16 = 0;
@@ -239,6 +243,11 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ordered before the ids written by phase C
                 }
                 // ---- A: order of every m-mer, window minima by doubling ----
+                // rounds of 64 m-mer positions this unit needs (wave-uniform): its nk k-mers look at m-mers 0 .. nk + W - 2, and the window
+                // minima read up to 15 positions past a k-mer's first m-mer; a unit at the short end of an instantiation (129 k-mers in the
+                // one for up to 256) leaves the last rounds out — they were a fifth of the kernel's time at 159 bases
+                const int na = HALVES == 1 ? NA : max(1, min(NA, (int)((nk + 14u + 63u) >> 6)));  // m-mers 0 .. nk + 13
+                const int nb = HALVES == 1 ? NA - 1 : min(NA - 1, (int)((nk + 63u) >> 6));          // k-mers 0 .. nk - 1
                 mn[64 * (NA - 1) + 16 + lane] = 0xFFFFFFFFu;  // positions past the last round are "infinite"
                 uint32_t v[NA];
                 {
@@ -248,6 +257,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                     const uint32_t* pw = L.span[0] + (at >> 5);
 #pragma unroll
                     for (int a = 0; a < NA; ++a) {
+                        if (a >= na) break;
                         const uint32_t lo = __builtin_amdgcn_alignbit(pw[2 * a + 1], pw[2 * a], at);
                         const uint32_t hi = __builtin_amdgcn_alignbit(pw[SPW + 2 * a + 1], pw[SPW + 2 * a], at);
                         v[a] = (minimizer_order(lo, hi & maskm, m) << ORDER_POS_BITS) | (uint32_t)(64 * a + lane);
@@ -260,9 +270,13 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                     // [i + 8, i + 12), [i + 11, i + 15)): two rounds through LDS (doubling by 1, 2, 4 and the tail took four)
                     uint32_t n1[NA], n2[NA], n3[NA];
 #pragma unroll
-                    for (int a = 0; a < NA; ++a) { n1[a] = mn[64 * a + lane + 1]; n2[a] = mn[64 * a + lane + 2]; n3[a] = mn[64 * a + lane + 3]; }
+                    for (int a = 0; a < NA; ++a) {
+                        if (a >= na) break;
+                        n1[a] = mn[64 * a + lane + 1]; n2[a] = mn[64 * a + lane + 2]; n3[a] = mn[64 * a + lane + 3];
+                    }
 #pragma unroll
                     for (int a = 0; a < NA; ++a) {  // in place: every lane has read before any lane writes
+                        if (a >= na) break;
                         v[a] = min(min(v[a], n1[a]), min(n2[a], n3[a]));
                         if (a < NA - 1 || lane < 16) mn[64 * a + lane] = v[a];
                     }
@@ -272,9 +286,13 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                     for (uint32_t st = 1; st < span; st <<= 1) {  // in place: every lane reads before any lane writes
                         uint32_t nb_[NA];
 #pragma unroll
-                        for (int a = 0; a < NA; ++a) nb_[a] = mn[64 * a + lane + st];
+                        for (int a = 0; a < NA; ++a) {
+                            if (a >= na) break;
+                            nb_[a] = mn[64 * a + lane + st];
+                        }
 #pragma unroll
                         for (int a = 0; a < NA; ++a) {
+                            if (a >= na) break;
                             v[a] = min(v[a], nb_[a]);
                             if (a < NA - 1 || lane < 16) mn[64 * a + lane] = v[a];
                         }
@@ -292,6 +310,9 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                 R = 0;
 #pragma unroll
                 for (int a = 0; a < NA - 1; ++a) {
+                    H[a] = 0;
+                    pos[a] = 0;
+                    if (a >= nb) continue;  // (wave-uniform: no k-mer of the unit in this round)
                     // [i, i + span) and [i + W - span, i + W) cover the window
                     if (WFIX) pos[a] = min(min(v[a], mn[64 * a + lane + 4]), min(mn[64 * a + lane + 8], mn[64 * a + lane + 11])) & POSM;
                     else pos[a] = min(v[a], mn[64 * a + lane + tail]) & POSM;

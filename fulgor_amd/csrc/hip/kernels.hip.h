@@ -1251,6 +1251,126 @@ __device__ FG_MUX_INLINE uint32_t mux_union_read(const uint32_t* __restrict__ ro
     return pc;
 }
 
+// Threshold union of a read with more free lists than the multiplexer tree takes (round 6; 17 % of the reads at tau = 0.8, a third at
+// tau = 0.5, and more than half of the kernel's vector instructions while they went through byte counters). A colour passes iff the
+// multiplicities of the free lists that do NOT contain it add up to at most slack = P - min_score (and every mandatory list contains
+// it). These DEFICITS are counted bit-sliced over the 32 colours of a row word: B planes D[0 .. B-1], B = bits of slack + 1, and a
+// sticky overflow plane — adding the wave-uniform constant mu under the mask ~row is a ripple of at most three instructions per plane
+// from mu's lowest set bit up (two where mu has a zero), against the 24 per list and word of the byte counters (eight planes of
+// shift, mask, multiply-add); the comparison D <= slack at the end is two instructions per plane.
+// MEASURED (profiles/r6/k3r_variants_r6.txt) and NOT in the shipped build (-DFG_K3R_DEFICIT compiles it in): on the bench workload
+// at tau = 0.8 the kernel takes 12.2 ms with it against 6.36 ms without (tau = 0.5: 15.1 against 7.55). The addend's bits are
+// wave-uniform but only known at run time: every plane of every list is a scalar branch into one of three bodies, the kernel grows
+// from 1508 to 2820 static vector instructions and from no scratch to 36 spilled vector registers at the 72 it may use (7 waves per
+// SIMD; 24 spilled at 80), and the ripple's dependent chain hides none of the row loads. A branch-free form (the addend's bit as a
+// scalar mask: four instructions per plane whatever the bit) is 5 x 4 + 2 per list and word against the byte counters' 24: nothing.
+template <int B, int R>
+__device__ __forceinline__ void deficit_add(uint32_t (&D)[B][R], uint32_t (&OV)[R], const uint32_t (&x)[R], uint32_t mu) {
+    uint32_t carry[R];
+    bool started = false;  // (wave-uniform: mu is)
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        if ((mu >> b) & 1u) {
+            if (!started) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) { const uint32_t d = D[b][r]; D[b][r] = d ^ x[r]; carry[r] = d & x[r]; }
+                started = true;
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t d = D[b][r], t = d ^ x[r];
+                    D[b][r] = t ^ carry[r];
+                    carry[r] = (t & carry[r]) | (~t & d);  // majority(d, x, carry): v_bfi_b32
+                }
+            }
+        } else if (started) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const uint32_t d = D[b][r]; D[b][r] = d ^ carry[r]; carry[r] = d & carry[r]; }
+        }
+    }
+    if (started) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) OV[r] |= carry[r];
+    }
+}
+template <int B, int R>
+__device__ __forceinline__ uint32_t deficit_union_read(const uint32_t* __restrict__ rows, uint32_t W, uint32_t Wn, uint32_t n, uint64_t FREE, uint64_t MAND,
+                                                       uint32_t id_l, uint32_t mu_l, uint32_t slack, uint32_t* __restrict__ bm, int lane) {
+    uint32_t pc = 0;
+    for (uint32_t w0 = 0; w0 < Wn; w0 += 64 * R) {
+        uint32_t wi[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) wi[r] = min(w0 + 64u * r + (uint32_t)lane, W - 1) << 2;  // byte offset in a row (lanes past the row load its last word and store nothing)
+        uint32_t D[B][R], OV[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            OV[r] = 0;
+#pragma unroll
+            for (int b = 0; b < B; ++b) D[b][r] = 0;
+        }
+        // the words of the next list are requested before the current one is added
+        uint64_t ff = FREE;
+        uint32_t x[R], mu = 0;
+        {
+            const int a = (int)__builtin_ctzll(ff);
+            const uint32_t* row = rows + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)id_l, a) * W;
+            mu = (uint32_t)__builtin_amdgcn_readlane((int)mu_l, a);
+#pragma unroll
+            for (int r = 0; r < R; ++r) x[r] = ~row_word(row, wi[r]);
+        }
+        for (;;) {
+            ff &= ff - 1;
+            uint32_t xn[R], mun = 0;
+            if (ff) {
+                const int a = (int)__builtin_ctzll(ff);
+                const uint32_t* row = rows + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)id_l, a) * W;
+                mun = (uint32_t)__builtin_amdgcn_readlane((int)mu_l, a);
+#pragma unroll
+                for (int r = 0; r < R; ++r) xn[r] = ~row_word(row, wi[r]);
+            }
+            deficit_add<B, R>(D, OV, x, mu);
+            if (!ff) break;
+#pragma unroll
+            for (int r = 0; r < R; ++r) x[r] = xn[r];
+            mu = mun;
+        }
+        uint32_t m[R];
+        {   // D <= slack, from the top plane down: lt = already smaller, eq = equal so far
+            uint32_t lt[R], eq[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { lt[r] = 0; eq[r] = 0xFFFFFFFFu; }
+#pragma unroll
+            for (int b = B - 1; b >= 0; --b) {
+                if ((slack >> b) & 1u) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) { lt[r] |= eq[r] & ~D[b][r]; eq[r] &= D[b][r]; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) eq[r] &= ~D[b][r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) m[r] = (lt[r] | eq[r]) & ~OV[r];
+        }
+        for (uint64_t mm = MAND; mm; mm &= mm - 1) {  // (wave-uniform)
+            const uint32_t* row = rows + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)id_l, (int)__builtin_ctzll(mm)) * W;
+#pragma unroll
+            for (int r = 0; r < R; ++r) m[r] &= row_word(row, wi[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t w = w0 + 64u * r + (uint32_t)lane;
+            uint32_t v = m[r];
+            if (w >= (n >> 5)) v &= w == (n >> 5) ? (1u << (n & 31u)) - 1u : 0u;  // (only the last words hold colours >= n)
+            if (w < W) {
+                bm[w] = v;
+                pc += __popc(v);
+            }
+        }
+    }
+    return pc;
+}
+
 template <int BITS, bool BIASED = true, bool SCORES = false>
 // (7 waves per SIMD for the 8-bit counters: 72 VGPRs and 94 SGPRs leave 4 scalars spilled and no scratch, and it is the fastest of 6 / 7 / 8:
 // 7.08 / 6.43 / 6.58 ms, profiles/r5/k3r_variants_r5.txt)
@@ -1260,7 +1380,10 @@ template <int BITS, bool BIASED = true, bool SCORES = false>
 #ifndef FG_K3R_WAVES32
 #define FG_K3R_WAVES32 4
 #endif
-__global__ __launch_bounds__(256, BITS == 8 ? 7 : (BITS == 16 ? FG_K3R_WAVES16 : FG_K3R_WAVES32)) void k3r_union(const uint32_t* __restrict__ rows, uint32_t W, uint32_t n,
+#ifndef FG_K3R_WAVES8
+#define FG_K3R_WAVES8 7
+#endif
+__global__ __launch_bounds__(256, BITS == 8 ? FG_K3R_WAVES8 : (BITS == 16 ? FG_K3R_WAVES16 : FG_K3R_WAVES32)) void k3r_union(const uint32_t* __restrict__ rows, uint32_t W, uint32_t n,
                                                                   const uint32_t* __restrict__ npos, const uint32_t* __restrict__ nids,
                                                                   const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
                                                                   const uint32_t* __restrict__ cnt_pool, double tau, uint64_t n_reads,
@@ -1342,6 +1465,21 @@ __global__ __launch_bounds__(256, BITS == 8 ? 7 : (BITS == 16 ? FG_K3R_WAVES16 :
                     if (ln == 0) out_count[r] = pcm;
                     continue;
                 }
+#ifdef FG_K3R_DEFICIT  // (measured in round 6 and left out of the shipped build: correct — the tau grid passes — and twice as slow as the byte counters it was to replace; see the comment at deficit_add)
+                if (slack < 255u) {  // more free lists than the tree takes: bit-sliced deficit counters of 5, 6 or 8 planes
+                    uint32_t pcm;
+#ifndef FG_K3R_DEFICIT_PLANES  // (variant builds: 0 = planes of 5 / 6 / 8, 1 = 6 / 8, 2 = 8 only)
+#define FG_K3R_DEFICIT_PLANES 0
+#endif
+                    if (FG_K3R_DEFICIT_PLANES == 0 && slack < 31u) pcm = deficit_union_read<5, 3>(rows, W, Wn, n, FREE, MAND, id_l, mu_l, slack, bm, ln);
+                    else if (FG_K3R_DEFICIT_PLANES <= 1 && slack < 63u) pcm = deficit_union_read<6, 3>(rows, W, Wn, n, FREE, MAND, id_l, mu_l, slack, bm, ln);
+                    else pcm = deficit_union_read<8, 3>(rows, W, Wn, n, FREE, MAND, id_l, mu_l, slack, bm, ln);
+                    for (uint32_t w = ((Wn + 63) & ~63u) + ln; w < W; w += 64) bm[w] = 0;  // (padding words behind the last round)
+                    pcm = wave_sum_u32(pcm);
+                    if (ln == 0) out_count[r] = pcm;
+                    continue;
+                }
+#endif
             }
             const uint32_t start = (BIASED ? HALF - min_score : 0u) * ONES;
             const uint32_t thr_c = (256u - min_score) & 0xFFu;  // (unbiased counters only)
@@ -2351,6 +2489,79 @@ __global__ __launch_bounds__(256) void k_account(DevColors c, const uint32_t* __
     if (lane_id() == 0) {
         if (in_bytes) atomicAdd(out, (unsigned long long)in_bytes);
         if (out_bytes) atomicAdd(out + 1, (unsigned long long)out_bytes);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// --deduplicate on the device (tools/pseudoalign.cpp:91-226, src/ps_utils.cpp:307-415: the reference writes the colour-set ids of
+// every read to a temporary file, sorts the records by id list and intersects every distinct list once). Here, per pass: a 64-bit
+// hash of every read's id list, a radix sort of (hash, read), neighbours of the order compared EXACTLY (a read opens a group unless
+// its list equals its predecessor's: two lists that collide in the hash are two groups, at worst a list is intersected twice), the
+// intersection kernel runs over one list per group, and every read takes the row / colours / size of its group.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dd_hash(const uint32_t* __restrict__ nids, const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
+                                                 uint64_t n_reads, unsigned long long* __restrict__ hash, uint32_t* __restrict__ idx) {
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t cnt = nids[r];
+        const uint32_t* ids = ids_pool + idoff[r];
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ cnt;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            h = (h ^ ids[i]) * 0xff51afd7ed558ccdULL;
+            h ^= h >> 32;
+        }
+        hash[r] = h;
+        idx[r] = (uint32_t)r;
+    }
+}
+// head[i] = 1 when the read at position i of the order opens a group
+__global__ __launch_bounds__(256) void k_dd_heads(const unsigned long long* __restrict__ hash_sorted, const uint32_t* __restrict__ idx_sorted,
+                                                  const uint32_t* __restrict__ nids, const uint64_t* __restrict__ idoff, const uint32_t* __restrict__ ids_pool,
+                                                  uint64_t n_reads, uint32_t* __restrict__ head) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t is_head = 1;
+        if (i && hash_sorted[i] == hash_sorted[i - 1]) {
+            const uint32_t r = idx_sorted[i], p = idx_sorted[i - 1];
+            const uint32_t cnt = nids[r];
+            if (cnt == nids[p]) {
+                const uint32_t* a = ids_pool + idoff[r];
+                const uint32_t* b = ids_pool + idoff[p];
+                uint32_t j = 0;
+                while (j < cnt && a[j] == b[j]) ++j;
+                is_head = j < cnt;
+            }
+        }
+        head[i] = is_head;
+    }
+}
+// group_off = exclusive scan of head: position i belongs to group group_off[i] + head[i] - 1
+__global__ __launch_bounds__(256) void k_dd_groups(const uint32_t* __restrict__ idx_sorted, const uint32_t* __restrict__ head, const uint64_t* __restrict__ group_off,
+                                                   const uint32_t* __restrict__ nids, const uint64_t* __restrict__ idoff, uint64_t n_reads,
+                                                   uint32_t* __restrict__ group_of, uint32_t* __restrict__ nids_u, uint64_t* __restrict__ idoff_u) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = idx_sorted[i], h = head[i];
+        const uint32_t g = (uint32_t)(group_off[i] + h - 1);
+        group_of[r] = g;
+        if (h) { nids_u[g] = nids[r]; idoff_u[g] = idoff[r]; }
+    }
+}
+// one wave per read: the result of its group becomes its own
+__global__ __launch_bounds__(256) void k_dd_fanout(const uint32_t* __restrict__ group_of, const uint32_t* __restrict__ bitmap_u, const uint32_t* __restrict__ counts_u,
+                                                   const uint32_t* __restrict__ small_u, uint64_t n_reads, uint32_t W, uint32_t* __restrict__ bitmap,
+                                                   uint32_t* __restrict__ counts, uint32_t* __restrict__ small) {
+    const uint32_t lane = lane_id();
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave; r < n_reads; r += waves) {
+        const uint64_t g = group_of[r];
+        const uint32_t cnt = counts_u[g];
+        if (lane == 0) counts[r] = cnt;
+        if (cnt == 0) continue;
+        if (small_u && cnt <= SMALL_RESULT) {
+            if (lane < SMALL_RESULT) small[r * SMALL_RESULT + lane] = small_u[g * SMALL_RESULT + lane];
+            continue;
+        }
+        const u32x4* src = (const u32x4*)(bitmap_u + g * W);
+        u32x4* dst = (u32x4*)(bitmap + r * W);
+        for (uint32_t q = lane; q < W / 4; q += 64) dst[q] = src[q];
     }
 }
 

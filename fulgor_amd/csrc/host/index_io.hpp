@@ -275,66 +275,122 @@ struct LoadClock {
     }
 };
 
+// the container mapped: sections are found by walking their length words, their bytes copied where they are needed
+struct MappedFile {
+    const char* p = nullptr;
+    uint64_t size = 0, at = 0;
+    explicit MappedFile(const std::string& path) {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open index file");
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size == 0) { ::close(fd); throw std::runtime_error("cannot open index file"); }
+        size = (uint64_t)st.st_size;
+        p = (const char*)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (p == MAP_FAILED) { p = nullptr; throw std::runtime_error("cannot map index file"); }
+    }
+    ~MappedFile() { if (p) munmap((void*)p, size); }
+    MappedFile(const MappedFile&) = delete;
+    MappedFile& operator=(const MappedFile&) = delete;
+    template <typename T>
+    void rd(T& v) {
+        if (at + sizeof(T) > size) throw std::runtime_error("truncated index file");
+        memcpy(&v, p + at, sizeof(T));
+        at += sizeof(T);
+    }
+    // a vector section: where its elements lie and how many (nothing is copied yet)
+    template <typename T>
+    struct View { const T* data = nullptr; uint64_t n = 0; void into(std::vector<T>& v) const { v.assign(data, data + n); } };
+    template <typename T>
+    View<T> view() {
+        uint64_t n;
+        rd(n);
+        if (n > (1ULL << 40)) throw std::runtime_error("corrupt index file");
+        if (at + n * sizeof(T) > size) throw std::runtime_error("truncated index file");
+        View<T> v{reinterpret_cast<const T*>(p + at), n};
+        at += n * sizeof(T);
+        return v;
+    }
+};
+
 inline void load_binary(const std::string& path, HostIndex& idx, bool host_table = true) {
     using namespace detail;
     LoadClock clk;
-    std::ifstream i(path, std::ios::binary);
-    if (!i.is_open()) throw std::runtime_error("cannot open index file");
-    char magic[8];
-    i.read(magic, 8);
-    if (i && std::memcmp(magic, FGIDX_MAGIC, 5) == 0 && std::memcmp(magic, FGIDX_MAGIC, 8) != 0)
+    MappedFile f(path);
+    char magic[8] = {0};
+    if (f.size >= 8) { memcpy(magic, f.p, 8); f.at = 8; }
+    if (f.size >= 8 && std::memcmp(magic, FGIDX_MAGIC, 5) == 0 && std::memcmp(magic, FGIDX_MAGIC, 8) != 0)
         throw std::runtime_error("this .fgidx file has container version " + std::string(magic + 5, 3) + ", this build reads " + std::string(FGIDX_MAGIC + 5, 3) +
                                  ": rebuild the index from its dump files (the super-k-mer records depend on the build's minimizer order)");
-    if (!i || std::memcmp(magic, FGIDX_MAGIC, 8) != 0) throw std::runtime_error("not an .fgidx file (bad magic)");
+    if (f.size < 8 || std::memcmp(magic, FGIDX_MAGIC, 8) != 0) throw std::runtime_error("not an .fgidx file (bad magic)");
     int32_t type;
-    rd(i, type);
+    f.rd(type);
     idx.type = type;
     Dict& d = idx.dict;
-    rd(i, d.k); rd(i, d.m); rd(i, d.num_kmers); rd(i, d.total_bases); rd(i, d.seed);
-    rdv(i, d.strings); rdv(i, d.records);
-    rdv(i, d.unitig_off); rdv(i, d.unitig_csid);
+    f.rd(d.k); f.rd(d.m); f.rd(d.num_kmers); f.rd(d.total_bases); f.rd(d.seed);
+    const auto v_strings = f.view<uint64_t>();
+    const auto v_records = f.view<uint32_t>();
+    const auto v_unitig_off = f.view<uint64_t>();
+    const auto v_unitig_csid = f.view<uint32_t>();
     HybridSets& h = idx.hybrid;
-    rd(i, h.num_colors); rd(i, h.sparse_thr); rd(i, h.dense_thr); rd(i, h.nbits);
-    rdv(i, h.offsets); rdv(i, h.bits);
-    clk.lap("read the container");
-    {   // a truncated, stale or corrupt container must fail here, not index out of bounds later
-        auto bad = [](const char* what) { throw std::runtime_error(std::string("corrupt index file: ") + what); };
-        try { check_dict_params(d.k, d.m); } catch (std::exception&) { bad("k / m"); }
-        if (d.strings.size() < (d.total_bases + 31) / 32 + 2) bad("unitig strings shorter than total_bases");
-        if (d.records.size() % REC_WORDS) bad("record array");
-        if (d.unitig_off.size() != d.unitig_csid.size() + 1 || d.unitig_off.empty() || d.unitig_off[0] != 0 ||
-            d.unitig_off.back() != d.total_bases) bad("unitig table");
-        for (size_t u = 0; u + 1 < d.unitig_off.size(); ++u)
-            if (d.unitig_off[u + 1] < d.unitig_off[u] + d.k) bad("unitig offsets");
-        if (h.offsets.empty() || h.offsets[0] > h.offsets.back() || h.offsets.back() != h.nbits) bad("colour-set offsets");
-        for (size_t s = 0; s + 1 < h.offsets.size(); ++s)
-            if (h.offsets[s + 1] <= h.offsets[s]) bad("colour-set offsets are not increasing");
-        if (h.bits.size() * 64 < h.nbits) bad("colour-set stream shorter than nbits");
-        if (h.num_colors == 0 || h.num_colors > BLK_MAX_COLORS) bad("num_colors");
-        const uint64_t nsets = h.offsets.size() - 1;
-        for (uint32_t c : d.unitig_csid)
-            if (c >= nsets) bad("unitig colour-set id");
-        for (uint64_t r = 0; r < d.num_records(); ++r)
-            if ((d.records[r * REC_WORDS + 3] & REC_MAX_CSID) >= nsets) bad("record colour-set id");
-    }
-    clk.lap("validate");
-    if (host_table) {
-        build_dict_table(d);
-        clk.lap("dictionary table from the records");
-    } else {
-        dict_table_geometry(d);  // (the table itself is built on the device: hip/dict_build.hip.h)
-    }
+    f.rd(h.num_colors); f.rd(h.sparse_thr); f.rd(h.dense_thr); f.rd(h.nbits);
+    const auto v_offsets = f.view<uint64_t>();
+    const auto v_bits = f.view<uint64_t>();
+    auto bad = [](const char* what) { throw std::runtime_error(std::string("corrupt index file: ") + what); };
+    // The two halves of the container do not depend on each other: the dictionary's sections are copied out and checked on a thread of
+    // their own while this one takes the colour sets and cuts their packed blocks (a truncated, stale or corrupt container must fail
+    // here, not index out of bounds later).
+    std::string dict_error;
+    std::thread dict_thread([&] {
+        try {
+            v_strings.into(d.strings);
+            v_records.into(d.records);
+            v_unitig_off.into(d.unitig_off);
+            v_unitig_csid.into(d.unitig_csid);
+            try { check_dict_params(d.k, d.m); } catch (std::exception&) { bad("k / m"); }
+            if (d.strings.size() < (d.total_bases + 31) / 32 + 2) bad("unitig strings shorter than total_bases");
+            if (d.records.size() % REC_WORDS) bad("record array");
+            if (d.unitig_off.size() != d.unitig_csid.size() + 1 || d.unitig_off.empty() || d.unitig_off[0] != 0 ||
+                d.unitig_off.back() != d.total_bases) bad("unitig table");
+            for (size_t u = 0; u + 1 < d.unitig_off.size(); ++u)
+                if (d.unitig_off[u + 1] < d.unitig_off[u] + d.k) bad("unitig offsets");
+            const uint64_t nsets = v_offsets.n ? v_offsets.n - 1 : 0;
+            for (uint32_t c : d.unitig_csid)
+                if (c >= nsets) bad("unitig colour-set id");
+            for (uint64_t r = 0; r < d.num_records(); ++r)
+                if ((d.records[r * REC_WORDS + 3] & REC_MAX_CSID) >= nsets) bad("record colour-set id");
+            if (host_table) build_dict_table(d);
+            else dict_table_geometry(d);  // (the table itself is built on the device: hip/dict_build.hip.h)
+        } catch (std::exception& e) {
+            dict_error = e.what();
+        }
+    });
+    struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join{dict_thread};
+    v_offsets.into(h.offsets);
+    v_bits.into(h.bits);
+    if (h.offsets.empty() || h.offsets[0] > h.offsets.back() || h.offsets.back() != h.nbits) bad("colour-set offsets");
+    for (size_t s = 0; s + 1 < h.offsets.size(); ++s)
+        if (h.offsets[s + 1] <= h.offsets[s]) bad("colour-set offsets are not increasing");
+    if (h.bits.size() * 64 < h.nbits) bad("colour-set stream shorter than nbits");
+    if (h.num_colors == 0 || h.num_colors > BLK_MAX_COLORS) bad("num_colors");
+    clk.lap("colour sets read and checked");
     h.bits.resize((h.nbits + 63) / 64 + 4, 0);  // the device reads up to 256 bits past a bitmap list
     hybrid_build_blocks(h);
     clk.lap("packed blocks of the gap lists");
+    dict_thread.join();
+    if (!dict_error.empty()) throw std::runtime_error(dict_error);
+    clk.lap(host_table ? "dictionary read, checked, table built (beside the colour sets)" : "dictionary read and checked (beside the colour sets)");
     if (idx.type != IDX_HYBRID) {
         GenericSets& g = idx.generic;
         g.type = idx.type;
-        rd(i, g.num_colors); rd(i, g.partition_size); rd(i, g.cluster_size); rd(i, g.num_partitions);
-        rd(i, g.num_partial_sets); rd(i, g.num_clusters); rd(i, g.nbits);
-        rdv(i, g.bits); rdv(i, g.ops); rdv(i, g.set_ops_off); rdv(i, g.set_ops); rdv(i, g.set_bytes);
+        f.rd(g.num_colors); f.rd(g.partition_size); f.rd(g.cluster_size); f.rd(g.num_partitions);
+        f.rd(g.num_partial_sets); f.rd(g.num_clusters); f.rd(g.nbits);
+        f.view<uint64_t>().into(g.bits);
+        f.view<SetOp>().into(g.ops);
+        f.view<uint64_t>().into(g.set_ops_off);
+        f.view<uint32_t>().into(g.set_ops);
+        f.view<uint32_t>().into(g.set_bytes);
         {
-            auto bad = [](const char* what) { throw std::runtime_error(std::string("corrupt index file: ") + what); };
             if (g.num_colors != h.num_colors) bad("codec colour count");
             if (g.bits.size() * 64 < g.nbits) bad("codec arena shorter than nbits");
             if (g.set_ops_off.size() != h.offsets.size() || g.set_ops_off[0] != 0 || g.set_ops_off.back() != g.set_ops.size())
@@ -350,12 +406,11 @@ inline void load_binary(const std::string& path, HostIndex& idx, bool host_table
         build_generic_device(g);
     }
     uint64_t nf;
-    rd(i, nf);
+    f.rd(nf);
     idx.filenames.clear();
-    for (uint64_t f = 0; f < nf; ++f) {
-        std::vector<char> c;
-        rdv(i, c);
-        idx.filenames.emplace_back(c.begin(), c.end());
+    for (uint64_t i = 0; i < nf; ++i) {
+        const auto c = f.view<char>();
+        idx.filenames.emplace_back(c.data, c.data + c.n);
     }
 }
 

@@ -430,6 +430,8 @@ int fgpu_prepare_host(int device, unsigned reader_threads, unsigned workers, uin
         if (device >= ndev) throw std::runtime_error("invalid device ordinal");
         HIP_TRY(hipSetDevice(device));
         install_pinned_allocator();
+        // (an index that is being opened finishes starting its device first: the two would slow each other down)
+        for (int waited = 0; g_device_startups.load() > 0 && waited < 2000; ++waited) std::this_thread::sleep_for(std::chrono::milliseconds(1));
         if (reader_threads == 0) reader_threads = FastxReader::default_threads();
         if (workers == 0) workers = (unsigned)env_u64("FULGOR_STREAM_WORKERS", 5);
         if (batch_reads == 0) batch_reads = env_u64("FULGOR_STREAM_BATCH", 1u << 18);

@@ -130,6 +130,12 @@ class Result:
         _native.check(self._L.fgpu_result_algorithmic_bytes(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"lists": a.value, "output": b.value, "lookup": c.value}
 
+    def distinct_lists(self):
+        """distinct id lists of the last pass under tune(deduplicate=True) (0: the pass was not deduplicated)"""
+        n = C.c_uint64()
+        _native.check(self._L.fgpu_result_distinct_lists(self._h, C.byref(n)))
+        return n.value
+
     def checksum(self):
         """(from the lists, from the rows): two independent device-side checksums of the u32 colour lists of the last pass —
         {#entries, sum, xor} each; equal when the expansion kernel wrote every colour at its place (fgpu_result_checksum)"""
@@ -182,6 +188,7 @@ class Index:
         h = C.c_void_p()
         _native.check(self._L.fgpu_open(str(path).encode(), int(device), C.byref(h)))
         self._h = h
+        self.device = int(device)
         vals = [C.c_uint64() for _ in range(5)]
         t = C.c_int()
         _native.check(self._L.fgpu_info(h, *[C.byref(v) for v in vals], C.byref(t)))
@@ -345,14 +352,18 @@ class Index:
         finally:
             self._L.fgpu_free(p)
 
-    def tune(self, order_min_reads=None, small_results=None, dense_rows=None):
-        """execution knobs of the colour stage (fgpu_tune); results never depend on them"""
+    def tune(self, order_min_reads=None, small_results=None, dense_rows=None, deduplicate=None):
+        """execution knobs of the colour stage (fgpu_tune); results never depend on them. deduplicate: `--deduplicate` on the
+        device (every distinct id list of a pass intersected once)"""
+        if deduplicate is not None:
+            _native.check(self._L.fgpu_tune(self._h, 3, 1 if deduplicate else 0))
         if order_min_reads is not None:
             _native.check(self._L.fgpu_tune(self._h, 0, int(order_min_reads) if order_min_reads >= 0 else 0xFFFFFFFFFFFFFFFF))
         if small_results is not None:
             _native.check(self._L.fgpu_tune(self._h, 1, 1 if small_results else 0))
         if dense_rows is not None:
             _native.check(self._L.fgpu_tune(self._h, 2, 1 if dense_rows else 0))
+        return self
 
     def timing_enable(self, on=True):
         _native.check(self._L.fgpu_timing_enable(self._h, 1 if on else 0))

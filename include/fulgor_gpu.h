@@ -156,8 +156,15 @@ int fgpu_result_algorithmic_bytes(const fgpu_result* res, uint64_t* list_bytes, 
  *                              between the intersection and the expansion kernel as colours instead of as a bitmap row.
  *   FGPU_TUNE_DENSE_ROWS       1 (default; environment FULGOR_DENSE_ROWS=0): the full intersection of a hybrid index runs on
  *                              dense rows (every colour set as a plain bitmap row in HBM, built at load while they fit a quarter
- *                              of the device's memory: FULGOR_ROWS_MAX_BYTES); 0: on the packed blocks of the gap-coded lists. */
-enum { FGPU_TUNE_ORDER_MIN_READS = 0, FGPU_TUNE_SMALL_RESULTS = 1, FGPU_TUNE_DENSE_ROWS = 2 };
+ *                              of the device's memory: FULGOR_ROWS_MAX_BYTES); 0: on the packed blocks of the gap-coded lists.
+ *   FGPU_TUNE_DEDUPLICATE      0 (default; environment FULGOR_DEDUPLICATE=1): 1 = `--deduplicate` (tools/pseudoalign.cpp:91-226): the full
+ *                              intersection of a pass runs once per DISTINCT list of colour-set ids — the reads are ordered by a hash
+ *                              of their id lists on the device, neighbours compared exactly, every read takes its group's result.
+ *                              Same results, in file order, in every format.
+ */
+enum { FGPU_TUNE_ORDER_MIN_READS = 0, FGPU_TUNE_SMALL_RESULTS = 1, FGPU_TUNE_DENSE_ROWS = 2, FGPU_TUNE_DEDUPLICATE = 3 };
+/* distinct id lists of the last pass of `res` under FGPU_TUNE_DEDUPLICATE (0: the pass was not deduplicated) */
+int fgpu_result_distinct_lists(const fgpu_result* res, uint64_t* num_lists);
 int fgpu_tune(fgpu_index* idx, int knob, uint64_t value);
 
 /* One line about the device a handle lives on — ordinal, name, PCI address, CUs, free / total memory, the host NUMA node, and which

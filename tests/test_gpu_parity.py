@@ -532,6 +532,53 @@ def test_deduplicated_path_equals_direct_path(s4546):
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
 
 
+def test_device_side_deduplication_equals_direct_path(s4546, colour_stage, tmp_path):
+    """`--deduplicate` on the device (fgpu_tune(FGPU_TUNE_DEDUPLICATE); tools/pseudoalign.cpp:91-226): the reads of a pass are ordered
+    by a hash of their id lists, neighbours compared exactly, the intersection runs once per group and every read takes its group's
+    result. A batch in which every read occurs several times (and some not at all mapped): the same CSR as the direct path, on the
+    dense rows and on the packed blocks; the number of distinct lists is at most the number of distinct reads; the command line with
+    --deduplicate writes the bytes the command line without it writes, in every format."""
+    import subprocess
+    from conftest import DATA
+    from fulgor_amd import synth
+    ix, _, gen = s4546
+    b, o = gen.generate(700000, 6000, 150, 42)
+    rng = np.random.default_rng(3)
+    pick = rng.integers(0, 6000, size=40000)  # every read about seven times, in random order
+    bb = np.ascontiguousarray(np.asarray(b).reshape(6000, 150)[pick].reshape(-1))
+    oo = np.arange(40001, dtype=np.uint64) * np.uint64(150)
+    with stage(ix, colour_stage):
+        want = ix.pseudoalign_full_intersection_batch(bb, oo)
+        ix.tune(deduplicate=True)
+        try:
+            got = ix.pseudoalign_full_intersection_batch(bb, oo)
+            rd, res = ix.upload_reads(bb, oo), ix.new_result()
+            ix.run(rd, res, fulgor_amd.FULL_INTERSECTION, 0.0)
+            groups = res.distinct_lists()
+            tu = ix.pseudoalign_threshold_union_batch(bb[:150 * 2000], oo[:2001], 0.8)  # (the knob leaves the union alone)
+        finally:
+            ix.tune(deduplicate=False)
+        tu_want = ix.pseudoalign_threshold_union_batch(bb[:150 * 2000], oo[:2001], 0.8)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(tu[0], tu_want[0]) and np.array_equal(tu[1], tu_want[1])
+    assert 0 < groups <= len(np.unique(pick)) + 1
+    if colour_stage:  # the command line, once
+        fg, _ = synth.ensure_s4546(DATA, S10_GENOMES)
+        q = tmp_path / "dup.fq"
+        with open(q, "wb") as f:
+            for i in range(12000):
+                f.write(b"@r%d\n%s\n+\n%s\n" % (i, bytes(bb[150 * i:150 * (i + 1)]), b"I" * 150))
+        for fmt in ("ascii", "compressed"):
+            outs = []
+            for extra in ([], ["--deduplicate"]):
+                out = tmp_path / ("o_%s_%d" % (fmt, len(extra)))
+                r = subprocess.run([sys.executable, "-m", "fulgor_amd", "pseudoalign", "-i", fg, "-q", str(q), "-o", str(out), "--format", fmt] + extra,
+                                   cwd=ROOT, capture_output=True, text=True, timeout=600)
+                assert r.returncode == 0, r.stdout + r.stderr
+                outs.append(open(out, "rb").read())
+            assert outs[0] == outs[1] and len(outs[0]) > 12000
+
+
 def test_gpu_kmer_conservation_and_matches(s10_gpu, s10_oracle):
     """the reference's two other query tools on the same lookup kernel: per-k-mer colour-set ids ->
     kmer_conservation triples (src/kmer_conservation.cpp:7-54); un-thresholded union scores -> kmer_matches
@@ -1549,10 +1596,12 @@ def test_bench_pipelined_passes_count_every_read():
                            stderr=subprocess.PIPE, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         lines.append(json.loads(r.stdout.strip().splitlines()[-1]))
+        lines[-1]["_detail"] = json.load(open(os.path.join(ROOT, lines[-1]["detail"])))  # (the launch counts are in the detail file beside the compact line)
     a, b = lines
     assert a["config"]["reads_per_gpu"] == b["config"]["reads_per_gpu"] == 150000 and b["value"] > 0 and b["steps"] == 2
     assert a["config"]["mapped_fraction"] == b["config"]["mapped_fraction"] and a["config"]["avg_colours_per_read"] == b["config"]["avg_colours_per_read"]
-    assert b["kernels"]["k1_lookup"]["launches"] == a["kernels"]["k1_lookup"]["launches"] == 8  # four passes per step
+    assert b["_detail"]["kernels"]["k1_lookup"]["launches"] == a["_detail"]["kernels"]["k1_lookup"]["launches"] == 8  # four passes per step
+    assert set(a["kernels_ms"]) == set(b["kernels_ms"]) and a["kernels_ms"]["k1_lookup"] > 0
 
 
 def test_gpu_reads_with_one_run_per_kmer(built, tmp_path):
