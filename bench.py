@@ -394,7 +394,11 @@ def main():
     print("[bench] rank %d/%d, %s ranks: %s" % (rank, world, ("RCCL" if backend == "nccl" else backend) if world > 1 else "no collective,", report), file=sys.stderr, flush=True)
     rank_reports = [None] * world
     if world > 1:
-        dist.all_gather_object(rank_reports, {"rank": rank, "device": local_rank, "report": report})
+        try:
+            dist.all_gather_object(rank_reports, {"rank": rank, "device": local_rank, "report": report})
+        except Exception as e:  # noqa: BLE001 — the reports are a courtesy: the run does not depend on them
+            print("[bench] rank %d: the per-rank reports were not gathered (%s)" % (rank, str(e)[:200]), file=sys.stderr, flush=True)
+            rank_reports = [{"rank": rank, "device": local_rank, "report": report}]
     else:
         rank_reports = [{"rank": 0, "device": local_rank, "report": report}]
     if args.order is not None or args.small is not None or args.rows is not None:

@@ -89,7 +89,7 @@ def lib():
     L.fgpu_pseudoalign_stream.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_uint64, C.c_int, C.c_uint64, C.c_uint,
                                           u64p, u64p]
     L.fgpu_last_stream_report.argtypes = [C.POINTER(vp)]
-    L.fgpu_prepare_host.argtypes = [C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]
+    L.fgpu_prepare_host.argtypes = [C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64]
     L.fgpu_stream_prepare.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint, C.c_uint32, C.c_uint64]
     L.fgpu_result_algorithmic_bytes.argtypes = [vp, u64p, u64p, u64p]
     L.fgpu_result_checksum.argtypes = [vp, u64p, u64p]

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
     foreign_writes_acquire();  // (the bases and offsets may have been written by a copy engine that the HIP runtime knows nothing about)
     constexpr int KMAX = 128 * HALVES;      // k-mers per unit
 #ifndef FG_K1_TICKET2
-#define FG_K1_TICKET2 6
+#define FG_K1_TICKET2 6  // (units of up to 256 k-mers; round 6: tickets of 12 / 16 are 7 % slower at 159-286 bases, profiles/r6/read_length_sweep_variants_r6.txt)
 #endif
     constexpr uint32_t TICKET = HALVES == 1 ? K1_TICKET : (HALVES == 2 ? FG_K1_TICKET2 : 1);  // longer units: one to three per pass, and the planes of a ticket's span live in LDS: short tickets
     constexpr int NA = 2 * HALVES + 1;      // rounds of 64 m-mer positions (the last one: 16 positions)

@@ -421,7 +421,7 @@ int fgpu_pseudoalign_stream(fgpu_index* ix, fgpu_fastx* query, int out_fd, int a
 }
 
 int fgpu_prepare_host(int device, unsigned reader_threads, unsigned workers, uint64_t batch_reads, uint64_t text_bytes_per_read, int fastq,
-                      uint64_t out_bytes_per_read) {
+                      uint64_t out_bytes_per_read, uint64_t total_text_bytes) {
     if (device < 0) return fail(-EINVAL, "invalid device ordinal");
     return guarded([&] {
         int ndev = 0;
@@ -438,7 +438,11 @@ int fgpu_prepare_host(int device, unsigned reader_threads, unsigned workers, uin
         const uint64_t range = FastxReader::default_range_bytes();
         // chunks alive at a time: the ranges parsed ahead of the workers (the reader's window) and the batches in flight
         const uint64_t per_batch = (batch_reads * std::max<uint64_t>(1, text_bytes_per_read) + range - 1) / range + 1;
-        const uint64_t chunks = std::min<uint64_t>((uint64_t)reader_threads + 8 + workers * per_batch, 256);
+        uint64_t chunks = std::min<uint64_t>((uint64_t)reader_threads + 8 + workers * per_batch, 256);
+        if (total_text_bytes) {  // a small query: no more chunks than it has ranges, no larger batches than it has reads
+            chunks = std::min<uint64_t>(chunks, total_text_bytes / range + 2);
+            batch_reads = std::min<uint64_t>(batch_reads, total_text_bytes / std::max<uint64_t>(1, text_bytes_per_read) + 1);
+        }
         size_t bb = 0, ob = 0;
         FastxChunk::slab_requests(range, fastq != 0, bb, ob);
         struct Held { void* p; size_t bytes; bool pinned; };

@@ -349,8 +349,14 @@ def pseudoalign_sharded(open_index, query, output, algo=FULL_INTERSECTION, thres
         rec_bytes, max_len, fastq = query_head_stats(query)
         # (output records: 256 bytes per read is typical of the compressed format on thousands of colours; ascii / binary records are
         # sized by the first batch)
+        try:  # (this rank's share of a plain file; a compressed one is several times its size: unknown)
+            with open(query, "rb") as qf:
+                plain = qf.read(2) != b"\x1f\x8b"
+            part_bytes = (min(end, os.path.getsize(query)) - begin) if plain else 0
+        except OSError:
+            part_bytes = 0
         kw = dict(device=prepare_device, reader_threads=reader_threads_per_rank(io_threads, world), batch=batch, text_bytes_per_read=rec_bytes,
-                  fastq=fastq, out_bytes_per_read=256 if fmt == "compressed" else 0)
+                  fastq=fastq, out_bytes_per_read=256 if fmt == "compressed" else 0, total_text_bytes=max(0, part_bytes))
         prep = threading.Thread(target=lambda: _quiet(prepare_host, **kw))
         prep.start()
     _mark("preparation thread started" if prep is not None else "no preparation thread")

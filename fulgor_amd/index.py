@@ -51,11 +51,11 @@ def _take_csr(L, n, p_off, p_val):
     return offs, vals
 
 
-def prepare_host(device=0, reader_threads=0, workers=0, batch=0, text_bytes_per_read=320, fastq=True, out_bytes_per_read=0):
+def prepare_host(device=0, reader_threads=0, workers=0, batch=0, text_bytes_per_read=320, fastq=True, out_bytes_per_read=0, total_text_bytes=0):
     """opt-in, needs no index (fgpu_prepare_host): starts the HIP runtime on `device` and pins the host buffers one run of the streamed
     worker loop will use into the process-wide pool. The command line calls it on a thread of its own while the index opens."""
     _native.check(_native.lib().fgpu_prepare_host(int(device), int(reader_threads), int(workers), int(batch), int(text_bytes_per_read),
-                                                  1 if fastq else 0, int(out_bytes_per_read)))
+                                                  1 if fastq else 0, int(out_bytes_per_read), int(total_text_bytes)))
 
 
 class Reads:

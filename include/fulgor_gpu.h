@@ -252,7 +252,7 @@ int fgpu_pseudoalign_stream(fgpu_index* idx, fgpu_fastx* query, int out_fd, int 
  * 0 for reader_threads / workers / batch_reads: the loop's defaults. Neither is ever called by the library itself: a library user
  * that never streams is not charged the pinned memory. */
 int fgpu_prepare_host(int device, unsigned reader_threads, unsigned workers, uint64_t batch_reads, uint64_t text_bytes_per_read, int fastq,
-                      uint64_t out_bytes_per_read);
+                      uint64_t out_bytes_per_read, uint64_t total_text_bytes /* of the query, 0 = unknown: a small query pins less */);
 int fgpu_stream_prepare(fgpu_index* idx, int format, uint64_t batch_reads, unsigned workers, uint32_t max_read_bases, uint64_t out_bytes_per_read);
 /* timeline of the last fgpu_pseudoalign_stream of this process as text (per batch: when it was acquired from the parser, queued,
  * through the colour stage, formatted and copied out, written), plus what the parser threads spent; malloc'd: fgpu_free */

@@ -1,5 +1,5 @@
 """What a process that used the GPU costs AFTER its last line of Python: wall of a subprocess minus the time at which it reports being
-done, for (a) the HIP runtime started and nothing else, (b) the bench index open on the device, (c) the index open and 0.7 GB of host
+done, for (a) the HIP runtime started and 40 MB pinned, (b) the bench index open on the device, (c) the index open and 0.7 GB of host
 memory pinned (fgpu_prepare_host), (d) as (c) plus the five worker results (fgpu_stream_prepare). All exit through os._exit."""
 import glob, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,14 +15,8 @@ import fulgor_amd
 from fulgor_amd import _native
 from fulgor_amd.index import prepare_host
 L = _native.lib()
-if what == "runtime":
-    import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
-    n = C.c_int()
-    hip.hipGetDeviceCount(C.byref(n))
-    hip.hipSetDevice(0)
-    p = C.c_void_p()
-    hip.hipMalloc(C.byref(p), 1 << 20)
+if what == "runtime":  # the HIP runtime started on device 0 and ten small buffers pinned (40 MB): as little as the library lets one ask for
+    prepare_host(0, reader_threads=1, workers=1, batch=1, text_bytes_per_read=1, out_bytes_per_read=0)
 else:
     ix = fulgor_amd.Index(fg, device=0)
     if what in ("pinned", "results"):
