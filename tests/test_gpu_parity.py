@@ -2001,7 +2001,8 @@ def test_no_kernel_leaves_its_buffers_under_the_guard_allocator(built):
     mapped block to show: once in a dozen runs). The tests of awkward inputs run again in that mode, in a process of their own."""
     import subprocess
     pick = ("fuzz_against_the_batch or kmer_tools_fuzz or only_empty_reads or ragged_and_long or reads_of_any_length or other_kmer_lengths or "
-            "empty_wrapped_and_broken or device_formatters_are_byte_identical or compressed_formatter_parses_back")
+            "empty_wrapped_and_broken or device_formatters_are_byte_identical or compressed_formatter_parses_back or "
+            "device_side_deduplication or materialised_only_on_demand")  # (round 6: the grouping kernels, the checksum kernels; every open builds the dictionary table on the device)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k", pick,
                         "-p", "no:cacheprovider"], env=dict(os.environ, FULGOR_GUARD_ALLOC="1"), capture_output=True, text=True, timeout=1500)
     tail = (r.stdout + r.stderr)[-3000:]
