@@ -472,6 +472,21 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                         uint32_t mine = 0, msum = 0, mid = 0;
 #pragma unroll
                         for (int r = 0; r < (int)BUCKET_RECS; ++r) {
+#ifdef FG_K1_SLOT_SKIP
+                            // (round 6, measured and left out of the shipped build) The slots of a bucket fill from the first: at 0.6 records per
+                            // bucket the last slot holds a record (or the redirect) in one bucket of a hundred, so in most passes it is empty in
+                            // EVERY bucket the wave looks at and its comparison, a quarter of this loop, could be skipped for the whole wave (an
+                            // empty slot has smin > smax and can only yield an empty range of windows). 5.067 against 5.072 ms per 10 M reads
+                            // testing the last slot, 5.028 testing the last two (profiles/r6/k1_slot_skip_r6.txt): under one per cent —
+                            // the kernel does not wait for these instructions.
+#ifndef FG_K1_SKIP_FROM
+#define FG_K1_SKIP_FROM 3  // (variant builds: 2 = the last two slots are tested)
+#endif
+                            if (r >= FG_K1_SKIP_FROM) {
+                                const bool holds = live && rec_smin(rec[r].z) <= rec_smax(rec[r].w);
+                                if (!__any(holds)) { hv[r] = 0; hc[r] = 0; continue; }
+                            }
+#endif
                             const uint32_t w0 = rec[r].x, w1 = rec[r].y, w2 = rec[r].z;
                             const uint32_t x0 = (T[0] ^ w0) | (T[1] ^ w1) | T[2];
                             // bases 32..: the two planes lie side by side in w2 as in T[3]; only bits 0 .. k - m - 2 of x1 are looked at

@@ -355,6 +355,8 @@ def pseudoalign_sharded(open_index, query, output, algo=FULL_INTERSECTION, thres
             part_bytes = (min(end, os.path.getsize(query)) - begin) if plain else 0
         except OSError:
             part_bytes = 0
+        if part_bytes > 0 and not batch:  # a query smaller than one default batch: its batch (and what is pinned and allocated for it) is its size
+            batch = max(1024, min(1 << 18 if fmt == "compressed" else 1 << 15, part_bytes // max(1, rec_bytes) + 1))
         kw = dict(device=prepare_device, reader_threads=reader_threads_per_rank(io_threads, world), batch=batch, text_bytes_per_read=rec_bytes,
                   fastq=fastq, out_bytes_per_read=256 if fmt == "compressed" else 0, total_text_bytes=max(0, part_bytes))
         prep = threading.Thread(target=lambda: _quiet(prepare_host, **kw))

@@ -1403,6 +1403,74 @@ def test_pooled_buffers_and_reused_stream_results(s10_gpu, s10_oracle, tmp_path)
     assert len(getattr(s10_gpu, "_stream_results", [])) == 3  # the second stream found the results of the first
 
 
+def test_one_cold_command_is_prepared_timed_like_the_reference_and_leaves_fast(s10_fgidx, s10_oracle, tmp_path):
+    """round-5 review, item 2. (1) The one-run preparation (fgpu_prepare_host + fgpu_stream_prepare: host buffers pinned, worker
+    results created ahead of the first batch) changes no byte: a prepared stream, an unprepared one, a prepared one on a tiny file, one
+    prepared for another format and for shorter reads than come (buffers grow) all write the oracle's records; no host buffer is
+    pinned during a prepared run. (2) The command line says when the index is loaded and starts its `elapsed` clock behind the load,
+    where the reference starts its own (tools/pseudoalign.cpp:59-60): elapsed is far less than the wall of the command; with and
+    without the preparation, leaving through _exit or through the interpreter (FULGOR_ORDERLY_EXIT), the output is the same file."""
+    import subprocess
+    import time
+    from fulgor_amd.index import prepare_host
+    from fulgor_amd.reads import FastxReader, ReadGenerator
+    gen = ReadGenerator(S10_GENOMES)
+    n = 60000
+    b, o = gen.generate(77, n, 150, 3)
+    q = tmp_path / "reads.fq"
+    with open(q, "wb") as f:
+        for i in range(n):
+            f.write(b"@r%d\n%s\n+\n%s\n" % (i, bytes(b[int(o[i]):int(o[i + 1])]), b"I" * 150))
+    oo, oc = s10_oracle.full_intersection(b, o, threads=32)
+    want = s10_oracle.format_ascii(oo, oc)
+    ix = fulgor_amd.Index(s10_fgidx, device=0)
+    prepare_host(0, reader_threads=3, workers=3, batch=8192, text_bytes_per_read=316, fastq=True, out_bytes_per_read=64, total_text_bytes=os.path.getsize(q))
+    ix.stream_prepare(0, 8192, 3, 100, 64)  # (ascii, reads of up to 100 bases: the 150-base reads that come make the buffers grow)
+    for fmt in (0, 2):
+        out = tmp_path / ("stream_%d" % fmt)
+        rd = FastxReader(str(q), batch=8192, copy=False, threads=3)
+        with open(out, "wb") as sink:
+            got, mapped = ix.pseudoalign_stream(rd, sink.fileno(), 0, 0.0, fmt, 0, True, 8192, 3)
+        rd.close()
+        assert got == n
+        if fmt == 0:
+            assert out.read_bytes() == want
+        else:
+            from oracle.pyoracle import parse_compressed
+            ids, po, pc = parse_compressed(out.read_bytes())
+            assert np.array_equal(ids, np.arange(n)) and np.array_equal(po, oo) and np.array_equal(pc, oc)
+    tiny = tmp_path / "tiny.fq"
+    tiny.write_bytes(b"".join(open(q, "rb").read(316 * 8).splitlines(True)[:28]))  # seven records
+    prepare_host(0, text_bytes_per_read=316, fastq=True, out_bytes_per_read=256, total_text_bytes=os.path.getsize(tiny))
+    rd = FastxReader(str(tiny), batch=1 << 18, copy=False, threads=2)
+    with open(tmp_path / "tiny.out", "wb") as sink:
+        got, _ = ix.pseudoalign_stream(rd, sink.fileno(), 0, 0.0, 0, 0, True, 0, 0)
+    rd.close()
+    assert got == 7 and (tmp_path / "tiny.out").read_bytes() == b"".join(want.splitlines(True)[:7])
+    ix.close()
+    # (2) the command line
+    outs = {}
+    for tag, env_extra in (("prepared", {}), ("unprepared", {"FULGOR_NO_PREPARE": "1"}), ("orderly", {"FULGOR_ORDERLY_EXIT": "1"})):
+        out = tmp_path / ("cli_" + tag)
+        t0 = time.time()
+        r = subprocess.run([sys.executable, "-m", "fulgor_amd", "pseudoalign", "-i", s10_fgidx, "-q", str(q), "-o", str(out), "--verbose"],
+                           cwd=ROOT, env=dict(os.environ, FULGOR_CLI_TIMELINE="%.6f" % t0, **env_extra), capture_output=True, text=True, timeout=600)
+        wall = time.time() - t0
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = r.stdout.splitlines()
+        i_start, i_done = [i for i, l in enumerate(lines) if "*** START: loading the index" in l], [i for i, l in enumerate(lines) if "*** DONE: loading the index" in l]
+        assert i_start and i_done and i_start[0] < i_done[0] < [i for i, l in enumerate(lines) if l.startswith("processed %d reads" % n)][0]
+        open_ms = int(lines[i_done[0]].split("(")[1].split()[0])
+        elapsed_ms = int([l for l in lines if l.startswith("elapsed = ")][0].split()[2])
+        assert elapsed_ms + open_ms <= wall * 1000 + 5 and elapsed_ms < 0.6 * wall * 1000, (elapsed_ms, open_ms, wall)  # the clock does not cover the load
+        outs[tag] = out.read_bytes()
+    assert outs["prepared"] == want and outs["unprepared"] == want and outs["orderly"] == want
+    # compressed records (what the preparation sizes the output buffers for): nothing is pinned during the prepared run
+    r = subprocess.run([sys.executable, "-m", "fulgor_amd", "pseudoalign", "-i", s10_fgidx, "-q", str(q), "-o", str(tmp_path / "cli_c"), "--format", "compressed"],
+                       cwd=ROOT, env=dict(os.environ, FULGOR_CLI_TIMELINE="%.6f" % time.time()), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "host buffers pinned anew during the run: 0 " in r.stderr, r.stderr[-1500:]
+
+
 def test_s4546_execution_knobs_do_not_change_results(s4546):
     """fgpu_tune: dense rows (k2r_intersect) or packed blocks (k2a_intersect), the locality order of a pass (k_order_*: reads
     sorted by their rarest colour set, results at the read's own row) and the small-result bypass (results of at most 16 colours travel from k2a to k2b as colours, no bitmap row) are
