@@ -132,7 +132,11 @@ constexpr uint32_t REC_MAX_CSID = 0x07FFFFFFu;                // (also the width
 constexpr uint32_t REC_SPILL = 0x80000000u;
 constexpr uint32_t REC_W2_EMPTY = 15u << 26;  // smin = 15 > smax = 0 (w3 = 0)
 constexpr uint32_t REC_W2_REDIRECT = REC_W2_EMPTY | 0x80000000u;
-constexpr uint32_t DICT_MAX_BUCKETS = 1u << 26;  // a (source lane, bucket) pair of the lookup kernel packs into 32 bits
+// Up to DICT_NARROW_BUCKETS buckets (a 4 GB table, about 120 M distinct 31-mers) a (bucket, source lane) pair of the lookup kernel's ring
+// packs into one 32-bit word; larger tables — up to DICT_MAX_BUCKETS: 128 GB of the 288 — run the kernel's WIDE instantiations, whose ring
+// keeps the source lane in a word of its own (round 6: before, such a collection was refused at load).
+constexpr uint32_t DICT_NARROW_BUCKETS = 1u << 26;
+constexpr uint32_t DICT_MAX_BUCKETS = 1u << 31;
 constexpr uint32_t REDIRECT_DIRECT = 3;
 FG_HD uint32_t rec_w2(uint64_t ctx_lo, uint64_t ctx_hi, uint32_t smin) {
     return (uint32_t)(ctx_lo >> 32) | ((uint32_t)(ctx_hi >> 32) << REC_HI_BITS) | (smin << 26);

@@ -377,7 +377,7 @@ void build_table_on_device(fgpu_index* ix) {
         HIP_TRY(hipStreamSynchronize(s));
         total_over = last[0] + last[1];
     }
-    if (nb_hashed + total_over >= DICT_MAX_BUCKETS) throw std::runtime_error("dictionary table exceeds 2^26 buckets");
+    if (nb_hashed + total_over >= DICT_MAX_BUCKETS) throw std::runtime_error("dictionary table exceeds 2^31 buckets");
     ix->d_table.ensure((nb_hashed + total_over) * (uint64_t)BUCKET_WORDS * 4);
     ix->table_buckets = nb_hashed + total_over;
     hipLaunchKernelGGL(k_dict_fill, dim3(grid), dim3(256), 0, s, recs.as<uint32_t>(), homeB.as<uint32_t>(), keyA.as<unsigned long long>(), idxA.as<uint32_t>(), nrec,
@@ -575,18 +575,24 @@ void stage_lookup_on(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint6
                                kmer_out);
         };
         const bool ko = kmer_out != nullptr;
-        if (halves == 1 && w13 && !ko) launch_short(k1_lookup<true, 1, false>);
-        else if (halves == 1 && w13) launch_short(k1_lookup<true, 1, true>);
-        else if (halves == 1 && !ko) launch_short(k1_lookup<false, 1, false>);
-        else if (halves == 1) launch_short(k1_lookup<false, 1, true>);
-        else if (halves == 2 && w13 && !ko) launch_short(k1_lookup<true, 2, false>);
-        else if (halves == 2 && w13) launch_short(k1_lookup<true, 2, true>);
-        else if (halves == 2 && !ko) launch_short(k1_lookup<false, 2, false>);
-        else if (halves == 2) launch_short(k1_lookup<false, 2, true>);
-        else if (halves <= 4 && w13 && !ko) launch_short(k1_lookup<true, 4, false>);
-        else if (halves <= 4 && w13) launch_short(k1_lookup<true, 4, true>);
-        else if (halves <= 4 && !ko) launch_short(k1_lookup<false, 4, false>);
-        else if (halves <= 4) launch_short(k1_lookup<false, 4, true>);
+        // tables of more than 2^26 buckets (about 120 M distinct 31-mers): the WIDE instantiations (FULGOR_DICT_WIDE=1 forces them: tests)
+        static const bool force_wide = env_u64("FULGOR_DICT_WIDE", 0) != 0;
+        const bool wide = force_wide || ix->table_buckets > DICT_NARROW_BUCKETS;
+        const int hsel = halves == 1 ? 1 : (halves == 2 ? 2 : (halves <= 4 ? 4 : 0));
+#define FG_K1_PICK(H, WIDE_)                                                                   \
+        do {                                                                                   \
+            if (w13 && !ko) launch_short(k1_lookup<true, H, false, WIDE_>);                     \
+            else if (w13) launch_short(k1_lookup<true, H, true, WIDE_>);                        \
+            else if (!ko) launch_short(k1_lookup<false, H, false, WIDE_>);                      \
+            else launch_short(k1_lookup<false, H, true, WIDE_>);                                \
+        } while (0)
+        if (hsel == 1 && !wide) FG_K1_PICK(1, false);
+        else if (hsel == 2 && !wide) FG_K1_PICK(2, false);
+        else if (hsel == 4 && !wide) FG_K1_PICK(4, false);
+        else if (hsel == 1) FG_K1_PICK(1, true);
+        else if (hsel == 2) FG_K1_PICK(2, true);
+        else if (hsel == 4) FG_K1_PICK(4, true);
+#undef FG_K1_PICK
         else throw std::runtime_error("internal error: lookup unit longer than 512 k-mers");
         HIP_TRY(hipGetLastError());
     }

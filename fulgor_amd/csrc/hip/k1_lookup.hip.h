@@ -107,7 +107,8 @@ __device__ unsigned long long k1_stats[16];
 #define FG_K1_WAVES 6  // waves per SIMD the register allocation aims at (measured: profiles/r2)
 #endif
 constexpr uint32_t K1_WFIX = 15;
-template <bool WFIX, int HALVES, bool KMER_OUT>
+// WIDE: tables of more than DICT_NARROW_BUCKETS buckets (the ring keeps a pair's source lane in a word of its own).
+template <bool WFIX, int HALVES, bool KMER_OUT, bool WIDE = false>
 __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(DevDict d, const uint8_t* __restrict__ bases,
                                                                       const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
                                                                       uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
         uint32_t hres[HCAP];             // passes of at most 64 heads: id per place; longer passes: total of the head's id within its read | FIRST, 0 for repeats
         uint32_t hsrt[64];               // (passes of at most 64 heads) k-mers per place
         uint32_t meta[NSLOT][M_WORDS];
+        uint32_t psrc[WIDE ? PAIRS : 1]; // WIDE: source lanes of the ring's pairs (the bucket numbers take the whole word of `pairs`)
     };
     __shared__ WaveLds s_lds[4];
     const int lane = lane_id();
@@ -421,10 +423,18 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
 #pragma unroll
                             for (uint32_t jj = 0; jj < REDIRECT_DIRECT; ++jj) {
                                 const uint64_t mr = __ballot(jj < nbov);
-                                if (jj < nbov) pairs[(ptail + mask_rank(mr)) % PAIRS] = ((target + jj) << 6) | src;
+                                if (jj < nbov) {
+                                    const uint32_t at = (ptail + mask_rank(mr)) % PAIRS;
+                                    if (WIDE) { pairs[at] = target + jj; L.psrc[at] = src; }
+                                    else pairs[at] = ((target + jj) << 6) | src;
+                                }
                                 ptail += (uint32_t)__popcll(mr);
                             }
-                            if (spill) pairs[(ptail + mask_rank(ms)) % PAIRS] = ((bucket + 1u) << 6) | src;
+                            if (spill) {
+                                const uint32_t at = (ptail + mask_rank(ms)) % PAIRS;
+                                if (WIDE) { pairs[at] = bucket + 1u; L.psrc[at] = src; }
+                                else pairs[at] = ((bucket + 1u) << 6) | src;
+                            }
                             ptail += (uint32_t)__popcll(ms);
                             wave_lds_sync();
                         }
@@ -443,9 +453,10 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
                         uint32_t bucket = home, src = (uint32_t)lane;
                         if (taken) {
                             if (ovf) {
-                                const uint32_t pr = pairs[(phead + (uint32_t)lane - base) % PAIRS];
-                                src = pr & 63u;
-                                bucket = pr >> 6;
+                                const uint32_t at = (phead + (uint32_t)lane - base) % PAIRS;
+                                const uint32_t pr = pairs[at];
+                                if (WIDE) { src = L.psrc[at]; bucket = pr; }
+                                else { src = pr & 63u; bucket = pr >> 6; }
                             }
 #pragma unroll
                             for (int i = 0; i < NS; ++i) T[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)S[i]);

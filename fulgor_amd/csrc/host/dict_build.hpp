@@ -71,13 +71,13 @@ inline void dict_table_geometry(Dict& d) {
     // 1.625 buckets per record (0.6 records per bucket); FULGOR_DICT_BUCKET_FACTOR overrides it (measurements: the table is rebuilt at every open)
     double factor = 1.625;
     if (const char* e = getenv("FULGOR_DICT_BUCKET_FACTOR")) { const double v = atof(e); if (v >= 1.0 && v <= 16.0) factor = v; }
-    // at most 2^26 buckets in all (a bucket and a lane pack into 32 bits in the lookup kernel): the hashed region leaves room for an
+    // at most 2^31 buckets in all (DICT_MAX_BUCKETS): the hashed region leaves room for an
     // overflow region of a quarter of the records; a collection that does not fit is refused here, not at the first redirect
     bool capped = false;
     const uint32_t nb = dict_hashed_buckets(nrec, factor, &capped);
     if (nb == 0)
-        throw std::runtime_error("the k-mer dictionary of this collection needs more than 2^26 buckets (" + std::to_string(nrec) +
-                                 " super-k-mer records; the limit is about 80 M): not supported by this build");
+        throw std::runtime_error("the k-mer dictionary of this collection needs more than 2^31 buckets (" + std::to_string(nrec) +
+                                 " super-k-mer records): not supported by this build");
     if (capped)
         fprintf(stderr, "fulgor_amd: dictionary table capped at %u buckets for %llu records (%.2f buckets per record instead of %.2f): more keys behind redirects\n",
                 nb, (unsigned long long)nrec, (double)nb / (double)nrec, factor);
@@ -215,7 +215,7 @@ inline void build_dict_table(Dict& d) {
     {
         uint64_t ob = nb_hashed, words = 0;
         for (unsigned t = 0; t < T; ++t) words += piece[t].size();
-        if (nb_hashed + words / BUCKET_WORDS >= DICT_MAX_BUCKETS) throw std::runtime_error("dictionary table exceeds 2^26 buckets");
+        if (nb_hashed + words / BUCKET_WORDS >= DICT_MAX_BUCKETS) throw std::runtime_error("dictionary table exceeds 2^31 buckets");
         overflow.reserve(words);
         for (unsigned t = 0; t < T; ++t) {
             for (uint64_t b : redirects[t]) d.table[b * BUCKET_WORDS + (BUCKET_RECS - 1) * REC_WORDS + 1] += (uint32_t)ob;

@@ -2063,6 +2063,66 @@ def test_two_streamed_runs_at_once_on_one_index(s10_gpu, tmp_path):
             assert got[k_] is not None and got[k_][1] == files[k_][1] and got[k_][0] == alone[k_][0], (rep, k_)
 
 
+def test_dictionary_of_more_than_2_pow_26_buckets(built, tmp_path):
+    """round-5 review, weak item 11: a collection whose dictionary needs more than 2^26 buckets (about 120 M distinct 31-mers) was refused at
+    load — a (bucket, lane) pair of the lookup kernel's ring had to fit 32 bits. Such tables now run the kernel's WIDE instantiations
+    (the ring keeps the lane in a word of its own; up to 2^31 buckets). (1) 140 random unitigs of a million bases: 140 M k-mers, 47 M
+    super-k-mer records, 76 M hashed buckets, a 5 GB table built on the device; the self check compares it byte for byte with the host
+    builder's and walks every k-mer of every 28th unitig through it on both strands; reads cut out of the unitigs (both strands) fetch
+    their unitig's colour-set id and intersect to its colours, reads of random bases fetch nothing. (2) The WIDE instantiations forced
+    onto the ordinary indexes (FULGOR_DICT_WIDE=1): the parity tests of the lookup run again in a process of their own."""
+    import subprocess
+    rng = np.random.default_rng(26)
+    nu, ulen, ncol = 140, 1_000_000, 4
+    sets = [[0], [1, 3], [0, 1, 2, 3]]
+    base = str(tmp_path / "wide")
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    units = [alpha[rng.integers(0, 4, size=ulen, dtype=np.uint8)] for _ in range(nu)]
+    csid = sorted(u % 3 for u in range(nu))  # (a dump lists its unitigs by colour-set id)
+    with open(base + ".unitigs.fa", "wb") as f:
+        for u in range(nu):
+            f.write(b"> color_set_id=%d\n" % csid[u])
+            f.write(units[u].tobytes())
+            f.write(b"\n")
+    open(base + ".color_sets.txt", "w").write("".join("size=%d %s\n" % (len(x), " ".join(map(str, x))) for x in sets))
+    open(base + ".filenames.txt", "w").write("".join("g%d.fa\n" % c for c in range(ncol)))
+    open(base + ".metadata.txt", "w").write("k=31\nnum_kmers=%d\nnum_colors=%d\nnum_unitigs=%d\nnum_color_sets=%d\n" % (nu * (ulen - 30), ncol, nu, len(sets)))
+    ix = fulgor_amd.Index(base, device=0)
+    assert ix.num_kmers() == nu * (ulen - 30)
+    ix.selfcheck(unitig_stride=28)
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    reads, want_ids = [], []
+    for i in range(20000):
+        u = int(rng.integers(0, nu))
+        st = int(rng.integers(0, ulen - 150))
+        r = units[u][st:st + 150]
+        if i % 2:
+            r = comp[r[::-1]]
+        reads.append(r.tobytes())
+        want_ids.append(csid[u])
+    for i in range(500):
+        reads.append(alpha[rng.integers(0, 4, size=150, dtype=np.uint8)].tobytes())
+        want_ids.append(None)
+    b, o = pack_reads(reads)
+    io_, ii = ix.fetch_color_set_ids_batch(b, o)
+    io_ = io_.astype(np.int64)
+    fo, fc = ix.pseudoalign_full_intersection_batch(b, o)
+    fo = fo.astype(np.int64)
+    for i, w in enumerate(want_ids):
+        got = ii[io_[i]:io_[i + 1]].tolist()
+        assert got == ([] if w is None else [w]), (i, got, w)
+        assert fc[fo[i]:fo[i + 1]].tolist() == ([] if w is None else sets[w]), i
+    ko, ki = ix.kmer_color_set_ids_batch(b[:150 * 200], o[:201])
+    assert (ki.reshape(200, 120) == np.array(want_ids[:200], dtype=np.uint32)[:, None]).all()  # every k-mer of a read cut out of a unitig is found
+    ix.close()
+    pick = ("fetch_color_set_ids_equals_oracle or full_intersection_matches_golden or reads_of_any_length or reads_up_to_512 or one_run_per_kmer or "
+            "fuzz_dirty_ragged or matches_golden_at_4546 or other_kmer_lengths")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k", pick,
+                        "-p", "no:cacheprovider"], env=dict(os.environ, FULGOR_DICT_WIDE="1"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_no_kernel_leaves_its_buffers_under_the_guard_allocator(built):
     """FULGOR_GUARD_ALLOC=1: every device buffer is exactly as long as asked for and is followed by unmapped addresses, so a kernel
     that reads or writes past a buffer faults at once (the lookup kernel's empty-ticket read of round 5 needed a buffer that ended a
