@@ -120,7 +120,10 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
 #ifndef FG_K1_TICKET2
 #define FG_K1_TICKET2 6  // (units of up to 256 k-mers; round 6: tickets of 12 / 16 are 7 % slower at 159-286 bases, profiles/r6/read_length_sweep_variants_r6.txt)
 #endif
-    constexpr uint32_t TICKET = HALVES == 1 ? K1_TICKET : (HALVES == 2 ? FG_K1_TICKET2 : 1);  // longer units: one to three per pass, and the planes of a ticket's span live in LDS: short tickets
+#ifndef FG_K1_TICKET4
+#define FG_K1_TICKET4 2  // (units of up to 512 k-mers; round 6: 1 / 2 / 4 units per ticket: 123 / 136 / 135 G k-mers/s at 300 bases, 157 / 176 / 169 at 400, profiles/r6/read_length_sweep_variants_r6.txt)
+#endif
+    constexpr uint32_t TICKET = HALVES == 1 ? K1_TICKET : (HALVES == 2 ? FG_K1_TICKET2 : FG_K1_TICKET4);  // longer units: one to three per pass, and the planes of a ticket's span live in LDS: short tickets
     constexpr int NA = 2 * HALVES + 1;      // rounds of 64 m-mer positions (the last one: 16 positions)
     constexpr int SPAN_BASES = (int)TICKET * (KMAX + 30) + 16;  // the units of a ticket + what the 16-byte alignment of its first load adds
     constexpr int NIT = (SPAN_BASES + 1023) / 1024;              // rounds of 64 lanes x 16 bases that cover the span
@@ -149,7 +152,9 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
         uint32_t queue[QCAP + 1];        // run descriptors (+ one: a lane also looks at the entry behind its own)
         uint32_t hid[HCAP];              // heads: colour-set id
         uint32_t hcnt[HCAP];             //        k-mers | read slot << 16 | place of the slot in the pass << 20
-        uint32_t hres[HCAP];             // passes of at most 64 heads: id per place; longer passes: total of the head's id within its read | FIRST, 0 for repeats
+        // (the 512-k-mer instantiation keeps hres in the place of mn — phase E runs when the window minima are long dead —: 38 instead of
+        // 46 KB of LDS per block, four blocks per CU instead of three)
+        uint32_t hres[HALVES >= 4 ? 1 : HCAP];  // passes of at most 64 heads: id per place; longer passes: total of the head's id within its read | FIRST, 0 for repeats
         uint32_t hsrt[64];               // (passes of at most 64 heads) k-mers per place
         uint32_t meta[NSLOT][M_WORDS];
         uint32_t psrc[WIDE ? PAIRS : 1]; // WIDE: source lanes of the ring's pairs (the bucket numbers take the whole word of `pairs`)
@@ -162,7 +167,8 @@ __global__ __launch_bounds__(256, HALVES <= 2 ? FG_K1_WAVES : 4) void k1_lookup(
     uint32_t* pairs = L.pairs;
     uint32_t* hid = L.hid;
     uint32_t* hcnt = L.hcnt;
-    uint32_t* hres = L.hres;
+    static_assert(HALVES < 4 || KMAX + 80 >= HCAP, "hres takes the place of mn");
+    uint32_t* hres = HALVES >= 4 ? L.mn : L.hres;
     uint32_t* hsrt = L.hsrt;
     uint32_t (*meta)[M_WORDS] = L.meta;
     const uint32_t k = d.k, m = d.m, km = k - m, W = WFIX ? K1_WFIX : km + 1, CL = 2 * k - m;

@@ -11,7 +11,7 @@ fg, extra = synth.ensure_s4546(os.path.join(ROOT, "data"), g)
 gen = ReadGenerator(g, raw_sequences=extra)
 ix = fulgor_amd.Index(fg, device=0)
 n = 2_000_000
-for length in (75, 100, 125, 150, 158, 159, 180, 200, 222, 223, 250, 286, 287, 300, 400, 542):
+for length in [int(x) for x in os.environ.get("FULGOR_SWEEP_LENGTHS", "75,100,125,150,158,159,180,200,222,223,250,286,287,300,400,542").split(",")]:
     b, o = gen.generate(0, n, length, 42)
     reads = ix.upload_reads(b, o)
     res = ix.new_result()
