@@ -563,7 +563,6 @@ void stage_lookup_on(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint6
     if (units == 0) return;
     const bool w13 = ix->dd.k - ix->dd.m + 1 == K1_WFIX;  // (the window count the kernel unrolls for)
     // units of at most 128 k-mers: one window each; up to 512 k-mers (250- to 500-base reads, segments of longer reads): 2 to 4 windows
-    const int halves = (int)((std::max<uint32_t>(rd->max_kmers, 1) + 127) / 128);
     {
         auto launch_short = [&](auto kernel) {
             const uint32_t grid = resident_grid(kernel, units, 4, ix->num_cus, 256, 0);
@@ -578,7 +577,9 @@ void stage_lookup_on(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint6
         // tables of more than 2^26 buckets (about 120 M distinct 31-mers): the WIDE instantiations (FULGOR_DICT_WIDE=1 forces them: tests)
         static const bool force_wide = env_u64("FULGOR_DICT_WIDE", 0) != 0;
         const bool wide = force_wide || ix->table_buckets > DICT_NARROW_BUCKETS;
-        const int hsel = halves == 1 ? 1 : (halves == 2 ? 2 : (halves <= 4 ? 4 : 0));
+        // units of up to 128 / 192 / 256 / 512 k-mers (158 / 222 / 286 / 542 bases at k = 31)
+        const uint32_t quarters = (std::max<uint32_t>(rd->max_kmers, 1) + 63) / 64;
+        const int hsel = quarters <= 2 ? 2 : (quarters == 3 ? 3 : (quarters == 4 ? 4 : (quarters <= 8 ? 8 : 0)));
 #define FG_K1_PICK(H, WIDE_)                                                                   \
         do {                                                                                   \
             if (w13 && !ko) launch_short(k1_lookup<true, H, false, WIDE_>);                     \
@@ -586,12 +587,14 @@ void stage_lookup_on(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint6
             else if (!ko) launch_short(k1_lookup<false, H, false, WIDE_>);                      \
             else launch_short(k1_lookup<false, H, true, WIDE_>);                                \
         } while (0)
-        if (hsel == 1 && !wide) FG_K1_PICK(1, false);
-        else if (hsel == 2 && !wide) FG_K1_PICK(2, false);
+        if (hsel == 2 && !wide) FG_K1_PICK(2, false);
+        else if (hsel == 3 && !wide) FG_K1_PICK(3, false);
         else if (hsel == 4 && !wide) FG_K1_PICK(4, false);
-        else if (hsel == 1) FG_K1_PICK(1, true);
+        else if (hsel == 8 && !wide) FG_K1_PICK(8, false);
         else if (hsel == 2) FG_K1_PICK(2, true);
+        else if (hsel == 3) FG_K1_PICK(3, true);
         else if (hsel == 4) FG_K1_PICK(4, true);
+        else if (hsel == 8) FG_K1_PICK(8, true);
 #undef FG_K1_PICK
         else throw std::runtime_error("internal error: lookup unit longer than 512 k-mers");
         HIP_TRY(hipGetLastError());

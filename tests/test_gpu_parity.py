@@ -140,16 +140,16 @@ def test_gpu_edge_batches(s10_gpu):
             s10_gpu.pseudoalign_full_intersection_batch(base, np.array(bad, dtype=np.uint64))
 
 
-@pytest.mark.parametrize("windows", [2, 3, 4])
+@pytest.mark.parametrize("windows", [1.5, 2, 3, 4])
 def test_gpu_reads_up_to_512_kmers(s10_gpu, s10_oracle, windows, colour_stage):
-    """batches whose longest read has 129..512 k-mers (250- to 500-base reads) run the 2-, 3- and 4-window variants of the
-    short-read lookup kernel: every length around the window boundaries, invalid bases in several windows, substitutions."""
+    """batches whose longest read has 129..512 k-mers (159- to 542-base reads) run the lookup kernel's instantiations for units of up to
+    192 (round 6), 256 and 512 k-mers: every length around the window boundaries, invalid bases in several windows, substitutions."""
     from oracle.kmer_oracle import read_fasta
-    rng = np.random.default_rng(250 + windows)
+    rng = np.random.default_rng(250 + int(2 * windows))
     src = max(read_fasta(S10_GENOMES[3]), key=len)
-    top = 128 * windows + 30
+    top = int(128 * windows) + 30
     lens = [top, top - 1, top - 36, 250, 159, 160, 158, 157, 191, 192, 193, 222, 223, 224, 200, 100, 31, 30, 0, 64, 128, 129, top]
-    for j in range(1, windows):
+    for j in range(1, int(windows)):
         lens += [128 * j + 29, 128 * j + 30, 128 * j + 31, 128 * j + 94]
     lens = [min(l, top) for l in lens]
     reads = []
