@@ -1480,6 +1480,70 @@ __global__ __launch_bounds__(256, BITS == 8 ? FG_K3R_WAVES8 : (BITS == 16 ? FG_K
                     continue;
                 }
 #endif
+#ifdef FG_K3R_SPLIT_COUNTERS  // (round 6: measured, no gain — 6.49 against 6.47 ms at tau = 0.8, 7.95 against 7.63 at 0.5, profiles/r6/k3r_variants_r6.txt — and left out)
+                // More free lists than the tree takes: byte counters as below, but over the FREE lists only — a mandatory list
+                // costs one AND per row word at the end instead of a spread into eight planes (24 instructions per word), and the
+                // threshold the counters are held against is what the free lists have to bring: min_score less the mandatory lists'
+                // multiplicities. Reads of this kind have 8.3 free lists and about 10 in all at tau = 0.8.
+                if (BITS == 8) {
+                    const uint32_t free_sum = wave_sum_u32(has && mu_l <= slack ? mu_l : 0u);
+                    const uint32_t mand_sum = positive - free_sum;
+                    const uint32_t min_free = min_score > mand_sum ? min_score - mand_sum : 0u;
+                    const uint32_t start_f = (BIASED ? HALF - min_free : 0u) * ONES;
+                    const uint32_t thr_f = (256u - min_free) & 0xFFu;  // (unbiased counters only)
+                    const uint32_t add7_f = (thr_f & 0x7Fu) * 0x01010101u, top7_f = (thr_f & 0x80u) ? 0xFFFFFFFFu : 0u;
+                    const uint32_t all_pass_f = min_free == 0 ? 0xFFFFFFFFu : 0u;
+                    uint32_t pcs = 0;
+                    for (uint32_t w0 = 0; w0 < Wn; w0 += 64) {
+                        const uint32_t w = w0 + (uint32_t)ln;
+                        const uint32_t wi = min(w, W - 1);  // (lanes past the row load its last word and store nothing)
+                        uint32_t cnt[PLANES];
+#pragma unroll
+                        for (uint32_t q = 0; q < PLANES; ++q) cnt[q] = start_f;
+                        for (uint64_t ff = FREE; ff;) {  // the row words of four free lists in flight
+                            u32x4 id, mu;
+                            uint32_t kk = 0;
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; ++j) {
+                                const uint32_t a = ff ? (uint32_t)__builtin_ctzll(ff) : 0u;
+                                id[j] = ff ? (uint32_t)__builtin_amdgcn_readlane((int)id_l, a) : 0u;
+                                mu[j] = ff ? (uint32_t)__builtin_amdgcn_readlane((int)mu_l, a) : 0u;
+                                kk += ff ? 1u : 0u;
+                                ff &= ff - 1;
+                            }
+                            switch (kk) {  // (wave-uniform)
+                                case 1: rows_spread<1, BITS>(rows, W, id, mu, wi, cnt); break;
+                                case 2: rows_spread<2, BITS>(rows, W, id, mu, wi, cnt); break;
+                                case 3: rows_spread<3, BITS>(rows, W, id, mu, wi, cnt); break;
+                                default: rows_spread<4, BITS>(rows, W, id, mu, wi, cnt); break;
+                            }
+                        }
+                        uint32_t m = 0;
+#pragma unroll
+                        for (uint32_t q = 0; q < PLANES; ++q) {
+                            const uint32_t x = cnt[q];
+                            if (BIASED) {
+                                m = (m >> 1) | (x & (ONES << (BITS - 1)));
+                            } else {
+                                const uint32_t low = (x & 0x7F7F7F7Fu) + add7_f;
+                                const uint32_t out = (x & low) | ((x ^ low) & top7_f);
+                                m |= (((out | all_pass_f) >> 7) & ONES) << q;
+                            }
+                        }
+                        for (uint64_t mm = MAND; mm; mm &= mm - 1)  // (wave-uniform)
+                            m &= row_word(rows + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)id_l, (int)__builtin_ctzll(mm)) * W, wi << 2);
+                        if (w >= (n >> 5)) m &= w == (n >> 5) ? (1u << (n & 31u)) - 1u : 0u;  // (only the last words hold colours >= n)
+                        if (w < W) {
+                            bm[w] = m;
+                            pcs += __popc(m);
+                        }
+                    }
+                    for (uint32_t w = ((Wn + 63) & ~63u) + ln; w < W; w += 64) bm[w] = 0;  // (padding words behind the last round)
+                    pcs = wave_sum_u32(pcs);
+                    if (ln == 0) out_count[r] = pcs;
+                    continue;
+                }
+#endif
             }
             const uint32_t start = (BIASED ? HALF - min_score : 0u) * ONES;
             const uint32_t thr_c = (256u - min_score) & 0xFFu;  // (unbiased counters only)
