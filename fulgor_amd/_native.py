@@ -56,6 +56,7 @@ def lib():
     L.fgpu_kmer_matches.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp)]
     L.fgpu_kmer_emitter_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.fgpu_kmer_emitter_add.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.POINTER(vp), u64p]
+    L.fgpu_kmer_emitter_write.argtypes = [vp, vp, vp, C.c_uint64, vp, vp, C.c_int, u64p]
     L.fgpu_kmer_emitter_free.argtypes = [vp]
     L.fgpu_kmer_emitter_free.restype = None
     L.fgpu_threshold_union.argtypes = [vp, vp, vp, C.c_uint64, C.c_double, C.POINTER(vp), C.POINTER(vp)]

@@ -222,7 +222,8 @@ def _query_tool(argv, prog, tool):
             if cnt == 0:
                 break
             pn, pno = batches.names_raw()
-            out.write(emitter.add(pb, po, pn, pno, cnt))
+            out.flush()
+            emitter.write(pb, po, pn, pno, cnt, out.fileno())
             n += cnt
     emitter.close()
     batches.close()

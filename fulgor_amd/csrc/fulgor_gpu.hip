@@ -1940,6 +1940,12 @@ struct fgpu_kmer_emitter {
     fgpu_result* res = nullptr;
     std::vector<uint8_t> prev_flags;    // kmer-matches: what the last record of at least k bases left behind
     std::vector<uint32_t> prev_counts;
+    // buffers of a batch, kept from one add to the next (tens of megabytes each: allocated anew per batch they cost more in page
+    // faults than the formatting — the first index of a process ran at 2 M records/s, the second, with a warmed-up allocator, at 8 M)
+    HostVec<uint32_t> raw, counts;      // what comes down from the device: pinned slabs of the pool
+    std::vector<uint64_t> ko;
+    std::vector<uint32_t> ki;
+    std::vector<std::string> parts;
 };
 
 }  // extern "C"
@@ -1954,11 +1960,13 @@ inline void put_u32(std::string& o, uint32_t x) {
 }
 
 // per-k-mer colour-set ids of an uploaded batch on the host: o[r] .. o[r + 1] index v (0xFFFFFFFF = negative k-mer)
-void kmer_ids_to_host(fgpu_index* ix, const fgpu_reads* rd, fgpu_result* res, const uint64_t* offs, uint64_t n, std::vector<uint64_t>& o, std::vector<uint32_t>& v) {
+void kmer_ids_to_host(fgpu_index* ix, const fgpu_reads* rd, fgpu_result* res, const uint64_t* offs, uint64_t n, std::vector<uint64_t>& o, std::vector<uint32_t>& v,
+                      HostVec<uint32_t>& raw) {
     const uint32_t k = ix->host.dict.k;
     const uint64_t stride = std::max<uint32_t>(1, rd->max_kmers);
     const uint64_t units = rd->has_long ? rd->seg_first[n] : n;
-    std::vector<uint32_t> raw(units * stride);
+    raw.clear();
+    raw.resize(std::max<uint64_t>(1, units * stride));
     if (units) HIP_TRY(hipMemcpy(raw.data(), res->d_kmer_ids.p, units * stride * 4, hipMemcpyDeviceToHost));
     o.resize(n + 1);
     for (uint64_t r = 0; r <= n; ++r) o[r] = rd->kmers_before(r);
@@ -2010,10 +2018,25 @@ void fgpu_kmer_emitter_free(fgpu_kmer_emitter* e) {
     delete e;
 }
 
+static int kmer_emitter_batch(fgpu_kmer_emitter* e, const char* bases, const uint64_t* offs, uint64_t n, const char* names, const uint64_t* name_offs,
+                              char** out, int out_fd, uint64_t* out_len);
+
 int fgpu_kmer_emitter_add(fgpu_kmer_emitter* e, const char* bases, const uint64_t* offs, uint64_t n, const char* names, const uint64_t* name_offs,
                           char** out, uint64_t* out_len) {
-    if (!e || !offs || !name_offs || !out || !out_len || (n && (!bases || !names))) return fail(-EINVAL, "null argument");
-    *out = nullptr;
+    if (!out) return fail(-EINVAL, "null argument");
+    return kmer_emitter_batch(e, bases, offs, n, names, name_offs, out, -1, out_len);
+}
+
+int fgpu_kmer_emitter_write(fgpu_kmer_emitter* e, const char* bases, const uint64_t* offs, uint64_t n, const char* names, const uint64_t* name_offs,
+                            int out_fd, uint64_t* out_len) {
+    if (out_fd < 0) return fail(-EINVAL, "bad file descriptor");
+    return kmer_emitter_batch(e, bases, offs, n, names, name_offs, nullptr, out_fd, out_len);
+}
+
+static int kmer_emitter_batch(fgpu_kmer_emitter* e, const char* bases, const uint64_t* offs, uint64_t n, const char* names, const uint64_t* name_offs,
+                              char** out, int out_fd, uint64_t* out_len) {
+    if (!e || !offs || !name_offs || !out_len || (n && (!bases || !names))) return fail(-EINVAL, "null argument");
+    if (out) *out = nullptr;
     *out_len = 0;
     fgpu_index* ix = e->ix;
     fgpu_reads* rd = nullptr;
@@ -2026,21 +2049,25 @@ int fgpu_kmer_emitter_add(fgpu_kmer_emitter* e, const char* bases, const uint64_
         res->want_kmer_ids = true;
         res->want_scores = e->tool == FGPU_TOOL_KMER_MATCHES;
         stage_lookup(ix, rd, 0, n, res);
-        std::vector<uint32_t> counts;
+        install_pinned_allocator();
+        HostVec<uint32_t>& counts = e->counts;
         if (e->tool == FGPU_TOOL_KMER_MATCHES) {
             stage_descriptors(ix, res, res->total_kmers, FGPU_THRESHOLD_UNION);
             stage_colors(ix, FGPU_THRESHOLD_UNION, 1.0, res);  // (the threshold only shapes the discarded bitmap; the scores are the counts)
+            counts.clear();
             counts.resize(std::max<uint64_t>(1, n * nc));
             if (n) HIP_TRY(hipMemcpy(counts.data(), res->d_scores.p, n * nc * 4, hipMemcpyDeviceToHost));
         } else {
             HIP_TRY(hipStreamSynchronize(res->stream));
             if (ix->timing) ix->collect_timing(res->pending);
         }
-        std::vector<uint64_t> ko;
-        std::vector<uint32_t> ki;
-        kmer_ids_to_host(ix, rd, res, offs, n, ko, ki);
+        std::vector<uint64_t>& ko = e->ko;
+        std::vector<uint32_t>& ki = e->ki;
+        kmer_ids_to_host(ix, rd, res, offs, n, ko, ki, e->raw);
         const unsigned T = parallel_ranges_threads(n);
-        std::vector<std::string> parts(T);
+        std::vector<std::string>& parts = e->parts;
+        if (parts.size() < T) parts.resize(T);
+        for (std::string& p_ : parts) p_.clear();  // (capacity kept)
         if (e->tool == FGPU_TOOL_KMER_CONSERVATION) {
             // `name <tab> #triples [<tab>(start num_kmers color_set_id)]...`: maximal runs of consecutive positive k-mers with one colour-set id
             parallel_ranges(n, [&](unsigned t, uint64_t a, uint64_t b) {
@@ -2106,16 +2133,29 @@ int fgpu_kmer_emitter_add(fgpu_kmer_emitter* e, const char* bases, const uint64_
                 const uint64_t q = (uint64_t)last;
                 e->prev_flags.resize(ko[q + 1] - ko[q]);
                 for (uint64_t i = 0; i < e->prev_flags.size(); ++i) e->prev_flags[i] = ki[ko[q] + i] != 0xFFFFFFFFu;
-                e->prev_counts.assign(counts.begin() + q * nc, counts.begin() + (q + 1) * nc);
+                e->prev_counts.assign(counts.data() + q * nc, counts.data() + (q + 1) * nc);
             }
         }
         uint64_t total = 0;
         for (const std::string& p : parts) total += p.size();
-        char* buf = (char*)malloc(std::max<uint64_t>(1, total));
-        if (!buf) throw std::bad_alloc();
-        uint64_t at = 0;
-        for (const std::string& p : parts) { memcpy(buf + at, p.data(), p.size()); at += p.size(); }
-        *out = buf;
+        if (out) {
+            char* buf = (char*)malloc(std::max<uint64_t>(1, total));
+            if (!buf) throw std::bad_alloc();
+            uint64_t at = 0;
+            for (const std::string& p : parts) { memcpy(buf + at, p.data(), p.size()); at += p.size(); }
+            *out = buf;
+        } else {  // straight to the file, the threads' pieces in order (kmer-matches writes 14 KB per record at 4546 colours: no second copy)
+            for (const std::string& p : parts) {
+                const char* q = p.data();
+                size_t left = p.size();
+                while (left) {
+                    const ssize_t w = ::write(out_fd, q, left);
+                    if (w < 0) { if (errno == EINTR) continue; throw std::runtime_error(std::string("cannot write the output: ") + strerror(errno)); }
+                    q += w;
+                    left -= (size_t)w;
+                }
+            }
+        }
         *out_len = total;
     });
     fgpu_reads_free(rd);

@@ -171,6 +171,14 @@ class KmerEmitter:
         _native.check(self._L.fgpu_kmer_emitter_add(self._h, addr(bases), addr(offs), int(n), addr(names), addr(name_offs), C.byref(p), C.byref(ln)))
         return _native.take_bytes(p, ln.value)
 
+    def write(self, bases, offs, names, name_offs, n, out_fd):
+        """as add(), the lines written to the file descriptor out_fd; returns the number of bytes"""
+        def addr(x):
+            return C.c_void_p(x) if isinstance(x, int) else _ptr(x)
+        ln = C.c_uint64()
+        _native.check(self._L.fgpu_kmer_emitter_write(self._h, addr(bases), addr(offs), int(n), addr(names), addr(name_offs), int(out_fd), C.byref(ln)))
+        return ln.value
+
     def close(self):
         if self._h:
             self._L.fgpu_kmer_emitter_free(self._h)

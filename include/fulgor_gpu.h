@@ -96,6 +96,9 @@ enum { FGPU_TOOL_KMER_CONSERVATION = 0, FGPU_TOOL_KMER_MATCHES = 1 };
 int fgpu_kmer_emitter_create(fgpu_index* idx, int tool, fgpu_kmer_emitter** out);
 int fgpu_kmer_emitter_add(fgpu_kmer_emitter* e, const char* bases, const uint64_t* offs, uint64_t n, const char* names, const uint64_t* name_offs,
                           char** out, uint64_t* out_len);
+/* the same, the lines written to the file descriptor out_fd (no copy of the text: kmer-matches writes one count per colour and record) */
+int fgpu_kmer_emitter_write(fgpu_kmer_emitter* e, const char* bases, const uint64_t* offs, uint64_t n, const char* names, const uint64_t* name_offs,
+                            int out_fd, uint64_t* out_len);
 void fgpu_kmer_emitter_free(fgpu_kmer_emitter* e);
 void fgpu_free(void* p);
 

@@ -39,9 +39,7 @@ def tool_loop(ix, path, tool, batch):
             if cnt == 0:
                 break
             pn, pno = rd.names_raw()
-            text = em.add(pb, po, pn, pno, cnt)
-            out.write(text)
-            out_bytes += len(text)
+            out_bytes += em.write(pb, po, pn, pno, cnt, out.fileno())
             n += cnt
     em.close()
     rd.close()
@@ -50,7 +48,10 @@ def tool_loop(ix, path, tool, batch):
 
 path = "/dev/shm/tools_%d.fq" % os.getpid()
 try:
-    for name, ensure in (("s4546core (core-heavy profile)", synth.ensure_s4546_core), ("s4546syn", synth.ensure_s4546)):
+    order = [("s4546core (core-heavy profile)", synth.ensure_s4546_core), ("s4546syn", synth.ensure_s4546)]
+    if os.environ.get("FULGOR_TOOLS_SWAP"):
+        order.reverse()
+    for name, ensure in order:
         fg, extra = ensure(os.path.join(ROOT, "data"), g)
         ix = fulgor_amd.Index(fg, device=0)
         gen = ReadGenerator(g, raw_sequences=extra)
