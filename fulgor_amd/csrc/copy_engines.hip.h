@@ -133,7 +133,8 @@ private:
             } else (void)hipGetLastError();
         }
         if (!cache_path.empty()) {
-            if (FILE* f = fopen(cache_path.c_str(), "r")) {
+            const int cfd = ::open(cache_path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+            if (FILE* f = cfd >= 0 ? fdopen(cfd, "r") : nullptr) {
                 unsigned in0 = 0, in1 = 0, out = 0, nin = 0;
                 double rate = 0;
                 char text[1024] = {0};
@@ -167,7 +168,7 @@ private:
         }
         // One process per GPU probes at the same moment when a multi-GPU run starts: the probes take turns under a host-wide lock
         // (each is 64 copies of 4 MB, about 20 ms), so that a rank's engines are timed against an otherwise quiet host.
-        int lock_fd = ::open("/tmp/fulgor_amd_copy_engines.lock", O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+        int lock_fd = ::open("/tmp/fulgor_amd_copy_engines.lock", O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);
         if (lock_fd >= 0 && flock(lock_fd, LOCK_EX) != 0) { ::close(lock_fd); lock_fd = -1; }
         struct Unlock { int fd; ~Unlock() { if (fd >= 0) { (void)flock(fd, LOCK_UN); ::close(fd); } } } unlock{lock_fd};
         std::vector<std::pair<uint32_t, double>> rate;  // engine, GB/s of a 4 MB copy out (best of four)
@@ -214,7 +215,9 @@ private:
             double out_rate = 0;
             for (auto& r : rate) if (r.first == out_) out_rate = r.second;
             const std::string tmp = cache_path + "." + std::to_string((long)getpid());
-            if (FILE* f = fopen(tmp.c_str(), "w")) {
+            // (a new file of this user's, never through a link somebody else left under /tmp)
+            const int tfd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+            if (FILE* f = tfd >= 0 ? fdopen(tfd, "w") : nullptr) {
                 fprintf(f, "v1 %u %x %x %x %.1f\n%s\n", (unsigned)in_.size(), in_[0], in_.size() > 1 ? in_[1] : 0u, out_, out_rate, report_.c_str());
                 fclose(f);
                 if (rename(tmp.c_str(), cache_path.c_str()) != 0) (void)remove(tmp.c_str());

@@ -1098,7 +1098,7 @@ int fgpu_open(const char* path, int device, fgpu_index** out) {
         upload_index(ix, forms);
         if (ix->host.type != IDX_HYBRID) upload_generic(ix);
     });
-    if (rc) { delete ix; return rc; }
+    if (rc) { fgpu_close(ix); return rc; }  // (what the device thread created so far goes with it)
     *out = ix;
     return 0;
 }
