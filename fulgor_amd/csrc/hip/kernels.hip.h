@@ -1371,6 +1371,102 @@ __device__ __forceinline__ uint32_t deficit_union_read(const uint32_t* __restric
     return pc;
 }
 
+// Threshold union by byte counters for a whole read at once (round 6): the three rounds of 64 row words of a 4546-colour row go
+// through the counters together (three words per lane, as in the multiplexer tree), the row words of FOUR lists — twelve per lane — are
+// requested in one go, and the next four lists' words are requested before the current ones are spread into the counters. The loop of
+// the first five rounds fetched four words per lane, waited, counted, and did that nine times for a read of ten lists: the knock-out
+// builds say its reads cost 1.8 of the kernel's 6.5 ms at a sixth of the reads, and neither fewer instructions (counters over the free
+// lists only) nor other counters (bit-sliced deficits) moved that.
+// MEASURED and NOT in the shipped build (-DFG_K3R_WHOLE_READ_COUNTERS): groups of 1 / 2 / 4 lists, 7 and 6 waves per SIMD: 10.2 / 11.7 /
+// 14.3 ms against the 6.4-6.5 ms of the round-by-round loop (profiles/r6/k3r_variants_r6.txt). Twenty-four counter registers beside the
+// words in flight do not fit the 72 (80) registers the kernel may use beside the multiplexer tree's paths: 16 to 41 vector registers
+// are spilled to scratch, inside the loop. The kernel as it stands is the best this register budget gives; the three restructurings
+// of this round (deficit counters, counters over the free lists, whole-read counters) all paid more in spills than they saved.
+template <bool BIASED>
+__device__ __forceinline__ uint32_t counter_union_read(const uint32_t* __restrict__ rows, uint32_t W, uint32_t Wn, uint32_t n, const uint32_t* __restrict__ ids,
+                                                       const uint32_t* __restrict__ mults, uint32_t nl, uint32_t min_score, uint32_t* __restrict__ bm, int lane) {
+#ifndef FG_K3R_GROUP
+#define FG_K3R_GROUP 2
+#endif
+    constexpr int R = 3, PLANES = 8, GL = FG_K3R_GROUP;
+    constexpr uint32_t ONES = 0x01010101u, HALF = 128u;
+    const uint32_t start = (BIASED ? HALF - min_score : 0u) * ONES;
+    const uint32_t thr_c = (256u - min_score) & 0xFFu;  // (unbiased counters only)
+    const uint32_t add7 = (thr_c & 0x7Fu) * 0x01010101u, top7 = (thr_c & 0x80u) ? 0xFFFFFFFFu : 0u;
+    const uint32_t all_pass = min_score == 0 ? 0xFFFFFFFFu : 0u;
+    uint32_t pc = 0;
+    for (uint32_t w0 = 0; w0 < Wn; w0 += 64 * R) {
+        uint32_t wi[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) wi[r] = min(w0 + 64u * r + (uint32_t)lane, W - 1) << 2;  // byte offset in a row (lanes past the row load its last word and store nothing)
+        uint32_t cnt[PLANES][R];
+#pragma unroll
+        for (int q = 0; q < PLANES; ++q)
+#pragma unroll
+            for (int r = 0; r < R; ++r) cnt[q][r] = start;
+        // a group = GL lists (the last one padded with its first list at multiplicity 0: a row that is in the cache, a product that is 0)
+        auto fetch = [&](uint32_t i, uint32_t (&x)[GL][R], uint32_t (&mu)[GL]) {
+            const uint32_t left = nl - i;
+            // ids and multiplicities through the scalar cache (the slabs have room behind a read's last id: what is read past it is not used)
+            typedef const __attribute__((address_space(4))) uint32_t* s1_ptr;
+            uint32_t idv[GL], muv[GL];
+#pragma unroll
+            for (int j = 0; j < GL; ++j) { idv[j] = *(s1_ptr)(ids + i + j); muv[j] = *(s1_ptr)(mults + i + j); }
+#pragma unroll
+            for (int j = 0; j < GL; ++j) {
+                const bool there = (uint32_t)j < left;  // (wave-uniform)
+                const uint32_t* row = rows + (uint64_t)(there ? idv[j] : idv[0]) * W;
+                mu[j] = there ? muv[j] : 0u;
+#pragma unroll
+                for (int r = 0; r < R; ++r) x[j][r] = row_word(row, wi[r]);
+            }
+        };
+        uint32_t xa[GL][R], ma[GL];
+        fetch(0, xa, ma);
+        for (uint32_t i = 0; i < nl; i += GL) {
+            uint32_t xb[GL][R], mb[GL];
+            const bool more = i + GL < nl;  // (wave-uniform)
+            if (more) fetch(i + GL, xb, mb);
+#pragma unroll
+            for (int j = 0; j < GL; ++j)
+#pragma unroll
+                for (int q = 0; q < PLANES; ++q)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) cnt[q][r] += ((xa[j][r] >> q) & ONES) * ma[j];
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < GL; ++j) {
+                    ma[j] = mb[j];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) xa[j][r] = xb[j][r];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int q = 0; q < PLANES; ++q) {
+                const uint32_t x = cnt[q][r];
+                if (BIASED) {
+                    m = (m >> 1) | (x & (ONES << 7));  // plane q ends 7 - q places below its field's top bit
+                } else {  // byte >= min_score  <=>  carry out of byte + (256 - min_score); min_score = 0 keeps every colour
+                    const uint32_t low = (x & 0x7F7F7F7Fu) + add7;
+                    const uint32_t out = (x & low) | ((x ^ low) & top7);
+                    m |= (((out | all_pass) >> 7) & ONES) << q;
+                }
+            }
+            const uint32_t w = w0 + 64u * r + (uint32_t)lane;
+            if (w >= (n >> 5)) m &= w == (n >> 5) ? (1u << (n & 31u)) - 1u : 0u;  // (only the last words hold colours >= n)
+            if (w < W) {
+                bm[w] = m;
+                pc += __popc(m);
+            }
+        }
+    }
+    return pc;
+}
+
 template <int BITS, bool BIASED = true, bool SCORES = false>
 // (7 waves per SIMD for the 8-bit counters: 72 VGPRs and 94 SGPRs leave 4 scalars spilled and no scratch, and it is the fastest of 6 / 7 / 8:
 // 7.08 / 6.43 / 6.58 ms, profiles/r5/k3r_variants_r5.txt)
@@ -1431,6 +1527,13 @@ __global__ __launch_bounds__(256, BITS == 8 ? FG_K3R_WAVES8 : (BITS == 16 ? FG_K
                 const uint32_t slack = positive - min_score;
                 const uint64_t FREE = __ballot(has && mu_l <= slack), MAND = __ballot(has && mu_l > slack);
                 const uint32_t nfree = (uint32_t)__popcll(FREE);
+#ifdef FG_K3R_KNOCKOUT  // (timing experiments, results wrong: 1 = the reads of the multiplexer tree are skipped, 2 = those of the byte counters)
+                if ((FG_K3R_KNOCKOUT == 1) == (nfree <= K3R_MUX_LISTS)) {
+                    for (uint32_t w = ln; w < W; w += 64) bm[w] = 0;
+                    if (ln == 0) out_count[r] = 0;
+                    continue;
+                }
+#endif
                 if (nfree <= K3R_MUX_LISTS) {
                     uint32_t idf[K3R_MUX_LISTS], muf[K3R_MUX_LISTS];
                     uint64_t ff = FREE;
@@ -1545,6 +1648,15 @@ __global__ __launch_bounds__(256, BITS == 8 ? FG_K3R_WAVES8 : (BITS == 16 ? FG_K
                 }
 #endif
             }
+#ifdef FG_K3R_WHOLE_READ_COUNTERS  // (round 6: measured — 9.8 to 14.3 ms against 6.4-6.5 — and left out; see counter_union_read)
+            if (BITS == 8 && !SCORES) {
+                uint32_t pcs = counter_union_read<BIASED>(rows, W, Wn, n, ids_pool + off, cnt_pool + off, nl, min_score, bm, ln);
+                for (uint32_t w = ((Wn + 191) / 192 * 192) + ln; w < W; w += 64) bm[w] = 0;  // (padding words behind the last chunk of three rounds)
+                pcs = wave_sum_u32(pcs);
+                if (ln == 0) out_count[r] = pcs;
+                continue;
+            }
+#endif
             const uint32_t start = (BIASED ? HALF - min_score : 0u) * ONES;
             const uint32_t thr_c = (256u - min_score) & 0xFFu;  // (unbiased counters only)
             const uint32_t add7 = (thr_c & 0x7Fu) * 0x01010101u, top7 = (thr_c & 0x80u) ? 0xFFFFFFFFu : 0u;
