@@ -577,9 +577,9 @@ void stage_lookup_on(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint6
         // tables of more than 2^26 buckets (about 120 M distinct 31-mers): the WIDE instantiations (FULGOR_DICT_WIDE=1 forces them: tests)
         static const bool force_wide = env_u64("FULGOR_DICT_WIDE", 0) != 0;
         const bool wide = force_wide || ix->table_buckets > DICT_NARROW_BUCKETS;
-        // units of up to 128 / 192 / 256 / 512 k-mers (158 / 222 / 286 / 542 bases at k = 31)
+        // units of up to 128 / 192 / 256 / 384 / 512 k-mers (158 / 222 / 286 / 414 / 542 bases at k = 31)
         const uint32_t quarters = (std::max<uint32_t>(rd->max_kmers, 1) + 63) / 64;
-        const int hsel = quarters <= 2 ? 2 : (quarters == 3 ? 3 : (quarters == 4 ? 4 : (quarters <= 8 ? 8 : 0)));
+        const int hsel = quarters <= 2 ? 2 : (quarters == 3 ? 3 : (quarters == 4 ? 4 : (quarters <= 6 ? 6 : (quarters <= 8 ? 8 : 0))));
 #define FG_K1_PICK(H, WIDE_)                                                                   \
         do {                                                                                   \
             if (w13 && !ko) launch_short(k1_lookup<true, H, false, WIDE_>);                     \
@@ -590,10 +590,12 @@ void stage_lookup_on(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint6
         if (hsel == 2 && !wide) FG_K1_PICK(2, false);
         else if (hsel == 3 && !wide) FG_K1_PICK(3, false);
         else if (hsel == 4 && !wide) FG_K1_PICK(4, false);
+        else if (hsel == 6 && !wide) FG_K1_PICK(6, false);
         else if (hsel == 8 && !wide) FG_K1_PICK(8, false);
         else if (hsel == 2) FG_K1_PICK(2, true);
         else if (hsel == 3) FG_K1_PICK(3, true);
         else if (hsel == 4) FG_K1_PICK(4, true);
+        else if (hsel == 6) FG_K1_PICK(6, true);
         else if (hsel == 8) FG_K1_PICK(8, true);
 #undef FG_K1_PICK
         else throw std::runtime_error("internal error: lookup unit longer than 512 k-mers");

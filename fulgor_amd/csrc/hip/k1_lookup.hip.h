@@ -107,16 +107,17 @@ __device__ unsigned long long k1_stats[16];
 #endif
 constexpr uint32_t K1_WFIX = 15;
 // WIDE: tables of more than DICT_NARROW_BUCKETS buckets (the ring keeps a pair's source lane in a word of its own).
-// Q = 2, 3, 4, 8: units of up to 64 * Q k-mers (round 6: 3 — reads of 159 to 222 bases at k = 31 ran the 256-k-mer instantiation).
+// Q = 2, 3, 4, 6, 8: units of up to 64 * Q k-mers (round 6: 3 and 6 — reads of 159 to 222 bases at k = 31 ran the 256-k-mer
+// instantiation, reads of 287 to 414 bases the 512-k-mer one).
 template <bool WFIX, int Q, bool KMER_OUT, bool WIDE = false>
-__global__ __launch_bounds__(256, Q <= 4 ? FG_K1_WAVES : 4) void k1_lookup(DevDict d, const uint8_t* __restrict__ bases,
+__global__ __launch_bounds__(256, Q <= 4 ? FG_K1_WAVES : (Q <= 6 ? 5 : 4)) void k1_lookup(DevDict d, const uint8_t* __restrict__ bases,
                                                                       const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
                                                                       uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
                                                                       uint64_t* __restrict__ idoff, uint32_t* __restrict__ ids_pool,
                                                                       uint32_t* __restrict__ cnt_pool, uint32_t stride, unsigned int* tickets,
                                                                       uint32_t* __restrict__ kmer_out) {
     foreign_writes_acquire();  // (the bases and offsets may have been written by a copy engine that the HIP runtime knows nothing about)
-    constexpr int HALVES = (Q + 1) / 2;     // 1, 2, 2, 4: which set of tuning constants applies
+    constexpr int HALVES = Q <= 4 ? (Q + 1) / 2 : 4;  // 1, 2, 2, 4, 4: which set of tuning constants applies
     constexpr int KMAX = 64 * Q;            // k-mers per unit
 #ifndef FG_K1_TICKET2
 #define FG_K1_TICKET2 6  // (units of up to 256 k-mers; round 6: tickets of 12 / 16 are 7 % slower at 159-286 bases, profiles/r6/read_length_sweep_variants_r6.txt)
@@ -127,12 +128,15 @@ __global__ __launch_bounds__(256, Q <= 4 ? FG_K1_WAVES : 4) void k1_lookup(DevDi
 #ifndef FG_K1_TICKET3
 #define FG_K1_TICKET3 16  // (units of up to 192 k-mers; round 6: 6 / 8 / 12 / 16 units per ticket: 178 / 176 / 181 / 184 G k-mers/s at 159 bases, profiles/r6/read_length_sweep_variants_r6.txt)
 #endif
-    constexpr uint32_t TICKET = Q == 2 ? K1_TICKET : (Q == 3 ? FG_K1_TICKET3 : (Q == 4 ? FG_K1_TICKET2 : FG_K1_TICKET4));  // longer units: one to three per pass, and the planes of a ticket's span live in LDS: short tickets
+#ifndef FG_K1_TICKET6
+#define FG_K1_TICKET6 4
+#endif
+    constexpr uint32_t TICKET = Q == 2 ? K1_TICKET : (Q == 3 ? FG_K1_TICKET3 : (Q == 4 ? FG_K1_TICKET2 : (Q == 6 ? FG_K1_TICKET6 : FG_K1_TICKET4)));  // longer units: one to three per pass, and the planes of a ticket's span live in LDS: short tickets
     constexpr int NA = Q + 1;               // rounds of 64 m-mer positions (the last one: 16 positions)
     constexpr int SPAN_BASES = (int)TICKET * (KMAX + 30) + 16;  // the units of a ticket + what the 16-byte alignment of its first load adds
     constexpr int NIT = (SPAN_BASES + 1023) / 1024;              // rounds of 64 lanes x 16 bases that cover the span
     constexpr int SPW = 1 + 32 * NIT + 3;   // plane words: one pad word in front, three behind (a context reaches 14 bases past its read)
-    constexpr int GROUP = Q == 2 ? 6 : (Q == 3 ? 4 : (Q == 4 ? 3 : 1));  // most reads whose runs share one pass of phase C
+    constexpr int GROUP = Q == 2 ? 6 : (Q == 3 ? 4 : (Q == 4 ? 3 : (Q == 6 ? 2 : 1)));  // most reads whose runs share one pass of phase C
     constexpr int NSLOT = GROUP + 1;        // read slots (a ring): the reads of a pass plus the read waiting for the next one
     constexpr int QCAP = KMAX + 64;         // the runs of a pass (at most 64, or one unit: at most one run per k-mer) + those of the next read
     constexpr int HCAP = KMAX;              // heads per pass; a single unit has at most one head per k-mer
