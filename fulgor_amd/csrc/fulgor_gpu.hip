@@ -587,7 +587,11 @@ void stage_lookup_on(fgpu_index* ix, const fgpu_reads* rd, uint64_t first, uint6
             else if (!ko) launch_short(k1_lookup<false, H, false, WIDE_>);                      \
             else launch_short(k1_lookup<false, H, true, WIDE_>);                                \
         } while (0)
-        if (hsel == 2 && !wide) FG_K1_PICK(2, false);
+        // (reads of up to 144 bases: 114 k-mers look at 128 m-mer positions, two rounds of 64; FULGOR_K1_SHORT=0: the general instantiation)
+        static const bool allow_short = env_u64("FULGOR_K1_SHORT", 1) != 0;
+        const bool short_units = allow_short && hsel == 2 && w13 && !ko && !wide && rd->max_kmers + K1_WFIX - 1 <= 128;
+        if (short_units) launch_short(k1_lookup<true, 2, false, false, true>);
+        else if (hsel == 2 && !wide) FG_K1_PICK(2, false);
         else if (hsel == 3 && !wide) FG_K1_PICK(3, false);
         else if (hsel == 4 && !wide) FG_K1_PICK(4, false);
         else if (hsel == 6 && !wide) FG_K1_PICK(6, false);

@@ -109,7 +109,8 @@ constexpr uint32_t K1_WFIX = 15;
 // WIDE: tables of more than DICT_NARROW_BUCKETS buckets (the ring keeps a pair's source lane in a word of its own).
 // Q = 2, 3, 4, 6, 8: units of up to 64 * Q k-mers (round 6: 3 and 6 — reads of 159 to 222 bases at k = 31 ran the 256-k-mer
 // instantiation, reads of 287 to 414 bases the 512-k-mer one).
-template <bool WFIX, int Q, bool KMER_OUT, bool WIDE = false>
+// SHORT (Q = 2 only): every unit of the launch has at most 114 k-mers (reads of up to 144 bases): two rounds of m-mer positions instead of three.
+template <bool WFIX, int Q, bool KMER_OUT, bool WIDE = false, bool SHORT = false>
 __global__ __launch_bounds__(256, Q <= 4 ? FG_K1_WAVES : (Q <= 6 ? 5 : 4)) void k1_lookup(DevDict d, const uint8_t* __restrict__ bases,
                                                                       const uint64_t* __restrict__ offs, uint64_t first, uint64_t n_reads,
                                                                       uint32_t* __restrict__ nids, uint32_t* __restrict__ npos,
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256, Q <= 4 ? FG_K1_WAVES : (Q <= 6 ? 5 : 4)) void 
                 // rounds of 64 m-mer positions this unit needs (wave-uniform): its nk k-mers look at m-mers 0 .. nk + W - 2, and the window
                 // minima read up to 15 positions past a k-mer's first m-mer; a unit at the short end of an instantiation (129 k-mers in the
                 // one for up to 256) leaves the last rounds out — they were a fifth of the kernel's time at 159 bases
-                const int na = HALVES == 1 ? NA : max(1, min(NA, (int)((nk + 14u + 63u) >> 6)));  // m-mers 0 .. nk + 13
+                const int na = HALVES == 1 ? (SHORT ? NA - 1 : NA) : max(1, min(NA, (int)((nk + 14u + 63u) >> 6)));  // m-mers 0 .. nk + 13
                 const int nb = HALVES == 1 ? NA - 1 : min(NA - 1, (int)((nk + 63u) >> 6));          // k-mers 0 .. nk - 1
                 mn[64 * (NA - 1) + 16 + lane] = 0xFFFFFFFFu;  // positions past the last round are "infinite"
                 uint32_t v[NA];

@@ -182,6 +182,38 @@ def test_gpu_reads_up_to_512_kmers(s10_gpu, s10_oracle, windows, colour_stage):
         assert conservation_triples(ids) == s10_oracle.kmer_conservation(r)
 
 
+@pytest.mark.parametrize("top", [144, 100, 145])
+def test_gpu_batches_of_short_reads(s10_gpu, s10_oracle, top):
+    """batches whose longest read has at most 114 k-mers (144 bases) run the SHORT instantiation of the lookup kernel (two rounds of
+    m-mer positions instead of three; round 6); 145 bases: the general one. Every length up to the top, substitutions, invalid bases,
+    lower case; ids, both algorithms and the per-k-mer ids against the oracle."""
+    from oracle.kmer_oracle import read_fasta
+    from fulgor_amd.index import conservation_triples
+    rng = np.random.default_rng(top)
+    src = max(read_fasta(S10_GENOMES[5]), key=len)
+    lens = list(range(0, top + 1)) * 3 + [top] * 200 + [top - 1] * 50 + [31] * 20
+    reads = []
+    for i, l in enumerate(lens):
+        st = int(rng.integers(0, len(src) - 300))
+        r = bytearray(src[st:st + l])
+        if i % 3 == 1 and l > 40:
+            for p_ in rng.integers(0, l, 2):
+                r[p_] = b"ACGT"[int(rng.integers(0, 4))]
+        if i % 5 == 2 and l > 40:
+            r[int(rng.integers(0, l))] = ord("N")
+        if i % 7 == 3:
+            r = bytearray(bytes(r).lower())
+        reads.append(bytes(r))
+    b, o = pack_reads(reads)
+    got3 = (s10_gpu.pseudoalign_full_intersection_batch(b, o), s10_gpu.pseudoalign_threshold_union_batch(b, o, 0.8), s10_gpu.fetch_color_set_ids_batch(b, o))
+    want3 = (s10_oracle.full_intersection(b, o), s10_oracle.threshold_union(b, o, 0.8), s10_oracle.fetch_color_set_ids(b, o))
+    for got, want in zip(got3, want3):
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    ko, ki = s10_gpu.kmer_color_set_ids_batch(b[:int(o[300])], o[:301])
+    for j in range(300):
+        assert conservation_triples(ki[int(ko[j]):int(ko[j + 1])]) == s10_oracle.kmer_conservation(reads[j])
+
+
 def test_gpu_threshold_union_reads_of_128_to_255_kmers(s10_gpu, s10_oracle, colour_stage):
     """batches whose longest read has 128..255 k-mers (e.g. 250-base reads) keep 8-bit score counters, unbiased, and
     compare them with the threshold byte-wise: thresholds on both sides of 128, zero, and equal to the score; chimeric reads
