@@ -1252,107 +1252,137 @@ __device__ FG_MUX_INLINE uint32_t mux_union_read(const uint32_t* __restrict__ ro
 }
 
 // Threshold union of a read with more free lists than the multiplexer tree takes (round 6; 17 % of the reads at tau = 0.8, a third at
-// tau = 0.5, and more than half of the kernel's vector instructions while they went through byte counters). A colour passes iff the
-// multiplicities of the free lists that do NOT contain it add up to at most slack = P - min_score (and every mandatory list contains
-// it). These DEFICITS are counted bit-sliced over the 32 colours of a row word: B planes D[0 .. B-1], B = bits of slack + 1, and a
-// sticky overflow plane — adding the wave-uniform constant mu under the mask ~row is a ripple of at most three instructions per plane
-// from mu's lowest set bit up (two where mu has a zero), against the 24 per list and word of the byte counters (eight planes of
-// shift, mask, multiply-add); the comparison D <= slack at the end is two instructions per plane.
-// MEASURED (profiles/r6/k3r_variants_r6.txt) and NOT in the shipped build (-DFG_K3R_DEFICIT compiles it in): on the bench workload
-// at tau = 0.8 the kernel takes 12.2 ms with it against 6.36 ms without (tau = 0.5: 15.1 against 7.55). The addend's bits are
-// wave-uniform but only known at run time: every plane of every list is a scalar branch into one of three bodies, the kernel grows
-// from 1508 to 2820 static vector instructions and from no scratch to 36 spilled vector registers at the 72 it may use (7 waves per
-// SIMD; 24 spilled at 80), and the ripple's dependent chain hides none of the row loads. A branch-free form (the addend's bit as a
-// scalar mask: four instructions per plane whatever the bit) is 5 x 4 + 2 per list and word against the byte counters' 24: nothing.
-template <int B, int R>
-__device__ __forceinline__ void deficit_add(uint32_t (&D)[B][R], uint32_t (&OV)[R], const uint32_t (&x)[R], uint32_t mu) {
-    uint32_t carry[R];
-    bool started = false;  // (wave-uniform: mu is)
+// tau = 0.5): bit-sliced DEFICIT counters. A colour passes iff the multiplicities of the free lists that do NOT contain it add up to
+// at most slack = P - min_score (and every mandatory list contains it: one AND per row word). The deficits of the 32 colours of a row
+// word are B bit planes (B = 5 for slack < 32, 6 for slack < 64) that START at 2^B - 1 - slack, so a colour fails exactly when one
+// of the additions carries out of the top plane (a sticky OV plane; nothing to compare at the end). Adding the wave-uniform mu under
+// the mask ~x is a full adder per plane with the addend's bit as a scalar mask: and, xor3, majority = three instructions, 16 / 19 per
+// list and word against the 24 of the byte counters (eight planes of shift, mask, multiply-add) — and six / seven registers per row
+// word instead of eight, which is what lets a lane hold THREE row words (the whole 4546-colour row in one go, as the multiplexer
+// tree does) without spilling: a read of ten lists waits for its row words three times (groups of G lists) instead of nine.
+// How it got here (profiles/r6/k3r_variants_r6.txt; the byte counters take 6.4 ms at tau = 0.8 and 7.6 at 0.5):
+//   1. a ripple from mu's lowest set bit up, two or three instructions per plane by scalar branches on mu's bits, three words per
+//      lane, planes of 5 / 6 / 8: 12.2 / 15.1 ms (the kernel doubled, 36 vector registers spilled);
+//   2. branch-free, one word per lane: 6.33 ms (the compiler makes four instructions of a plane), 6.15-6.23 with the adder spelled
+//      as two v_bitop3; tau = 0.5 no better than the byte counters;
+//   3. the adder specialised on the length of mu (half adders above its top bit: the lists' multiplicities have 1 / 2 / 3 / 4 / 5
+//      bits in 10 / 17 / 27 / 33 / 13 % of the cases): FEWER instructions and slower, 6.29-6.37 one word per lane, 5.73 with three;
+//   4. form 2 with three words per lane and groups of 3 (5 planes) / 2 (6 planes) lists: **5.36-5.43 ms at tau = 0.8, 6.09 at 0.5**
+//      (groups of 4 / 3: four registers spilled, 5.42-5.43; groups of 2: 5.55; 8 waves per SIMD: 5.79). Shipped.
+// The kernel is held both by its vector instructions (82 % of the cycles) and by the chain of dependent loads of a read: fewer
+// instructions alone (forms 2, 3, and the counters over the free lists only) or a shorter chain alone (whole-read byte counters:
+// spills) moved little; both at once took 16-20 % off.
+#ifndef FG_K3R_D5_R  // (variant builds: rounds of 64 row words per lane, lists in flight for 5 / 6 planes, adders by length)
+#define FG_K3R_D5_R 3
+#endif
+#ifndef FG_K3R_D5_G
+#define FG_K3R_D5_G 3
+#endif
+#ifndef FG_K3R_D6_G
+#define FG_K3R_D6_G 2
+#endif
+#ifndef FG_K3R_D5_LEN
+#define FG_K3R_D5_LEN 0
+#endif
+template <int LEN, int B>  // LEN = bits of mu (the planes above are half adders on the carry), or B + 1: every plane a full adder under the bit's mask
+__device__ __forceinline__ void deficit_add_len(uint32_t (&D)[B], uint32_t& OV, uint32_t x, uint32_t mu) {
+    uint32_t c = 0;
+    const uint32_t nx = ~x;
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-        if ((mu >> b) & 1u) {
-            if (!started) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) { const uint32_t d = D[b][r]; D[b][r] = d ^ x[r]; carry[r] = d & x[r]; }
-                started = true;
-            } else {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const uint32_t d = D[b][r], t = d ^ x[r];
-                    D[b][r] = t ^ carry[r];
-                    carry[r] = (t & carry[r]) | (~t & d);  // majority(d, x, carry): v_bfi_b32
-                }
+        const uint32_t d = D[b];
+        if (b < LEN - 1) {
+            const uint32_t a = nx & (0u - ((mu >> b) & 1u));  // (s_bfe_i32: mu is wave-uniform)
+            if (b == 0) {
+                D[b] = d ^ a;
+                c = d & a;
+            } else {  // (left to itself the compiler makes four instructions of a plane: d ^ a, d & a, sum, carry)
+                D[b] = __builtin_amdgcn_bitop3_b32(d, a, c, 0x96);
+                c = __builtin_amdgcn_bitop3_b32(d, a, c, 0xe8);
             }
-        } else if (started) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) { const uint32_t d = D[b][r]; D[b][r] = d ^ carry[r]; carry[r] = d & carry[r]; }
+        } else if (b == LEN - 1) {
+            if (b == 0) {
+                D[b] = d ^ nx;
+                c = d & nx;
+            } else {
+                D[b] = __builtin_amdgcn_bitop3_b32(d, x, c, 0x69);  // d ^ ~x ^ c
+                c = __builtin_amdgcn_bitop3_b32(d, x, c, 0xb2);     // majority(d, ~x, c)
+            }
+        } else {
+            D[b] = d ^ c;
+            c = d & c;
         }
     }
-    if (started) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) OV[r] |= carry[r];
+    OV |= c;
+}
+template <int B>
+__device__ __forceinline__ void deficit_add_any(uint32_t (&D)[B], uint32_t& OV, uint32_t x, uint32_t mu) {
+    switch (32 - __builtin_clz(mu)) {  // (wave-uniform; 1 <= mu <= slack < 2^B)
+        case 1: deficit_add_len<1, B>(D, OV, x, mu); break;
+        case 2: deficit_add_len<2, B>(D, OV, x, mu); break;
+        case 3: deficit_add_len<3, B>(D, OV, x, mu); break;
+        case 4: deficit_add_len<4, B>(D, OV, x, mu); break;
+        case 5: deficit_add_len<5, B>(D, OV, x, mu); break;
+        default: deficit_add_len<B, B>(D, OV, x, mu); break;
     }
 }
-template <int B, int R>
+// The whole read: chunks of R rounds of 64 row words, R words per lane; returns the lane's share of the result's cardinality. FREE /
+// MAND = masks over the lanes whose id_l / mu_l are the lists that count / that every result colour must be in.
+template <int B, int R, int G>
 __device__ __forceinline__ uint32_t deficit_union_read(const uint32_t* __restrict__ rows, uint32_t W, uint32_t Wn, uint32_t n, uint64_t FREE, uint64_t MAND,
                                                        uint32_t id_l, uint32_t mu_l, uint32_t slack, uint32_t* __restrict__ bm, int lane) {
     uint32_t pc = 0;
+    const uint32_t start = ((1u << B) - 1u) - slack;
     for (uint32_t w0 = 0; w0 < Wn; w0 += 64 * R) {
         uint32_t wi[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) wi[r] = min(w0 + 64u * r + (uint32_t)lane, W - 1) << 2;  // byte offset in a row (lanes past the row load its last word and store nothing)
-        uint32_t D[B][R], OV[R];
+        uint32_t D[R][B], OV[R], m[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             OV[r] = 0;
+            m[r] = 0xFFFFFFFFu;
 #pragma unroll
-            for (int b = 0; b < B; ++b) D[b][r] = 0;
+            for (int b = 0; b < B; ++b) D[r][b] = 0u - ((start >> b) & 1u);
         }
-        // the words of the next list are requested before the current one is added
-        uint64_t ff = FREE;
-        uint32_t x[R], mu = 0;
-        {
-            const int a = (int)__builtin_ctzll(ff);
-            const uint32_t* row = rows + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)id_l, a) * W;
-            mu = (uint32_t)__builtin_amdgcn_readlane((int)mu_l, a);
+        uint64_t mm = MAND;
+        if (mm) {  // (wave-uniform) the first mandatory list's words travel with the first group's
+            const uint32_t* row = rows + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)id_l, (int)__builtin_ctzll(mm)) * W;
 #pragma unroll
-            for (int r = 0; r < R; ++r) x[r] = ~row_word(row, wi[r]);
+            for (int r = 0; r < R; ++r) m[r] = row_word(row, wi[r]);
+            mm &= mm - 1;
         }
-        for (;;) {
-            ff &= ff - 1;
-            uint32_t xn[R], mun = 0;
-            if (ff) {
-                const int a = (int)__builtin_ctzll(ff);
-                const uint32_t* row = rows + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)id_l, a) * W;
-                mun = (uint32_t)__builtin_amdgcn_readlane((int)mu_l, a);
+        for (uint64_t ff = FREE; ff;) {  // the row words of G free lists in flight
+            uint32_t idv[G], muv[G], kk = 0;
 #pragma unroll
-                for (int r = 0; r < R; ++r) xn[r] = ~row_word(row, wi[r]);
+            for (int j = 0; j < G; ++j) {
+                const uint32_t a = ff ? (uint32_t)__builtin_ctzll(ff) : 0u;
+                idv[j] = ff ? (uint32_t)__builtin_amdgcn_readlane((int)id_l, a) : 0u;
+                muv[j] = ff ? (uint32_t)__builtin_amdgcn_readlane((int)mu_l, a) : 0u;
+                kk += ff ? 1u : 0u;
+                ff &= ff - 1;
             }
-            deficit_add<B, R>(D, OV, x, mu);
-            if (!ff) break;
+            uint32_t x[G][R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) x[r] = xn[r];
-            mu = mun;
-        }
-        uint32_t m[R];
-        {   // D <= slack, from the top plane down: lt = already smaller, eq = equal so far
-            uint32_t lt[R], eq[R];
+            for (int j = 0; j < G; ++j)
+                if ((uint32_t)j < kk) {  // (wave-uniform)
+                    const uint32_t* row = rows + (uint64_t)idv[j] * W;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { lt[r] = 0; eq[r] = 0xFFFFFFFFu; }
-#pragma unroll
-            for (int b = B - 1; b >= 0; --b) {
-                if ((slack >> b) & 1u) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) { lt[r] |= eq[r] & ~D[b][r]; eq[r] &= D[b][r]; }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) eq[r] &= ~D[b][r];
+                    for (int r = 0; r < R; ++r) x[j][r] = row_word(row, wi[r]);
                 }
-            }
 #pragma unroll
-            for (int r = 0; r < R; ++r) m[r] = (lt[r] | eq[r]) & ~OV[r];
+            for (int j = 0; j < G; ++j)
+                if ((uint32_t)j < kk) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if (FG_K3R_D5_LEN) deficit_add_any<B>(D[r], OV[r], x[j][r], muv[j]);
+                        else deficit_add_len<B + 1, B>(D[r], OV[r], x[j][r], muv[j]);
+                    }
+                }
         }
-        for (uint64_t mm = MAND; mm; mm &= mm - 1) {  // (wave-uniform)
+#pragma unroll
+        for (int r = 0; r < R; ++r) m[r] &= ~OV[r];
+        for (; mm; mm &= mm - 1) {  // (wave-uniform)
             const uint32_t* row = rows + (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)id_l, (int)__builtin_ctzll(mm)) * W;
 #pragma unroll
             for (int r = 0; r < R; ++r) m[r] &= row_word(row, wi[r]);
@@ -1490,7 +1520,10 @@ __global__ __launch_bounds__(256, BITS == 8 ? FG_K3R_WAVES8 : (BITS == 16 ? FG_K
     const int lane = lane_id();
     const uint32_t Wn = (n + 31) >> 5;  // words that hold colours
     typedef const __attribute__((address_space(4))) u32x4_a4* s4_ptr;  // scalar loads, as in k2r_intersect
-    const WorkQueue wq{tickets, n_reads, 8};
+    #ifndef FG_K3R_TICKET  // (variant builds: reads per ticket. 4 / 8 / 16 / 32: 5.85 / 5.17 / 5.06-5.11 / 5.03 ms at tau = 0.8, profiles/r6/k3r_variants_r6.txt)
+#define FG_K3R_TICKET 16
+#endif
+    const WorkQueue wq{tickets, n_reads, FG_K3R_TICKET};
     uint64_t t_first;
     uint32_t t_count;
     while (wq.pull(t_first, t_count)) {
@@ -1499,8 +1532,26 @@ __global__ __launch_bounds__(256, BITS == 8 ? FG_K3R_WAVES8 : (BITS == 16 ? FG_K
         const uint64_t off_l = idoff[rl];
         const uint32_t np_l = npos[rl];
         const uint32_t min_l = (uint32_t)(unsigned long long)((double)np_l * tau);  // ps_threshold_union.cpp:389
+#ifndef FG_K3R_NO_PREFETCH_IDS
+        // the next read's ids and multiplicities are requested before the current read's rows: a read waits once, for its rows
+        uint32_t nx_id = 0, nx_mu = 0;
+        if (!SCORES && t_count) {
+            const uint32_t nl0 = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, 0);
+            const uint64_t off0 = readlane_u64(off_l, 0);
+            if ((uint32_t)lane < nl0) { nx_id = ids_pool[off0 + lane]; nx_mu = cnt_pool[off0 + lane]; }
+        }
+#endif
         for (uint32_t ri = 0; ri < t_count; ++ri) {
             const uint64_t r = t_first + ri;
+#ifndef FG_K3R_NO_PREFETCH_IDS
+            const uint32_t pf_id = nx_id, pf_mu = nx_mu;
+            nx_id = 0; nx_mu = 0;
+            if (!SCORES && ri + 1 < t_count) {
+                const uint32_t nl1 = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, ri + 1);
+                const uint64_t off1 = readlane_u64(off_l, ri + 1);
+                if ((uint32_t)lane < nl1) { nx_id = ids_pool[off1 + lane]; nx_mu = cnt_pool[off1 + lane]; }
+            }
+#endif
             // (the lane number is made opaque once per read: everything derived from it — two dozen lane masks of this loop nest — would
             // otherwise be computed once in front of the ticket loop and kept in scalar register pairs, more of them than there are
             // registers: they were spilled to vector lanes and read back instruction by instruction)
@@ -1523,7 +1574,11 @@ __global__ __launch_bounds__(256, BITS == 8 ? FG_K3R_WAVES8 : (BITS == 16 ? FG_K
             // colour: with at most six of them, the multiplexer tree; no counters.
             if (!SCORES && nl <= 64u) {
                 const bool has = (uint32_t)ln < nl;
+#ifndef FG_K3R_NO_PREFETCH_IDS
+                const uint32_t id_l = pf_id, mu_l = pf_mu;
+#else
                 const uint32_t id_l = has ? ids_pool[off + ln] : 0u, mu_l = has ? cnt_pool[off + ln] : 0u;
+#endif
                 const uint32_t slack = positive - min_score;
                 const uint64_t FREE = __ballot(has && mu_l <= slack), MAND = __ballot(has && mu_l > slack);
                 const uint32_t nfree = (uint32_t)__popcll(FREE);
@@ -1568,16 +1623,12 @@ __global__ __launch_bounds__(256, BITS == 8 ? FG_K3R_WAVES8 : (BITS == 16 ? FG_K
                     if (ln == 0) out_count[r] = pcm;
                     continue;
                 }
-#ifdef FG_K3R_DEFICIT  // (measured in round 6 and left out of the shipped build: correct — the tau grid passes — and twice as slow as the byte counters it was to replace; see the comment at deficit_add)
-                if (slack < 255u) {  // more free lists than the tree takes: bit-sliced deficit counters of 5, 6 or 8 planes
+#ifndef FG_K3R_NO_DEFICIT  // (variant builds: the byte counters below for every read the tree does not take)
+                if (slack < 64u) {  // more free lists than the tree takes: five or six planes of deficit counters (deficit_union_read)
                     uint32_t pcm;
-#ifndef FG_K3R_DEFICIT_PLANES  // (variant builds: 0 = planes of 5 / 6 / 8, 1 = 6 / 8, 2 = 8 only)
-#define FG_K3R_DEFICIT_PLANES 0
-#endif
-                    if (FG_K3R_DEFICIT_PLANES == 0 && slack < 31u) pcm = deficit_union_read<5, 3>(rows, W, Wn, n, FREE, MAND, id_l, mu_l, slack, bm, ln);
-                    else if (FG_K3R_DEFICIT_PLANES <= 1 && slack < 63u) pcm = deficit_union_read<6, 3>(rows, W, Wn, n, FREE, MAND, id_l, mu_l, slack, bm, ln);
-                    else pcm = deficit_union_read<8, 3>(rows, W, Wn, n, FREE, MAND, id_l, mu_l, slack, bm, ln);
-                    for (uint32_t w = ((Wn + 63) & ~63u) + ln; w < W; w += 64) bm[w] = 0;  // (padding words behind the last round)
+                    if (slack < 32u) pcm = deficit_union_read<5, FG_K3R_D5_R, FG_K3R_D5_G>(rows, W, Wn, n, FREE, MAND, id_l, mu_l, slack, bm, ln);
+                    else pcm = deficit_union_read<6, FG_K3R_D5_R, FG_K3R_D6_G>(rows, W, Wn, n, FREE, MAND, id_l, mu_l, slack, bm, ln);
+                    for (uint32_t w = ((Wn + 64 * FG_K3R_D5_R - 1) / (64 * FG_K3R_D5_R) * (64 * FG_K3R_D5_R)) + ln; w < W; w += 64) bm[w] = 0;  // (padding words behind the last chunk)
                     pcm = wave_sum_u32(pcm);
                     if (ln == 0) out_count[r] = pcm;
                     continue;

@@ -14,6 +14,7 @@ b, o = gen.generate(0, n, 150, 42)
 ko, ki = ix.kmer_color_set_ids_batch(b, o)
 ko = ko.astype(np.int64)
 nl_all, free_all, P_all, slack_all = [], [], [], []
+free_mu = []  # multiplicities of the not-mandatory lists of the reads that have more than six of them
 for r in range(n):
     ids = ki[ko[r]:ko[r + 1]]
     ids = ids[ids != 0xFFFFFFFF]
@@ -22,6 +23,8 @@ for r in range(n):
     _, m = np.unique(ids, return_counts=True)
     P = int(m.sum()); ms = int(P * tau); slack = P - ms
     nl_all.append(len(m)); free_all.append(int((m <= slack).sum())); P_all.append(P); slack_all.append(slack)
+    if (m <= slack).sum() > 6:
+        free_mu.extend(m[m <= slack].tolist())
 nl, fr = np.array(nl_all), np.array(free_all)
 print("workload:", desc)
 print("reads %d tau %.2f; lists per read mean %.2f; reads with > 6 lists %.1f%%" % (n, tau, nl.mean(), 100 * (nl > 6).mean()))
@@ -40,3 +43,8 @@ if over.any():
     bits = np.ceil(np.log2(sl[over] + 2)).astype(int)
     print("slack P - min_score of those reads: mean %.1f, max %d; bits of a saturating deficit counter (ceil log2(slack + 2)): %s" % (
         sl[over].mean(), sl[over].max(), " ".join("%d:%.1f%%" % (i, 100.0 * c / over.sum()) for i, c in enumerate(np.bincount(bits)) if c)))
+if free_mu:
+    fm = np.array(free_mu)
+    print("multiplicities of those reads' not-mandatory lists: mean %.1f; bits: %s; values 1..8: %s" % (
+        fm.mean(), " ".join("%d:%.1f%%" % (i, 100.0 * c / len(fm)) for i, c in enumerate(np.bincount(np.ceil(np.log2(fm + 1)).astype(int))) if c),
+        " ".join("%d:%.1f%%" % (i, 100.0 * (fm == i).mean()) for i in range(1, 9))))
