@@ -1624,10 +1624,13 @@ __global__ __launch_bounds__(256, BITS == 8 ? FG_K3R_WAVES8 : (BITS == 16 ? FG_K
                     continue;
                 }
 #ifndef FG_K3R_NO_DEFICIT  // (variant builds: the byte counters below for every read the tree does not take)
-                if (slack < 64u) {  // more free lists than the tree takes: five or six planes of deficit counters (deficit_union_read)
+                // (seven planes, slack < 128, only in the instantiations for reads of more than 127 k-mers: in the other one they cost six spilled registers)
+                constexpr bool D7 = BITS > 8 || !BIASED;
+                if (slack < (D7 ? 128u : 64u)) {  // more free lists than the tree takes: five to seven planes of deficit counters (deficit_union_read)
                     uint32_t pcm;
                     if (slack < 32u) pcm = deficit_union_read<5, FG_K3R_D5_R, FG_K3R_D5_G>(rows, W, Wn, n, FREE, MAND, id_l, mu_l, slack, bm, ln);
-                    else pcm = deficit_union_read<6, FG_K3R_D5_R, FG_K3R_D6_G>(rows, W, Wn, n, FREE, MAND, id_l, mu_l, slack, bm, ln);
+                    else if (!D7 || slack < 64u) pcm = deficit_union_read<6, FG_K3R_D5_R, FG_K3R_D6_G>(rows, W, Wn, n, FREE, MAND, id_l, mu_l, slack, bm, ln);
+                    else pcm = deficit_union_read<7, FG_K3R_D5_R, FG_K3R_D6_G>(rows, W, Wn, n, FREE, MAND, id_l, mu_l, slack, bm, ln);
                     for (uint32_t w = ((Wn + 64 * FG_K3R_D5_R - 1) / (64 * FG_K3R_D5_R) * (64 * FG_K3R_D5_R)) + ln; w < W; w += 64) bm[w] = 0;  // (padding words behind the last chunk)
                     pcm = wave_sum_u32(pcm);
                     if (ln == 0) out_count[r] = pcm;
