@@ -813,7 +813,10 @@ const u32x4* __restrict__ rows4, uint32_t W, const uint32_t* __restrict__ nids,
                                                      uint64_t n_reads, uint32_t* __restrict__ out_bitmap,
                                                      uint32_t* __restrict__ out_count, unsigned int* tickets,
                                                      const uint32_t* __restrict__ order, uint32_t* __restrict__ small_out) {
-    constexpr uint32_t BATCH = 16;
+#ifndef FG_K2R_TICKET  // (variant builds: reads per ticket. 8 / 16 / 32: 3.76 / 3.42 / 3.41 ms; the next read's ids requested a read ahead: 3.43 — the kernel is bound by the bytes it fetches)
+#define FG_K2R_TICKET 16
+#endif
+    constexpr uint32_t BATCH = FG_K2R_TICKET;
     const int lane = lane_id();
     const uint32_t W4 = W >> 2;
     const WorkQueue wq{tickets, n_reads, BATCH};
@@ -1405,13 +1408,13 @@ __device__ __forceinline__ uint32_t deficit_union_read(const uint32_t* __restric
 // through the counters together (three words per lane, as in the multiplexer tree), the row words of FOUR lists — twelve per lane — are
 // requested in one go, and the next four lists' words are requested before the current ones are spread into the counters. The loop of
 // the first five rounds fetched four words per lane, waited, counted, and did that nine times for a read of ten lists: the knock-out
-// builds say its reads cost 1.8 of the kernel's 6.5 ms at a sixth of the reads, and neither fewer instructions (counters over the free
-// lists only) nor other counters (bit-sliced deficits) moved that.
+// builds say its reads cost 1.8 of the kernel's 6.5 ms at a sixth of the reads, and fewer instructions alone (counters over the free
+// lists only; bit-sliced deficits with one word per lane) did not move that.
 // MEASURED and NOT in the shipped build (-DFG_K3R_WHOLE_READ_COUNTERS): groups of 1 / 2 / 4 lists, 7 and 6 waves per SIMD: 10.2 / 11.7 /
 // 14.3 ms against the 6.4-6.5 ms of the round-by-round loop (profiles/r6/k3r_variants_r6.txt). Twenty-four counter registers beside the
 // words in flight do not fit the 72 (80) registers the kernel may use beside the multiplexer tree's paths: 16 to 41 vector registers
-// are spilled to scratch, inside the loop. The kernel as it stands is the best this register budget gives; the three restructurings
-// of this round (deficit counters, counters over the free lists, whole-read counters) all paid more in spills than they saved.
+// are spilled to scratch, inside the loop. (What did shorten the chain is deficit_union_read above: its counters take six to eight
+// registers per row word, so three words fit a lane.)
 template <bool BIASED>
 __device__ __forceinline__ uint32_t counter_union_read(const uint32_t* __restrict__ rows, uint32_t W, uint32_t Wn, uint32_t n, const uint32_t* __restrict__ ids,
                                                        const uint32_t* __restrict__ mults, uint32_t nl, uint32_t min_score, uint32_t* __restrict__ bm, int lane) {
