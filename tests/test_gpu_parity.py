@@ -404,8 +404,10 @@ def test_s4546_full_intersection_equals_oracle(s4546, colour_stage):
     assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
 
 
-@pytest.mark.parametrize("tau", [0.8, 0.3, 1.0])
+@pytest.mark.parametrize("tau", [0.8, 0.3, 1.0, 0.5])
 def test_s4546_threshold_union_equals_oracle(s4546, tau, colour_stage):
+    """(k3r_union: tau 0.8 and 1.0 = five planes of deficit counters for the reads the multiplexer tree does not take, 0.5 = six,
+    0.3 = byte counters; seven planes: test_s4546_longer_reads_equal_oracle at 500 bases)"""
     ix, orc, gen = s4546
     b, o = gen.generate(100000, 20000, 150, 42)
     with stage(ix, colour_stage):
