@@ -1592,7 +1592,17 @@ __global__ __launch_bounds__(256, BITS == 8 ? FG_K3R_WAVES8 : (BITS == 16 ? FG_K
                     continue;
                 }
 #endif
-                if (nfree <= K3R_MUX_LISTS) {
+#ifndef FG_K3R_TREE_LISTS  // (variant builds: free lists up to which the tree is preferred to the deficit counters where both apply)
+#define FG_K3R_TREE_LISTS 6
+#endif
+#ifndef FG_K3R_NO_DEFICIT
+                // (seven planes, slack < 128, only in the instantiations for reads of more than 127 k-mers: in the other one they cost six spilled registers)
+                constexpr bool D7 = BITS > 8 || !BIASED;
+                constexpr uint32_t deficit_limit = D7 ? 128u : 64u;
+#else
+                constexpr uint32_t deficit_limit = 0u;
+#endif
+                if (nfree <= FG_K3R_TREE_LISTS || (nfree <= K3R_MUX_LISTS && slack >= deficit_limit)) {
                     uint32_t idf[K3R_MUX_LISTS], muf[K3R_MUX_LISTS];
                     uint64_t ff = FREE;
                     uint32_t free_total = 0;
@@ -1627,9 +1637,7 @@ __global__ __launch_bounds__(256, BITS == 8 ? FG_K3R_WAVES8 : (BITS == 16 ? FG_K
                     continue;
                 }
 #ifndef FG_K3R_NO_DEFICIT  // (variant builds: the byte counters below for every read the tree does not take)
-                // (seven planes, slack < 128, only in the instantiations for reads of more than 127 k-mers: in the other one they cost six spilled registers)
-                constexpr bool D7 = BITS > 8 || !BIASED;
-                if (slack < (D7 ? 128u : 64u)) {  // more free lists than the tree takes: five to seven planes of deficit counters (deficit_union_read)
+                if (slack < deficit_limit) {  // more free lists than the tree takes: five to seven planes of deficit counters (deficit_union_read)
                     uint32_t pcm;
                     if (slack < 32u) pcm = deficit_union_read<5, FG_K3R_D5_R, FG_K3R_D5_G>(rows, W, Wn, n, FREE, MAND, id_l, mu_l, slack, bm, ln);
                     else if (!D7 || slack < 64u) pcm = deficit_union_read<6, FG_K3R_D5_R, FG_K3R_D6_G>(rows, W, Wn, n, FREE, MAND, id_l, mu_l, slack, bm, ln);
