@@ -109,7 +109,7 @@ void upload(DevBuf& b, const std::vector<T>& v, hipStream_t s) {
     if (!v.empty()) HIP_TRY(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
 }
 
-constexpr size_t TICKET_BYTES = 3 * 8 * TICKET_STRIDE * sizeof(unsigned int);
+constexpr size_t TICKET_BYTES = (2 * 8 + K2B_MAX_PARTS) * TICKET_STRIDE * sizeof(unsigned int);  // lookup, colour stage: 8 counters each; expansion: up to K2B_MAX_PARTS
 
 const char* KERNEL_NAMES[FGPU_K_COUNT] = {"k1_lookup", "k2_intersect", "k3_union", "scan", "k2b_expand", "k_hits", "k_desc", "k_format", "k_order", "h2d", "d2h"};
 
@@ -954,7 +954,7 @@ void stage_expand(fgpu_index* ix, fgpu_result* res) {
                                              res->hits_folded ? cap_grid : 1u);
     if (res->hits_folded) res->d_partial.ensure((size_t)grid * W * 32 * 4);
     if (res->total > res->d_colors.cap / 4) res->d_colors.ensure(res->total * 4 + res->total + 16);  // 25 % headroom: later passes of the same size fit
-    HIP_TRY(hipMemsetAsync(res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE, 0, 8 * TICKET_STRIDE * sizeof(unsigned int), s));
+    HIP_TRY(hipMemsetAsync(res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE, 0, K2B_MAX_PARTS * TICKET_STRIDE * sizeof(unsigned int), s));
     {
         Timed t(ix, res, FGPU_K_EXPAND);
         hipLaunchKernelGGL(k2b_expand, dim3(grid), dim3(K2B_THREADS), lds, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),

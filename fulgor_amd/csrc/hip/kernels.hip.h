@@ -120,8 +120,9 @@ struct WorkQueue {
     unsigned int* counters;  // 8 * TICKET_STRIDE words, zeroed before every launch
     uint64_t n;
     uint32_t batch;          // reads per pull
+    uint32_t max_parts = 8;  // (k2b_expand: FG_K2B_PARTS, its counters have room for K2B_MAX_PARTS)
     __device__ __forceinline__ bool pull(uint64_t& first, uint32_t& count) const {
-        const uint32_t parts = min(8u, gridDim.x);
+        const uint32_t parts = min(max_parts, gridDim.x);
         const uint64_t per = (n + parts - 1) / parts;
         uint32_t part = blockIdx.x % parts;
         for (uint32_t tries = 0; tries < parts; ++tries) {
@@ -2078,6 +2079,10 @@ __global__ __launch_bounds__(256) void scan_apply(const uint32_t* __restrict__ c
 // (16-bit entries relative to the round's first colour), then the wave copies the staged run out with
 // full-width coalesced stores. 64 words (2048 colours) per round.
 // ---------------------------------------------------------------------------------------------
+#ifndef FG_K2B_PARTS  // (variant builds: contiguous pieces of the pass that are written at the same time)
+#define FG_K2B_PARTS 8
+#endif
+constexpr uint32_t K2B_MAX_PARTS = 256;
 constexpr uint32_t K2B_THREADS = 1024;  // 16 waves share one LDS hit histogram: 2 blocks per CU = 8 waves/SIMD
 // Per-wave stage of 16-bit entries: slot i lives at entry i + 2 * (i / 32) — dense words (prefix = 32 * lane) would
 // otherwise share 2 banks, and a skew of two entries keeps every aligned group of 4 slots contiguous and 4-byte aligned.
@@ -2149,7 +2154,7 @@ __global__ __launch_bounds__(K2B_THREADS) void k2b_expand(const uint32_t* __rest
         if (threadIdx.x == 0) s_taken = 0;
         __syncthreads();
     }
-    const WorkQueue wq{tickets, n_reads, 32};
+    const WorkQueue wq{tickets, n_reads, 32, FG_K2B_PARTS};
     uint64_t t_first;
     uint32_t t_count;
     auto may_pull = [&]() -> bool {
