@@ -814,7 +814,7 @@ const u32x4* __restrict__ rows4, uint32_t W, const uint32_t* __restrict__ nids,
                                                      uint64_t n_reads, uint32_t* __restrict__ out_bitmap,
                                                      uint32_t* __restrict__ out_count, unsigned int* tickets,
                                                      const uint32_t* __restrict__ order, uint32_t* __restrict__ small_out) {
-#ifndef FG_K2R_TICKET  // (variant builds: reads per ticket. 8 / 16 / 32: 3.76 / 3.42 / 3.41 ms; the next read's ids requested a read ahead: 3.43 — the kernel is bound by the bytes it fetches)
+#ifndef FG_K2R_TICKET  // (variant builds: reads per ticket. 8 / 16 / 32: 3.76 / 3.42 / 3.41 ms; the next read's ids requested a read ahead: 3.43; the next read's first six ROWS requested before the current result is counted and stored, hand-written loads, 7 waves per SIMD: 3.45 — the kernel is bound by the bytes it fetches)
 #define FG_K2R_TICKET 16
 #endif
     constexpr uint32_t BATCH = FG_K2R_TICKET;
