@@ -1503,7 +1503,7 @@ __device__ __forceinline__ uint32_t counter_union_read(const uint32_t* __restric
 
 template <int BITS, bool BIASED = true, bool SCORES = false>
 // (7 waves per SIMD for the 8-bit counters: 72 VGPRs and 94 SGPRs leave 4 scalars spilled and no scratch, and it is the fastest of 6 / 7 / 8:
-// 7.08 / 6.43 / 6.58 ms, profiles/r5/k3r_variants_r5.txt)
+// 7.08 / 6.43 / 6.58 ms, profiles/r5/k3r_variants_r5.txt; round 6, with the deficit counters: 5.4 / 5.05-5.13 / 6.15 ms)
 #ifndef FG_K3R_WAVES16  // (variant builds: waves per SIMD of the 16- and 32-bit counter instantiations)
 #define FG_K3R_WAVES16 6
 #endif
