@@ -34,8 +34,13 @@ for seed, first in ((7, 50_000_000), (8, 90_000_000)):
     check("fetched ids, %d reads, seed %d" % (n, seed), ix.fetch_color_set_ids_batch(b, o), orc.fetch_color_set_ids(b, o, threads=T))
     print("  (%.0f s)" % (time.time() - t0), flush=True)
 b, o = gen.generate(123_000_000, n // 2, 150, 9)
-for tau in (0.8, 0.25):
+for tau in (0.8, 0.25, 0.5):  # (k3r_union: five planes of deficit counters, byte counters, six planes)
     check("threshold union tau %.2f, %d reads" % (tau, n // 2), ix.pseudoalign_threshold_union_batch(b, o, tau), orc.threshold_union(b, o, tau, threads=T))
+# longer reads: the lookup kernel's instantiations for up to 192 / 256 / 384 / 512 k-mers, the threshold union's six / seven planes and 16-bit counters
+for length, tau in ((200, 0.8), (300, 0.8), (300, 0.5), (540, 0.8)):
+    bl, ol = gen.generate(200_000_000 + length, 300_000, length, 12)
+    check("reads of %d bases, full intersection" % length, ix.pseudoalign_full_intersection_batch(bl, ol), orc.full_intersection(bl, ol, threads=T))
+    check("reads of %d bases, threshold union %.1f" % (length, tau), ix.pseudoalign_threshold_union_batch(bl, ol, tau), orc.threshold_union(bl, ol, tau, threads=T))
 # dirty, ragged reads: random lengths 0..400, 3 % N, lower case
 rng = np.random.default_rng(5)
 b, o = gen.generate(7_000_000, 200_000, 400, 10)
