@@ -427,9 +427,8 @@ __global__ __launch_bounds__(256, Q <= 4 ? FG_K1_WAVES : (Q <= 6 ? 5 : 4)) void 
                     // Buckets still to be looked at go through the ring `pairs` as (bucket << 6 | lane that owns the run): the overflow
                     // bucket behind this key's redirect slot, the next bucket behind a spill flag. found(...) is run on freshly loaded buckets.
                     uint32_t ptail = 0, phead = 0;  // ring counters (wave-uniform)
-                    auto found = [&](bool loaded, uint32_t bucket, uint32_t src) {
+                    auto found = [&](bool loaded, uint32_t bucket, uint32_t src, const u32x4 last) {
                         // the bucket's redirect (its last slot): first overflow bucket, how many to read at once
-                        const u32x4 last = rec[BUCKET_RECS - 1];
                         const uint32_t target = last.y;
                         const uint32_t nbov = loaded && (int32_t)last.z < 0 ? min(last.w & REC_MAX_CSID, REDIRECT_DIRECT) : 0u;
                         const bool spill = loaded && (int32_t)last.w < 0;
@@ -454,21 +453,33 @@ __global__ __launch_bounds__(256, Q <= 4 ? FG_K1_WAVES : (Q <= 6 ? 5 : 4)) void 
                             wave_lds_sync();
                         }
                     };
-                    found(act, home, (uint32_t)lane);
+                    found(act, home, (uint32_t)lane, rec[BUCKET_RECS - 1]);
 
                     bool firstb = true;  // first batch: the run lanes look at their home bucket, free lanes take pairs
                     for (;;) {
                         // ---- lanes without a run take a waiting pair: the run's registers come over ds_bpermute ----
                         const uint32_t base = firstb ? qn : 0u;
                         const uint32_t waiting = ptail - phead;
+#ifndef FG_K1_NO_TRANSPOSE
+                        // Batches behind the first hold pairs only, 2.8 of them on average in a third of the passes: there a lane takes ONE
+                        // record of a pair's bucket (lane = 4 * pair + slot, sixteen pairs per batch) and the comparison below runs once, not
+                        // four times for three lanes' worth of work. Heads come out in the same order (pair by pair, slot by slot).
+                        const bool transposed = !firstb;  // (wave-uniform)
+                        const uint32_t taken = transposed ? min(waiting, 16u) : min(waiting, 64u - base);
+                        const uint32_t pidx = transposed ? (uint32_t)lane >> 2 : (uint32_t)lane - base;
+                        const bool ovf = transposed ? pidx < taken : (uint32_t)lane >= base && pidx < taken;
+#else
+                        const bool transposed = false;
                         const uint32_t taken = min(waiting, 64u - base);
-                        K1_STAT(3, 1); K1_STAT(5, taken);
+                        const uint32_t pidx = (uint32_t)lane - base;
                         const bool ovf = (uint32_t)lane >= base && (uint32_t)lane - base < taken;
+#endif
+                        K1_STAT(3, 1); K1_STAT(5, taken);
                         uint32_t T[NS];
                         uint32_t bucket = home, src = (uint32_t)lane;
                         if (taken) {
                             if (ovf) {
-                                const uint32_t at = (phead + (uint32_t)lane - base) % PAIRS;
+                                const uint32_t at = (phead + pidx) % PAIRS;
                                 const uint32_t pr = pairs[at];
                                 if (WIDE) { src = L.psrc[at]; bucket = pr; }
                                 else { src = pr & 63u; bucket = pr >> 6; }
@@ -477,11 +488,16 @@ __global__ __launch_bounds__(256, Q <= 4 ? FG_K1_WAVES : (Q <= 6 ? 5 : 4)) void 
                             for (int i = 0; i < NS; ++i) T[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)S[i]);
                             if (ovf) {
                                 const u32x4* bp = (const u32x4*)(d.table + (size_t)bucket * BUCKET_WORDS);
+                                if (transposed) {
+                                    rec[0] = bp[(uint32_t)lane & 3u];
+                                } else {
 #pragma unroll
-                                for (int r = 0; r < (int)BUCKET_RECS; ++r) rec[r] = bp[r];
+                                    for (int r = 0; r < (int)BUCKET_RECS; ++r) rec[r] = bp[r];
+                                }
                             }
                             phead += taken;
-                            found(ovf, bucket, src);
+                            if (transposed) found(ovf && ((uint32_t)lane & 3u) == BUCKET_RECS - 1, bucket, src, rec[0]);  // (the lane that holds the bucket's last slot)
+                            else found(ovf, bucket, src, rec[BUCKET_RECS - 1]);
                         } else {
 #pragma unroll
                             for (int i = 0; i < NS; ++i) T[i] = S[i];
@@ -498,6 +514,7 @@ __global__ __launch_bounds__(256, Q <= 4 ? FG_K1_WAVES : (Q <= 6 ? 5 : 4)) void 
                         uint32_t mine = 0, msum = 0, mid = 0;
 #pragma unroll
                         for (int r = 0; r < (int)BUCKET_RECS; ++r) {
+                            if (transposed && r > 0) { hv[r] = 0; hc[r] = 0; continue; }  // (wave-uniform: a lane holds one record, in rec[0])
 #ifdef FG_K1_SLOT_SKIP
                             // (round 6, measured and left out of the shipped build) The slots of a bucket fill from the first: at 0.6 records per
                             // bucket the last slot holds a record (or the redirect) in one bucket of a hundred, so in most passes it is empty in
