@@ -953,17 +953,58 @@ void stage_expand(fgpu_index* ix, fgpu_result* res) {
     const uint32_t grid = std::max<uint32_t>(resident_grid(k2b_expand, n, K2B_THREADS / 64, ix->num_cus, K2B_THREADS, lds),
                                              res->hits_folded ? cap_grid : 1u);
     if (res->hits_folded) res->d_partial.ensure((size_t)grid * W * 32 * 4);
-    if (res->total > res->d_colors.cap / 4) res->d_colors.ensure(res->total * 4 + res->total + 16);  // 25 % headroom: later passes of the same size fit
-    HIP_TRY(hipMemsetAsync(res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE, 0, K2B_MAX_PARTS * TICKET_STRIDE * sizeof(unsigned int), s));
-    {
-        Timed t(ix, res, FGPU_K_EXPAND);
+    auto launch = [&](DevBuf& colors) {
+        HIP_TRY(hipMemsetAsync(res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE, 0, K2B_MAX_PARTS * TICKET_STRIDE * sizeof(unsigned int), s));
         hipLaunchKernelGGL(k2b_expand, dim3(grid), dim3(K2B_THREADS), lds, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
-                           res->d_offsets.as<uint64_t>(), n, W, res->d_colors.as<uint32_t>(),
+                           res->d_offsets.as<uint64_t>(), n, W, colors.as<uint32_t>(),
                            res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE,
                            res->hits_folded ? res->d_partial.as<uint32_t>() : (uint32_t*)nullptr, res->d_totals.as<uint64_t>(),
-                           (uint64_t)(res->d_colors.cap / 4), block_cap,
+                           (uint64_t)(colors.cap / 4), block_cap,
                            res->small_mode ? res->d_small.as<uint32_t>() : (const uint32_t*)nullptr);
         HIP_TRY(hipGetLastError());
+    };
+    if (res->total > res->d_colors.cap / 4) {
+        const size_t bytes = res->total * 4 + res->total + 16;  // 25 % headroom: later passes of the same size fit
+        res->d_colors.ensure(bytes);
+        // Which memory the driver hands out for the colour lists decides how fast this kernel stores into them: one allocation in three is
+        // of a kind on which it takes 5 to 14 % longer (6.0 / 6.3 ms full intersection, 11.7 / 12.7 threshold union, 12.0 / 14.0 on dense
+        // results; profiles/r6/k2b_allocation_r6.txt), and the time belongs to the allocation for as long as it lives. So a LARGE buffer is
+        // chosen among up to three allocations, each timed on this very pass (its second run: the first pays for the first use of the
+        // memory): a few tens of milliseconds, once per result and size, while a second buffer of that size fits the free memory.
+        // FULGOR_EXPAND_LOTTERY = extra allocations tried (0: none).
+        static const uint64_t extra = env_u64("FULGOR_EXPAND_LOTTERY", 2);
+        if (extra && res->d_colors.cap >= (2ull << 30) && !DevBuf::guard_mode()) {
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            auto timed = [&](DevBuf& b) {
+                launch(b);
+                HIP_TRY(hipEventRecord(e0, s));
+                launch(b);
+                HIP_TRY(hipEventRecord(e1, s));
+                HIP_TRY(hipEventSynchronize(e1));
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+                return ms;
+            };
+            float best = timed(res->d_colors);
+            for (uint64_t c = 0; c < extra; ++c) {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < res->d_colors.cap + (8ull << 30)) break;
+                DevBuf cand;
+                try { cand.ensure(bytes); } catch (...) { (void)hipGetLastError(); break; }
+                float t = 0;
+                try { t = timed(cand); } catch (...) { cand.release(); throw; }
+                if (t < best) { std::swap(cand, res->d_colors); best = t; }
+                cand.release();
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+    }
+    {
+        Timed t(ix, res, FGPU_K_EXPAND);
+        launch(res->d_colors);
     }
     if (res->hits_folded) res->hit_rows = grid;
     HIP_TRY(hipStreamSynchronize(s));
