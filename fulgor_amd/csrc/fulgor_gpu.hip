@@ -953,9 +953,9 @@ void stage_expand(fgpu_index* ix, fgpu_result* res) {
     const uint32_t grid = std::max<uint32_t>(resident_grid(k2b_expand, n, K2B_THREADS / 64, ix->num_cus, K2B_THREADS, lds),
                                              res->hits_folded ? cap_grid : 1u);
     if (res->hits_folded) res->d_partial.ensure((size_t)grid * W * 32 * 4);
-    auto launch = [&](DevBuf& colors) {
+    auto launch = [&](DevBuf& colors, bool probe = false) {
         HIP_TRY(hipMemsetAsync(res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE, 0, K2B_MAX_PARTS * TICKET_STRIDE * sizeof(unsigned int), s));
-        hipLaunchKernelGGL(k2b_expand, dim3(grid), dim3(K2B_THREADS), lds, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
+        hipLaunchKernelGGL(probe ? k_probe_allocation : k2b_expand, dim3(grid), dim3(K2B_THREADS), lds, s, res->d_bitmap.as<uint32_t>(), res->d_counts.as<uint32_t>(),
                            res->d_offsets.as<uint64_t>(), n, W, colors.as<uint32_t>(),
                            res->d_tickets.as<unsigned int>() + 16 * TICKET_STRIDE,
                            res->hits_folded ? res->d_partial.as<uint32_t>() : (uint32_t*)nullptr, res->d_totals.as<uint64_t>(),
@@ -978,9 +978,9 @@ void stage_expand(fgpu_index* ix, fgpu_result* res) {
             HIP_TRY(hipEventCreate(&e0));
             HIP_TRY(hipEventCreate(&e1));
             auto timed = [&](DevBuf& b) {
-                launch(b);
+                launch(b, true);
                 HIP_TRY(hipEventRecord(e0, s));
-                launch(b);
+                launch(b, true);
                 HIP_TRY(hipEventRecord(e1, s));
                 HIP_TRY(hipEventSynchronize(e1));
                 float ms = 0;
