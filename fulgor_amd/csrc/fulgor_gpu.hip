@@ -2,6 +2,7 @@
 // one-time upload to HBM, batch plumbing, HIP-event timing. No CPU execution path for queries: every
 // query entry point launches the kernels in hip/kernels.hip.h or fails.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -968,11 +969,13 @@ void stage_expand(fgpu_index* ix, fgpu_result* res) {
         res->d_colors.ensure(bytes);
         // Which memory the driver hands out for the colour lists decides how fast this kernel stores into them: one allocation in three is
         // of a kind on which it takes 5 to 14 % longer (6.0 / 6.3 ms full intersection, 11.7 / 12.7 threshold union, 12.0 / 14.0 on dense
-        // results; profiles/r6/k2b_allocation_r6.txt), and the time belongs to the allocation for as long as it lives. So a LARGE buffer is
-        // chosen among up to three allocations, each timed on this very pass (its second run: the first pays for the first use of the
-        // memory): a few tens of milliseconds, once per result and size, while a second buffer of that size fits the free memory.
-        // FULGOR_EXPAND_LOTTERY = extra allocations tried (0: none).
-        static const uint64_t extra = env_u64("FULGOR_EXPAND_LOTTERY", 2);
+        // results; one in eight is 8 % FASTER on the full intersection; profiles/r6/k2b_allocation_r6.txt), and the time belongs to the
+        // allocation for as long as it lives. FULGOR_EXPAND_LOTTERY=<n> (OFF by default) tries n more allocations of a LARGE buffer, each
+        // timed on this very pass (its second run: the first pays for the first use of the memory), and keeps the fastest. It is off
+        // because allocating and freeing tens of gigabytes costs 0.7 s (34 GB) to 2.5 s (105 GB) per candidate — the driver clears the
+        // memory —, i.e. the 0.3 to 2 ms it can take off a pass of 10 M reads are earned back after thousands of passes: a knob for a
+        // service that keeps one result for days, not a default, and not what bench.py measures.
+        static const uint64_t extra = env_u64("FULGOR_EXPAND_LOTTERY", 0);
         if (extra && res->d_colors.cap >= (2ull << 30) && !DevBuf::guard_mode()) {
             hipEvent_t e0, e1;
             HIP_TRY(hipEventCreate(&e0));
@@ -987,7 +990,10 @@ void stage_expand(fgpu_index* ix, fgpu_result* res) {
                 HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
                 return ms;
             };
+            static const bool trace = getenv("FULGOR_TRACE_ALLOC") != nullptr;
+            const auto lot0 = std::chrono::steady_clock::now();
             float best = timed(res->d_colors);
+            if (trace) fprintf(stderr, "[lottery] colour lists of %zu bytes: first allocation %.3f ms\n", res->d_colors.cap, best);
             for (uint64_t c = 0; c < extra; ++c) {
                 size_t free_b = 0, total_b = 0;
                 if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < res->d_colors.cap + (8ull << 30)) break;
@@ -995,11 +1001,13 @@ void stage_expand(fgpu_index* ix, fgpu_result* res) {
                 try { cand.ensure(bytes); } catch (...) { (void)hipGetLastError(); break; }
                 float t = 0;
                 try { t = timed(cand); } catch (...) { cand.release(); throw; }
+                if (trace) fprintf(stderr, "[lottery] candidate %llu: %.3f ms\n", (unsigned long long)c + 1, t);
                 if (t < best) { std::swap(cand, res->d_colors); best = t; }
                 cand.release();
             }
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
+            if (trace) fprintf(stderr, "[lottery] kept %.3f ms; the lottery took %.1f ms\n", best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - lot0).count());
         }
     }
     {
