@@ -1183,6 +1183,50 @@ print("ok")
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
 
 
+def test_colour_lists_in_the_fastest_of_several_allocations(s4546):
+    """FULGOR_EXPAND_LOTTERY=2 (off by default; read once per process, hence the subprocess): a result's colour lists of 2 GB or more
+    are allocated up to three times when they are first sized, the expansion kernel is timed on each (as k_probe_allocation) and the
+    fastest allocation is kept. The lists it ends up with carry the same checksum as the result rows, and the hit vector equals the
+    row-counting one."""
+    import subprocess
+    from conftest import DATA
+    fg = os.path.join(DATA, "s4546syn.v9.fgidx")
+    code = r'''
+import glob, os, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+import fulgor_amd
+from fulgor_amd import synth
+from fulgor_amd.reads import ReadGenerator
+g = sorted(glob.glob(os.path.join(%r, "tests", "data", "salmonella_10", "*.fasta.gz")))
+fg, extra = synth.ensure_s4546(%r, g)
+gen = ReadGenerator(g, raw_sequences=extra)
+n = 1200000
+b, o = gen.generate(5000000, n, 150, 21)
+ix = fulgor_amd.Index(fg, device=0)
+ix.timing_enable(True)
+reads = ix.upload_reads(b, o)
+res = ix.new_result()
+nc = ix.num_colors()
+for algo, tau in ((fulgor_amd.FULL_INTERSECTION, 0.0), (fulgor_amd.THRESHOLD_UNION, 0.8)):
+    ix.run(reads, res, algo, tau)
+    lazy = torch.zeros(nc + 2, dtype=torch.int64, device="cuda:0")
+    res.accumulate_hits(lazy.data_ptr())  # (from the rows: nobody has asked for the lists yet)
+    res.expand()
+    from_lists, from_rows = res.checksum()
+    assert from_lists == from_rows and from_lists[0] == res.sizes()[1] > 0, (from_lists, from_rows)
+    hist = torch.zeros(nc + 2, dtype=torch.int64, device="cuda:0")
+    res.accumulate_hits(hist.data_ptr())
+    assert torch.equal(hist, lazy)
+assert ix.timing()["k2b_expand"][1] == 2, ix.timing()["k2b_expand"]  # (the timing runs are not this kernel's launches)
+print("ok")
+''' % (ROOT, ROOT, DATA)
+    env = dict(os.environ, FULGOR_EXPAND_LOTTERY="2", FULGOR_TRACE_ALLOC="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stderr.count("[lottery] kept") >= 1 and "[lottery] candidate 2" in r.stderr, r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("cu_split", ["", "96"])
 def test_gpu_lookup_and_colour_stage_as_two_calls(s10_fgidx, cu_split):
     """fgpu_run_lookup + fgpu_run_colours (a worker loop that keeps the lookup of the next batch in flight beside the colour stage
