@@ -2,6 +2,7 @@
 // one-time upload to HBM, batch plumbing, HIP-event timing. No CPU execution path for queries: every
 // query entry point launches the kernels in hip/kernels.hip.h or fails.
 #include <hip/hip_runtime.h>
+#include <unordered_map>
 #include <chrono>
 #include <cerrno>
 #include <cstdio>
@@ -176,6 +177,13 @@ struct fgpu_index {
     std::vector<std::pair<DevBuf, DevBuf>> reads_pool;  // (bases, offsets)
     static constexpr size_t READS_POOL_MAX = 8;
     std::mutex tmu;  // results on different streams may be driven from different host threads
+    // results of finished host-buffer calls (fgpu_full_intersection / fgpu_threshold_union: the calls of a reference worker, one per
+    // chunk of reads from several threads), kept for the next call: creating a result is three streams and a pinned allocation, its
+    // device buffers are a dozen hipMalloc — 2 ms for a chunk of a thousand reads whose kernels take 0.1
+    std::mutex host_mu;
+    std::vector<fgpu_result*> host_results;
+    static constexpr size_t HOST_RESULTS_MAX = 4;
+    static constexpr size_t HOST_RESULT_KEEP_BYTES = (size_t)1 << 30;  // a result that has grown beyond this is not kept (the index holds on to 4 GB at most)
 
     hipEvent_t get_event() {
         std::lock_guard<std::mutex> g(tmu);
@@ -1163,6 +1171,8 @@ void fgpu_close(fgpu_index* ix) {
     if (ix->device == FGPU_HOST_ONLY) { delete ix; return; }
     (void)hipSetDevice(ix->device);
     fgpu_stream_cache_release(ix);  // the results the streaming worker loop keeps with the index
+    for (fgpu_result* r : ix->host_results) fgpu_result_free(r);
+    ix->host_results.clear();
     for (DevBuf* b : {&ix->d_table, &ix->d_bmp_rows, &ix->d_offsets, &ix->d_set_rank, &ix->d_rows,
                       &ix->d_set_desc, &ix->d_blk_words, &ix->d_gops, &ix->d_gset_ops_off, &ix->d_gset_ops,
                       &ix->d_garena, &ix->d_gblk_hdr, &ix->d_gblk_words, &ix->d_gset_bytes})
@@ -1198,7 +1208,46 @@ int fgpu_info(const fgpu_index* ix, uint64_t* k, uint64_t* num_colors, uint64_t*
     return 0;
 }
 
-void fgpu_free(void* p) { free(p); }
+// Output arrays of the host-buffer calls come from the process-wide pool of pinned slabs while they are small enough to be worth
+// pinning (the copy out of the device runs at the link's speed into pinned memory, at a fifth of it into pageable memory), and go
+// back to it in fgpu_free; larger ones, and every other output of the library, are malloc'd.
+namespace {
+struct OutRegistry {
+    std::mutex mu;
+    std::unordered_map<void*, std::pair<size_t, bool>> held;  // pointer -> (slab bytes, pinned)
+};
+OutRegistry& out_registry() { static OutRegistry* r = new OutRegistry(); return *r; }
+constexpr size_t OUT_POOLED_MAX = (size_t)512 << 20;
+void* out_alloc(size_t bytes) {
+    bytes = std::max<size_t>(bytes, 1);
+    if (bytes > OUT_POOLED_MAX) return malloc(bytes);
+    install_pinned_allocator();
+    size_t got = 0;
+    bool pinned = false;
+    void* p = SlabPool::get().take(bytes, got, pinned);
+    OutRegistry& r = out_registry();
+    std::lock_guard<std::mutex> g(r.mu);
+    r.held[p] = {got, pinned};
+    return p;
+}
+}  // namespace
+
+void fgpu_free(void* p) {
+    if (!p) return;
+    {
+        OutRegistry& r = out_registry();
+        std::unique_lock<std::mutex> g(r.mu);
+        auto it = r.held.find(p);
+        if (it != r.held.end()) {
+            const std::pair<size_t, bool> sl = it->second;
+            r.held.erase(it);
+            g.unlock();
+            SlabPool::get().give(p, sl.first, sl.second);
+            return;
+        }
+    }
+    free(p);
+}
 
 int fgpu_convert(fgpu_index* ix, int index_type, uint32_t partition_size, uint32_t cluster_size) {
     if (!ix) return fail(-EINVAL, "null argument");
@@ -1433,6 +1482,18 @@ int fgpu_result_create(fgpu_index* ix, fgpu_result** out) {
     if (rc) { fgpu_result_free(r); return rc; }  // (what was created so far goes with it)
     *out = r;
     return 0;
+}
+
+static size_t result_device_bytes(const fgpu_result* cr) {
+    fgpu_result* r = const_cast<fgpu_result*>(cr);
+    size_t total = 0;
+    for (DevBuf* b : {&r->d_nids, &r->d_npos, &r->d_idoff, &r->d_ids_pool, &r->d_cnt_pool, &r->d_cursor, &r->d_bitmap,
+                      &r->d_counts, &r->d_offsets, &r->d_block_sums, &r->d_block_mapped, &r->d_totals, &r->d_colors, &r->d_acct, &r->d_partial, &r->d_tickets, &r->d_idcsr, &r->d_desc, &r->d_kmer_ids, &r->d_scores, &r->d_fmt_sizes, &r->d_fmt_off, &r->d_fmt_out,
+                      &r->d_nids2, &r->d_npos2, &r->d_idoff2, &r->d_ids_pool2, &r->d_cnt_pool2, &r->d_order_keys, &r->d_order_hist,
+                      &r->d_order_off, &r->d_order, &r->d_small, &r->d_dd_hash, &r->d_dd_hash2, &r->d_dd_idx, &r->d_dd_idx2, &r->d_dd_head, &r->d_dd_goff,
+                      &r->d_dd_group, &r->d_dd_nids, &r->d_dd_idoff, &r->d_dd_bitmap, &r->d_dd_counts, &r->d_dd_small, &r->d_dd_tmp})
+        total += b->cap;
+    return total;
 }
 
 void fgpu_result_free(fgpu_result* r) {
@@ -1788,6 +1849,7 @@ int fgpu_timing_get(fgpu_index* ix, int kernel, double* total_ms, uint64_t* laun
 }
 
 // ---- host-buffer convenience calls -------------------------------------------------------------------
+static size_t result_device_bytes(const fgpu_result* r);
 static int run_host(fgpu_index* ix, const char* bases, const uint64_t* offs, uint64_t n, int algo, double tau,
                     uint64_t** out_offsets, uint32_t** out_colors) {
     if (!ix || !out_offsets || !out_colors) return fail(-EINVAL, "null argument");
@@ -1796,16 +1858,26 @@ static int run_host(fgpu_index* ix, const char* bases, const uint64_t* offs, uin
     fgpu_reads* rd = nullptr;
     fgpu_result* res = nullptr;
     int rc = fgpu_reads_upload(ix, bases, offs, n, &rd);
-    if (!rc) rc = fgpu_result_create(ix, &res);
+    if (!rc) {  // a result a finished call left behind, or a new one
+        std::lock_guard<std::mutex> g(ix->host_mu);
+        if (!ix->host_results.empty()) { res = ix->host_results.back(); ix->host_results.pop_back(); }
+    }
+    if (!rc && !res) rc = fgpu_result_create(ix, &res);
     if (!rc) rc = fgpu_run(ix, rd, 0, n, algo, tau, res);
     if (!rc) {  // (fgpu_result_download materialises the colour lists)
-        uint64_t* o = (uint64_t*)malloc((n + 1) * 8);
-        uint32_t* c = (uint32_t*)malloc(std::max<uint64_t>(1, res->total) * 4);
-        if (!o || !c) { free(o); free(c); rc = fail(-ENOMEM, "out of host memory"); }
-        else {
-            rc = fgpu_result_download(res, o, c);
-            if (rc) { free(o); free(c); } else { *out_offsets = o; *out_colors = c; }
-        }
+        uint64_t* o = nullptr;
+        uint32_t* c = nullptr;
+        rc = guarded([&] {
+            o = (uint64_t*)out_alloc((n + 1) * 8);
+            c = (uint32_t*)out_alloc(res->total * 4);
+            if (!o || !c) throw std::bad_alloc();
+        });
+        if (!rc) rc = fgpu_result_download(res, o, c);
+        if (rc) { fgpu_free(o); fgpu_free(c); } else { *out_offsets = o; *out_colors = c; }
+    }
+    if (res && !rc && result_device_bytes(res) <= fgpu_index::HOST_RESULT_KEEP_BYTES) {
+        std::lock_guard<std::mutex> g(ix->host_mu);
+        if (ix->host_results.size() < fgpu_index::HOST_RESULTS_MAX) { ix->host_results.push_back(res); res = nullptr; }
     }
     fgpu_result_free(res);
     fgpu_reads_free(rd);

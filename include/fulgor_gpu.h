@@ -61,7 +61,7 @@ int fgpu_save(const fgpu_index* idx, const char* path);
 int fgpu_info(const fgpu_index* idx, uint64_t* k, uint64_t* num_colors, uint64_t* num_color_sets,
               uint64_t* num_unitigs, uint64_t* num_kmers, int* index_type);
 
-/* ---- host-buffer calls: one per reference member; outputs are malloc'd, release with fgpu_free ---- */
+/* ---- host-buffer calls: one per reference member; outputs belong to the library (malloc'd, or slabs of its pinned pool): release them with fgpu_free ONLY ---- */
 /* index::fetch_color_set_ids (src/ps_full_intersection.cpp:334-374) */
 int fgpu_fetch_color_set_ids(fgpu_index* idx, const char* bases, const uint64_t* offs, uint64_t n,
                              uint64_t** out_offsets, uint32_t** out_ids);
