@@ -2110,6 +2110,43 @@ def test_stream_loop_reports_an_output_that_cannot_be_written(s10_gpu, tmp_path)
     assert n == 30000 and out.count(b"\n") == 30000
 
 
+def test_host_buffer_calls_from_several_threads(s10_gpu, seeded_reads):
+    """fgpu_full_intersection / fgpu_threshold_union as a reference worker pool calls them: one call per chunk of reads from several
+    threads at once (the binding releases the GIL inside the call). The index hands every call a result of its own — one a finished call
+    left behind, or a new one — and the outputs come from (and go back to) the pool of pinned slabs: every chunk's lists equal the ones
+    a single thread gets, chunk sizes from one read to a few thousand, six rounds over eight threads."""
+    import threading
+    ix = s10_gpu
+    b, o = seeded_reads
+    rng = np.random.default_rng(17)
+    cuts = [0]
+    while cuts[-1] < 40000:
+        cuts.append(min(40000, cuts[-1] + int(rng.integers(1, 4000))))
+    chunks = []
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        lo, hi = int(o[a]), int(o[e])
+        chunks.append((np.ascontiguousarray(b[lo:hi]), np.ascontiguousarray(o[a:e + 1] - o[a])))
+    want = [(ix.pseudoalign_full_intersection_batch(cb, co), ix.pseudoalign_threshold_union_batch(cb, co, 0.7)) for cb, co in chunks]
+    bad = []
+
+    def work(k):
+        for _ in range(6):
+            for i in range(k, len(chunks), 8):
+                cb, co = chunks[i]
+                fi = ix.pseudoalign_full_intersection_batch(cb, co)
+                tu = ix.pseudoalign_threshold_union_batch(cb, co, 0.7)
+                if not (np.array_equal(fi[0], want[i][0][0]) and np.array_equal(fi[1], want[i][0][1]) and
+                        np.array_equal(tu[0], want[i][1][0]) and np.array_equal(tu[1], want[i][1][1])):
+                    bad.append(i)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not bad, sorted(set(bad))[:10]
+
+
 def test_two_streamed_runs_at_once_on_one_index(s10_gpu, tmp_path):
     """two callers stream two different files through the same index at the same time (a server that answers two requests): each gets
     its own workers from the index's cache, the pinned slabs and the copy engines are shared; both outputs equal what the runs give
